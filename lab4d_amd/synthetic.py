@@ -1,0 +1,163 @@
+"""Seeded synthetic weights, per-frame inputs and rays for tests and bench.py.
+
+There is no dataset or checkpoint offline, so everything is generated:
+  * weights: the per-sample parameters of the reference's fg field
+    `Deformable("skel-quad", num_freq_dir=-1, appr_channels=32, num_inst=1, init_scale=0.2)`
+    (lab4d/nnutils/multifields.py:77-84) with the reference's own state_dict names and
+    shapes, default-PyTorch-style init (U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for Linear,
+    N(0,1) for Embedding) drawn from a seeded CPU generator;
+  * per-frame inputs: camera pose, intrinsics, near/far, bone articulations and the
+    per-frame codes that the reference's per-frame MLPs (outside the hot path) would produce.
+Pure torch-CPU; results are moved to the device by the caller.
+"""
+import math
+
+import torch
+
+NUM_BONES = 25  # skel-quad (lab4d/utils/skel_utils.py quad skeleton)
+# left<->right bone permutation of the quad skeleton (skel_utils.py:349-357 QUAD_SYMM_IDX, 0-based);
+# SkinningField.get_gauss averages log_gauss over it (skinning.py:142-153)
+QUAD_SYMM_IDX = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15, 16, 21, 22, 23, 24, 17, 18, 19, 20]
+
+# (name, out, in) for every per-sample Linear on the fg hot path (SURVEY.md 8a notes)
+FG_LINEARS = [
+    ("basefield.linear_1.0", 256, 95), ("basefield.linear_2.0", 256, 256), ("basefield.linear_3.0", 256, 256),
+    ("basefield.linear_4.0", 256, 256), ("basefield.linear_5.0", 256, 351), ("basefield.linear_6.0", 256, 256),
+    ("basefield.linear_7.0", 256, 256), ("basefield.linear_8.0", 256, 256), ("basefield.linear_final.0", 256, 256),
+    ("colorfield.linear_1.0", 256, 107), ("colorfield.linear_2.0", 256, 256), ("colorfield.linear_final.0", 256, 256),
+    ("sdf", 1, 256), ("rgb.0", 128, 288), ("rgb.2", 3, 128),
+    ("vis_mlp.basefield.linear_1.0", 64, 95), ("vis_mlp.basefield.linear_2.0", 64, 64),
+    ("vis_mlp.basefield.linear_final", 1, 64),
+    ("feature_field.linear_1.0", 128, 39), ("feature_field.linear_2.0", 128, 128),
+    ("feature_field.linear_3.0", 128, 128), ("feature_field.linear_4.0", 128, 128),
+    ("feature_field.linear_5.0", 128, 167), ("feature_field.linear_final", 16, 128),
+    ("warp.skinning_model.delta_field.linear_1.0", 64, 235), ("warp.skinning_model.delta_field.linear_2.0", 64, 64),
+    ("warp.skinning_model.delta_field.linear_final", NUM_BONES, 64),
+]
+FG_EMBEDDINGS = [
+    ("basefield.inst_embedding.mapping.weight", 32), ("colorfield.inst_embedding.mapping.weight", 32),
+    ("vis_mlp.basefield.inst_embedding.mapping.weight", 32),
+    ("warp.skinning_model.delta_field.inst_embedding.mapping.weight", 32),
+]
+
+
+def make_weights(seed=0, num_inst=1, sdf_bias=None):
+    """Flat dict of fp32 CPU tensors keyed by the reference's state_dict names."""
+    g = torch.Generator().manual_seed(seed)
+    P = {}
+    for name, o, i in FG_LINEARS:
+        bound = 1.0 / math.sqrt(i)
+        P[name + ".weight"] = (torch.rand(o, i, generator=g) * 2 - 1) * bound
+        P[name + ".bias"] = (torch.rand(o, generator=g) * 2 - 1) * bound
+    for name, c in FG_EMBEDDINGS:
+        P[name] = torch.randn(num_inst, c, generator=g)
+    P["logibeta"] = torch.tensor([-math.log(0.1)])  # nerf.py:144-145
+    P["logscale"] = torch.tensor([math.log(0.2)])  # nerf.py:147-148, init_scale=0.2
+    P["logsigma"] = torch.tensor([0.0])  # feature.py:86-87
+    P["warp.logibeta"] = torch.tensor([-math.log(0.01)])  # warping.py:273-275
+    P["warp.skinning_model.log_gauss"] = torch.full((NUM_BONES, 3), math.log(0.03))  # skinning.py:62-66
+    P["warp.skinning_model.log_gauss"] += 0.1 * torch.randn(NUM_BONES, 3, generator=g)
+    P["warp.skinning_model.symm_idx"] = torch.tensor(QUAD_SYMM_IDX, dtype=torch.long)
+    P["aabb"] = torch.tensor([[-0.12, -0.12, -0.12], [0.12, 0.12, 0.12]])  # proxy sphere r=0.12
+    if sdf_bias is not None:
+        P["sdf.bias"] = torch.tensor([float(sdf_bias)])
+    return P
+
+
+def _rand_unit_quat(g, n, angle):
+    axis = torch.randn(n, 3, generator=g)
+    axis = axis / axis.norm(dim=-1, keepdim=True)
+    ang = angle * (torch.rand(n, 1, generator=g) * 2 - 1)
+    return torch.cat([torch.cos(ang / 2), axis * torch.sin(ang / 2)], -1)
+
+
+def _qmul(a, b):
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+def _qt_to_dq(q, t):
+    # quaternion_translation_to_dual_quaternion (quat_transform.py:290-297): q_d = 0.5 * t * q
+    tq = torch.cat([torch.zeros_like(t[..., :1]), t], -1)
+    return q, 0.5 * _qmul(tq, q)
+
+
+def make_frames(seed, M, res, num_inst=1):
+    """Per-frame inputs for M frames (M even: consecutive frames form a pair, nerf.py:929-946)."""
+    g = torch.Generator().manual_seed(seed)
+    fr = {}
+    # intrinsics: focal = res, principal point = res/2; Kinv = K^-1
+    K = torch.tensor([[res, 0, res / 2], [0, res, res / 2], [0, 0, 1]], dtype=torch.float32)
+    fr["Kinv"] = torch.linalg.inv(K)[None].repeat(M, 1, 1).contiguous()
+    # camera: small rotation about a random axis, object 0.6 in front (3.0 * init_scale 0.2)
+    q = _rand_unit_quat(g, M, 0.5)
+    t = torch.tensor([0.0, 0.0, 0.6]).repeat(M, 1) + 0.02 * torch.randn(M, 3, generator=g)
+    fr["field2cam"] = (q.contiguous(), t.contiguous())
+    fr["near_far"] = torch.stack([t[:, 2] - 0.18, t[:, 2] + 0.18], -1).contiguous()
+    # bones: rest centres inside the r=0.1 ball, identity rest rotation; time-t = small motion
+    centres = 0.06 * torch.randn(NUM_BONES, 3, generator=g)
+    rest_q = torch.tensor([1.0, 0, 0, 0]).repeat(M, NUM_BONES, 1)
+    rest_t = centres[None].repeat(M, 1, 1)
+    fr["rest_articulation"] = tuple(x.contiguous() for x in _qt_to_dq(rest_q, rest_t))
+    dq_q = _rand_unit_quat(g, M * NUM_BONES, 0.6).view(M, NUM_BONES, 4)
+    t_t = rest_t + 0.01 * torch.randn(M, NUM_BONES, 3, generator=g)
+    fr["t_articulation"] = tuple(x.contiguous() for x in _qt_to_dq(dq_q, t_t))
+    fr["t_embed"] = 0.5 * torch.randn(M, 128, generator=g)
+    fr["t_embed_mean"] = 0.5 * torch.randn(1, 128, generator=g)
+    fr["appr_code"] = 0.5 * torch.randn(M, 32, generator=g)
+    fr["frame_id"] = torch.arange(M, dtype=torch.long)
+    fr["inst_id"] = torch.zeros(M, dtype=torch.long)
+    return fr
+
+
+def add_codes(fr, P):
+    """Instance codes = InstEmbedding lookups (embedding.py:246-264), num_inst == 1 -> row 0."""
+    def look(name):
+        w = P[name]
+        idx = fr["inst_id"] if w.shape[0] > 1 else torch.zeros_like(fr["inst_id"])
+        return w[idx]
+    fr["code_base"] = look("basefield.inst_embedding.mapping.weight")
+    fr["code_color"] = look("colorfield.inst_embedding.mapping.weight")
+    fr["code_vis"] = look("vis_mlp.basefield.inst_embedding.mapping.weight")
+    fr["code_skin"] = look("warp.skinning_model.delta_field.inst_embedding.mapping.weight")
+    return fr
+
+
+def make_rays(res, M, rows=None):
+    """Full pixel grid hxy (M, N, 3) = (x+0.5?, ...) -- the reference's create_xy_grid
+    (trainer.py:493-506) uses integer pixel coordinates [0,res) with homogeneous 1."""
+    ys, xs = torch.meshgrid(torch.arange(res, dtype=torch.float32), torch.arange(res, dtype=torch.float32), indexing="ij")
+    if rows is not None:
+        ys, xs = ys[rows[0]:rows[1]], xs[rows[0]:rows[1]]
+    hxy = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(xs.numel())], -1)
+    return hxy[None].repeat(M, 1, 1).contiguous()
+
+
+def make_targets(seed, M, N, res, hxy):
+    """Loss targets: rgb~U(0,1), mask = disc of radius res/4, depth=1, flow=0, ..."""
+    g = torch.Generator().manual_seed(seed)
+    c = res / 2
+    b = {}
+    b["rgb"] = torch.rand(M, N, 3, generator=g)
+    b["mask"] = ((hxy[..., :2] - c).norm(dim=-1, keepdim=True) < res / 4)
+    b["depth"] = torch.ones(M, N, 1)
+    b["flow"] = torch.zeros(M, N, 2)
+    b["flow_uct"] = torch.ones(M, N, 1)
+    b["vis2d"] = torch.ones(M, N, 1)
+    b["is_detected"] = torch.ones(M)
+    f = torch.randn(M, N, 16, generator=g)
+    b["feature"] = f / f.norm(dim=-1, keepdim=True)
+    b["hxy"] = hxy
+    return b
+
+
+def to_device(x, device):
+    if torch.is_tensor(x):
+        return x.to(device)
+    if isinstance(x, tuple):
+        return tuple(to_device(t, device) for t in x)
+    if isinstance(x, dict):
+        return {k: to_device(v, device) for k, v in x.items()}
+    return x

@@ -1,0 +1,271 @@
+"""Generate golden vectors by running the REFERENCE's own Python on CPU.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+Writes tests/golden/*.pt (small, committed).  The -m "not gpu" tests check the oracle
+(oracle/lab4d_oracle.py) against these files; the -m gpu tests check the HIP path against
+the oracle.  Weights are NOT stored: they are regenerated from lab4d_amd.synthetic
+.make_weights(seed) and loaded into the reference modules with load_state_dict, a
+checksum is stored instead.
+"""
+import os
+import sys
+from functools import partial
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+from oracle import ref_shim  # noqa: E402
+from lab4d_amd import synthetic  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def weight_checksum(P):
+    return float(sum(v.double().abs().sum() for k, v in sorted(P.items()) if v.dtype.is_floating_point))
+
+
+def compress_grad(g):
+    """Big gradients are stored as (norm, strided subsample) to keep the fixture small."""
+    if g.numel() <= 4096:
+        return {"full": g.clone()}
+    stride = g.numel() // 1024
+    return {"norm": g.double().norm().float(), "stride": stride, "sub": g.flatten()[::stride].clone()}
+
+
+def build_reference_field(ns, P):
+    torch.manual_seed(0)
+    di = ref_shim.synthetic_data_info(64)
+    f = ns.deformable.Deformable("skel-quad", di, num_freq_dir=-1, appr_channels=32, num_inst=1, init_scale=0.2)
+    f.category = "fg"
+    sd = {k: v for k, v in P.items() if k in f.state_dict()}
+    missing = [k for k in P if k not in f.state_dict() and k != "warp.skinning_model.symm_idx"]
+    assert not missing, missing
+    f.load_state_dict(sd, strict=False)
+    assert list(f.warp.skinning_model.symm_idx) == synthetic.QUAD_SYMM_IDX
+    return f
+
+
+def frames_from_reference(f, fr):
+    """Per-frame codes the reference's own per-frame modules produce for these frame ids."""
+    with torch.no_grad():
+        fid = fr["frame_id"]
+        fr["t_embed"] = f.warp.skinning_model.time_embedding(fid).clone()
+        fr["t_embed_mean"] = f.warp.skinning_model.time_embedding.get_mean_embedding("cpu").clone()
+        fr["appr_code"] = f.appr_embedding.get_vals(fid).clone()
+    return fr
+
+
+def samples_dict_of(fr, hxy, feature):
+    return {
+        "Kinv": fr["Kinv"], "field2cam": fr["field2cam"], "frame_id": fr["frame_id"], "inst_id": fr["inst_id"],
+        "near_far": fr["near_far"], "hxy": hxy, "feature": feature,
+        "t_articulation": fr["t_articulation"], "rest_articulation": fr["rest_articulation"],
+    }
+
+
+def leafify(fr, names):
+    out = dict(fr)
+    leaves = {}
+    for n in names:
+        v = fr[n]
+        if isinstance(v, tuple):
+            v = tuple(t.clone().requires_grad_(True) for t in v)
+            for i, t in enumerate(v):
+                leaves[f"{n}.{i}"] = t
+        else:
+            v = v.clone().requires_grad_(True)
+            leaves[n] = v
+        out[n] = v
+    return out, leaves
+
+
+def gen_train(ns, tag, M, N, D, res, seed, alpha=None):
+    P = synthetic.make_weights(seed)
+    f = build_reference_field(ns, P)
+    f.train()
+    f.pos_embedding.set_alpha(alpha)
+    f.pos_embedding_color.set_alpha(alpha)
+    fr = synthetic.make_frames(seed + 1, M, res)
+    fr = frames_from_reference(f, fr)
+    g = torch.Generator().manual_seed(seed + 2)
+    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
+    batch = synthetic.make_targets(seed + 3, M, N, res, hxy)
+    eik_n = max(M * N // 16, 1)
+    eik_inds = torch.randperm(M * N, generator=g)[:eik_n]
+    match_perm = torch.randperm(M * N * D, generator=g)[: min(1024, M * N * D)]
+    # inject host-side randomness (nerf.py:438-439 multinomial, feature.py:177 randperm)
+    ns.nerf.torch.multinomial = lambda probs, n, replacement=False: eik_inds.clone()
+    ns.feature.torch = ns.nerf.torch.__class__(**vars(ns.nerf.torch))
+    ns.feature.torch.randperm = lambda n: torch.cat([match_perm, torch.arange(n)])  # [:num_candidates] is taken
+    # D samples per ray (n_depth is reachable only through the kwarg)
+    ns.nerf.sample_cam_rays = partial(ns.render_utils.sample_cam_rays, n_depth=D)
+
+    fr_l, leaves = leafify(fr, ["Kinv", "field2cam", "t_articulation", "rest_articulation"])
+    sd = samples_dict_of(fr_l, hxy, batch["feature"])
+    feat_dict, deltas, aux = f.query_field(sd, flow_thresh=float(res))
+    rendered = ns.render_utils.render_pixel(feat_dict, deltas)
+    aux_fg = dict(aux)
+    aux_fg.update(ns.render_utils.render_pixel(feat_dict, deltas))
+    results = {"rendered": dict(rendered), "aux_dict": {"fg": aux_fg}}
+    results["rendered"]["xyz_matches"] = aux["xyz_matches"]
+    results["rendered"]["xyz_reproj"] = aux["xyz_reproj"]
+
+    import importlib
+    model = importlib.import_module("lab4d.engine.model").dvr_model
+    config = {"field_type": "fg", "train_res": res}
+    loss_dict = {}
+    model.compute_recon_loss(loss_dict, results, batch, config)
+    model.mask_losses(loss_dict, batch, config)
+    loss_dict["reg_eikonal"] = rendered["eikonal"]
+    loss_dict["reg_deform_cyc"] = aux_fg["cyc_dist"]
+    loss_dict["reg_delta_skin"] = aux_fg["delta_skin"]
+    loss_dict["reg_skin_entropy"] = aux_fg["skin_entropy"]
+    from oracle.lab4d_oracle import DEFAULT_LOSS_WT
+    config.update(DEFAULT_LOSS_WT)
+    model.apply_loss_weights(loss_dict, config)
+    total = sum(loss_dict.values())
+    params = dict(f.named_parameters())
+    gnames = [k for k in P if k in params and params[k].requires_grad]
+    grads = torch.autograd.grad(total, [params[k] for k in gnames] + list(leaves.values()), allow_unused=True)
+    gd = {}
+    for k, gv in zip(gnames + ["frame:" + k for k in leaves], grads):
+        if gv is not None:
+            gd[k] = compress_grad(gv.detach())
+    out = {
+        "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "alpha": alpha,
+                 "weight_checksum": weight_checksum(P), "flow_thresh": float(res)},
+        "frames": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in fr.items()},
+        "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds, "match_perm": match_perm},
+        "feat_dict": {k: v.detach() for k, v in feat_dict.items()}, "deltas": deltas.detach(),
+        "rendered": {k: v.detach() for k, v in results["rendered"].items()},
+        "aux_fg": {k: v.detach() for k, v in aux_fg.items()},
+        "loss": {k: v.detach() for k, v in loss_dict.items()}, "grads": gd,
+    }
+    path = os.path.join(HERE, f"train_{tag}.pt")
+    torch.save(out, path)
+    print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", {k: float(v) for k, v in loss_dict.items()})
+
+
+def gen_eval(ns, tag, M, N, D, res, seed):
+    P = synthetic.make_weights(seed, sdf_bias=-0.02)
+    f = build_reference_field(ns, P)
+    f.eval()
+    fr = synthetic.make_frames(seed + 1, M, res)
+    fr = frames_from_reference(f, fr)
+    g = torch.Generator().manual_seed(seed + 2)
+    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
+    # n_depth for the eval branch (nerf.py:696)
+    orig = f.importance_sampling
+    f.importance_sampling = lambda *a, **k: orig(*a, n_depth=D, **k)
+    sd = samples_dict_of(fr, hxy, None)
+    del sd["feature"]
+    captured = {}
+    _sp = ns.render_utils.sample_pdf
+    _ss = torch.searchsorted
+
+    def searchsorted(cdf, u, right=False):
+        r = _ss(cdf, u, right=right)
+        captured["inds"] = r.clone()
+        return r
+
+    ns.render_utils.torch.searchsorted = searchsorted
+    _gv = f.get_valid_idx
+
+    def get_valid_idx(*a, **k):
+        v = _gv(*a, **k)
+        captured["valid"] = v.clone()
+        return v
+
+    f.get_valid_idx = get_valid_idx
+    try:
+        feat_dict, deltas, aux = f.query_field(sd)
+    finally:
+        ns.render_utils.torch.searchsorted = _ss
+    rendered = ns.render_utils.render_pixel(feat_dict, deltas)
+    out = {
+        "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "weight_checksum": weight_checksum(P), "sdf_bias": -0.02},
+        "frames": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in fr.items()},
+        "hxy": hxy, "feat_dict": {k: v.detach() for k, v in feat_dict.items()}, "deltas": deltas.detach(),
+        "rendered": {k: v.detach() for k, v in rendered.items()},
+        "inds": captured["inds"], "valid": captured["valid"],
+    }
+    path = os.path.join(HERE, f"eval_{tag}.pt")
+    torch.save(out, path)
+    print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "valid frac", float(captured["valid"].float().mean()))
+
+
+def gen_ops(ns):
+    """Op-level goldens straight from the reference functions."""
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    # PosEmbedding incl. annealing window (embedding.py:69-125; reference test: tests/test_ops.py:64-133)
+    x = torch.randn(5, 7, 3, generator=g) * 0.3
+    for L, alpha in [(10, None), (12, 0.37), (6, 0.9), (0, None)]:
+        pe = ns.embedding.PosEmbedding(3, L)
+        pe.set_alpha(alpha)
+        out[f"posenc_L{L}_a{alpha}"] = (x, pe(x).clone())
+    # quaternion algebra (quat_transform.py)
+    a, b = torch.randn(11, 4, generator=g), torch.randn(11, 4, generator=g)
+    v = torch.randn(11, 3, generator=g)
+    qt = ns.quat_transform
+    out["qmul44"] = (a, b, qt.quaternion_mul(a, b))
+    out["qmul43"] = (a, v, qt.quaternion_mul(a, v))
+    out["qmul34"] = (v, b, qt.quaternion_mul(v, b))
+    out["qconj"] = (a, qt.quaternion_conjugate(a))
+    out["qapply"] = (a, v, qt.quaternion_apply(a, v))
+    dq1, dq2 = (a, b), (torch.randn(11, 4, generator=g), torch.randn(11, 4, generator=g))
+    out["dqmul"] = (dq1, dq2, qt.dual_quaternion_mul(dq1, dq2))
+    out["dqapply"] = (dq1, v, qt.dual_quaternion_apply(dq1, v))
+    out["dq2qt"] = (dq1, qt.dual_quaternion_to_quaternion_translation(dq1))
+    # compositing (render_utils.py)
+    dens = torch.rand(2, 5, 9, 1, generator=g) * 30
+    deltas = torch.rand(2, 5, 9, 1, generator=g) * 0.05
+    w, t = ns.render_utils.compute_weights(dens, deltas)
+    out["compute_weights"] = (dens, deltas, w, t)
+    bins = torch.sort(torch.rand(6, 15, generator=g), -1)[0]
+    wts = torch.rand(6, 14, generator=g)
+    wts[2] = 0  # degenerate ray: every bin has weight 0
+    wts[3, 3:9] = 0
+    captured = {}
+    _ss = torch.searchsorted
+
+    def searchsorted(cdf, u, right=False):
+        r = _ss(cdf, u, right=right)
+        captured["inds"] = r.clone()
+        return r
+
+    ns.render_utils.torch.searchsorted = searchsorted
+    try:
+        s = ns.render_utils.sample_pdf(bins, wts, 16, det=True)
+    finally:
+        ns.render_utils.torch.searchsorted = _ss
+    out["sample_pdf"] = (bins, wts, s, captured["inds"])
+    hxy = torch.cat([torch.rand(2, 4, 2, generator=g) * 64, torch.ones(2, 4, 1)], -1)
+    Kinv = torch.linalg.inv(torch.tensor([[64.0, 0, 32], [0, 64, 32], [0, 0, 1]]))[None].repeat(2, 1, 1)
+    nf = torch.tensor([[0.4, 0.8], [0.5, 0.9]])
+    out["sample_cam_rays"] = (hxy, Kinv, nf, ns.render_utils.sample_cam_rays(hxy, Kinv, nf, n_depth=7))
+    # compose_fields (multifields.py:339-398) for two fake fields
+    fdA = {"density": torch.rand(2, 3, 4, 1, generator=g), "rgb": torch.rand(2, 3, 4, 3, generator=g),
+           "depth": torch.sort(torch.rand(2, 3, 4, 1, generator=g), 2)[0], "cyc_dist": torch.rand(2, 3, 4, 1, generator=g)}
+    fdB = {"density": torch.rand(2, 3, 4, 1, generator=g), "rgb": torch.rand(2, 3, 4, 3, generator=g),
+           "depth": torch.sort(torch.rand(2, 3, 4, 1, generator=g), 2)[0]}
+    dA, dB = torch.rand(2, 3, 4, 1, generator=g), torch.rand(2, 3, 4, 1, generator=g)
+    comp, dcomp = ns.multifields.MultiFields.compose_fields({"fg": dict(fdA), "bg": dict(fdB)}, {"fg": dA, "bg": dB})
+    out["compose_fields"] = (fdA, fdB, dA, dB, {k: v.clone() for k, v in comp.items()}, dcomp)
+    path = os.path.join(HERE, "ops.pt")
+    torch.save(out, path)
+    print("ops ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    ns = ref_shim.load()
+    # give render_utils a private torch namespace so searchsorted can be observed
+    import types
+    ns.render_utils.torch = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
+    gen_ops(ns)
+    gen_train(ns, "small", M=2, N=6, D=8, res=64, seed=11)
+    gen_train(ns, "alpha", M=4, N=5, D=6, res=64, seed=21, alpha=0.45)
+    gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)
