@@ -1,0 +1,147 @@
+/*
+ * lab4d_hip.h -- C ABI of the MI355X-native differentiable volume renderer (liblab4d_hip.so).
+ *
+ * This is the drop-in boundary for the Lab4D rendering hot path.  Every entry point takes
+ * plain device pointers + sizes + a hipStream_t (passed as void*), launches hand-written
+ * gfx950 kernels on that stream and returns 0 on success or a negative LAB4D_E* code
+ * (lab4d_last_error() gives the message).  Nothing allocates, nothing retains pointers, the
+ * caller owns all memory (reference convention: third_party/quaternion/quaternion.py:20-21).
+ * All tensors are contiguous row-major.  M = frames, N = rays per frame, D = samples per ray,
+ * S = M*N*D samples, B = bones.
+ *
+ * Each block cites the reference interface it replaces (paths relative to lab4d/).
+ */
+#ifndef LAB4D_HIP_H
+#define LAB4D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAB4D_OK 0
+#define LAB4D_EINVAL (-1)   /* bad argument (null pointer, unsupported size/dtype) */
+#define LAB4D_ELAUNCH (-2)  /* hipLaunch / runtime error */
+
+/* dtype codes for the dqtorch-compatible entry points (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * third_party/quaternion/src/quaternion.cu:280-399) */
+#define LAB4D_F32 0
+#define LAB4D_F16 1
+#define LAB4D_F64 2
+
+const char* lab4d_last_error(void);
+int lab4d_version(void);
+/* returns the gfx arch string the library was compiled for ("gfx950") */
+const char* lab4d_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. dqtorch replacement -- third_party/quaternion/src/bindings.cpp:8-16, quaternion.h:11-24,
+ *    matinv.h:7-11.  Same argument order as the pybind functions, raw pointers instead of
+ *    at::Tensor, plus dtype and stream.  Launches on `stream` (the reference launches on the
+ *    legacy default stream, quaternion.cu:240).
+ * ------------------------------------------------------------------------------------------ */
+/* out[b,:4] = in1[b] (x) in2[b]; D1,D2 in {3,4}: a 3-vector is a pure quaternion (quaternion.cu:29-64) */
+int lab4d_quaternion_mul_forward(const void* in1, const void* in2, void* out, uint32_t B, uint32_t D1,
+                                 uint32_t D2, int dtype, void* stream);
+/* quaternion.cu:67-125 */
+int lab4d_quaternion_mul_backward(const void* grad, uint32_t B, uint32_t D1, uint32_t D2, const void* in1,
+                                  const void* in2, void* grad_in1, void* grad_in2, int dtype, void* stream);
+/* quaternion.cu:128-199 (second order; needed by eikonal/normal through warps) */
+int lab4d_quaternion_mul_backward_backward(const void* grad_out_1, const void* grad_out_2, uint32_t B,
+                                           uint32_t D1, uint32_t D2, const void* grad, const void* in1,
+                                           const void* in2, void* grad_grad, void* grad_grad_in1,
+                                           void* grad_grad_in2, int dtype, void* stream);
+/* quaternion.cu:202-217 */
+int lab4d_quaternion_conjugate(const void* in, uint32_t B, void* out, int dtype, void* stream);
+/* matinv.cu:42-62 / 80-116 / mat3x3_inv_forward / 119-240 */
+int lab4d_mat3x3_det_forward(const void* in, void* out, uint32_t B, int dtype, void* stream);
+int lab4d_mat3x3_scale_adjoint_forward(const void* in, const void* scales, void* out, uint32_t B, int dtype,
+                                       void* stream);
+int lab4d_mat3x3_inv_forward(const void* in, void* out, void* out_scales, uint32_t B, int dtype, void* stream);
+int lab4d_mat3x3_inv_backward(const void* grad, const void* inv_mats, void* grad_in, uint32_t B, int dtype,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Ray sampling -- utils/render_utils.py:8-56 (sample_cam_rays, perturb=False) fused with
+ *    nnutils/nerf.py:821-844 (NeRF.cam_to_field).  fp32.
+ *    hxy (M,N,3), Kinv (M,3,3), near_far (M,2); depth_in (M,N,D) or NULL (uniform in [near,far]).
+ *    cam2field_q (M,4)/cam2field_t (M,3) or NULL: if given also emits field-space points.
+ *    Outputs (any may be NULL): xyz_cam,dir_cam (S,3), deltas,depth (S), xyz_field,dir_field (S,3).
+ * ------------------------------------------------------------------------------------------ */
+int lab4d_ray_samples_forward(const float* hxy, const float* Kinv, const float* near_far, const float* depth_in,
+                              const float* cam2field_q, const float* cam2field_t, int M, int N, int D,
+                              float* xyz_cam, float* dir_cam, float* deltas, float* depth, float* xyz_field,
+                              float* dir_field, void* stream);
+/* Adjoint: accumulates (atomicAdd) into g_Kinv (M,9), g_q (M,4), g_t (M,3); caller zero-fills.
+ * Any g_* input may be NULL (treated as zero). */
+int lab4d_ray_samples_backward(const float* hxy, const float* Kinv, const float* near_far, const float* depth_in,
+                               const float* cam2field_q, const float* cam2field_t, int M, int N, int D,
+                               const float* g_xyz_cam, const float* g_dir_cam, const float* g_deltas,
+                               const float* g_xyz_field, const float* g_dir_field, float* g_Kinv, float* g_q,
+                               float* g_t, void* stream);
+
+/* utils/render_utils.py:187-233 sample_pdf(det=True): bins (R,n_samples+1... see below), weights (R,n_w).
+ * bins has n_w+1 entries per ray.  Writes samples (R,n_imp) and the searchsorted(right=True) indices
+ * inds (R,n_imp) int64 -- bit-exact vs torch (sequential fp32 cumsum). */
+int lab4d_sample_pdf(const float* bins, const float* weights, int R, int n_w, int n_imp, float eps,
+                     float* samples, int64_t* inds, void* stream);
+/* nnutils/nerf.py:731: sort(cat([depth_a, depth_b], -1)) per ray; a,b: (R,na),(R,nb) -> out (R,na+nb). */
+int lab4d_sort_depth(const float* a, int na, const float* b, int nb, int R, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. Compositing -- utils/render_utils.py:59-184 (render_pixel / compute_weights / integrate).
+ *    One launch renders every per-sample field of a ray batch.  R = M*N rays, D samples.
+ *    fields[i]: (R,D,channels[i]) fp32; modes[i]: 0 = normalised weights w/(sum w+1e-6),
+ *    1 = same weights but detached (key_freeze, render_utils.py:147), 2 = plain mean over D
+ *    (eikonal / delta_skin, render_utils.py:75-80).
+ * ------------------------------------------------------------------------------------------ */
+#define LAB4D_MAX_FIELDS 16
+typedef struct {
+  int n_fields;
+  const float* fields[LAB4D_MAX_FIELDS];
+  int channels[LAB4D_MAX_FIELDS];
+  int modes[LAB4D_MAX_FIELDS];
+} lab4d_field_list;
+typedef struct {
+  int n_fields;
+  float* fields[LAB4D_MAX_FIELDS];
+} lab4d_field_grads;
+
+/* density, deltas: (R,D).  Optional (NULL to skip): flow (R,D,3) = (u,v,valid), vis (R,D) logits,
+ * gauss_density (R,D).  Outputs: weights,transmit (R,D) (may be NULL), mask (R), out (R,sum channels)
+ * in field order, flow_out (R,2), vis_num (R) = -mean_D(logsigmoid(vis)*T), t_sum (R) = sum_D T,
+ * gauss_mask (R). */
+int lab4d_composite_forward(const float* density, const float* deltas, const lab4d_field_list* fl,
+                            const float* flow, const float* vis, const float* gauss_density, int R, int D,
+                            float* weights, float* transmit, float* mask, float* out, float* flow_out,
+                            float* vis_num, float* t_sum, float* gauss_mask, void* stream);
+/* Adjoint of the above.  g_* inputs: g_mask (R), g_out (R,sumC), g_flow_out (R,2), g_vis_num (R),
+ * g_gauss_mask (R); each may be NULL.  Outputs (each may be NULL): g_density, g_deltas (R,D),
+ * g_fields[i] (R,D,c_i), g_flow (R,D,3; valid channel gets 0), g_vis (R,D), g_gauss_density (R,D). */
+int lab4d_composite_backward(const float* density, const float* deltas, const lab4d_field_list* fl,
+                             const float* flow, const float* vis, const float* gauss_density, int R, int D,
+                             const float* g_mask, const float* g_out, const float* g_flow_out,
+                             const float* g_vis_num, const float* g_gauss_mask, float* g_density,
+                             float* g_deltas, const lab4d_field_grads* g_fields, float* g_flow, float* g_vis,
+                             float* g_gauss_density, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Fused positional-encoding + MLP stack -- nnutils/embedding.py:69-125 (PosEmbedding),
+ *    nnutils/base.py:65-78,123-150 (BaseMLP/CondMLP), as used by nnutils/nerf.py:167-215,
+ *    visibility.py:53-63, feature.py:136-150, skinning.py:108-119, warping.py:143-170.
+ *    See lab4d_mlp.h for the network descriptor.
+ * ------------------------------------------------------------------------------------------ */
+#include "lab4d_mlp.h"
+
+/* ------------------------------------------------------------------------------------------
+ * 5. Linear-blend skinning with dual quaternions -- nnutils/warping.py:277-336,
+ *    skinning.py:89-153, utils/transforms.py:9-25, utils/geom_utils.py:45-83,
+ *    utils/loss_utils.py:21-42.  See lab4d_skin.h.
+ * ------------------------------------------------------------------------------------------ */
+#include "lab4d_skin.h"
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAB4D_HIP_H */

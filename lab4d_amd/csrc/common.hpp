@@ -1,0 +1,66 @@
+// Shared helpers for the gfx950 kernels of liblab4d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "lab4d_hip.h"
+
+namespace lab4d {
+
+void set_error(const char* fmt, ...);
+
+#define LAB4D_REQUIRE(cond, ...)              \
+  do {                                        \
+    if (!(cond)) {                            \
+      lab4d::set_error(__VA_ARGS__);          \
+      return LAB4D_EINVAL;                    \
+    }                                         \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return LAB4D_ELAUNCH;
+  }
+  return LAB4D_OK;
+}
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+// inclusive suffix sum (sum over lanes >= this lane)
+__device__ __forceinline__ float wave_rscan_incl(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_down(v, o, 64);
+    if (lane + o < 64) v += t;
+  }
+  return v;
+}
+
+inline int div_up(long a, long b) { return (int)((a + b - 1) / b); }
+__device__ __forceinline__ int div_up_dev(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace lab4d

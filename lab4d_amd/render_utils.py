@@ -1,0 +1,269 @@
+"""Host-side mirror of lab4d/utils/render_utils.py -- same function names and signatures
+(sample_cam_rays, render_pixel, compute_weights, integrate, sample_pdf), executed by the
+gfx950 kernels of liblab4d_hip.so (csrc/raymarch.hip, csrc/composite.hip)."""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+KEY_SKIP = ["density", "vis", "flow", "eikonal", "xy_reproj", "xyz_reproj", "gauss_density"]  # render_utils.py:138-146
+KEY_FREEZE = ["cyc_dist", "xyz_cam", "skin_entropy"]  # render_utils.py:147
+KEY_MEAN = ["eikonal", "delta_skin"]  # render_utils.py:75-80
+
+
+def _f32(*ts):
+    _lib.require_device(*ts)
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("this op is fp32 only (the reference path is fp32, SURVEY F6); got %s" % t.dtype)
+
+
+class _RaySamples(Function):
+    """sample_cam_rays (render_utils.py:8-56, perturb=False) fused with NeRF.cam_to_field
+    (nerf.py:821-844).  Differentiable wrt Kinv and the cam->field rigid transform."""
+
+    @staticmethod
+    def forward(ctx, hxy, Kinv, near_far, depth_in, cq, ct, D):
+        hxy, Kinv = hxy.contiguous(), Kinv.contiguous()
+        near_far = near_far.contiguous() if near_far is not None else None
+        depth_in = depth_in.contiguous() if depth_in is not None else None
+        cq = cq.contiguous() if cq is not None else None
+        ct = ct.contiguous() if ct is not None else None
+        _f32(hxy, Kinv, near_far, depth_in, cq, ct)
+        M, N = hxy.shape[:2]
+        if depth_in is not None:
+            D = depth_in.shape[2]
+        dev = hxy.device
+        xyz_cam = torch.empty(M, N, D, 3, device=dev)
+        dir_cam = torch.empty(M, N, D, 3, device=dev)
+        deltas = torch.empty(M, N, D, 1, device=dev)
+        depth = torch.empty(M, N, D, 1, device=dev)
+        xyz_f = torch.empty(M, N, D, 3, device=dev) if cq is not None else None
+        dir_f = torch.empty(M, N, D, 3, device=dev) if cq is not None else None
+        _lib.check(_lib.lib().lab4d_ray_samples_forward(
+            _lib.ptr(hxy), _lib.ptr(Kinv), _lib.ptr(near_far), _lib.ptr(depth_in), _lib.ptr(cq), _lib.ptr(ct), M, N, D,
+            _lib.ptr(xyz_cam), _lib.ptr(dir_cam), _lib.ptr(deltas), _lib.ptr(depth), _lib.ptr(xyz_f), _lib.ptr(dir_f),
+            _lib.stream()), "ray_samples_forward")
+        ctx.save_for_backward(hxy, Kinv, near_far, depth_in, cq, ct)
+        ctx.dims = (M, N, D)
+        ctx.mark_non_differentiable(depth)
+        if cq is None:
+            return xyz_cam, dir_cam, deltas, depth
+        return xyz_cam, dir_cam, deltas, depth, xyz_f, dir_f
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_xyz, g_dir, g_deltas, g_depth, g_xyzf=None, g_dirf=None):
+        hxy, Kinv, near_far, depth_in, cq, ct = ctx.saved_tensors
+        M, N, D = ctx.dims
+        dev = hxy.device
+
+        def c(g):
+            return g.contiguous() if g is not None else None
+
+        g_xyz, g_dir, g_deltas, g_xyzf, g_dirf = c(g_xyz), c(g_dir), c(g_deltas), c(g_xyzf), c(g_dirf)
+        gK = torch.zeros(M, 3, 3, device=dev)
+        gq = torch.zeros(M, 4, device=dev) if cq is not None else None
+        gt = torch.zeros(M, 3, device=dev) if cq is not None else None
+        _lib.check(_lib.lib().lab4d_ray_samples_backward(
+            _lib.ptr(hxy), _lib.ptr(Kinv), _lib.ptr(near_far), _lib.ptr(depth_in), _lib.ptr(cq), _lib.ptr(ct), M, N, D,
+            _lib.ptr(g_xyz), _lib.ptr(g_dir), _lib.ptr(g_deltas), _lib.ptr(g_xyzf), _lib.ptr(g_dirf), _lib.ptr(gK),
+            _lib.ptr(gq), _lib.ptr(gt), _lib.stream()), "ray_samples_backward")
+        return None, gK, None, None, gq, gt, None
+
+
+def sample_cam_rays(hxy, Kinv, near_far, n_depth=64, depth=None, perturb=False):
+    """Same contract as render_utils.sample_cam_rays (render_utils.py:8-56).  `perturb=True`
+    (stratified jitter) is implemented in the reference but no caller enables it."""
+    if perturb:
+        raise NotImplementedError("perturb=True is never used by the reference call sites (nerf.py:618,703,735)")
+    return _RaySamples.apply(hxy, Kinv, near_far, depth, None, None, n_depth)
+
+
+def ray_samples(hxy, Kinv, near_far, cam2field, n_depth=64, depth=None):
+    """Fused sample_cam_rays + cam_to_field: returns xyz_cam, dir_cam, deltas, depth, xyz_field, dir_field."""
+    return _RaySamples.apply(hxy, Kinv, near_far, depth, cam2field[0], cam2field[1], n_depth)
+
+
+class _Composite(Function):
+    @staticmethod
+    def forward(ctx, density, deltas, flow, vis, gdens, modes, *fields):
+        M, N, D = density.shape[:3]
+        R = M * N
+        density, deltas = density.contiguous(), deltas.contiguous()
+        fields = [f.contiguous() for f in fields]
+        flow = flow.contiguous() if flow is not None else None
+        vis = vis.contiguous() if vis is not None else None
+        gdens = gdens.contiguous() if gdens is not None else None
+        _f32(density, deltas, flow, vis, gdens, *fields)
+        dev = density.device
+        fl = _lib.FieldList()
+        fl.n_fields = len(fields)
+        sumC = 0
+        for i, (f, m) in enumerate(zip(fields, modes)):
+            fl.fields[i] = f.data_ptr()
+            fl.channels[i] = f.shape[-1]
+            fl.modes[i] = m
+            sumC += 1 if m == 2 else f.shape[-1]
+        weights = torch.empty(M, N, D, device=dev)
+        transmit = torch.empty(M, N, D, device=dev)
+        mask = torch.empty(M, N, 1, device=dev)
+        out = torch.empty(M, N, max(sumC, 1), device=dev)
+        flow_out = torch.empty(M, N, 2, device=dev) if flow is not None else None
+        vis_num = torch.empty(M, N, 1, device=dev) if vis is not None else None
+        t_sum = torch.empty(M, N, 1, device=dev) if vis is not None else None
+        gmask = torch.empty(M, N, 1, device=dev) if gdens is not None else None
+        _lib.check(_lib.lib().lab4d_composite_forward(
+            _lib.ptr(density), _lib.ptr(deltas), fl, _lib.ptr(flow), _lib.ptr(vis), _lib.ptr(gdens), R, D, _lib.ptr(weights),
+            _lib.ptr(transmit), _lib.ptr(mask), _lib.ptr(out), _lib.ptr(flow_out), _lib.ptr(vis_num), _lib.ptr(t_sum),
+            _lib.ptr(gmask), _lib.stream()), "composite_forward")
+        ctx.save_for_backward(density, deltas, flow, vis, gdens, *fields)
+        ctx.modes = tuple(modes)
+        ctx.dims = (M, N, D, sumC)
+        ctx.mark_non_differentiable(weights, transmit)
+        if t_sum is not None:
+            ctx.mark_non_differentiable(t_sum)
+        return mask, out, flow_out, vis_num, t_sum, gmask, weights, transmit
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_mask, g_out, g_flow_out, g_vis_num, g_t_sum, g_gmask, g_w, g_T):
+        density, deltas, flow, vis, gdens, *fields = ctx.saved_tensors
+        M, N, D, sumC = ctx.dims
+        R = M * N
+
+        def c(g):
+            return g.contiguous() if g is not None else None
+
+        g_mask, g_out, g_flow_out, g_vis_num, g_gmask = c(g_mask), c(g_out), c(g_flow_out), c(g_vis_num), c(g_gmask)
+        fl = _lib.FieldList()
+        gf = _lib.FieldGrads()
+        fl.n_fields = gf.n_fields = len(fields)
+        gfields = []
+        for i, (f, m) in enumerate(zip(fields, ctx.modes)):
+            fl.fields[i] = f.data_ptr()
+            fl.channels[i] = f.shape[-1]
+            fl.modes[i] = m
+            need = ctx.needs_input_grad[6 + i]
+            g = torch.empty_like(f) if need else None
+            gfields.append(g)
+            gf.fields[i] = g.data_ptr() if g is not None else None
+        g_density = torch.empty_like(density)
+        g_deltas = torch.empty_like(deltas)
+        g_flow = torch.empty_like(flow) if (flow is not None and ctx.needs_input_grad[2]) else None
+        g_vis = torch.empty_like(vis) if (vis is not None and ctx.needs_input_grad[3]) else None
+        g_gd = torch.empty_like(gdens) if (gdens is not None and ctx.needs_input_grad[4]) else None
+        _lib.check(_lib.lib().lab4d_composite_backward(
+            _lib.ptr(density), _lib.ptr(deltas), fl, _lib.ptr(flow), _lib.ptr(vis), _lib.ptr(gdens), R, D, _lib.ptr(g_mask),
+            _lib.ptr(g_out), _lib.ptr(g_flow_out), _lib.ptr(g_vis_num), _lib.ptr(g_gmask), _lib.ptr(g_density),
+            _lib.ptr(g_deltas), gf, _lib.ptr(g_flow), _lib.ptr(g_vis), _lib.ptr(g_gd), _lib.stream()), "composite_backward")
+        return (g_density, g_deltas, g_flow, g_vis, g_gd, None, *gfields)
+
+
+def _composite(field_dict, deltas):
+    """Runs the fused compositor over a reference-style field_dict; returns the raw pieces."""
+    keys, modes, fields = [], [], []
+    for k, v in field_dict.items():
+        if k in KEY_MEAN:
+            keys.append(k); modes.append(2); fields.append(v)
+        elif k in KEY_SKIP:
+            continue
+        else:
+            keys.append(k); modes.append(1 if k in KEY_FREEZE else 0); fields.append(v)
+    flow = field_dict.get("flow")
+    vis = field_dict.get("vis")
+    gd = field_dict.get("gauss_density")
+    if len(fields) > 16:
+        raise RuntimeError("render_pixel: more than 16 fields")
+    res = _Composite.apply(field_dict["density"], deltas, flow, vis, gd, tuple(modes), *fields)
+    return keys, modes, fields, res
+
+
+class _Weights(Function):
+    """compute_weights with a device-side adjoint (used outside the fused render_pixel path)."""
+
+    @staticmethod
+    def forward(ctx, density, deltas):
+        res = _Composite.apply(density.detach(), deltas.detach(), None, None, None, ())
+        w, T = res[6], res[7]
+        ctx.save_for_backward(density, deltas, w, T)
+        ctx.mark_non_differentiable(T)
+        return w, T
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gw, gT):
+        density, deltas, w, T = ctx.saved_tensors
+        # dL/dtau_d = gw_d T_d - sum_{i>d} gw_i w_i
+        x = gw * w
+        suffix = torch.flip(torch.cumsum(torch.flip(x, [-1]), -1), [-1]) - x
+        gtau = (gw * T - suffix)[..., None]
+        return gtau * deltas, gtau * density
+
+
+def compute_weights(density, deltas):
+    """render_utils.py:99-126 -> (weights, transmit), both (M,N,D)."""
+    return _Weights.apply(density, deltas)
+
+
+def integrate(field_dict, weights):
+    """render_utils.py:129-184.  Kept for API parity; render_pixel() uses the fused kernel."""
+    raise NotImplementedError("use render_pixel(field_dict, deltas); integrate() is fused into it on this backend")
+
+
+def render_pixel(field_dict, deltas):
+    """Same contract as render_utils.render_pixel (render_utils.py:59-96)."""
+    keys, modes, fields, (mask, out, flow_out, vis_num, t_sum, gmask, w, T) = _composite(field_dict, deltas)
+    rendered = {"mask": mask}
+    co = 0
+    for k, m, f in zip(keys, modes, fields):
+        c = 1 if m == 2 else f.shape[-1]
+        v = out[..., co:co + c]
+        co += c
+        rendered[k] = v[..., 0] if m == 2 else v  # means are (M,N) in the reference (render_utils.py:76,79)
+    if flow_out is not None:
+        rendered["flow"] = flow_out
+    if "normal" in rendered:
+        rendered["normal"] = F.normalize(rendered["normal"], 2, -1)
+    dkeys = [k for k in rendered if "density_" in k]
+    if dkeys:
+        dsum = torch.cat([rendered[k] for k in dkeys], -1).sum(-1, keepdim=True) + 1e-6
+        for k in dkeys:
+            rendered[k.replace("density_", "mask_")] = rendered[k] / dsum
+            del rendered[k]
+    if vis_num is not None:
+        M, N, D = field_dict["density"].shape[:3]
+        rendered["vis"] = vis_num / (t_sum.sum() / (M * N * D)).detach()
+    if gmask is not None:
+        rendered["gauss_mask"] = gmask
+    return rendered
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, return_inds=False):
+    """render_utils.py:187-233; det=True only (nerf.py:721-727 always evaluates with det=not training
+    and importance sampling only runs in eval)."""
+    if not det:
+        raise NotImplementedError("sample_pdf(det=False) is unreachable in the reference (importance sampling is eval-only)")
+    bins, weights = bins.contiguous(), weights.contiguous()
+    _f32(bins, weights)
+    R, n_w = weights.shape
+    if bins.shape != (R, n_w + 1):
+        raise RuntimeError("sample_pdf: bins must be (R, n_w+1)")
+    samples = torch.empty(R, N_importance, device=bins.device)
+    inds = torch.empty(R, N_importance, dtype=torch.int64, device=bins.device)
+    _lib.check(_lib.lib().lab4d_sample_pdf(_lib.ptr(bins), _lib.ptr(weights), R, n_w, N_importance, float(eps), _lib.ptr(samples),
+                                           _lib.ptr(inds), _lib.stream()), "sample_pdf")
+    return (samples, inds) if return_inds else samples
+
+
+def sort_depth(a, b):
+    """sort(cat([a, b], -1), -1) for two per-ray depth lists (nerf.py:731)."""
+    a, b = a.contiguous(), b.contiguous()
+    _f32(a, b)
+    R = a.shape[0]
+    out = torch.empty(R, a.shape[1] + b.shape[1], device=a.device)
+    _lib.check(_lib.lib().lab4d_sort_depth(_lib.ptr(a), a.shape[1], _lib.ptr(b), b.shape[1], R, _lib.ptr(out), _lib.stream()),
+               "sort_depth")
+    return out

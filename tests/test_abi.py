@@ -1,0 +1,66 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol that include/*.h declares (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from lab4d_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = []
+    for f in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not f.endswith(".h"):
+            continue
+        src = open(os.path.join(ROOT, "include", f)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"\b(lab4d_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def so():
+    _lib.build(verbose=False)
+    return ctypes.CDLL(_lib.SO_PATH)
+
+
+def test_library_exports_every_declared_symbol(so):
+    names = declared_symbols()
+    assert len(names) >= 14
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, missing
+
+
+def test_python_signatures_cover_the_header():
+    sig = set(_lib.SIGNATURES)
+    hdr = set(declared_symbols()) - {"lab4d_last_error", "lab4d_version", "lab4d_arch"}
+    assert hdr <= sig, sorted(hdr - sig)
+
+
+def test_library_targets_gfx950(so):
+    so.lab4d_arch.restype = ctypes.c_char_p
+    assert so.lab4d_arch() == b"gfx950"
+    assert so.lab4d_version() >= 1
+
+
+def test_bad_arguments_are_rejected_without_a_gpu(so):
+    # argument validation happens before any launch, so it is testable on CPU
+    so.lab4d_last_error.restype = ctypes.c_char_p
+    rc = so.lab4d_quaternion_mul_forward(None, None, None, 4, 4, 4, 0, None)
+    assert rc == -1 and b"null" in so.lab4d_last_error()
+    buf = ctypes.create_string_buffer(64)
+    rc = so.lab4d_quaternion_mul_forward(buf, buf, buf, ctypes.c_uint32(1), ctypes.c_uint32(5), ctypes.c_uint32(4), 0, None)
+    assert rc == -1 and b"3 or 4" in so.lab4d_last_error()
+    rc = so.lab4d_quaternion_conjugate(buf, ctypes.c_uint32(1), buf, 9, None)
+    assert rc == -1 and b"dtype" in so.lab4d_last_error()
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from lab4d_amd import quaternion
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        quaternion.quaternion_mul(torch.randn(3, 4), torch.randn(3, 4))
