@@ -1,0 +1,120 @@
+/*
+ * lab4d_mlp.h -- fused positional-encoding + MLP-stack entry points of liblab4d_hip.so.
+ * Included by lab4d_hip.h.
+ *
+ * Replaces, for the per-sample networks of the Lab4D field (paths relative to lab4d/):
+ *   nnutils/embedding.py:69-125   PosEmbedding.forward (incl. the annealing window)
+ *   nnutils/base.py:65-78         BaseMLP.forward  (Linear+ReLU stack, skip = cat([x, out]))
+ *   nnutils/base.py:123-150       CondMLP.forward  (per-frame code appended to the input)
+ * as used by NeRF.forward (nerf.py:167-215), VisField.forward (visibility.py:53-63),
+ * FeatureNeRF.compute_feat (feature.py:136-150) and SkinningField.forward (skinning.py:108-119).
+ *
+ * Execution model (csrc/mlp.hip): one wavefront owns a tile of 64 (bf16) / 32 (fp32) samples and
+ * carries their activations through ALL layers in registers: the 32x32 MFMA accumulator layout of
+ * layer l is, by construction of the packed weights, exactly the B-operand layout of layer l+1,
+ * so no LDS, no barrier and no cross-lane traffic is needed between layers.  Weights stream from
+ * L2 as pre-packed 1-KiB A-fragments (coalesced 16 B per lane).  Per-frame conditioning inputs
+ * (instance code, appearance code, time embedding: constant over the samples of a frame) are folded
+ * by the host into a per-frame bias, so the kernel never materialises the (S, C) broadcast the
+ * reference builds (base.py:139-146).
+ *
+ * Training stores every post-activation in a [feature][sample] layout (bf16 or fp32); the
+ * backward chain kernel re-reads it for the ReLU masks and writes dZ in the same layout; the
+ * weight-gradient kernel contracts the two over samples with MFMA (both operands K-contiguous).
+ */
+#ifndef LAB4D_MLP_H
+#define LAB4D_MLP_H
+
+#include <stdint.h>
+
+#define LAB4D_MLP_MAX_LAYERS 12
+
+/* networks (compile-time layer tables live in csrc/mlp_nets.hpp; lab4d_mlp_describe returns them) */
+#define LAB4D_NET_FG_BASE 0   /* posenc10 -> basefield (8+1 layers, skip at 4) -> sdf head          */
+#define LAB4D_NET_FG_COLOR 1  /* posenc12 -> colorfield (2+1) (+ basefield feature) -> rgb (2)      */
+#define LAB4D_NET_VIS 2       /* posenc10 -> 64 -> 64 -> 1                                           */
+#define LAB4D_NET_FEAT 3      /* posenc6  -> feature_field (5 layers W=128, skip at 4) -> 16         */
+#define LAB4D_NET_SKIN 4      /* raw 75 bone coords -> 64 -> 64 -> 25 (delta skinning weights)       */
+#define LAB4D_NET_COUNT 5
+
+#define LAB4D_PREC_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32, parity path                       */
+#define LAB4D_PREC_BF16 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate: throughput path            */
+
+typedef struct {
+  int ke;      /* input columns taken from the embedded input (padded slot count, multiple of 32; 0 = none) */
+  int kin;     /* input columns taken from the previous layer's activation                                  */
+  int mout;    /* real output features                                                                       */
+  int mout_pad;/* padded to a multiple of 32                                                                 */
+  int relu;    /* ReLU after the affine map                                                                  */
+  int pf_bias; /* layer takes a per-frame bias (M, mout_pad) in addition to its bias                         */
+  int add_ext; /* after the activation, add the external feature tensor `ext` ([mout_pad][S_pad])           */
+  int ext_grad;/* backward: an external gradient tensor is added to dL/d(output of this layer)               */
+} lab4d_mlp_layer;
+
+typedef struct {
+  int n_layers;
+  int emb_kind;   /* 0: posenc of a 3-vector with n_freq bands; 1: raw input with c_in channels             */
+  int n_freq;
+  int c_in;       /* raw input channels (emb_kind 1) or 3                                                   */
+  int emb_slots;  /* real embedding slots: 6*n_freq+3 or c_in                                               */
+  int ke;         /* padded embedding slots                                                                  */
+  int c_out;      /* head channels                                                                            */
+  lab4d_mlp_layer layers[LAB4D_MLP_MAX_LAYERS];
+} lab4d_mlp_desc;
+
+/* Embedding slot order of the posenc nets (what column j of the `ke` block means):
+ *   slot 2*(3f+a)   = w_f * sin(2^f x_a)      slot 2*(3f+a)+1 = w_f * cos(2^f x_a)    f < n_freq, a < 3
+ *   slot 6*n_freq+a = x_a ;  remaining slots are zero padding.
+ * (the reference's channel order is [x, (f, {sin,cos}, a)], embedding.py:96-108; the host maps
+ * weight columns with the col_map argument of lab4d_mlp_pack.) */
+int lab4d_mlp_describe(int net, lab4d_mlp_desc* out);
+
+/* bytes of the packed weight block of one layer (same for forward and transposed) */
+int64_t lab4d_mlp_packed_bytes(int net, int layer, int precision);
+
+/* Pack one layer's weight matrix into MFMA A-fragment order.
+ *   W_ref: (mout, k_ref) fp32 row-major = the reference nn.Linear.weight (device pointer)
+ *   col_map: (ke+kin) int32 device array: kernel input column -> column of W_ref, or -1 (zero)
+ *   transposed = 0: forward operand (rows = outputs); 1: dgrad operand (rows = inputs) */
+int lab4d_mlp_pack(int net, int layer, int precision, int transposed, const float* W_ref, int k_ref,
+                   const int32_t* col_map, void* packed, void* stream);
+
+typedef struct {
+  int net, precision;
+  int S;       /* samples                                                                                  */
+  int S_pad;   /* leading dimension of every [feature][sample] buffer: multiple of 64, >= S               */
+  int spf;     /* samples per frame (N*D); frame of sample s = s / spf                                     */
+  const float* x;        /* (S,3) points or (S,c_in) raw inputs, fp32                                      */
+  const float* freq_w;   /* (n_freq) annealing window weights or NULL (all ones)                           */
+  const void* W[LAB4D_MLP_MAX_LAYERS];        /* packed forward weights                                    */
+  const float* bias[LAB4D_MLP_MAX_LAYERS];    /* (mout_pad) fp32                                           */
+  const float* pf_bias[LAB4D_MLP_MAX_LAYERS]; /* (M, mout_pad) fp32 or NULL                                */
+  void* act[LAB4D_MLP_MAX_LAYERS];  /* [mout_pad][S_pad] stored post-activation or NULL (not stored)       */
+  void* emb;                        /* [ke][S_pad] stored embedding or NULL                                */
+  const void* ext;                  /* [mout_pad][S_pad] tensor added at the add_ext layer                 */
+  float* out;                       /* (S, c_out) raw head output, fp32                                    */
+} lab4d_mlp_fwd_args;
+int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream);
+
+typedef struct {
+  int net, precision, S, S_pad, spf;
+  const void* WT[LAB4D_MLP_MAX_LAYERS];        /* packed transposed weights                                */
+  const void* act[LAB4D_MLP_MAX_LAYERS];       /* stored post-activations from the forward                 */
+  const void* emb;                             /* stored embedding (posenc Jacobian)                       */
+  const void* ext;                             /* forward `ext` (to recover relu(z) = y - ext)             */
+  const float* d_out;                          /* (S, c_out) gradient of the head output                   */
+  const void* ext_gin;                         /* [mout_pad][S_pad] gradient added at the ext_grad layer   */
+  void* ext_gout;                              /* [mout_pad][S_pad] gradient wrt `ext` (written) or NULL   */
+  void* dz[LAB4D_MLP_MAX_LAYERS];              /* [mout_pad][S_pad] dL/d(pre-activation) (written)         */
+  float* d_x;                                  /* (S,3) or (S,c_in) gradient wrt the input, or NULL        */
+} lab4d_mlp_bwd_args;
+int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream);
+
+/* Weight / bias gradients of one layer: dW[o][k] = sum_s dz[o][s] * X[k][s], db[o] = sum_s dz[o][s],
+ * X = [emb (ke rows) ; act_prev (kin rows)].  dW: (mout_pad, ke+kin) fp32 row-major, db: (mout_pad);
+ * both are ACCUMULATED into (atomicAdd) -- zero-fill first.  pf_db: (M, mout_pad) per-frame bias
+ * gradient or NULL. */
+int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int spf, const void* dz, const void* emb,
+                    const void* act_prev, float* dW, float* db, float* pf_db, int M, void* stream);
+
+#endif /* LAB4D_MLP_H */

@@ -127,7 +127,7 @@ def lib():
         for name, at in SIGNATURES.items():
             fn = getattr(_LIB, name)
             fn.argtypes = at
-            fn.restype = ci
+            fn.restype = ctypes.c_int64 if name == "lab4d_mlp_packed_bytes" else ci
     return _LIB
 
 

@@ -1,0 +1,304 @@
+// Host API of the fused MLP stack (include/lab4d_mlp.h) + weight-gradient GEMM + weight packing.
+// The chain kernels live in mlp_kernels.hpp / mlp_inst_*.hip.
+#include "mlp_kernels.hpp"
+
+namespace lab4d {
+
+// =================================================================================================
+// weight gradient: dW[o][k] += sum_s dz[o][s] X[k][s]   (both operands [feature][sample])
+// =================================================================================================
+template <class P, int TM>
+__global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __restrict__ dz, const typename P::store_t* __restrict__ emb,
+                                                    const typename P::store_t* __restrict__ actp, int mo_tiles, int ke, int kin,
+                                                    int S_pad, int chunk, float* __restrict__ dW, float* __restrict__ db) {
+  constexpr int TN = 4;
+  constexpr int SPS = P::BF16 ? 16 : 8;  // samples per step
+  const int lane = threadIdx.x & 63, row = lane & 31, h = lane >> 5;
+  const int K = ke + kin, nk_tiles = K / 32;
+  const int ob_n = (mo_tiles + TM - 1) / TM, kb_n = (nk_tiles + TN - 1) / TN;
+  const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nchunks = (S_pad + chunk - 1) / chunk;
+  if (job >= ob_n * kb_n * nchunks) return;
+  const int c = job / (ob_n * kb_n), rem = job - c * (ob_n * kb_n);
+  const int ob = rem / kb_n, kb = rem - ob * kb_n;
+  const int s_begin = c * chunk, s_end = min(S_pad, s_begin + chunk);
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float rs[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rs[i] = 0.f;
+
+  const typename P::store_t* ap[TM];
+  const typename P::store_t* bp[TN];
+  bool av_[TM], bv_[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int t = ob * TM + i;
+    av_[i] = t < mo_tiles;
+    ap[i] = dz + (size_t)(32 * (av_[i] ? t : 0) + row) * S_pad;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int t = kb * TN + j;
+    bv_[j] = t < nk_tiles;
+    const int kr = 32 * (bv_[j] ? t : 0) + row;
+    bp[j] = kr < ke ? emb + (size_t)kr * S_pad : actp + (size_t)(kr - ke) * S_pad;
+  }
+  const int off = P::BF16 ? 8 * h : 4 * h;
+  for (int s = s_begin; s < s_end; s += SPS) {
+    uint4 a4[TM], b4[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a4[i] = av_[i] ? *reinterpret_cast<const uint4*>(ap[i] + s + off) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b4[j] = bv_[j] ? *reinterpret_cast<const uint4*>(bp[j] + s + off) : make_uint4(0, 0, 0, 0);
+    if (kb == 0 && db) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (P::BF16) {
+          const unsigned int w[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rs[i] += bf2f((unsigned short)(w[q] & 0xffffu)) + bf2f((unsigned short)(w[q] >> 16));
+        } else {
+          rs[i] += __uint_as_float(a4[i].x) + __uint_as_float(a4[i].y) + __uint_as_float(a4[i].z) + __uint_as_float(a4[i].w);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (P::BF16) {
+          bf16x8_t x, y;
+          __builtin_memcpy(&x, &a4[i], 16);
+          __builtin_memcpy(&y, &b4[j], 16);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4[i].x), __uint_as_float(b4[j].x), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4[i].y), __uint_as_float(b4[j].y), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4[i].z), __uint_as_float(b4[j].z), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4[i].w), __uint_as_float(b4[j].w), acc[i][j], 0, 0, 0);
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (!av_[i]) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (!bv_[j]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = 32 * (ob * TM + i) + drow(r, h);
+        const int k = 32 * (kb * TN + j) + row;
+        atomicAdd(dW + (size_t)o * K + k, acc[i][j][r]);
+      }
+    }
+    if (kb == 0 && db) {
+      const float v = rs[i] + __shfl_xor(rs[i], 32, 64);
+      if (h == 0) atomicAdd(db + 32 * (ob * TM + i) + row, v);
+    }
+  }
+}
+
+// per-frame bias gradient: pf_db[m][o] = sum_{s in frame m} dz[o][s] ; one wave per (o, m)
+template <class P>
+__global__ void __launch_bounds__(256) k_rowsum_pf(const typename P::store_t* __restrict__ dz, int mo_pad, int S, int S_pad, int spf,
+                                                    int M, float* __restrict__ pf_db) {
+  const int lane = threadIdx.x & 63;
+  const long job = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (job >= (long)mo_pad * M) return;
+  const int o = (int)(job % mo_pad), m = (int)(job / mo_pad);
+  const long b = (long)m * spf, e = min((long)S, b + spf);
+  float s = 0.f;
+  for (long i = b + lane; i < e; i += 64) {
+    if constexpr (P::BF16) s += bf2f(dz[(size_t)o * S_pad + i]);
+    else s += dz[(size_t)o * S_pad + i];
+  }
+  s = wave_sum(s);
+  if (lane == 0) pf_db[(size_t)m * mo_pad + o] = s;
+}
+
+// =================================================================================================
+// weight packing
+// =================================================================================================
+template <class P>
+__global__ void __launch_bounds__(256) k_pack(const float* __restrict__ Wref, int mout, int k_ref, const int32_t* __restrict__ col_map,
+                                               int ke, int kin, int mo_pad, int transposed, typename P::store_t* __restrict__ out) {
+  constexpr int EPL = P::BF16 ? 8 : 4;  // elements per lane per group
+  const int K = ke + kin;
+  const int rows = transposed ? K : mo_pad;      // A rows
+  const int kdim = transposed ? mo_pad : K;      // contraction length
+  const int G = kdim / P::FPG;
+  const long total = (long)(rows / 32) * G * 64 * EPL;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e % EPL);
+    const int lane = (int)((e / EPL) % 64);
+    const int g = (int)((e / (EPL * 64)) % G);
+    const int mt = (int)(e / ((long)EPL * 64 * G));
+    const int row = 32 * mt + (lane & 31), h = lane >> 5;
+    // contraction index -> "natural" index along the contracted dimension
+    const int ge = transposed ? 0 : ke / P::FPG;  // identity-ordered groups (embedding block) come first in the forward operand
+    int kk;
+    if (g < ge) {
+      kk = P::BF16 ? 16 * g + 8 * h + j : 2 * (4 * g + j) + h;
+    } else {
+      const int gg = g - ge;
+      int b, r;
+      if (P::BF16) { b = gg >> 1; r = 8 * (gg & 1) + j; }
+      else { const int kap = 4 * gg + j; b = kap >> 4; r = kap & 15; }
+      kk = (transposed ? 0 : ke) + 32 * b + drow(r, h);
+    }
+    const int o = transposed ? kk : row;   // output feature
+    const int c = transposed ? row : kk;   // kernel input column
+    float v = 0.f;
+    if (o < mout && c < K) {
+      const int cr = col_map[c];
+      if (cr >= 0) v = Wref[(size_t)o * k_ref + cr];
+    }
+    if constexpr (P::BF16) out[e] = f2bf(v);
+    else out[e] = v;
+  }
+}
+
+}  // namespace lab4d
+using namespace lab4d;
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+template <class F>
+int with_net(int net, F&& f) {
+  switch (net) {
+    case LAB4D_NET_FG_BASE: return f(NetFgBase{});
+    case LAB4D_NET_FG_COLOR: return f(NetFgColor{});
+    case LAB4D_NET_VIS: return f(NetVis{});
+    case LAB4D_NET_FEAT: return f(NetFeat{});
+    case LAB4D_NET_SKIN: return f(NetSkin{});
+    default: set_error("unknown net id %d", net); return LAB4D_EINVAL;
+  }
+}
+
+}  // namespace
+
+extern "C" int lab4d_mlp_describe(int net, lab4d_mlp_desc* out) {
+  LAB4D_REQUIRE(out, "mlp_describe: null out");
+  memset(out, 0, sizeof(*out));
+  return with_net(net, [&](auto n) { fill_desc<decltype(n)>(out); return LAB4D_OK; });
+}
+
+extern "C" int64_t lab4d_mlp_packed_bytes(int net, int layer, int precision) {
+  lab4d_mlp_desc d;
+  if (lab4d_mlp_describe(net, &d) != LAB4D_OK || layer < 0 || layer >= d.n_layers) return -1;
+  const lab4d_mlp_layer& L = d.layers[layer];
+  return (int64_t)L.mout_pad * (L.ke + L.kin) * (precision == LAB4D_PREC_BF16 ? 2 : 4);
+}
+
+extern "C" int lab4d_mlp_pack(int net, int layer, int precision, int transposed, const float* W_ref, int k_ref,
+                              const int32_t* col_map, void* packed, void* stream) {
+  lab4d_mlp_desc d;
+  if (int e = lab4d_mlp_describe(net, &d)) return e;
+  LAB4D_REQUIRE(layer >= 0 && layer < d.n_layers, "mlp_pack: bad layer %d", layer);
+  LAB4D_REQUIRE(W_ref && col_map && packed, "mlp_pack: null pointer");
+  const lab4d_mlp_layer& L = d.layers[layer];
+  const long total = (long)L.mout_pad * (L.ke + L.kin);
+  int grid = div_up(total, 256); if (grid > 2048) grid = 2048;
+  if (precision == LAB4D_PREC_BF16)
+    hipLaunchKernelGGL((k_pack<PBF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, W_ref, L.mout, k_ref, col_map, L.ke, L.kin,
+                       L.mout_pad, transposed, (unsigned short*)packed);
+  else if (precision == LAB4D_PREC_F32)
+    hipLaunchKernelGGL((k_pack<PF32>), dim3(grid), dim3(256), 0, (hipStream_t)stream, W_ref, L.mout, k_ref, col_map, L.ke, L.kin,
+                       L.mout_pad, transposed, (float*)packed);
+  else { set_error("mlp_pack: bad precision %d", precision); return LAB4D_EINVAL; }
+  return check_launch("mlp_pack");
+}
+
+extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
+  LAB4D_REQUIRE(a, "mlp_forward: null args");
+  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0, "mlp_forward: bad sizes S=%d S_pad=%d spf=%d", a->S, a->S_pad, a->spf);
+  LAB4D_REQUIRE(a->x && a->out, "mlp_forward: null x/out");
+  if (a->S == 0) return LAB4D_OK;
+  return with_net(a->net, [&](auto n) {
+    using Net = decltype(n);
+    FwdK k;
+    memset(&k, 0, sizeof(k));
+    k.S = a->S; k.S_pad = a->S_pad; k.spf = a->spf; k.x = a->x; k.freq_w = a->freq_w; k.emb = a->emb; k.ext = a->ext; k.out = a->out;
+    for (int l = 0; l < Net::NL; ++l) {
+      LAB4D_REQUIRE(a->W[l] && a->bias[l], "mlp_forward: layer %d weights/bias missing", l);
+      LAB4D_REQUIRE(!Net::L[l].pf || a->pf_bias[l], "mlp_forward: layer %d needs a per-frame bias", l);
+      LAB4D_REQUIRE(!Net::L[l].add_ext || a->ext, "mlp_forward: layer %d needs ext", l);
+      k.W[l] = a->W[l]; k.bias[l] = a->bias[l]; k.pf_bias[l] = a->pf_bias[l]; k.act[l] = a->act[l];
+    }
+    return launch_mlp_fwd<Net>(a->precision, k, a->S, (hipStream_t)stream);
+  });
+}
+
+extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
+  LAB4D_REQUIRE(a, "mlp_backward: null args");
+  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0, "mlp_backward: bad sizes");
+  LAB4D_REQUIRE(a->d_out, "mlp_backward: null d_out");
+  if (a->S == 0) return LAB4D_OK;
+  return with_net(a->net, [&](auto n) {
+    using Net = decltype(n);
+    BwdK k;
+    memset(&k, 0, sizeof(k));
+    k.S = a->S; k.S_pad = a->S_pad; k.spf = a->spf; k.emb = a->emb; k.ext = a->ext; k.d_out = a->d_out; k.ext_gin = a->ext_gin;
+    k.ext_gout = a->ext_gout; k.d_x = a->d_x;
+    LAB4D_REQUIRE(!(a->d_x && Net::EMB == 0) || a->emb, "mlp_backward: d_x needs the stored embedding");
+    for (int l = 0; l < Net::NL; ++l) {
+      LAB4D_REQUIRE(a->WT[l], "mlp_backward: layer %d transposed weights missing", l);
+      LAB4D_REQUIRE(!(Net::L[l].relu && l + 1 < Net::NL) || a->act[l], "mlp_backward: layer %d stored activation missing", l);
+      LAB4D_REQUIRE(!Net::L[l].ext_grad || a->ext_gin, "mlp_backward: layer %d needs ext_gin", l);
+      LAB4D_REQUIRE(!Net::L[l].add_ext || a->ext, "mlp_backward: layer %d needs ext", l);
+      k.WT[l] = a->WT[l]; k.act[l] = a->act[l]; k.dz[l] = a->dz[l];
+    }
+    return launch_mlp_bwd<Net>(a->precision, k, a->S, (hipStream_t)stream);
+  });
+}
+
+extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int spf, const void* dz, const void* emb,
+                               const void* act_prev, float* dW, float* db, float* pf_db, int M, void* stream) {
+  lab4d_mlp_desc d;
+  if (int e = lab4d_mlp_describe(net, &d)) return e;
+  LAB4D_REQUIRE(layer >= 0 && layer < d.n_layers, "mlp_wgrad: bad layer %d", layer);
+  const lab4d_mlp_layer& L = d.layers[layer];
+  LAB4D_REQUIRE(dz && dW, "mlp_wgrad: null dz/dW");
+  LAB4D_REQUIRE(L.ke == 0 || emb, "mlp_wgrad: layer %d needs the stored embedding", layer);
+  LAB4D_REQUIRE(L.kin == 0 || act_prev, "mlp_wgrad: layer %d needs the previous activation", layer);
+  LAB4D_REQUIRE(S_pad % 64 == 0 && S_pad >= S, "mlp_wgrad: bad S_pad");
+  if (S == 0) return LAB4D_OK;
+  const int mo_tiles = L.mout_pad / 32, nk_tiles = (L.ke + L.kin) / 32;
+  const int TM = mo_tiles >= 4 ? 4 : (mo_tiles >= 2 ? 2 : 1);
+  const int ob_n = div_up(mo_tiles, TM), kb_n = div_up(nk_tiles, 4);
+  // ~2048 wave jobs in total; chunks are multiples of 64 samples
+  int nchunks = 2048 / (ob_n * kb_n); if (nchunks < 1) nchunks = 1;
+  int chunk = div_up(div_up(S_pad, nchunks), 64) * 64; if (chunk < 256) chunk = 256;
+  nchunks = div_up(S_pad, chunk);
+  const int jobs = ob_n * kb_n * nchunks;
+  const dim3 grid(div_up(jobs, 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define WG(P, TMV) hipLaunchKernelGGL((k_mlp_wgrad<P, TMV>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
+                                      (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, dW, db)
+  if (precision == LAB4D_PREC_BF16) { if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
+  else if (precision == LAB4D_PREC_F32) { if (TM == 4) WG(PF32, 4); else if (TM == 2) WG(PF32, 2); else WG(PF32, 1); }
+  else { set_error("mlp_wgrad: bad precision %d", precision); return LAB4D_EINVAL; }
+#undef WG
+  if (int e = check_launch("mlp_wgrad")) return e;
+  if (pf_db) {
+    LAB4D_REQUIRE(M > 0 && spf > 0, "mlp_wgrad: pf_db needs M and spf");
+    const long jobs2 = (long)L.mout_pad * M;
+    if (precision == LAB4D_PREC_BF16)
+      hipLaunchKernelGGL((k_rowsum_pf<PBF16>), dim3(div_up(jobs2, 4)), dim3(256), 0, st, (const unsigned short*)dz, L.mout_pad, S, S_pad, spf, M, pf_db);
+    else
+      hipLaunchKernelGGL((k_rowsum_pf<PF32>), dim3(div_up(jobs2, 4)), dim3(256), 0, st, (const float*)dz, L.mout_pad, S, S_pad, spf, M, pf_db);
+    return check_launch("mlp_rowsum_pf");
+  }
+  return LAB4D_OK;
+}

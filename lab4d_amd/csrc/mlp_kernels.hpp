@@ -1,0 +1,609 @@
+// Fused positional-encoding + MLP stack for gfx950: forward chain and backward (dgrad) chain
+// kernel templates.  Instantiated per network in mlp_inst_*.hip (one translation unit each, so the
+// nets compile in parallel); host API in mlp.hip.  Contract: include/lab4d_mlp.h.
+//
+// Wave-resident chain.  A wavefront owns TILE = 32*NT samples (NT = 2 for bf16, 1 for fp32) and
+// carries them through ALL layers without ever exchanging data with another wave:
+// lane l = (n = l & 31, h = l >> 5) owns sample column n of each 32-sample n-tile.  For the 32x32
+// MFMA shapes used here (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32):
+//   * accumulator D:  lane (n,h), register r  <->  output feature  32*mt + (r&3) + 8*(r>>2) + 4*h
+//   * B operand:      lane (n,h) supplies k-slots {8h..8h+7} (bf16) or {h} (fp32) of column n
+// The contraction over k does not care about the order of k as long as A and B agree, so the packed
+// A-fragments of layer l+1 are laid out such that "k-slot (step, h, j)" means exactly the feature a
+// lane already holds in accumulator register (step, j) of layer l: the accumulator IS the next B
+// operand (after bias/ReLU/convert) -- no transposition, no cross-lane traffic, no barrier.
+// (Verified on hardware by tests/test_gpu_ops.py::test_mfma_layout_probe.)
+//
+// A layer's inputs live in registers as 16-byte "units" (one A-group's worth of B data: 8 bf16 or
+// 4 fp32 k-steps).  Outputs are produced M-tile by M-tile in a *runtime* loop and parked in a
+// wave-private LDS slab addressed [n-tile][unit][lane] -- every lane reads and writes only its own
+// 16-byte slots (lane-linear ds_read/write_b128, conflict-free, no synchronisation); the slab is
+// just dynamically-indexable register space.  The next layer reloads its inputs from the slab.
+// Weights stream from L2 as pre-packed, lane-linear 1-KiB A-groups (global_load_dwordx4).
+#pragma once
+#include <type_traits>
+
+#include "common.hpp"
+#include "mlp_nets.hpp"
+
+namespace lab4d {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct PBF16 {
+  static constexpr bool BF16 = true;
+  static constexpr int NT = 2, TILE = 64, FPG = 16, UPT = 2;  // features per 16-byte unit, units per 32-feature tile
+  using store_t = unsigned short;
+};
+struct PF32 {
+  static constexpr bool BF16 = false;
+  static constexpr int NT = 1, TILE = 32, FPG = 8, UPT = 4;
+  using store_t = float;
+};
+
+__device__ __forceinline__ unsigned short f2bf(float x) {  // round to nearest even; NaN stays NaN
+  unsigned int u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) { return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16); }
+
+// feature (row) held by accumulator register r of lane-half h inside a 32-row tile
+__host__ __device__ __forceinline__ constexpr int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+
+// 16-byte A group load: the packed block of (mt, g) is 1 KiB, lane-linear.
+__device__ __forceinline__ uint4 load_a(const void* base, int G, int mt, int g, int lane) {
+  return *(reinterpret_cast<const uint4*>(base) + ((size_t)(mt * G + g) * 64 + lane));
+}
+
+// acc += A(group) * B(unit)
+template <class P>
+__device__ __forceinline__ void mma_unit(f32x16_t& acc, const uint4& a, const uint4& b) {
+  if constexpr (P::BF16) {
+    bf16x8_t av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+}
+
+// accumulator tile -> the UPT B units of that 32-feature tile
+template <class P>
+__device__ __forceinline__ void tile_to_units(const f32x16_t& c, uint4* u) {
+  if constexpr (P::BF16) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      u[q] = make_uint4(pack2bf(c[8 * q + 0], c[8 * q + 1]), pack2bf(c[8 * q + 2], c[8 * q + 3]),
+                        pack2bf(c[8 * q + 4], c[8 * q + 5]), pack2bf(c[8 * q + 6], c[8 * q + 7]));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      u[e] = make_uint4(__float_as_uint(c[4 * e + 0]), __float_as_uint(c[4 * e + 1]), __float_as_uint(c[4 * e + 2]),
+                        __float_as_uint(c[4 * e + 3]));
+  }
+}
+
+// ---- [feature][sample] tile IO in accumulator layout -------------------------------------------
+// bf16: lane n holds samples (s0+2n, s0+2n+1) packed in one dword ; fp32: sample s0+n.
+template <class P>
+__device__ __forceinline__ void store_tile(void* buf, int S_pad, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
+  const int n = lane & 31, h = lane >> 5;
+  if constexpr (P::BF16) {
+    unsigned int* p = reinterpret_cast<unsigned int*>(buf);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const size_t row = (size_t)(32 * mt + drow(r, h));
+      p[(row * S_pad + s0) / 2 + n] = pack2bf(c[0][r], c[1][r]);
+    }
+  } else {
+    float* p = reinterpret_cast<float*>(buf);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[(size_t)(32 * mt + drow(r, h)) * S_pad + s0 + n] = c[0][r];
+  }
+}
+template <class P>
+__device__ __forceinline__ void load_tile(const void* buf, int S_pad, int s0, int mt, int lane, f32x16_t* c /*[NT]*/) {
+  const int n = lane & 31, h = lane >> 5;
+  if constexpr (P::BF16) {
+    const unsigned int* p = reinterpret_cast<const unsigned int*>(buf);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const size_t row = (size_t)(32 * mt + drow(r, h));
+      const unsigned int u = p[(row * S_pad + s0) / 2 + n];
+      c[0][r] = bf2f((unsigned short)(u & 0xffffu));
+      c[1][r] = bf2f((unsigned short)(u >> 16));
+    }
+  } else {
+    const float* p = reinterpret_cast<const float*>(buf);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[0][r] = p[(size_t)(32 * mt + drow(r, h)) * S_pad + s0 + n];
+  }
+}
+
+// ---- kernel argument blocks (passed by value) ---------------------------------------------------
+struct FwdK {
+  int S, S_pad, spf, ntiles;
+  const float* x;
+  const float* freq_w;
+  const void* W[LAB4D_MLP_MAX_LAYERS];
+  const float* bias[LAB4D_MLP_MAX_LAYERS];
+  const float* pf_bias[LAB4D_MLP_MAX_LAYERS];
+  void* act[LAB4D_MLP_MAX_LAYERS];
+  void* emb;
+  const void* ext;
+  float* out;
+};
+struct BwdK {
+  int S, S_pad, spf, ntiles;
+  const void* WT[LAB4D_MLP_MAX_LAYERS];
+  const void* act[LAB4D_MLP_MAX_LAYERS];
+  const void* emb;
+  const void* ext;
+  const float* d_out;
+  const void* ext_gin;
+  void* ext_gout;
+  void* dz[LAB4D_MLP_MAX_LAYERS];
+  float* d_x;
+};
+
+// values of embedding slots (2*pair, 2*pair+1) for a point x -- posenc nets
+template <class Net>
+__device__ __forceinline__ void emb_pair(int pair, const float* x, const float* freq_w, float& v0, float& v1) {
+  // pair p < 3L: (sin, cos)(2^f x_a) * w_f with f = p / 3, a = p % 3 ; then x_0,x_1,x_2 ; then zeros
+  constexpr int L = Net::NFREQ;
+  if (pair < 3 * L) {
+    const int f = pair / 3, a = pair - 3 * f;
+    const float xa = a == 0 ? x[0] : (a == 1 ? x[1] : x[2]);
+    const float ang = ldexpf(xa, f);  // exact 2^f * x  (embedding.py:50,104)
+    float s, c;
+    sincosf(ang, &s, &c);
+    const float w = freq_w ? freq_w[f] : 1.0f;
+    v0 = s * w;
+    v1 = c * w;
+  } else {
+    const int s0 = 2 * pair - 6 * L;  // slot index relative to the raw block
+    v0 = s0 == 0 ? x[0] : (s0 == 1 ? x[1] : (s0 == 2 ? x[2] : 0.f));
+    v1 = s0 + 1 == 1 ? x[1] : (s0 + 1 == 2 ? x[2] : 0.f);
+  }
+}
+
+template <class Net, class P>
+struct Slab {
+  static constexpr int W = net_wmax<Net>();
+  static constexpr int UW = W / P::FPG;                 // units per n-tile
+  static constexpr int UNITS_PER_WAVE = P::NT * UW * 64;  // uint4 slots
+};
+
+// =================================================================================================
+// forward chain
+// =================================================================================================
+template <class Net, class P>
+__global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
+  constexpr int NT = P::NT, TILE = P::TILE, KE = Net::KE, UE = KE / P::FPG, UW = Slab<Net, P>::UW;
+  __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  uint4* slab = slab_all + (threadIdx.x >> 6) * Slab<Net, P>::UNITS_PER_WAVE + lane;  // + (t*UW + u)*64
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+
+  for (int tile = wave; tile < a.ntiles; tile += nwaves) {
+    const int s0 = tile * TILE;
+    int sidx[NT], frame[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int s = s0 + NT * n + t;
+      sidx[t] = s;
+      frame[t] = (s < a.S ? s : a.S - 1) / a.spf;  // padded tail recomputes the last sample (finite, never written out)
+    }
+    // ---- embedding as B units (identity slot order) ----
+    uint4 emb[NT][UE];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int s = sidx[t] < a.S ? sidx[t] : a.S - 1;
+      if constexpr (Net::EMB == 0) {
+        const float x[3] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2]};
+        if constexpr (P::BF16) {
+#pragma unroll
+          for (int g = 0; g < UE; ++g) {
+            unsigned int w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // slots 16g + 8h + 2i, +1  = pair 8g + 4h + i
+              float v0, v1;
+              emb_pair<Net>(8 * g + 4 * h + i, x, a.freq_w, v0, v1);
+              w[i] = pack2bf(v0, v1);
+            }
+            emb[t][g] = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < UE; ++g) {
+            float w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // k-step 4g+e, slot 2(4g+e) + h
+              float v0, v1;
+              emb_pair<Net>(4 * g + e, x, a.freq_w, v0, v1);
+              w[e] = h ? v1 : v0;
+            }
+            emb[t][g] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
+          }
+        }
+      } else {  // raw channels
+        const float* xr = a.x + (size_t)s * Net::CIN;
+#pragma unroll
+        for (int g = 0; g < UE; ++g) {
+          if constexpr (P::BF16) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int c = 16 * g + 8 * h + j;
+              v[j] = c < Net::CIN ? xr[c] : 0.f;
+            }
+            emb[t][g] = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+          } else {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c = 2 * (4 * g + e) + h;
+              v[e] = c < Net::CIN ? xr[c] : 0.f;
+            }
+            emb[t][g] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+          }
+        }
+      }
+    }
+    // store the embedding [slot][sample] for the backward / wgrad
+    if (a.emb) {
+      if constexpr (P::BF16) {
+        unsigned int* p = reinterpret_cast<unsigned int*>(a.emb);
+#pragma unroll
+        for (int g = 0; g < UE; ++g) {
+          const unsigned int w0[4] = {emb[0][g].x, emb[0][g].y, emb[0][g].z, emb[0][g].w};
+          const unsigned int w1[4] = {emb[1][g].x, emb[1][g].y, emb[1][g].z, emb[1][g].w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const size_t row = 16 * g + 8 * h + j;
+            const unsigned int lo = (w0[j >> 1] >> (16 * (j & 1))) & 0xffffu, hi = (w1[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            p[(row * a.S_pad + s0) / 2 + n] = lo | (hi << 16);
+          }
+        }
+      } else {
+        float* p = reinterpret_cast<float*>(a.emb);
+#pragma unroll
+        for (int g = 0; g < UE; ++g) {
+          const unsigned int w[4] = {emb[0][g].x, emb[0][g].y, emb[0][g].z, emb[0][g].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[(size_t)(2 * (4 * g + e) + h) * a.S_pad + s0 + n] = __uint_as_float(w[e]);
+        }
+      }
+    }
+
+    // ---- layers ----
+    sfor<0, Net::NL>([&](auto li) {
+      constexpr int l = decltype(li)::value;
+      constexpr LS ls = Net::L[l];
+      constexpr int MT = pad32(ls.mout) / 32;
+      constexpr int GE = ls.ke / P::FPG, GA = ls.kin / P::FPG, G = GE + GA;
+      const void* Wl = a.W[l];
+      const float* bl = a.bias[l];
+      const float* pfl = a.pf_bias[l];
+      // inputs from the previous layer: slab -> registers
+      uint4 bin[NT][GA > 0 ? GA : 1];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < GA; ++u) bin[t][u] = slab[(t * UW + u) * 64];
+#pragma nounroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x16_t acc[NT];
+        // bias (+ per-frame bias): feature 32mt + 8i + 4h + (0..3)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bl + 32 * mt + 8 * i + 4 * h);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            float4 v = b4;
+            if constexpr (ls.pf != 0) {
+              const float4 p4 = *reinterpret_cast<const float4*>(pfl + (size_t)frame[t] * (32 * MT) + 32 * mt + 8 * i + 4 * h);
+              v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+            }
+            acc[t][4 * i + 0] = v.x; acc[t][4 * i + 1] = v.y; acc[t][4 * i + 2] = v.z; acc[t][4 * i + 3] = v.w;
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const uint4 av = load_a(Wl, G, mt, g, lane);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], av, g < GE ? emb[t][g < GE ? g : 0] : bin[t][g >= GE ? g - GE : 0]);
+        }
+        if constexpr (ls.relu != 0) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+        }
+        if constexpr (ls.add_ext != 0) {
+          f32x16_t e[NT];
+          load_tile<P>(a.ext, a.S_pad, s0, mt, lane, e);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += e[t][r];
+        }
+        if (a.act[l]) store_tile<P>(a.act[l], a.S_pad, s0, mt, lane, acc);
+        if constexpr (l + 1 < Net::NL) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            uint4 u[P::UPT];
+            tile_to_units<P>(acc[t], u);
+#pragma unroll
+            for (int q = 0; q < P::UPT; ++q) slab[(t * UW + P::UPT * mt + q) * 64] = u[q];
+          }
+        } else {
+          // head: raw outputs (S, COUT) fp32
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int f = 32 * mt + drow(r, h);
+              if (f < Net::COUT && sidx[t] < a.S) a.out[(size_t)sidx[t] * Net::COUT + f] = acc[t][r];
+            }
+        }
+      }
+    });
+  }
+}
+
+// =================================================================================================
+// backward (dgrad) chain
+// =================================================================================================
+template <class Net>
+constexpr int emb_layer_count() {
+  int c = 0;
+  for (int l = 0; l < Net::NL; ++l) c += Net::L[l].ke ? 1 : 0;
+  return c;
+}
+
+template <class Net, class P>
+__global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
+  static_assert(Net::EMB == 0 || emb_layer_count<Net>() == 1, "raw-input nets may use the input in one layer only");
+  constexpr int NT = P::NT, TILE = P::TILE, NL = Net::NL, UW = Slab<Net, P>::UW;
+  __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  uint4* slab = slab_all + (threadIdx.x >> 6) * Slab<Net, P>::UNITS_PER_WAVE + lane;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+
+  for (int tile = wave; tile < a.ntiles; tile += nwaves) {
+    const int s0 = tile * TILE;
+    int sidx[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sidx[t] = s0 + NT * n + t;
+    float dx[NT][3];  // posenc nets: gradient wrt the 3-vector (partial over this lane's slots)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dx[t][0] = dx[t][1] = dx[t][2] = 0.f;
+
+    // ---- head gradient: (S, COUT) fp32 -> accumulator layout -> stored + B units in the slab ----
+    {
+      f32x16_t g[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int f = drow(r, h);
+          g[t][r] = (f < Net::COUT && sidx[t] < a.S) ? a.d_out[(size_t)sidx[t] * Net::COUT + f] : 0.f;
+        }
+      if (a.dz[NL - 1]) store_tile<P>(a.dz[NL - 1], a.S_pad, s0, 0, lane, g);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        uint4 u[P::UPT];
+        tile_to_units<P>(g[t], u);
+#pragma unroll
+        for (int q = 0; q < P::UPT; ++q) slab[(t * UW + q) * 64] = u[q];
+      }
+    }
+
+    sfor<0, NL>([&](auto li) {
+      constexpr int l = NL - 1 - decltype(li)::value;  // NL-1 .. 0
+      constexpr LS ls = Net::L[l];
+      constexpr int GK = pad32(ls.mout) / P::FPG;        // K units = out features of layer l
+      constexpr int MTE = ls.ke / 32, MTA = ls.kin / 32;  // row tiles: embedding slots, then previous activation
+      const void* Wt = a.WT[l];
+      uint4 bin[NT][GK];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < GK; ++u) bin[t][u] = slab[(t * UW + u) * 64];
+
+      // (a) gradient wrt the embedding slots -> input gradient
+      if constexpr (MTE > 0) {
+        if (a.d_x) {
+#pragma nounroll
+          for (int mt = 0; mt < MTE; ++mt) {
+            f32x16_t acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < GK; ++g) {
+              const uint4 av = load_a(Wt, GK, mt, g, lane);
+#pragma unroll
+              for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], av, bin[t][g]);
+            }
+            if constexpr (Net::EMB == 0) {
+              f32x16_t e[NT];
+              load_tile<P>(a.emb, a.S_pad, s0, mt, lane, e);
+              constexpr int L = Net::NFREQ;
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const int slot = 32 * mt + drow(r, h);
+                  const float gv = acc[t][r];
+                  if (slot < 6 * L) {
+                    const int pair = slot >> 1, f = pair / 3, ax = pair - 3 * f;
+                    // d/dx [w sin(2^f x)] = 2^f (w cos) ; d/dx [w cos(2^f x)] = -2^f (w sin): partner slot = register r^1
+                    const float partner = e[t][r ^ 1];
+                    const float c = ldexpf((r & 1) ? -partner : partner, f) * gv;
+                    dx[t][0] += ax == 0 ? c : 0.f;
+                    dx[t][1] += ax == 1 ? c : 0.f;
+                    dx[t][2] += ax == 2 ? c : 0.f;
+                  } else if (slot < 6 * L + 3) {
+                    const int ax = slot - 6 * L;
+                    dx[t][0] += ax == 0 ? gv : 0.f;
+                    dx[t][1] += ax == 1 ? gv : 0.f;
+                    dx[t][2] += ax == 2 ? gv : 0.f;
+                  }
+                }
+            } else {
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const int c = 32 * mt + drow(r, h);
+                  if (c < Net::CIN && sidx[t] < a.S) a.d_x[(size_t)sidx[t] * Net::CIN + c] = acc[t][r];
+                }
+            }
+          }
+        }
+      }
+      // (b) gradient wrt the previous layer's output -> masked dZ_{l-1}
+      if constexpr (l > 0 && MTA > 0) {
+        constexpr LS lp = Net::L[l - 1];
+#pragma nounroll
+        for (int j = 0; j < MTA; ++j) {
+          const int mt = MTE + j;
+          f32x16_t acc[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+          for (int g = 0; g < GK; ++g) {
+            const uint4 av = load_a(Wt, GK, mt, g, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], av, bin[t][g]);
+          }
+          if constexpr (lp.ext_grad != 0) {
+            f32x16_t e[NT];
+            load_tile<P>(a.ext_gin, a.S_pad, s0, j, lane, e);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[t][r] += e[t][r];
+          }
+          if constexpr (lp.add_ext != 0) {
+            if (a.ext_gout) store_tile<P>(a.ext_gout, a.S_pad, s0, j, lane, acc);  // y = relu(z) + ext  ->  dL/dext = dL/dy
+          }
+          if constexpr (lp.relu != 0) {
+            f32x16_t y[NT];
+            load_tile<P>(a.act[l - 1], a.S_pad, s0, j, lane, y);
+            if constexpr (lp.add_ext != 0) {
+              f32x16_t e[NT];
+              load_tile<P>(a.ext, a.S_pad, s0, j, lane, e);
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[t][r] -= e[t][r];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[t][r] = y[t][r] > 0.f ? acc[t][r] : 0.f;
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (sidx[t] >= a.S) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            }
+          if (a.dz[l - 1]) store_tile<P>(a.dz[l - 1], a.S_pad, s0, j, lane, acc);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            uint4 u[P::UPT];
+            tile_to_units<P>(acc[t], u);
+#pragma unroll
+            for (int q = 0; q < P::UPT; ++q) slab[(t * UW + P::UPT * j + q) * 64] = u[q];
+          }
+        }
+      }
+    });
+
+    if constexpr (Net::EMB == 0) {
+      if (a.d_x) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dx[t][k] += __shfl_xor(dx[t][k], 32, 64);
+          if (h == 0 && sidx[t] < a.S) {
+            a.d_x[(size_t)sidx[t] * 3 + 0] = dx[t][0];
+            a.d_x[(size_t)sidx[t] * 3 + 1] = dx[t][1];
+            a.d_x[(size_t)sidx[t] * 3 + 2] = dx[t][2];
+          }
+        }
+      }
+    }
+  }
+}
+
+// launchers implemented by each mlp_inst_<net>.hip
+template <class Net>
+int launch_mlp_fwd(int precision, const FwdK& k, int S, hipStream_t st);
+template <class Net>
+int launch_mlp_bwd(int precision, const BwdK& k, int S, hipStream_t st);
+
+inline int mlp_grid(int ntiles) {
+  int g = (ntiles + 3) / 4;
+  if (g > 256) g = 256;  // persistent: one 4-wave block per CU (the slab takes most of the CU's LDS)
+  return g < 1 ? 1 : g;
+}
+
+#define LAB4D_MLP_INSTANTIATE(Net)                                                                                        \
+  namespace lab4d {                                                                                                       \
+  template <>                                                                                                             \
+  int launch_mlp_fwd<Net>(int precision, const FwdK& k0, int S, hipStream_t st) {                                         \
+    FwdK k = k0;                                                                                                          \
+    if (precision == LAB4D_PREC_BF16) {                                                                                   \
+      k.ntiles = k.S_pad / PBF16::TILE; /* padded tail tiles are processed too: they zero-fill dz */                                                                                  \
+      hipLaunchKernelGGL((k_mlp_fwd<Net, PBF16>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);                         \
+    } else if (precision == LAB4D_PREC_F32) {                                                                             \
+      k.ntiles = k.S_pad / PF32::TILE;                                                                                   \
+      hipLaunchKernelGGL((k_mlp_fwd<Net, PF32>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);                          \
+    } else {                                                                                                              \
+      set_error("mlp_forward: bad precision %d", precision);                                                              \
+      return LAB4D_EINVAL;                                                                                                \
+    }                                                                                                                     \
+    return check_launch("mlp_forward");                                                                                   \
+  }                                                                                                                       \
+  template <>                                                                                                             \
+  int launch_mlp_bwd<Net>(int precision, const BwdK& k0, int S, hipStream_t st) {                                         \
+    BwdK k = k0;                                                                                                          \
+    if (precision == LAB4D_PREC_BF16) {                                                                                   \
+      k.ntiles = k.S_pad / PBF16::TILE; /* padded tail tiles are processed too: they zero-fill dz */                                                                                  \
+      hipLaunchKernelGGL((k_mlp_bwd<Net, PBF16>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);                         \
+    } else if (precision == LAB4D_PREC_F32) {                                                                             \
+      k.ntiles = k.S_pad / PF32::TILE;                                                                                   \
+      hipLaunchKernelGGL((k_mlp_bwd<Net, PF32>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);                          \
+    } else {                                                                                                              \
+      set_error("mlp_backward: bad precision %d", precision);                                                             \
+      return LAB4D_EINVAL;                                                                                                \
+    }                                                                                                                     \
+    return check_launch("mlp_backward");                                                                                  \
+  }                                                                                                                       \
+  }
+
+}  // namespace lab4d

@@ -1,0 +1,71 @@
+// Compile-time layer tables of the per-sample networks (see include/lab4d_mlp.h).
+// Layer shapes follow the reference modules exactly (SURVEY.md 8a notes; verified against
+// state_dict shapes): per-frame conditioning columns are removed (folded into pf_bias).
+#pragma once
+#include "lab4d_mlp.h"
+
+namespace lab4d {
+
+struct LS {
+  int ke, kin, mout, relu, pf, add_ext, ext_grad;
+};
+constexpr int pad32(int x) { return (x + 31) / 32 * 32; }
+
+// nerf.py:99-109,134 : PosEmbedding(3,10) -> CondMLP(D=8,W=256,skips=[4],final_act) -> sdf Linear(256,1)
+struct NetFgBase {
+  static constexpr int ID = LAB4D_NET_FG_BASE, NL = 10, EMB = 0, NFREQ = 10, CIN = 3, SLOTS = 63, KE = 64, COUT = 1;
+  static constexpr LS L[NL] = {{64, 0, 256, 1, 1, 0, 0},  {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 0, 0},
+                               {0, 256, 256, 1, 0, 0, 0}, {64, 256, 256, 1, 1, 0, 0}, {0, 256, 256, 1, 0, 0, 0},
+                               {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 0, 1},
+                               {0, 256, 1, 0, 0, 0, 0}};
+};
+// nerf.py:112-123,135-139,208-213 : PosEmbedding(3,12) -> CondMLP(D=2,W=256,final_act) ; + basefield feature ;
+// rgb = Linear(256+32 appr, 128) ReLU Linear(128,3)   (appearance code folded into the per-frame bias)
+struct NetFgColor {
+  static constexpr int ID = LAB4D_NET_FG_COLOR, NL = 5, EMB = 0, NFREQ = 12, CIN = 3, SLOTS = 75, KE = 96, COUT = 3;
+  static constexpr LS L[NL] = {{96, 0, 256, 1, 1, 0, 0}, {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 1, 0},
+                               {0, 256, 128, 1, 1, 0, 0}, {0, 128, 3, 0, 0, 0, 0}};
+};
+// visibility.py:39-51 : PosEmbedding(3,10) -> CondMLP(D=2,W=64) -> 1
+struct NetVis {
+  static constexpr int ID = LAB4D_NET_VIS, NL = 3, EMB = 0, NFREQ = 10, CIN = 3, SLOTS = 63, KE = 64, COUT = 1;
+  static constexpr LS L[NL] = {{64, 0, 64, 1, 1, 0, 0}, {0, 64, 64, 1, 0, 0, 0}, {0, 64, 1, 0, 0, 0, 0}};
+};
+// feature.py:77-84 : PosEmbedding(3,6) -> BaseMLP(D=5,W=128,skips=[4]) -> 16
+struct NetFeat {
+  static constexpr int ID = LAB4D_NET_FEAT, NL = 6, EMB = 0, NFREQ = 6, CIN = 3, SLOTS = 39, KE = 64, COUT = 16;
+  static constexpr LS L[NL] = {{64, 0, 128, 1, 0, 0, 0}, {0, 128, 128, 1, 0, 0, 0}, {0, 128, 128, 1, 0, 0, 0},
+                               {0, 128, 128, 1, 0, 0, 0}, {64, 128, 128, 1, 0, 0, 0}, {0, 128, 16, 0, 0, 0, 0}};
+};
+// skinning.py:70-86 : 3B=75 bone coordinates (+128 time embedding +32 code as per-frame bias) -> 64 -> 64 -> B=25
+struct NetSkin {
+  static constexpr int ID = LAB4D_NET_SKIN, NL = 3, EMB = 1, NFREQ = 0, CIN = 75, SLOTS = 75, KE = 96, COUT = 25;
+  static constexpr LS L[NL] = {{96, 0, 64, 1, 1, 0, 0}, {0, 64, 64, 1, 0, 0, 0}, {0, 64, 25, 0, 0, 0, 0}};
+};
+
+template <class Net>
+constexpr int net_wmax() {
+  int w = 32;
+  for (int l = 0; l < Net::NL; ++l) {
+    if (Net::L[l].kin > w) w = Net::L[l].kin;
+    if (pad32(Net::L[l].mout) > w) w = pad32(Net::L[l].mout);
+  }
+  return w;
+}
+
+template <class Net>
+inline void fill_desc(lab4d_mlp_desc* d) {
+  d->n_layers = Net::NL;
+  d->emb_kind = Net::EMB;
+  d->n_freq = Net::NFREQ;
+  d->c_in = Net::CIN;
+  d->emb_slots = Net::SLOTS;
+  d->ke = Net::KE;
+  d->c_out = Net::COUT;
+  for (int l = 0; l < Net::NL; ++l) {
+    const LS& s = Net::L[l];
+    d->layers[l] = {s.ke, s.kin, s.mout, pad32(s.mout), s.relu, s.pf, s.add_ext, s.ext_grad};
+  }
+}
+
+}  // namespace lab4d

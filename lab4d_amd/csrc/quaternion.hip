@@ -210,9 +210,9 @@ using namespace lab4d;
 
 extern "C" int lab4d_quaternion_mul_forward(const void* in1, const void* in2, void* out, uint32_t B, uint32_t D1,
                                             uint32_t D2, int dtype, void* stream) {
+  if (B == 0) return LAB4D_OK;  // empty batch: nothing to do (pointers may be null)
   LAB4D_REQUIRE(in1 && in2 && out, "quaternion_mul_forward: null pointer");
   LAB4D_REQUIRE((D1 == 3 || D1 == 4) && (D2 == 3 || D2 == 4), "quaternion_mul_forward: D1,D2 must be 3 or 4 (got %u,%u)", D1, D2);
-  if (B == 0) return LAB4D_OK;
   LAB4D_DISPATCH(dtype, hipLaunchKernelGGL((k_qmul_fwd<T>), dim3(rows_grid(B)), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)in1, (const T*)in2, (T*)out, B, D1, D2));
   return check_launch("quaternion_mul_forward");
@@ -220,9 +220,9 @@ extern "C" int lab4d_quaternion_mul_forward(const void* in1, const void* in2, vo
 
 extern "C" int lab4d_quaternion_mul_backward(const void* grad, uint32_t B, uint32_t D1, uint32_t D2, const void* in1,
                                              const void* in2, void* g1, void* g2, int dtype, void* stream) {
+  if (B == 0) return LAB4D_OK;  // empty batch: nothing to do (pointers may be null)
   LAB4D_REQUIRE(grad && in1 && in2 && g1 && g2, "quaternion_mul_backward: null pointer");
   LAB4D_REQUIRE((D1 == 3 || D1 == 4) && (D2 == 3 || D2 == 4), "quaternion_mul_backward: D1,D2 must be 3 or 4");
-  if (B == 0) return LAB4D_OK;
   LAB4D_DISPATCH(dtype, hipLaunchKernelGGL((k_qmul_bwd<T>), dim3(rows_grid(B)), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)grad, B, D1, D2, (const T*)in1, (const T*)in2, (T*)g1, (T*)g2));
   return check_launch("quaternion_mul_backward");
@@ -231,9 +231,9 @@ extern "C" int lab4d_quaternion_mul_backward(const void* grad, uint32_t B, uint3
 extern "C" int lab4d_quaternion_mul_backward_backward(const void* go1, const void* go2, uint32_t B, uint32_t D1,
                                                       uint32_t D2, const void* grad, const void* in1, const void* in2,
                                                       void* gg, void* gga, void* ggb, int dtype, void* stream) {
+  if (B == 0) return LAB4D_OK;  // empty batch: nothing to do (pointers may be null)
   LAB4D_REQUIRE(go1 && go2 && grad && in1 && in2 && gg && gga && ggb, "quaternion_mul_backward_backward: null pointer");
   LAB4D_REQUIRE((D1 == 3 || D1 == 4) && (D2 == 3 || D2 == 4), "quaternion_mul_backward_backward: D1,D2 must be 3 or 4");
-  if (B == 0) return LAB4D_OK;
   LAB4D_DISPATCH(dtype, hipLaunchKernelGGL((k_qmul_bwd_bwd<T>), dim3(rows_grid(B)), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)go1, (const T*)go2, B, D1, D2, (const T*)grad, (const T*)in1,
                                            (const T*)in2, (T*)gg, (T*)gga, (T*)ggb));
@@ -241,38 +241,38 @@ extern "C" int lab4d_quaternion_mul_backward_backward(const void* go1, const voi
 }
 
 extern "C" int lab4d_quaternion_conjugate(const void* in, uint32_t B, void* out, int dtype, void* stream) {
+  if (B == 0) return LAB4D_OK;  // empty batch: nothing to do (pointers may be null)
   LAB4D_REQUIRE(in && out, "quaternion_conjugate: null pointer");
-  if (B == 0) return LAB4D_OK;
   LAB4D_DISPATCH(dtype, hipLaunchKernelGGL((k_qconj<T>), dim3(rows_grid(B)), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)in, B, (T*)out));
   return check_launch("quaternion_conjugate");
 }
 
 extern "C" int lab4d_mat3x3_det_forward(const void* in, void* out, uint32_t B, int dtype, void* stream) {
+  if (B == 0) return LAB4D_OK;  // empty batch: nothing to do (pointers may be null)
   LAB4D_REQUIRE(in && out, "mat3x3_det_forward: null pointer");
-  if (B == 0) return LAB4D_OK;
   LAB4D_DISPATCH(dtype, hipLaunchKernelGGL((k_mat3<T, 0>), dim3(rows_grid(B)), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)in, (const T*)nullptr, (T*)out, (T*)nullptr, B));
   return check_launch("mat3x3_det_forward");
 }
 extern "C" int lab4d_mat3x3_scale_adjoint_forward(const void* in, const void* scales, void* out, uint32_t B, int dtype,
                                                   void* stream) {
+  if (B == 0) return LAB4D_OK;  // empty batch: nothing to do (pointers may be null)
   LAB4D_REQUIRE(in && scales && out, "mat3x3_scale_adjoint_forward: null pointer");
-  if (B == 0) return LAB4D_OK;
   LAB4D_DISPATCH(dtype, hipLaunchKernelGGL((k_mat3<T, 1>), dim3(rows_grid(B)), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)in, (const T*)scales, (T*)out, (T*)nullptr, B));
   return check_launch("mat3x3_scale_adjoint_forward");
 }
 extern "C" int lab4d_mat3x3_inv_forward(const void* in, void* out, void* out_scales, uint32_t B, int dtype, void* stream) {
+  if (B == 0) return LAB4D_OK;  // empty batch: nothing to do (pointers may be null)
   LAB4D_REQUIRE(in && out && out_scales, "mat3x3_inv_forward: null pointer");
-  if (B == 0) return LAB4D_OK;
   LAB4D_DISPATCH(dtype, hipLaunchKernelGGL((k_mat3<T, 2>), dim3(rows_grid(B)), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)in, (const T*)nullptr, (T*)out, (T*)out_scales, B));
   return check_launch("mat3x3_inv_forward");
 }
 extern "C" int lab4d_mat3x3_inv_backward(const void* grad, const void* inv, void* gin, uint32_t B, int dtype, void* stream) {
+  if (B == 0) return LAB4D_OK;  // empty batch: nothing to do (pointers may be null)
   LAB4D_REQUIRE(grad && inv && gin, "mat3x3_inv_backward: null pointer");
-  if (B == 0) return LAB4D_OK;
   LAB4D_DISPATCH(dtype, hipLaunchKernelGGL((k_mat3_inv_bwd<T>), dim3(rows_grid(B)), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)grad, (const T*)inv, (T*)gin, B));
   return check_launch("mat3x3_inv_backward");

@@ -1,0 +1,357 @@
+"""Host side of the fused posenc + MLP chain (include/lab4d_mlp.h, csrc/mlp_kernels.hpp).
+
+Binds the reference's own parameters (nn.Linear weights in reference layout, state_dict names as
+in lab4d/nnutils/{nerf,visibility,feature,skinning}.py) to the kernel's layer tables:
+  * columns that multiply the positional embedding are permuted into the kernel's slot order,
+  * columns that multiply per-frame conditioning (instance / appearance / time codes) are split
+    off and turned into a per-frame bias with one tiny device matmul (base.py:139-146 would
+    broadcast them to every sample),
+  * weights are packed into MFMA A-fragment order by the device pack kernel, cached on the
+    parameter version so an optimizer step invalidates them.
+`MlpChain` is a torch.autograd.Function whose backward runs the dgrad chain kernel and the
+weight-gradient GEMMs and hands gradients back in the reference layout.
+"""
+import ctypes
+import weakref
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+MAXL = 12
+NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN = 0, 1, 2, 3, 4
+PREC_F32, PREC_BF16 = 0, 1
+vp, ci = ctypes.c_void_p, ctypes.c_int
+
+
+class LayerDesc(ctypes.Structure):
+    _fields_ = [(n, ci) for n in ("ke", "kin", "mout", "mout_pad", "relu", "pf_bias", "add_ext", "ext_grad")]
+
+
+class NetDesc(ctypes.Structure):
+    _fields_ = [(n, ci) for n in ("n_layers", "emb_kind", "n_freq", "c_in", "emb_slots", "ke", "c_out")] + [("layers", LayerDesc * MAXL)]
+
+
+class FwdArgs(ctypes.Structure):
+    _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("S_pad", ci), ("spf", ci), ("x", vp), ("freq_w", vp),
+                ("W", vp * MAXL), ("bias", vp * MAXL), ("pf_bias", vp * MAXL), ("act", vp * MAXL), ("emb", vp), ("ext", vp),
+                ("out", vp)]
+
+
+class BwdArgs(ctypes.Structure):
+    _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("S_pad", ci), ("spf", ci), ("WT", vp * MAXL), ("act", vp * MAXL),
+                ("emb", vp), ("ext", vp), ("d_out", vp), ("ext_gin", vp), ("ext_gout", vp), ("dz", vp * MAXL), ("d_x", vp)]
+
+
+_lib.register("lab4d_mlp_describe", [ci, ctypes.POINTER(NetDesc)])
+_lib.register("lab4d_mlp_pack", [ci, ci, ci, ci, vp, ci, vp, vp, vp])
+_lib.register("lab4d_mlp_forward", [ctypes.POINTER(FwdArgs), vp])
+_lib.register("lab4d_mlp_backward", [ctypes.POINTER(BwdArgs), vp])
+_lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp])
+_lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
+
+_DESC = {}
+
+
+def describe(net):
+    if net not in _DESC:
+        d = NetDesc()
+        _lib.check(_lib.lib().lab4d_mlp_describe(net, ctypes.byref(d)), "mlp_describe")
+        _DESC[net] = d
+    return _DESC[net]
+
+
+def store_dtype(prec):
+    return torch.bfloat16 if prec == PREC_BF16 else torch.float32
+
+
+def posenc_slot_to_ref_channel(n_freq, ke):
+    """Kernel slot order -> reference channel order (embedding.py:96-108: [x, (f, {sin,cos}, a)])."""
+    out = []
+    for slot in range(ke):
+        if slot < 6 * n_freq:
+            pair, t = slot >> 1, slot & 1
+            f, a = pair // 3, pair % 3
+            out.append(3 + f * 6 + t * 3 + a)
+        elif slot < 6 * n_freq + 3:
+            out.append(slot - 6 * n_freq)
+        else:
+            out.append(-1)
+    return out
+
+
+class LayerBinding:
+    """Which columns of the reference weight feed which kernel input block."""
+
+    def __init__(self, wname, bname, emb0=None, cond=None, prev0=None):
+        self.wname, self.bname = wname, bname
+        self.emb0 = emb0    # first reference column of the embedding block (or None)
+        self.cond = cond    # (first column, count) of the per-frame conditioning block (or None)
+        self.prev0 = prev0  # first reference column of the previous-activation block (or None)
+
+
+def bindings(net, prefix=""):
+    p = prefix
+    if net == NET_FG_BASE:  # nerf.py:99-109,134
+        b = [LayerBinding(p + "basefield.linear_1.0.weight", p + "basefield.linear_1.0.bias", emb0=0, cond=(63, 32))]
+        for i in (2, 3, 4):
+            b.append(LayerBinding(p + f"basefield.linear_{i}.0.weight", p + f"basefield.linear_{i}.0.bias", prev0=0))
+        b.append(LayerBinding(p + "basefield.linear_5.0.weight", p + "basefield.linear_5.0.bias", emb0=0, cond=(63, 32), prev0=95))
+        for i in (6, 7, 8):
+            b.append(LayerBinding(p + f"basefield.linear_{i}.0.weight", p + f"basefield.linear_{i}.0.bias", prev0=0))
+        b.append(LayerBinding(p + "basefield.linear_final.0.weight", p + "basefield.linear_final.0.bias", prev0=0))
+        b.append(LayerBinding(p + "sdf.weight", p + "sdf.bias", prev0=0))
+        return b
+    if net == NET_FG_COLOR:  # nerf.py:112-123,135-139
+        return [LayerBinding(p + "colorfield.linear_1.0.weight", p + "colorfield.linear_1.0.bias", emb0=0, cond=(75, 32)),
+                LayerBinding(p + "colorfield.linear_2.0.weight", p + "colorfield.linear_2.0.bias", prev0=0),
+                LayerBinding(p + "colorfield.linear_final.0.weight", p + "colorfield.linear_final.0.bias", prev0=0),
+                LayerBinding(p + "rgb.0.weight", p + "rgb.0.bias", prev0=0, cond=(256, 32)),
+                LayerBinding(p + "rgb.2.weight", p + "rgb.2.bias", prev0=0)]
+    if net == NET_VIS:  # visibility.py:39-51
+        q = p + "vis_mlp.basefield."
+        return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(63, 32)),
+                LayerBinding(q + "linear_2.0.weight", q + "linear_2.0.bias", prev0=0),
+                LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0)]
+    if net == NET_FEAT:  # feature.py:77-84
+        q = p + "feature_field."
+        b = [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0)]
+        for i in (2, 3, 4):
+            b.append(LayerBinding(q + f"linear_{i}.0.weight", q + f"linear_{i}.0.bias", prev0=0))
+        b.append(LayerBinding(q + "linear_5.0.weight", q + "linear_5.0.bias", emb0=0, prev0=39))
+        b.append(LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0))
+        return b
+    if net == NET_SKIN:  # skinning.py:70-86: [3B bone coords | 128 time embedding | 32 instance code]
+        q = p + "warp.skinning_model.delta_field."
+        return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(75, 160)),
+                LayerBinding(q + "linear_2.0.weight", q + "linear_2.0.bias", prev0=0),
+                LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0)]
+    raise ValueError(net)
+
+
+_COLMAP = {}
+
+
+def col_map(net, layer, device):
+    """(ke+kin) int32: kernel input column -> column of the reference weight (or -1)."""
+    key = (net, layer, str(device))
+    if key not in _COLMAP:
+        d = describe(net)
+        L = d.layers[layer]
+        bd = bindings(net)[layer]
+        cm = []
+        if L.ke:
+            if d.emb_kind == 0:
+                cm += [(-1 if c < 0 else bd.emb0 + c) for c in posenc_slot_to_ref_channel(d.n_freq, L.ke)]
+            else:
+                cm += [(bd.emb0 + c if c < d.c_in else -1) for c in range(L.ke)]
+        if L.kin:
+            cm += [bd.prev0 + j for j in range(L.kin)]
+        _COLMAP[key] = torch.tensor(cm, dtype=torch.int32, device=device)
+    return _COLMAP[key]
+
+
+_PACK_CACHE = {}  # id(weight tensor) -> (weakref to it, {(net, layer, prec, transposed): (version, packed)})
+
+
+def packed_weights(net, layer, prec, W, transposed):
+    """Pack one layer's weights for the chain kernels.  Cached per weight *object* and invalidated by its
+    autograd version counter (an in-place optimizer step bumps it); never keyed on addresses, which the
+    caching allocator recycles."""
+    key = (net, layer, prec, transposed)
+    ver = W._version
+    ent = _PACK_CACHE.get(id(W))
+    if ent is None or ent[0]() is not W:
+        ent = (weakref.ref(W), {})
+        _PACK_CACHE[id(W)] = ent
+        weakref.finalize(W, _PACK_CACHE.pop, id(W), None)
+    per = ent[1]
+    hit = per.get(key)
+    if hit is not None and hit[0] == ver and hit[1].device == W.device:
+        return hit[1]
+    d = describe(net)
+    L = d.layers[layer]
+    Wc = W.detach().contiguous()
+    _lib.require_device(Wc)
+    out = torch.empty(L.mout_pad * (L.ke + L.kin), dtype=store_dtype(prec), device=W.device)
+    cm = col_map(net, layer, W.device)
+    _lib.check(_lib.lib().lab4d_mlp_pack(net, layer, prec, 1 if transposed else 0, _lib.ptr(Wc), Wc.shape[1], _lib.ptr(cm),
+                                         _lib.ptr(out), _lib.stream()), "mlp_pack")
+    per[key] = (ver, out)
+    return out
+
+
+def clear_caches():
+    _PACK_CACHE.clear()
+    _COLMAP.clear()
+
+
+def pf_bias_of(net, layer, W, cond):
+    """Per-frame bias (M, mout) = cond (M, C) @ W[:, cond columns]^T  (CondMLP's appended code, base.py:139-146)."""
+    c0, n = bindings(net)[layer].cond
+    return cond @ W[:, c0:c0 + n].t()
+
+
+def s_pad_of(S):
+    return (S + 63) // 64 * 64
+
+
+class MlpChain(Function):
+    """out (S, c_out) [, export] = net(x; weights), differentiable wrt x, ext, per-frame biases, weights."""
+
+    @staticmethod
+    def forward(ctx, net, prec, spf, x, ext, freq_w, export_layer, n_pf, *rest):
+        d = describe(net)
+        NL = d.n_layers
+        pfs = list(rest[:n_pf])
+        params = list(rest[n_pf:])
+        assert len(params) == 2 * NL
+        Ws, bs = params[0::2], params[1::2]
+        x = x.contiguous()
+        _lib.require_device(x)
+        if x.dtype != torch.float32:
+            raise RuntimeError("MlpChain: x must be fp32")
+        S = x.shape[0]
+        S_pad = s_pad_of(S)
+        dev = x.device
+        sdt = store_dtype(prec)
+        need_grad = any(ctx.needs_input_grad)
+        a = FwdArgs()
+        a.net, a.precision, a.S, a.S_pad, a.spf = net, prec, S, S_pad, int(spf)
+        a.x = x.data_ptr()
+        if freq_w is not None:
+            freq_w = freq_w.contiguous().float()
+            a.freq_w = freq_w.data_ptr()
+        keep = []
+        acts = [None] * NL
+        pf_i = 0
+        pf_used = [None] * NL
+        for l in range(NL):
+            L = d.layers[l]
+            pw = packed_weights(net, l, prec, Ws[l], False)
+            a.W[l] = pw.data_ptr()
+            b = bs[l].detach().float()
+            if b.numel() != L.mout_pad:
+                b = torch.cat([b, torch.zeros(L.mout_pad - b.numel(), device=dev)])
+            b = b.contiguous()
+            a.bias[l] = b.data_ptr()
+            keep += [pw, b]
+            if L.pf_bias:
+                pf = pfs[pf_i].detach().contiguous().float()
+                pf_i += 1
+                if pf.shape[1] != L.mout_pad:
+                    raise RuntimeError("per-frame bias of layer %d must have %d columns" % (l, L.mout_pad))
+                a.pf_bias[l] = pf.data_ptr()
+                pf_used[l] = pf
+                keep.append(pf)
+            if (need_grad and l + 1 < NL) or l == export_layer:
+                acts[l] = torch.empty(L.mout_pad, S_pad, dtype=sdt, device=dev)
+                a.act[l] = acts[l].data_ptr()
+        emb = None
+        if need_grad:
+            emb = torch.empty(d.ke, S_pad, dtype=sdt, device=dev)
+            a.emb = emb.data_ptr()
+        if ext is not None:
+            ext = ext.contiguous()
+            if ext.dtype != sdt:
+                raise RuntimeError("ext must be stored as %s" % sdt)
+            a.ext = ext.data_ptr()
+        out = torch.empty(S, d.c_out, device=dev)
+        a.out = out.data_ptr()
+        _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
+        ctx.meta = (net, prec, int(spf), S, S_pad, export_layer, n_pf, pf_used)
+        ctx.acts, ctx.emb, ctx.ext = acts, emb, ext
+        ctx.params = params
+        ctx.x_shape = x.shape
+        if export_layer is not None and export_layer >= 0:
+            return out, acts[export_layer]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out, d_export=None):
+        net, prec, spf, S, S_pad, export_layer, n_pf, pf_used = ctx.meta
+        d = describe(net)
+        NL = d.n_layers
+        params = ctx.params
+        Ws, bs = params[0::2], params[1::2]
+        dev = d_out.device
+        sdt = store_dtype(prec)
+        a = BwdArgs()
+        a.net, a.precision, a.S, a.S_pad, a.spf = net, prec, S, S_pad, spf
+        keep = []
+        dz = [None] * NL
+        for l in range(NL):
+            L = d.layers[l]
+            pw = packed_weights(net, l, prec, Ws[l], True)
+            a.WT[l] = pw.data_ptr()
+            keep.append(pw)
+            if ctx.acts[l] is not None:
+                a.act[l] = ctx.acts[l].data_ptr()
+            dz[l] = torch.empty(L.mout_pad, S_pad, dtype=sdt, device=dev)
+            a.dz[l] = dz[l].data_ptr()
+            if L.ext_grad:
+                if d_export is None:
+                    d_export = torch.zeros(L.mout_pad, S_pad, dtype=sdt, device=dev)
+                d_export = d_export.contiguous()
+                a.ext_gin = d_export.data_ptr()
+        if ctx.emb is not None:
+            a.emb = ctx.emb.data_ptr()
+        ext_g = None
+        if ctx.ext is not None:
+            a.ext = ctx.ext.data_ptr()
+            if ctx.needs_input_grad[4]:
+                ext_g = torch.empty_like(ctx.ext)
+                a.ext_gout = ext_g.data_ptr()
+        d_out = d_out.contiguous().float()
+        a.d_out = d_out.data_ptr()
+        d_x = None
+        if ctx.needs_input_grad[3]:
+            d_x = torch.empty(ctx.x_shape, device=dev)
+            a.d_x = d_x.data_ptr()
+        _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(a), _lib.stream()), "mlp_backward")
+        # weight / bias gradients
+        M = (S + spf - 1) // spf
+        grads_pf, grads_params = [], []
+        for l in range(NL):
+            L = d.layers[l]
+            K = L.ke + L.kin
+            need_w = ctx.needs_input_grad[8 + n_pf + 2 * l]
+            need_b = ctx.needs_input_grad[8 + n_pf + 2 * l + 1]
+            need_pf = bool(L.pf_bias)
+            gW = gb = None
+            if need_w or need_b or need_pf:
+                dWk = torch.zeros(L.mout_pad, K, device=dev)
+                dbk = torch.zeros(L.mout_pad, device=dev)
+                pfd = torch.empty(M, L.mout_pad, device=dev) if need_pf else None
+                prev = ctx.acts[l - 1] if L.kin else None
+                _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, spf, _lib.ptr(dz[l]), _lib.ptr(ctx.emb), _lib.ptr(prev),
+                                                      _lib.ptr(dWk), _lib.ptr(dbk), _lib.ptr(pfd), M, _lib.stream()), "mlp_wgrad")
+                if need_w:
+                    cm = col_map(net, l, dev).long()
+                    valid = cm >= 0
+                    gW = torch.zeros_like(Ws[l], dtype=torch.float32)
+                    gW[:, cm[valid]] = dWk[:L.mout][:, valid]
+                if need_b:
+                    gb = dbk[:L.mout].reshape(bs[l].shape)
+                if need_pf:
+                    grads_pf.append(pfd)
+            grads_params += [gW, gb]
+        return (None, None, None, d_x, ext_g, None, None, None, *grads_pf, *grads_params)
+
+
+def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_layer=None, prefix=""):
+    """Convenience wrapper: P maps reference state_dict names -> device tensors; conds maps layer index ->
+    (M, C) per-frame conditioning input of that layer.  Returns out or (out, exported activation)."""
+    d = describe(net)
+    bd = bindings(net, prefix)
+    pfs = []
+    for l in range(d.n_layers):
+        if d.layers[l].pf_bias:
+            pfs.append(pf_bias_of(net, l, P[bd[l].wname], conds[l]))
+    params = []
+    for l in range(d.n_layers):
+        params += [P[bd[l].wname], P[bd[l].bname]]
+    return MlpChain.apply(net, prec, spf, x, ext, freq_w, -1 if export_layer is None else export_layer, len(pfs), *pfs, *params)
