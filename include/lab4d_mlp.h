@@ -47,7 +47,7 @@ typedef struct {
   int mout_pad;/* padded to a multiple of 32                                                                 */
   int relu;    /* ReLU after the affine map                                                                  */
   int pf_bias; /* layer takes a per-frame bias (M, mout_pad) in addition to its bias                         */
-  int add_ext; /* after the activation, add the external feature tensor `ext` ([mout_pad][S_pad])           */
+  int add_ext; /* after the activation, add the external feature tensor `ext` ([mout_pad][ld])           */
   int ext_grad;/* backward: an external gradient tensor is added to dL/d(output of this layer)               */
 } lab4d_mlp_layer;
 
@@ -82,30 +82,33 @@ int lab4d_mlp_pack(int net, int layer, int precision, int transposed, const floa
 typedef struct {
   int net, precision;
   int S;       /* samples                                                                                  */
-  int S_pad;   /* leading dimension of every [feature][sample] buffer: multiple of 64, >= S               */
+  int S_pad;   /* samples rounded up to a multiple of 64 (tail tiles are processed, never written to `out`) */
+  int ld;      /* leading dimension (elements) of every [feature][sample] buffer: >= S_pad, multiple of 8.
+                  Pad it so that ld*sizeof(store) is NOT a large power of two (e.g. S_pad*2 B + 4352 B):
+                  a power-of-two row stride maps every feature row to the same HBM channel.             */
   int spf;     /* samples per frame (N*D); frame of sample s = s / spf                                     */
   const float* x;        /* (S,3) points or (S,c_in) raw inputs, fp32                                      */
   const float* freq_w;   /* (n_freq) annealing window weights or NULL (all ones)                           */
   const void* W[LAB4D_MLP_MAX_LAYERS];        /* packed forward weights                                    */
   const float* bias[LAB4D_MLP_MAX_LAYERS];    /* (mout_pad) fp32                                           */
   const float* pf_bias[LAB4D_MLP_MAX_LAYERS]; /* (M, mout_pad) fp32 or NULL                                */
-  void* act[LAB4D_MLP_MAX_LAYERS];  /* [mout_pad][S_pad] stored post-activation or NULL (not stored)       */
-  void* emb;                        /* [ke][S_pad] stored embedding or NULL                                */
-  const void* ext;                  /* [mout_pad][S_pad] tensor added at the add_ext layer                 */
+  void* act[LAB4D_MLP_MAX_LAYERS];  /* [mout_pad][ld] stored post-activation or NULL (not stored)       */
+  void* emb;                        /* [ke][ld] stored embedding or NULL                                */
+  const void* ext;                  /* [mout_pad][ld] tensor added at the add_ext layer                 */
   float* out;                       /* (S, c_out) raw head output, fp32                                    */
 } lab4d_mlp_fwd_args;
 int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream);
 
 typedef struct {
-  int net, precision, S, S_pad, spf;
+  int net, precision, S, S_pad, ld, spf;
   const void* WT[LAB4D_MLP_MAX_LAYERS];        /* packed transposed weights                                */
   const void* act[LAB4D_MLP_MAX_LAYERS];       /* stored post-activations from the forward                 */
   const void* emb;                             /* stored embedding (posenc Jacobian)                       */
   const void* ext;                             /* forward `ext` (to recover relu(z) = y - ext)             */
   const float* d_out;                          /* (S, c_out) gradient of the head output                   */
-  const void* ext_gin;                         /* [mout_pad][S_pad] gradient added at the ext_grad layer   */
-  void* ext_gout;                              /* [mout_pad][S_pad] gradient wrt `ext` (written) or NULL   */
-  void* dz[LAB4D_MLP_MAX_LAYERS];              /* [mout_pad][S_pad] dL/d(pre-activation) (written)         */
+  const void* ext_gin;                         /* [mout_pad][ld] gradient added at the ext_grad layer   */
+  void* ext_gout;                              /* [mout_pad][ld] gradient wrt `ext` (written) or NULL   */
+  void* dz[LAB4D_MLP_MAX_LAYERS];              /* [mout_pad][ld] dL/d(pre-activation) (written)         */
   float* d_x;                                  /* (S,3) or (S,c_in) gradient wrt the input, or NULL        */
 } lab4d_mlp_bwd_args;
 int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream);
@@ -114,7 +117,7 @@ int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream);
  * X = [emb (ke rows) ; act_prev (kin rows)].  dW: (mout_pad, ke+kin) fp32 row-major, db: (mout_pad);
  * both are ACCUMULATED into (atomicAdd) -- zero-fill first.  pf_db: (M, mout_pad) per-frame bias
  * gradient or NULL. */
-int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int spf, const void* dz, const void* emb,
+int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int ld, int spf, const void* dz, const void* emb,
                     const void* act_prev, float* dW, float* db, float* pf_db, int M, void* stream);
 
 #endif /* LAB4D_MLP_H */

@@ -1,0 +1,40 @@
+/*
+ * lab4d_skin.h -- linear-blend skinning with dual quaternions (included by lab4d_hip.h).
+ *
+ * Replaces (paths relative to lab4d/):
+ *   utils/transforms.py:9-25        get_bone_coords            -> lab4d_bone_coords_*
+ *   nnutils/skinning.py:89-153      SkinningField.forward      (bone coords / gauss, dist2, delta = relu(mlp)*0.1)
+ *   nnutils/warping.py:316-333      softmax, skin_entropy, delta_skin
+ *   utils/geom_utils.py:45-83       dual_quaternion_skinning   (hemisphere fix, blend, normalise, apply)
+ *   utils/loss_utils.py:21-42       cross_entropy_skin_loss    -> lab4d_skin_blend_*
+ * The reference materialises ~10 tensors of shape (M,N,D,B,4) (210 MB each at 524k samples); here
+ * every per-(sample,bone) quantity lives in registers.  The delta-skinning MLP between the two
+ * stages is LAB4D_NET_SKIN of lab4d_mlp.h.  All fp32.  S samples, frame of sample s = s / spf,
+ * M frames, B bones (25).
+ */
+#ifndef LAB4D_SKIN_H
+#define LAB4D_SKIN_H
+
+/* xyz_bone[s][b][:] = apply(inverse(bone2obj[frame(s)][b]), xyz[s]) / gauss[b]   -> (S, 3B)
+ * art_r, art_d: (M,B,4) real / dual parts of the bone-to-object dual quaternions; gauss: (B,3). */
+int lab4d_bone_coords_forward(const float* xyz, const float* art_r, const float* art_d, const float* gauss, int S,
+                              int spf, int M, int B, float* xyz_bone, void* stream);
+/* g_bone (S,3B) -> g_xyz (S,3) written; g_art_r, g_art_d (M,B,4), g_gauss (B,3) accumulated (zero-fill first). */
+int lab4d_bone_coords_backward(const float* xyz, const float* art_r, const float* art_d, const float* gauss,
+                               const float* g_bone, int S, int spf, int M, int B, float* g_xyz, float* g_art_r,
+                               float* g_art_d, float* g_gauss, void* stream);
+
+/* skin = -(|xyz_bone_b|^2 + relu(delta_raw_b)*0.1); p = softmax(skin); blend the per-bone transforms se3
+ * (M,B,4)x2 with the arg-max bone's hemisphere; out = apply(blend, xyz).
+ * Outputs: out (S,3), entropy (S) = logsumexp(skin) - max(skin), dskin (S) = mean_b delta_b^2. */
+int lab4d_skin_blend_forward(const float* xyz, const float* xyz_bone, const float* delta_raw, const float* se3_r,
+                             const float* se3_d, int S, int spf, int M, int B, float* out, float* entropy,
+                             float* dskin, void* stream);
+/* Adjoint.  g_ent / g_dskin may be NULL.  Writes g_xyz (S,3), g_bone (S,3B), g_raw (S,B); accumulates
+ * g_se3_r, g_se3_d (M,B,4) (zero-fill first).  `work` is scratch of S*(B+8) floats. */
+int lab4d_skin_blend_backward(const float* xyz, const float* xyz_bone, const float* delta_raw, const float* se3_r,
+                              const float* se3_d, const float* g_out, const float* g_ent, const float* g_dskin,
+                              int S, int spf, int M, int B, float* g_xyz, float* g_bone, float* g_raw,
+                              float* g_se3_r, float* g_se3_d, float* work, void* stream);
+
+#endif /* LAB4D_SKIN_H */

@@ -10,7 +10,7 @@ namespace lab4d {
 template <class P, int TM>
 __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __restrict__ dz, const typename P::store_t* __restrict__ emb,
                                                     const typename P::store_t* __restrict__ actp, int mo_tiles, int ke, int kin,
-                                                    int S_pad, int chunk, float* __restrict__ dW, float* __restrict__ db) {
+                                                    int S_pad, int ld, int chunk, float* __restrict__ dW, float* __restrict__ db) {
   constexpr int TN = 4;
   constexpr int SPS = P::BF16 ? 16 : 8;  // samples per step
   const int lane = threadIdx.x & 63, row = lane & 31, h = lane >> 5;
@@ -41,14 +41,14 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
   for (int i = 0; i < TM; ++i) {
     const int t = ob * TM + i;
     av_[i] = t < mo_tiles;
-    ap[i] = dz + (size_t)(32 * (av_[i] ? t : 0) + row) * S_pad;
+    ap[i] = dz + (size_t)(32 * (av_[i] ? t : 0) + row) * ld;
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int t = kb * TN + j;
     bv_[j] = t < nk_tiles;
     const int kr = 32 * (bv_[j] ? t : 0) + row;
-    bp[j] = kr < ke ? emb + (size_t)kr * S_pad : actp + (size_t)(kr - ke) * S_pad;
+    bp[j] = kr < ke ? emb + (size_t)kr * ld : actp + (size_t)(kr - ke) * ld;
   }
   const int off = P::BF16 ? 8 * h : 4 * h;
   for (int s = s_begin; s < s_end; s += SPS) {
@@ -106,22 +106,31 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
   }
 }
 
-// per-frame bias gradient: pf_db[m][o] = sum_{s in frame m} dz[o][s] ; one wave per (o, m)
+// per-frame bias gradient: pf_db[m][o] += sum_{s in frame m} dz[o][s].  One wave per (row o, 4096-sample
+// segment); a segment that straddles frames flushes at the boundary.  pf_db is zero-filled by the caller.
 template <class P>
-__global__ void __launch_bounds__(256) k_rowsum_pf(const typename P::store_t* __restrict__ dz, int mo_pad, int S, int S_pad, int spf,
-                                                    int M, float* __restrict__ pf_db) {
+__global__ void __launch_bounds__(256) k_rowsum_pf(const typename P::store_t* __restrict__ dz, int mo_pad, int S, int ld, int spf,
+                                                    int M, int nseg, float* __restrict__ pf_db) {
+  constexpr int SEG = 4096;
   const int lane = threadIdx.x & 63;
   const long job = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (job >= (long)mo_pad * M) return;
-  const int o = (int)(job % mo_pad), m = (int)(job / mo_pad);
-  const long b = (long)m * spf, e = min((long)S, b + spf);
-  float s = 0.f;
-  for (long i = b + lane; i < e; i += 64) {
-    if constexpr (P::BF16) s += bf2f(dz[(size_t)o * S_pad + i]);
-    else s += dz[(size_t)o * S_pad + i];
+  if (job >= (long)mo_pad * nseg) return;
+  const int o = (int)(job / nseg), seg = (int)(job % nseg);
+  const long b = (long)seg * SEG, e = min((long)S, b + SEG);
+  const typename P::store_t* row = dz + (size_t)o * ld;
+  long i = b;
+  while (i < e) {
+    const int m = (int)(i / spf);
+    const long fe = min(e, (long)(m + 1) * spf);
+    float s = 0.f;
+    for (long k = i + lane; k < fe; k += 64) {
+      if constexpr (P::BF16) s += bf2f(row[k]);
+      else s += row[k];
+    }
+    s = wave_sum(s);
+    if (lane == 0) atomicAdd(pf_db + (size_t)m * mo_pad + o, s);
+    i = fe;
   }
-  s = wave_sum(s);
-  if (lane == 0) pf_db[(size_t)m * mo_pad + o] = s;
 }
 
 // =================================================================================================
@@ -222,14 +231,15 @@ extern "C" int lab4d_mlp_pack(int net, int layer, int precision, int transposed,
 
 extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
   LAB4D_REQUIRE(a, "mlp_forward: null args");
-  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0, "mlp_forward: bad sizes S=%d S_pad=%d spf=%d", a->S, a->S_pad, a->spf);
+  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0 && a->ld >= a->S_pad && a->ld % 8 == 0,
+                "mlp_forward: bad sizes S=%d S_pad=%d ld=%d spf=%d", a->S, a->S_pad, a->ld, a->spf);
   LAB4D_REQUIRE(a->x && a->out, "mlp_forward: null x/out");
   if (a->S == 0) return LAB4D_OK;
   return with_net(a->net, [&](auto n) {
     using Net = decltype(n);
     FwdK k;
     memset(&k, 0, sizeof(k));
-    k.S = a->S; k.S_pad = a->S_pad; k.spf = a->spf; k.x = a->x; k.freq_w = a->freq_w; k.emb = a->emb; k.ext = a->ext; k.out = a->out;
+    k.S = a->S; k.S_pad = a->S_pad; k.ld = a->ld; k.spf = a->spf; k.x = a->x; k.freq_w = a->freq_w; k.emb = a->emb; k.ext = a->ext; k.out = a->out;
     for (int l = 0; l < Net::NL; ++l) {
       LAB4D_REQUIRE(a->W[l] && a->bias[l], "mlp_forward: layer %d weights/bias missing", l);
       LAB4D_REQUIRE(!Net::L[l].pf || a->pf_bias[l], "mlp_forward: layer %d needs a per-frame bias", l);
@@ -242,14 +252,14 @@ extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
 
 extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
   LAB4D_REQUIRE(a, "mlp_backward: null args");
-  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0, "mlp_backward: bad sizes");
+  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0 && a->ld >= a->S_pad && a->ld % 8 == 0, "mlp_backward: bad sizes");
   LAB4D_REQUIRE(a->d_out, "mlp_backward: null d_out");
   if (a->S == 0) return LAB4D_OK;
   return with_net(a->net, [&](auto n) {
     using Net = decltype(n);
     BwdK k;
     memset(&k, 0, sizeof(k));
-    k.S = a->S; k.S_pad = a->S_pad; k.spf = a->spf; k.emb = a->emb; k.ext = a->ext; k.d_out = a->d_out; k.ext_gin = a->ext_gin;
+    k.S = a->S; k.S_pad = a->S_pad; k.ld = a->ld; k.spf = a->spf; k.emb = a->emb; k.ext = a->ext; k.d_out = a->d_out; k.ext_gin = a->ext_gin;
     k.ext_gout = a->ext_gout; k.d_x = a->d_x;
     LAB4D_REQUIRE(!(a->d_x && Net::EMB == 0) || a->emb, "mlp_backward: d_x needs the stored embedding");
     for (int l = 0; l < Net::NL; ++l) {
@@ -263,7 +273,7 @@ extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
   });
 }
 
-extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int spf, const void* dz, const void* emb,
+extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int ld, int spf, const void* dz, const void* emb,
                                const void* act_prev, float* dW, float* db, float* pf_db, int M, void* stream) {
   lab4d_mlp_desc d;
   if (int e = lab4d_mlp_describe(net, &d)) return e;
@@ -272,7 +282,7 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   LAB4D_REQUIRE(dz && dW, "mlp_wgrad: null dz/dW");
   LAB4D_REQUIRE(L.ke == 0 || emb, "mlp_wgrad: layer %d needs the stored embedding", layer);
   LAB4D_REQUIRE(L.kin == 0 || act_prev, "mlp_wgrad: layer %d needs the previous activation", layer);
-  LAB4D_REQUIRE(S_pad % 64 == 0 && S_pad >= S, "mlp_wgrad: bad S_pad");
+  LAB4D_REQUIRE(S_pad % 64 == 0 && S_pad >= S && ld >= S_pad && ld % 8 == 0, "mlp_wgrad: bad S_pad/ld");
   if (S == 0) return LAB4D_OK;
   const int mo_tiles = L.mout_pad / 32, nk_tiles = (L.ke + L.kin) / 32;
   const int TM = mo_tiles >= 4 ? 4 : (mo_tiles >= 2 ? 2 : 1);
@@ -285,7 +295,7 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   const dim3 grid(div_up(jobs, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define WG(P, TMV) hipLaunchKernelGGL((k_mlp_wgrad<P, TMV>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
-                                      (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, dW, db)
+                                      (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, ld, chunk, dW, db)
   if (precision == LAB4D_PREC_BF16) { if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
   else if (precision == LAB4D_PREC_F32) { if (TM == 4) WG(PF32, 4); else if (TM == 2) WG(PF32, 2); else WG(PF32, 1); }
   else { set_error("mlp_wgrad: bad precision %d", precision); return LAB4D_EINVAL; }
@@ -293,11 +303,12 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   if (int e = check_launch("mlp_wgrad")) return e;
   if (pf_db) {
     LAB4D_REQUIRE(M > 0 && spf > 0, "mlp_wgrad: pf_db needs M and spf");
-    const long jobs2 = (long)L.mout_pad * M;
+    const int nseg = div_up(S, 4096);
+    const long jobs2 = (long)L.mout_pad * nseg;
     if (precision == LAB4D_PREC_BF16)
-      hipLaunchKernelGGL((k_rowsum_pf<PBF16>), dim3(div_up(jobs2, 4)), dim3(256), 0, st, (const unsigned short*)dz, L.mout_pad, S, S_pad, spf, M, pf_db);
+      hipLaunchKernelGGL((k_rowsum_pf<PBF16>), dim3(div_up(jobs2, 4)), dim3(256), 0, st, (const unsigned short*)dz, L.mout_pad, S, ld, spf, M, nseg, pf_db);
     else
-      hipLaunchKernelGGL((k_rowsum_pf<PF32>), dim3(div_up(jobs2, 4)), dim3(256), 0, st, (const float*)dz, L.mout_pad, S, S_pad, spf, M, pf_db);
+      hipLaunchKernelGGL((k_rowsum_pf<PF32>), dim3(div_up(jobs2, 4)), dim3(256), 0, st, (const float*)dz, L.mout_pad, S, ld, spf, M, nseg, pf_db);
     return check_launch("mlp_rowsum_pf");
   }
   return LAB4D_OK;

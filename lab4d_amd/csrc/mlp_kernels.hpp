@@ -102,43 +102,43 @@ __device__ __forceinline__ void tile_to_units(const f32x16_t& c, uint4* u) {
 // ---- [feature][sample] tile IO in accumulator layout -------------------------------------------
 // bf16: lane n holds samples (s0+2n, s0+2n+1) packed in one dword ; fp32: sample s0+n.
 template <class P>
-__device__ __forceinline__ void store_tile(void* buf, int S_pad, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
+__device__ __forceinline__ void store_tile(void* buf, int ld, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
   const int n = lane & 31, h = lane >> 5;
   if constexpr (P::BF16) {
     unsigned int* p = reinterpret_cast<unsigned int*>(buf);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const size_t row = (size_t)(32 * mt + drow(r, h));
-      p[(row * S_pad + s0) / 2 + n] = pack2bf(c[0][r], c[1][r]);
+      p[(row * ld + s0) / 2 + n] = pack2bf(c[0][r], c[1][r]);
     }
   } else {
     float* p = reinterpret_cast<float*>(buf);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[(size_t)(32 * mt + drow(r, h)) * S_pad + s0 + n] = c[0][r];
+    for (int r = 0; r < 16; ++r) p[(size_t)(32 * mt + drow(r, h)) * ld + s0 + n] = c[0][r];
   }
 }
 template <class P>
-__device__ __forceinline__ void load_tile(const void* buf, int S_pad, int s0, int mt, int lane, f32x16_t* c /*[NT]*/) {
+__device__ __forceinline__ void load_tile(const void* buf, int ld, int s0, int mt, int lane, f32x16_t* c /*[NT]*/) {
   const int n = lane & 31, h = lane >> 5;
   if constexpr (P::BF16) {
     const unsigned int* p = reinterpret_cast<const unsigned int*>(buf);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const size_t row = (size_t)(32 * mt + drow(r, h));
-      const unsigned int u = p[(row * S_pad + s0) / 2 + n];
+      const unsigned int u = p[(row * ld + s0) / 2 + n];
       c[0][r] = bf2f((unsigned short)(u & 0xffffu));
       c[1][r] = bf2f((unsigned short)(u >> 16));
     }
   } else {
     const float* p = reinterpret_cast<const float*>(buf);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[0][r] = p[(size_t)(32 * mt + drow(r, h)) * S_pad + s0 + n];
+    for (int r = 0; r < 16; ++r) c[0][r] = p[(size_t)(32 * mt + drow(r, h)) * ld + s0 + n];
   }
 }
 
 // ---- kernel argument blocks (passed by value) ---------------------------------------------------
 struct FwdK {
-  int S, S_pad, spf, ntiles;
+  int S, S_pad, ld, spf, ntiles;
   const float* x;
   const float* freq_w;
   const void* W[LAB4D_MLP_MAX_LAYERS];
@@ -150,7 +150,7 @@ struct FwdK {
   float* out;
 };
 struct BwdK {
-  int S, S_pad, spf, ntiles;
+  int S, S_pad, ld, spf, ntiles;
   const void* WT[LAB4D_MLP_MAX_LAYERS];
   const void* act[LAB4D_MLP_MAX_LAYERS];
   const void* emb;
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
           for (int j = 0; j < 8; ++j) {
             const size_t row = 16 * g + 8 * h + j;
             const unsigned int lo = (w0[j >> 1] >> (16 * (j & 1))) & 0xffffu, hi = (w1[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-            p[(row * a.S_pad + s0) / 2 + n] = lo | (hi << 16);
+            p[(row * a.ld + s0) / 2 + n] = lo | (hi << 16);
           }
         }
       } else {
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         for (int g = 0; g < UE; ++g) {
           const unsigned int w[4] = {emb[0][g].x, emb[0][g].y, emb[0][g].z, emb[0][g].w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) p[(size_t)(2 * (4 * g + e) + h) * a.S_pad + s0 + n] = __uint_as_float(w[e]);
+          for (int e = 0; e < 4; ++e) p[(size_t)(2 * (4 * g + e) + h) * a.ld + s0 + n] = __uint_as_float(w[e]);
         }
       }
     }
@@ -338,13 +338,13 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         }
         if constexpr (ls.add_ext != 0) {
           f32x16_t e[NT];
-          load_tile<P>(a.ext, a.S_pad, s0, mt, lane, e);
+          load_tile<P>(a.ext, a.ld, s0, mt, lane, e);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] += e[t][r];
         }
-        if (a.act[l]) store_tile<P>(a.act[l], a.S_pad, s0, mt, lane, acc);
+        if (a.act[l]) store_tile<P>(a.act[l], a.ld, s0, mt, lane, acc);
         if constexpr (l + 1 < Net::NL) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
           const int f = drow(r, h);
           g[t][r] = (f < Net::COUT && sidx[t] < a.S) ? a.d_out[(size_t)sidx[t] * Net::COUT + f] : 0.f;
         }
-      if (a.dz[NL - 1]) store_tile<P>(a.dz[NL - 1], a.S_pad, s0, 0, lane, g);
+      if (a.dz[NL - 1]) store_tile<P>(a.dz[NL - 1], a.ld, s0, 0, lane, g);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         uint4 u[P::UPT];
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
             }
             if constexpr (Net::EMB == 0) {
               f32x16_t e[NT];
-              load_tile<P>(a.emb, a.S_pad, s0, mt, lane, e);
+              load_tile<P>(a.emb, a.ld, s0, mt, lane, e);
               constexpr int L = Net::NFREQ;
 #pragma unroll
               for (int t = 0; t < NT; ++t)
@@ -500,21 +500,21 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
           }
           if constexpr (lp.ext_grad != 0) {
             f32x16_t e[NT];
-            load_tile<P>(a.ext_gin, a.S_pad, s0, j, lane, e);
+            load_tile<P>(a.ext_gin, a.ld, s0, j, lane, e);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[t][r] += e[t][r];
           }
           if constexpr (lp.add_ext != 0) {
-            if (a.ext_gout) store_tile<P>(a.ext_gout, a.S_pad, s0, j, lane, acc);  // y = relu(z) + ext  ->  dL/dext = dL/dy
+            if (a.ext_gout) store_tile<P>(a.ext_gout, a.ld, s0, j, lane, acc);  // y = relu(z) + ext  ->  dL/dext = dL/dy
           }
           if constexpr (lp.relu != 0) {
             f32x16_t y[NT];
-            load_tile<P>(a.act[l - 1], a.S_pad, s0, j, lane, y);
+            load_tile<P>(a.act[l - 1], a.ld, s0, j, lane, y);
             if constexpr (lp.add_ext != 0) {
               f32x16_t e[NT];
-              load_tile<P>(a.ext, a.S_pad, s0, j, lane, e);
+              load_tile<P>(a.ext, a.ld, s0, j, lane, e);
 #pragma unroll
               for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             }
-          if (a.dz[l - 1]) store_tile<P>(a.dz[l - 1], a.S_pad, s0, j, lane, acc);
+          if (a.dz[l - 1]) store_tile<P>(a.dz[l - 1], a.ld, s0, j, lane, acc);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             uint4 u[P::UPT];

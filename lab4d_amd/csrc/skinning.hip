@@ -1,0 +1,346 @@
+// Linear-blend skinning with dual quaternions, forward + adjoint (fp32 VALU kernels).
+// Contract and reference citations: include/lab4d_skin.h.
+#include "common.hpp"
+
+namespace lab4d {
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 ldv3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void stv3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+// vector part of q (0,p) conj(q), q = (w, v) not necessarily unit (quat_transform.py:255-272)
+__device__ __forceinline__ V3 qrot(float w, V3 v, V3 p) { return p * (w * w - dot(v, v)) + v * (2.f * dot(v, p)) + cross(v, p) * (2.f * w); }
+__device__ __forceinline__ V3 qrot_t(float w, V3 v, V3 g) { return g * (w * w - dot(v, v)) + v * (2.f * dot(v, g)) - cross(v, g) * (2.f * w); }
+// gradient of g . qrot(q, p) wrt (w, v)
+__device__ __forceinline__ void qrot_gq(float w, V3 v, V3 p, V3 g, float& gw, V3& gv) {
+  const float gp = dot(g, p), gvv = dot(g, v), vp = dot(v, p);
+  gw = 2.f * w * gp + 2.f * dot(g, cross(v, p));
+  gv = v * (-2.f * gp) + p * (2.f * gvv) + g * (2.f * vp) + cross(p, g) * (2.f * w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bone coordinates
+// ---------------------------------------------------------------------------------------------
+// inverse bone transform of bone-to-object dq (r = (w,v), d = (dw,dv)):  rotation q = conj(r),
+// translation t = 2 vec(conj(d) r) = 2 (dw v - w dv + v x dv)      (transforms.py:19-24, quat_transform.py:337-344,441-465)
+__device__ __forceinline__ V3 bone_apply(float w, V3 v, float dw, V3 dv, V3 x) {
+  const V3 t = (v * dw - dv * w + cross(v, dv)) * 2.f;
+  return qrot(w, v * -1.f, x) + t;
+}
+
+template <int B>
+__global__ void __launch_bounds__(256) k_bone_fwd(const float* __restrict__ xyz, const float* __restrict__ ar, const float* __restrict__ ad,
+                                                   const float* __restrict__ gauss, long S, int spf, float* __restrict__ out) {
+  const long total = S * B;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long s = i / B;
+    const int b = (int)(i - s * B);
+    const int m = (int)(s / spf);
+    const float* r = ar + ((size_t)m * B + b) * 4;
+    const float* d = ad + ((size_t)m * B + b) * 4;
+    const V3 y = bone_apply(r[0], ldv3(r + 1), d[0], ldv3(d + 1), ldv3(xyz + s * 3));
+    const V3 gs = ldv3(gauss + 3 * b);
+    stv3(out + i * 3, {y.x / gs.x, y.y / gs.y, y.z / gs.z});
+  }
+}
+
+// g_xyz[s] = sum_b R_b^T (g_bone[s,b] / gauss_b): one thread per sample
+template <int B>
+__global__ void __launch_bounds__(256) k_bone_bwd_x(const float* __restrict__ ar, const float* __restrict__ gauss,
+                                                     const float* __restrict__ g_bone, long S, int spf, float* __restrict__ g_xyz) {
+  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(s / spf);
+    V3 acc = {0, 0, 0};
+#pragma unroll 5
+    for (int b = 0; b < B; ++b) {
+      const float* r = ar + ((size_t)m * B + b) * 4;
+      const V3 gs = ldv3(gauss + 3 * b);
+      const V3 g = ldv3(g_bone + (s * B + b) * 3);
+      acc = acc + qrot_t(r[0], ldv3(r + 1) * -1.f, {g.x / gs.x, g.y / gs.y, g.z / gs.z});
+    }
+    stv3(g_xyz + s * 3, acc);
+  }
+}
+
+// per-frame / per-bone parameter gradients: block = (frame m, chunk of samples), loop bones outermost
+// so that each (sample,bone) gradient element is read exactly once and the 11 reductions per bone are
+// amortised over the block's samples.
+template <int B>
+__global__ void __launch_bounds__(256) k_bone_bwd_p(const float* __restrict__ xyz, const float* __restrict__ ar, const float* __restrict__ ad,
+                                                     const float* __restrict__ gauss, const float* __restrict__ g_bone, long S, int spf,
+                                                     int chunk, float* __restrict__ g_ar, float* __restrict__ g_ad, float* __restrict__ g_gauss) {
+  __shared__ float red[4][11];
+  const int m = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long f0 = (long)m * spf, f1 = min(S, f0 + spf);
+  const long c0 = f0 + (long)blockIdx.x * chunk, c1 = min(f1, c0 + chunk);
+  if (c0 >= c1) return;
+  for (int b = 0; b < B; ++b) {
+    const float* r = ar + ((size_t)m * B + b) * 4;
+    const float* d = ad + ((size_t)m * B + b) * 4;
+    const float w = r[0], dw = d[0];
+    const V3 v = ldv3(r + 1), dv = ldv3(d + 1), gs = ldv3(gauss + 3 * b);
+    float a[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) a[k] = 0.f;
+    for (long s = c0 + threadIdx.x; s < c1; s += 256) {
+      const V3 x = ldv3(xyz + s * 3);
+      const V3 go = ldv3(g_bone + (s * B + b) * 3);
+      const V3 y = bone_apply(w, v, dw, dv, x);
+      const V3 gy = {go.x / gs.x, go.y / gs.y, go.z / gs.z};
+      // out = y / gauss
+      a[8] -= go.x * y.x / (gs.x * gs.x); a[9] -= go.y * y.y / (gs.y * gs.y); a[10] -= go.z * y.z / (gs.z * gs.z);
+      // rotation part: q = (w, -v)
+      float gqw; V3 gqv;
+      qrot_gq(w, v * -1.f, x, gy, gqw, gqv);
+      // translation part t = 2 (dw v - w dv + v x dv)
+      const float g_w = gqw - 2.f * dot(dv, gy);
+      const V3 g_v = gqv * -1.f + gy * (2.f * dw) + cross(dv, gy) * 2.f;
+      const float g_dw = 2.f * dot(v, gy);
+      const V3 g_dv = gy * (-2.f * w) + cross(gy, v) * 2.f;
+      a[0] += g_w; a[1] += g_v.x; a[2] += g_v.y; a[3] += g_v.z;
+      a[4] += g_dw; a[5] += g_dv.x; a[6] += g_dv.y; a[7] += g_dv.z;
+    }
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float t = wave_sum(a[k]);
+      if (lane == 0) red[wid][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 11) {
+      const int k = threadIdx.x;
+      const float t = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+      if (k < 4) atomicAdd(g_ar + ((size_t)m * B + b) * 4 + k, t);
+      else if (k < 8) atomicAdd(g_ad + ((size_t)m * B + b) * 4 + (k - 4), t);
+      else atomicAdd(g_gauss + 3 * b + (k - 8), t);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// skin weights + dual-quaternion blend
+// ---------------------------------------------------------------------------------------------
+template <int B>
+struct Blend {
+  float p[B];       // softmax weights
+  float sg[B];      // hemisphere signs (+-1)
+  float dl[B];      // delta = relu(raw) * 0.1
+  int anchor;
+  float lse_minus_max;
+  float rw[4], dw4[4];  // un-normalised blended real / dual parts
+  float inv;
+};
+
+template <int B>
+__device__ __forceinline__ void blend_forward(const float* __restrict__ bone, const float* __restrict__ raw, const float* __restrict__ sr,
+                                              const float* __restrict__ sd, Blend<B>& o) {
+  float skin[B];
+  float mx = -INFINITY;
+  int am = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const V3 c = ldv3(bone + 3 * b);
+    const float dlt = fmaxf(raw[b], 0.f) * 0.1f;   // skinning.py:119
+    o.dl[b] = dlt;
+    skin[b] = -(dot(c, c) + dlt);                  // skinning.py:120
+    if (skin[b] > mx) { mx = skin[b]; am = b; }    // first maximum, like torch.argmax
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int b = 0; b < B; ++b) { o.p[b] = expf(skin[b] - mx); sum += o.p[b]; }
+  const float isum = 1.f / sum;
+  o.anchor = am;
+  o.lse_minus_max = logf(sum);  // logsumexp - max  (loss_utils.py:21-42)
+  const float a0 = sr[4 * am], a1 = sr[4 * am + 1], a2 = sr[4 * am + 2], a3 = sr[4 * am + 3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { o.rw[k] = 0.f; o.dw4[k] = 0.f; }
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    o.p[b] *= isum;
+    const float* r = sr + 4 * b;
+    const float* d = sd + 4 * b;
+    const float sgn = (a0 * r[0] + a1 * r[1] + a2 * r[2] + a3 * r[3]) > 0.f ? 1.f : -1.f;  // geom_utils.py:66-70
+    o.sg[b] = sgn;
+    const float c = o.p[b] * sgn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o.rw[k] += c * r[k]; o.dw4[k] += c * d[k]; }
+  }
+  o.inv = 1.f / sqrtf(o.rw[0] * o.rw[0] + o.rw[1] * o.rw[1] + o.rw[2] * o.rw[2] + o.rw[3] * o.rw[3]);
+}
+
+// apply the normalised blended dq (r = (w,v), d = (dw,dv)):  out = qrot(r, x) + 2 (-dw v + w dv + v x dv)
+__device__ __forceinline__ V3 dq_apply(float w, V3 v, float dw, V3 dv, V3 x) {
+  return qrot(w, v, x) + (v * -dw + dv * w + cross(v, dv)) * 2.f;
+}
+
+template <int B>
+__global__ void __launch_bounds__(256) k_blend_fwd(const float* __restrict__ xyz, const float* __restrict__ bone, const float* __restrict__ raw,
+                                                    const float* __restrict__ sr, const float* __restrict__ sd, long S, int spf,
+                                                    float* __restrict__ out, float* __restrict__ ent, float* __restrict__ dskin) {
+  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(s / spf);
+    Blend<B> bl;
+    blend_forward<B>(bone + s * 3 * B, raw + s * B, sr + (size_t)m * B * 4, sd + (size_t)m * B * 4, bl);
+    const float i = bl.inv;
+    const V3 y = dq_apply(bl.rw[0] * i, V3{bl.rw[1], bl.rw[2], bl.rw[3]} * i, bl.dw4[0] * i, V3{bl.dw4[1], bl.dw4[2], bl.dw4[3]} * i,
+                          ldv3(xyz + s * 3));
+    stv3(out + s * 3, y);
+    if (ent) ent[s] = bl.lse_minus_max;
+    if (dskin) {
+      float q = 0.f;
+#pragma unroll
+      for (int b = 0; b < B; ++b) q += bl.dl[b] * bl.dl[b];
+      dskin[s] = q / (float)B;   // warping.py:332
+    }
+  }
+}
+
+// per-sample part of the adjoint.  work[s] = [c_b = p_b*sign_b (B) | g_rw (4) | g_dw (4)] for the per-frame reduction.
+template <int B>
+__global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz, const float* __restrict__ bone, const float* __restrict__ raw,
+                                                    const float* __restrict__ sr, const float* __restrict__ sd, const float* __restrict__ g_out,
+                                                    const float* __restrict__ g_ent, const float* __restrict__ g_dskin, long S, int spf,
+                                                    float* __restrict__ g_xyz, float* __restrict__ g_bone, float* __restrict__ g_raw,
+                                                    float* __restrict__ work) {
+  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(s / spf);
+    const float* srm = sr + (size_t)m * B * 4;
+    const float* sdm = sd + (size_t)m * B * 4;
+    Blend<B> bl;
+    blend_forward<B>(bone + s * 3 * B, raw + s * B, srm, sdm, bl);
+    const float i = bl.inv;
+    const float w = bl.rw[0] * i, dw = bl.dw4[0] * i;
+    const V3 v = V3{bl.rw[1], bl.rw[2], bl.rw[3]} * i, dv = V3{bl.dw4[1], bl.dw4[2], bl.dw4[3]} * i;
+    const V3 x = ldv3(xyz + s * 3), g = ldv3(g_out + s * 3);
+    stv3(g_xyz + s * 3, qrot_t(w, v, g));
+    float gqw; V3 gqv;
+    qrot_gq(w, v, x, g, gqw, gqv);
+    // t = 2 (-dw v + w dv + v x dv)
+    const float gn_w = gqw + 2.f * dot(dv, g);
+    const V3 gn_v = gqv + g * (-2.f * dw) + cross(dv, g) * 2.f;
+    const float gd_w = -2.f * dot(v, g);
+    const V3 gd_v = g * (2.f * w) + cross(g, v) * 2.f;
+    // normalisation: qn = rw * inv, dn = dw4 * inv, inv = 1/|rw|
+    const float qg = w * gn_w + dot(v, gn_v);           // qn . g_qn
+    const float dg = dw * gd_w + dot(dv, gd_v);          // dn . g_dn
+    float grw[4], gdw[4];
+    grw[0] = i * (gn_w - w * qg) - w * i * dg;
+    grw[1] = i * (gn_v.x - v.x * qg) - v.x * i * dg;
+    grw[2] = i * (gn_v.y - v.y * qg) - v.y * i * dg;
+    grw[3] = i * (gn_v.z - v.z * qg) - v.z * i * dg;
+    gdw[0] = i * gd_w; gdw[1] = i * gd_v.x; gdw[2] = i * gd_v.y; gdw[3] = i * gd_v.z;
+    float* wk = work + s * (B + 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { wk[B + k] = grw[k]; wk[B + 4 + k] = gdw[k]; }
+    // softmax / entropy / delta adjoint
+    float gp[B];
+    float pg = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const float* r = srm + 4 * b;
+      const float* d = sdm + 4 * b;
+      gp[b] = bl.sg[b] * (r[0] * grw[0] + r[1] * grw[1] + r[2] * grw[2] + r[3] * grw[3] + d[0] * gdw[0] + d[1] * gdw[1] + d[2] * gdw[2] + d[3] * gdw[3]);
+      pg += bl.p[b] * gp[b];
+      wk[b] = bl.p[b] * bl.sg[b];
+    }
+    const float ge = g_ent ? g_ent[s] : 0.f;
+    const float gds = g_dskin ? g_dskin[s] * (2.f / (float)B) : 0.f;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      // skin_b = -(dist2_b + delta_b);  entropy = lse(skin) - max(skin)
+      const float gskin = bl.p[b] * (gp[b] - pg) + ge * (bl.p[b] - (b == bl.anchor ? 1.f : 0.f));
+      const float gdelta = -gskin + gds * bl.dl[b];
+      g_raw[s * B + b] = raw[s * B + b] > 0.f ? 0.1f * gdelta : 0.f;
+      const V3 c = ldv3(bone + (s * B + b) * 3);
+      stv3(g_bone + (s * B + b) * 3, c * (-2.f * gskin));
+    }
+  }
+}
+
+// g_se3[m][b][c] += sum_{s in frame m} coef[s][b] * gw[s][c]: block = (frame, chunk); thread = (b, c)
+template <int B>
+__global__ void __launch_bounds__(256) k_blend_bwd_reduce(const float* __restrict__ work, long S, int spf, int chunk, float* __restrict__ g_sr,
+                                                           float* __restrict__ g_sd) {
+  const int m = blockIdx.y;
+  const long f0 = (long)m * spf, f1 = min(S, f0 + spf);
+  const long c0 = f0 + (long)blockIdx.x * chunk, c1 = min(f1, c0 + chunk);
+  const int t = threadIdx.x;
+  if (t >= B * 8 || c0 >= c1) return;
+  const int b = t >> 3, c = t & 7;
+  float acc = 0.f;
+  for (long s = c0; s < c1; ++s) {
+    const float* wk = work + s * (B + 8);
+    acc += wk[b] * wk[B + c];
+  }
+  if (c < 4) atomicAdd(g_sr + ((size_t)m * B + b) * 4 + c, acc);
+  else atomicAdd(g_sd + ((size_t)m * B + b) * 4 + (c - 4), acc);
+}
+
+}  // namespace lab4d
+using namespace lab4d;
+
+#define SKIN_DISPATCH(B, ...)                                                        \
+  switch (B) {                                                                        \
+    case 25: { constexpr int NB = 25; __VA_ARGS__; break; }                           \
+    case 18: { constexpr int NB = 18; __VA_ARGS__; break; }                           \
+    default: set_error("skinning kernels are instantiated for B = 25 (bob, skel-quad) and 18 (skel-human); got %d", B); \
+             return LAB4D_EINVAL;                                                     \
+  }
+
+static inline int sgrid(long n) { int g = div_up(n, 256); return g > 8192 ? 8192 : (g < 1 ? 1 : g); }
+
+extern "C" int lab4d_bone_coords_forward(const float* xyz, const float* ar, const float* ad, const float* gauss, int S, int spf, int M, int B,
+                                         float* out, void* stream) {
+  LAB4D_REQUIRE(xyz && ar && ad && gauss && out, "bone_coords_forward: null pointer");
+  LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "bone_coords_forward: M*spf < S");
+  if (S == 0) return LAB4D_OK;
+  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_fwd<NB>), dim3(sgrid((long)S * B)), dim3(256), 0, (hipStream_t)stream, xyz, ar, ad, gauss, (long)S, spf, out));
+  return check_launch("bone_coords_forward");
+}
+
+extern "C" int lab4d_bone_coords_backward(const float* xyz, const float* ar, const float* ad, const float* gauss, const float* g_bone, int S,
+                                          int spf, int M, int B, float* g_xyz, float* g_ar, float* g_ad, float* g_gauss, void* stream) {
+  LAB4D_REQUIRE(xyz && ar && ad && gauss && g_bone, "bone_coords_backward: null pointer");
+  LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "bone_coords_backward: M*spf < S");
+  if (S == 0) return LAB4D_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (g_xyz) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_x<NB>), dim3(sgrid(S)), dim3(256), 0, st, ar, gauss, g_bone, (long)S, spf, g_xyz)); }
+  if (g_ar || g_ad || g_gauss) {
+    LAB4D_REQUIRE(g_ar && g_ad && g_gauss, "bone_coords_backward: parameter gradients must be requested together");
+    const int chunk = 8192;
+    const dim3 grid(div_up(spf, chunk), M);
+    SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_p<NB>), grid, dim3(256), 0, st, xyz, ar, ad, gauss, g_bone, (long)S, spf, chunk, g_ar, g_ad, g_gauss));
+  }
+  return check_launch("bone_coords_backward");
+}
+
+extern "C" int lab4d_skin_blend_forward(const float* xyz, const float* bone, const float* raw, const float* sr, const float* sd, int S, int spf,
+                                        int M, int B, float* out, float* ent, float* dskin, void* stream) {
+  LAB4D_REQUIRE(xyz && bone && raw && sr && sd && out, "skin_blend_forward: null pointer");
+  LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "skin_blend_forward: M*spf < S");
+  if (S == 0) return LAB4D_OK;
+  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_fwd<NB>), dim3(sgrid(S)), dim3(256), 0, (hipStream_t)stream, xyz, bone, raw, sr, sd, (long)S, spf, out, ent, dskin));
+  return check_launch("skin_blend_forward");
+}
+
+extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* bone, const float* raw, const float* sr, const float* sd, const float* g_out,
+                                         const float* g_ent, const float* g_dskin, int S, int spf, int M, int B, float* g_xyz, float* g_bone,
+                                         float* g_raw, float* g_sr, float* g_sd, float* work, void* stream) {
+  LAB4D_REQUIRE(xyz && bone && raw && sr && sd && g_out && g_xyz && g_bone && g_raw && work, "skin_blend_backward: null pointer");
+  LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "skin_blend_backward: M*spf < S");
+  if (S == 0) return LAB4D_OK;
+  hipStream_t st = (hipStream_t)stream;
+  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB>), dim3(sgrid(S)), dim3(256), 0, st, xyz, bone, raw, sr, sd, g_out, g_ent, g_dskin, (long)S, spf,
+                                      g_xyz, g_bone, g_raw, work));
+  if (g_sr && g_sd) {
+    const int chunk = 2048;
+    const dim3 grid(div_up(spf, chunk), M);
+    SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd_reduce<NB>), grid, dim3(256), 0, st, work, (long)S, spf, chunk, g_sr, g_sd));
+  }
+  return check_launch("skin_blend_backward");
+}

@@ -1,0 +1,111 @@
+"""Host-side mirror of lab4d/nnutils/warping.py SkinningWarp.forward (+ skinning.py SkinningField,
+transforms.get_bone_coords, geom_utils.dual_quaternion_skinning, loss_utils.cross_entropy_skin_loss)
+on the gfx950 kernels of csrc/skinning.hip and the fused delta-skin MLP (LAB4D_NET_SKIN)."""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib, mlp
+from . import quat_utils as Q
+
+vp, ci = _lib.vp, _lib.ci
+_lib.register("lab4d_bone_coords_forward", [vp] * 4 + [ci] * 4 + [vp, vp])
+_lib.register("lab4d_bone_coords_backward", [vp] * 5 + [ci] * 4 + [vp] * 4 + [vp])
+_lib.register("lab4d_skin_blend_forward", [vp] * 5 + [ci] * 4 + [vp] * 3 + [vp])
+_lib.register("lab4d_skin_blend_backward", [vp] * 8 + [ci] * 4 + [vp] * 6 + [vp])
+
+
+class BoneCoords(Function):
+    """(S,3) points -> (S,3B) gaussian-scaled bone coordinates (transforms.py:9-25, skinning.py:126-140)."""
+
+    @staticmethod
+    def forward(ctx, xyz, art_r, art_d, gauss, spf):
+        xyz, art_r, art_d, gauss = xyz.contiguous(), art_r.contiguous(), art_d.contiguous(), gauss.contiguous()
+        _lib.require_device(xyz, art_r, art_d, gauss)
+        S, (M, B) = xyz.shape[0], art_r.shape[:2]
+        out = torch.empty(S, 3 * B, device=xyz.device)
+        _lib.check(_lib.lib().lab4d_bone_coords_forward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), S, spf, M, B,
+                                                        _lib.ptr(out), _lib.stream()), "bone_coords_forward")
+        ctx.save_for_backward(xyz, art_r, art_d, gauss)
+        ctx.spf = spf
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xyz, art_r, art_d, gauss = ctx.saved_tensors
+        S, (M, B) = xyz.shape[0], art_r.shape[:2]
+        g = g.contiguous()
+        gx = torch.empty_like(xyz)
+        gar, gad, gg = torch.zeros_like(art_r), torch.zeros_like(art_d), torch.zeros_like(gauss)
+        _lib.check(_lib.lib().lab4d_bone_coords_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(g), S, ctx.spf,
+                                                         M, B, _lib.ptr(gx), _lib.ptr(gar), _lib.ptr(gad), _lib.ptr(gg), _lib.stream()),
+                   "bone_coords_backward")
+        return gx, gar, gad, gg, None
+
+
+class SkinBlend(Function):
+    """skin weights + hemisphere-consistent dual-quaternion blend + apply (warping.py:322-333, geom_utils.py:45-83)."""
+
+    @staticmethod
+    def forward(ctx, xyz, bone, raw, se3_r, se3_d, spf):
+        xyz, bone, raw, se3_r, se3_d = [t.contiguous() for t in (xyz, bone, raw, se3_r, se3_d)]
+        _lib.require_device(xyz, bone, raw, se3_r, se3_d)
+        S, (M, B) = xyz.shape[0], se3_r.shape[:2]
+        out = torch.empty(S, 3, device=xyz.device)
+        ent = torch.empty(S, 1, device=xyz.device)
+        dsk = torch.empty(S, 1, device=xyz.device)
+        _lib.check(_lib.lib().lab4d_skin_blend_forward(_lib.ptr(xyz), _lib.ptr(bone), _lib.ptr(raw), _lib.ptr(se3_r), _lib.ptr(se3_d), S, spf, M, B,
+                                                       _lib.ptr(out), _lib.ptr(ent), _lib.ptr(dsk), _lib.stream()), "skin_blend_forward")
+        ctx.save_for_backward(xyz, bone, raw, se3_r, se3_d)
+        ctx.spf = spf
+        return out, ent, dsk
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out, g_ent, g_dsk):
+        xyz, bone, raw, se3_r, se3_d = ctx.saved_tensors
+        S, (M, B) = xyz.shape[0], se3_r.shape[:2]
+        g_out = g_out.contiguous()
+        g_ent = g_ent.contiguous() if g_ent is not None else None
+        g_dsk = g_dsk.contiguous() if g_dsk is not None else None
+        gx, gb, gr = torch.empty_like(xyz), torch.empty_like(bone), torch.empty_like(raw)
+        gsr, gsd = torch.zeros_like(se3_r), torch.zeros_like(se3_d)
+        work = torch.empty(S, B + 8, device=xyz.device)
+        _lib.check(_lib.lib().lab4d_skin_blend_backward(_lib.ptr(xyz), _lib.ptr(bone), _lib.ptr(raw), _lib.ptr(se3_r), _lib.ptr(se3_d),
+                                                        _lib.ptr(g_out), _lib.ptr(g_ent), _lib.ptr(g_dsk), S, ctx.spf, M, B, _lib.ptr(gx),
+                                                        _lib.ptr(gb), _lib.ptr(gr), _lib.ptr(gsr), _lib.ptr(gsd), _lib.ptr(work), _lib.stream()),
+                   "skin_blend_backward")
+        return gx, gb, gr, gsr, gsd, None
+
+
+def get_gauss(P):
+    """SkinningField.get_gauss (skinning.py:142-153)."""
+    lg = P["warp.skinning_model.log_gauss"]
+    symm = P.get("warp.skinning_model.symm_idx")
+    if symm is not None:
+        lg = (lg[symm] + lg) / 2
+    return lg.exp()
+
+
+def skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, prec=mlp.PREC_F32):
+    """SkinningWarp.forward (warping.py:277-336).  xyz: (M,N,D,3).  Returns warped xyz and
+    {"skin_entropy","delta_skin"} (M,N,D,1).  t_embed: (M,128) per-frame (backward warp) or (1,128)
+    mean embedding (forward warp, frame_id=None: warping.py:314)."""
+    shape = xyz.shape
+    M = shape[0]
+    spf = 1
+    for d in shape[1:-1]:
+        spf *= d
+    if backward:
+        se3 = Q.dual_quaternion_mul(rest_articulation, Q.dual_quaternion_inverse(t_articulation))
+        art = t_articulation
+    else:
+        se3 = Q.dual_quaternion_mul(t_articulation, Q.dual_quaternion_inverse(rest_articulation))
+        art = rest_articulation
+    x = xyz.reshape(-1, 3)
+    bone = BoneCoords.apply(x, art[0], art[1], get_gauss(P), spf)
+    cond = torch.cat([t_embed.expand(M, -1), code], -1)
+    raw = mlp.run_chain(mlp.NET_SKIN, prec, P, bone, spf, conds={0: cond})
+    out, ent, dsk = SkinBlend.apply(x, bone, raw, se3[0], se3[1], spf)
+    return out.view(shape), {"skin_entropy": ent.view(shape[:-1] + (1,)), "delta_skin": dsk.view(shape[:-1] + (1,))}
