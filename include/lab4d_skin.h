@@ -37,4 +37,12 @@ int lab4d_skin_blend_backward(const float* xyz, const float* xyz_bone, const flo
                               int S, int spf, int M, int B, float* g_xyz, float* g_bone, float* g_raw,
                               float* g_se3_r, float* g_se3_d, float* work, void* stream);
 
+/* Gaussian-bone density  max_b exp(-0.5 |x - c_b|^2 / 0.01^2) * ibeta  (nnutils/deformable.py:329-356,
+ * warping.py:355-387, utils/transforms.py:28-40).  centres: (B,3).  best: (S) int32 arg-min bone (saved for
+ * the adjoint).  Backward writes g_xyz (S,3) and accumulates g_centres (B,3), g_ibeta (1). */
+int lab4d_gauss_density_forward(const float* xyz, const float* centres, int B, float ibeta, int S, float* out,
+                                int* best, void* stream);
+int lab4d_gauss_density_backward(const float* xyz, const float* centres, int B, float ibeta, const int* best,
+                                 const float* g, int S, float* g_xyz, float* g_centres, float* g_ibeta, void* stream);
+
 #endif /* LAB4D_SKIN_H */

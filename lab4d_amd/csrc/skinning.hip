@@ -344,3 +344,63 @@ extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* bone, co
   }
   return check_launch("skin_blend_backward");
 }
+
+// ---------------------------------------------------------------------------------------------
+// gaussian-bone density: max_b exp(-0.5 |x - c_b|^2 / 0.01^2) * ibeta
+//   (deformable.py:329-356, warping.py:355-387, transforms.py:28-40; centres = frame-0 rest bones)
+// ---------------------------------------------------------------------------------------------
+namespace lab4d {
+__global__ void __launch_bounds__(256) k_gauss_density_fwd(const float* __restrict__ xyz, const float* __restrict__ centres, int B, float ibeta,
+                                                            long S, float* __restrict__ out, int* __restrict__ best) {
+  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
+    const V3 x = ldv3(xyz + s * 3);
+    float dmin = INFINITY;
+    int bi = 0;
+    for (int b = 0; b < B; ++b) {
+      const V3 d = x - ldv3(centres + 3 * b);
+      const float d2 = dot(d, d);
+      if (d2 < dmin) { dmin = d2; bi = b; }
+    }
+    out[s] = expf(-0.5f * (dmin / (0.01f * 0.01f))) * ibeta;
+    if (best) best[s] = bi;
+  }
+}
+// g_xyz (S,3) written; g_centres (B,3) and g_ibeta (1) accumulated
+__global__ void __launch_bounds__(256) k_gauss_density_bwd(const float* __restrict__ xyz, const float* __restrict__ centres, int B, float ibeta,
+                                                            const int* __restrict__ best, const float* __restrict__ g, long S,
+                                                            float* __restrict__ g_xyz, float* __restrict__ g_centres, float* __restrict__ g_ibeta) {
+  extern __shared__ float acc[];  // 3B + 1
+  for (int i = threadIdx.x; i < 3 * B + 1; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
+    const int b = best[s];
+    const V3 d = ldv3(xyz + s * 3) - ldv3(centres + 3 * b);
+    const float e = expf(-0.5f * (dot(d, d) / (0.01f * 0.01f)));
+    const float gs = g[s];
+    const V3 gx = d * (-gs * e * ibeta / (0.01f * 0.01f));
+    if (g_xyz) stv3(g_xyz + s * 3, gx);
+    atomicAdd(&acc[3 * b + 0], -gx.x); atomicAdd(&acc[3 * b + 1], -gx.y); atomicAdd(&acc[3 * b + 2], -gx.z);
+    atomicAdd(&acc[3 * B], gs * e);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * B; i += blockDim.x) if (acc[i] != 0.f) atomicAdd(g_centres + i, acc[i]);
+  if (threadIdx.x == 0 && g_ibeta) atomicAdd(g_ibeta, acc[3 * B]);
+}
+}  // namespace lab4d
+
+extern "C" int lab4d_gauss_density_forward(const float* xyz, const float* centres, int B, float ibeta, int S, float* out, int* best, void* stream) {
+  LAB4D_REQUIRE(xyz && centres && out, "gauss_density_forward: null pointer");
+  if (S == 0) return LAB4D_OK;
+  hipLaunchKernelGGL(lab4d::k_gauss_density_fwd, dim3(sgrid(S)), dim3(256), 0, (hipStream_t)stream, xyz, centres, B, ibeta, (long)S, out, best);
+  return check_launch("gauss_density_forward");
+}
+extern "C" int lab4d_gauss_density_backward(const float* xyz, const float* centres, int B, float ibeta, const int* best, const float* g, int S,
+                                            float* g_xyz, float* g_centres, float* g_ibeta, void* stream) {
+  LAB4D_REQUIRE(xyz && centres && best && g && g_centres, "gauss_density_backward: null pointer");
+  LAB4D_REQUIRE(B <= 64, "gauss_density_backward: B too large");
+  if (S == 0) return LAB4D_OK;
+  int grid = sgrid(S); if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(lab4d::k_gauss_density_bwd, dim3(grid), dim3(256), (3 * B + 1) * sizeof(float), (hipStream_t)stream, xyz, centres, B, ibeta, best, g,
+                     (long)S, g_xyz, g_centres, g_ibeta);
+  return check_launch("gauss_density_backward");
+}

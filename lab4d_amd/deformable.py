@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference's foreground field on the HIP kernels:
+Deformable.query_field (lab4d/nnutils/deformable.py:300-327 -> feature.py:89-134 -> nerf.py:580-684),
+NeRF.forward (nerf.py:167-215), backward/forward warps (deformable.py:119-171), compute_flow
+(nerf.py:948-997), cycle_loss (deformable.py:173-198), compute_feat / global_match / forward_project
+(feature.py:136-226), compute_gauss_density (deformable.py:329-356) and dvr_model.render_samples
+(engine/model.py:328-361) for field_type == "fg".
+
+Functional style: `P` maps the reference's state_dict names to device tensors, `fr` holds the per-frame
+inputs produced by the per-frame modules (camera / articulation / appearance / time / instance codes).
+Heavy per-sample work runs in liblab4d_hip.so; what is left in torch here is per-frame or per-ray glue plus
+a handful of element-wise epilogues that DESIGN.md lists as not yet folded into kernels.
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib, mlp
+from . import quat_utils as Q
+from . import render_utils as RU
+from .warping import skinning_warp
+
+vp, ci, cf = _lib.vp, _lib.ci, _lib.cf
+_lib.register("lab4d_gauss_density_forward", [vp, vp, ci, cf, ci, vp, vp, vp])
+_lib.register("lab4d_gauss_density_backward", [vp, vp, ci, cf, vp, vp, ci, vp, vp, vp, vp])
+
+
+def flip_pair(x):
+    """NeRF.flip_pair (nerf.py:929-946)."""
+    if torch.is_tensor(x):
+        if len(x) < 2:
+            return x
+        return x.view(x.shape[0] // 2, 2, -1).flip(1).view(x.shape)
+    if isinstance(x, tuple):
+        return tuple(flip_pair(t) for t in x)
+    if isinstance(x, dict):
+        return {k: flip_pair(v) for k, v in x.items()}
+    return x
+
+
+def _spf(x):
+    n = 1
+    for d in x.shape[1:-1]:
+        n *= d
+    return n
+
+
+def rigid_apply(q, t, x):
+    """quaternion_translation_apply with per-frame (M,4),(M,3) broadcast over (M,...,3) points
+    (field_to_cam, nerf.py:846-863):  (w^2 - v.v) x + 2 (v.x) v + 2 w (v x x) + t."""
+    shp = (x.shape[0],) + (1,) * (x.dim() - 2)
+    w = q[:, 0].view(shp + (1,))
+    v = q[:, 1:].view(shp + (3,))
+    out = (w * w - (v * v).sum(-1, keepdim=True)) * x + 2 * (v * x).sum(-1, keepdim=True) * v + 2 * w * torch.linalg.cross(v.expand_as(x), x)
+    return out + t.view(shp + (3,))
+
+
+def pinhole_projection(Kmat, xyz_cam):
+    """geom_utils.py:14-27."""
+    shp = (xyz_cam.shape[0],) + (1,) * (xyz_cam.dim() - 2)
+    K = Kmat.view(shp + (3, 3))
+    hxy = (K * xyz_cam.unsqueeze(-2)).sum(-1)
+    return hxy / (hxy[..., -1:] + 1e-6)
+
+
+class GaussDensity(Function):
+    @staticmethod
+    def forward(ctx, xyz, centres, ibeta):
+        xyz, centres = xyz.contiguous(), centres.contiguous()
+        _lib.require_device(xyz, centres)
+        S, B = xyz.shape[0], centres.shape[0]
+        out = torch.empty(S, 1, device=xyz.device)
+        best = torch.empty(S, dtype=torch.int32, device=xyz.device)
+        ib = float(ibeta)
+        _lib.check(_lib.lib().lab4d_gauss_density_forward(_lib.ptr(xyz), _lib.ptr(centres), B, ib, S, _lib.ptr(out), _lib.ptr(best), _lib.stream()),
+                   "gauss_density_forward")
+        ctx.save_for_backward(xyz, centres, best)
+        ctx.ib = ib
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xyz, centres, best = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(xyz)
+        gc = torch.zeros_like(centres)
+        gi = torch.zeros(1, device=xyz.device)
+        _lib.check(_lib.lib().lab4d_gauss_density_backward(_lib.ptr(xyz), _lib.ptr(centres), centres.shape[0], ctx.ib, _lib.ptr(best), _lib.ptr(g),
+                                                           xyz.shape[0], _lib.ptr(gx), _lib.ptr(gc), _lib.ptr(gi), _lib.stream()),
+                   "gauss_density_backward")
+        return gx, gc, gi
+
+
+def gauss_density(P, xyz, rest_articulation):
+    """Deformable.compute_gauss_density (deformable.py:329-356): bones of frame 0 at rest."""
+    _, centre = Q.dual_quaternion_to_quaternion_translation((rest_articulation[0][:1], rest_articulation[1][:1]))
+    ibeta = P["warp.logibeta"].exp()
+    out = GaussDensity.apply(xyz.reshape(-1, 3), centre[0], ibeta)
+    return out.view(xyz.shape[:-1] + (1,))
+
+
+def posenc_window(alpha, n_freq, device):
+    """PosEmbedding.apply_annealing window (embedding.py:112-125)."""
+    if alpha is None:
+        return None
+    w = torch.clamp(alpha * n_freq - torch.arange(n_freq, dtype=torch.float32, device=device), 0.0, 1.0)
+    return 0.5 * (1 + torch.cos(torch.pi * w + torch.pi))
+
+
+def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None):
+    """NeRF.forward (nerf.py:167-215), fg configuration (no view dependence, appearance code in the rgb head)."""
+    shape = xyz.shape
+    spf = _spf(xyz)
+    x = xyz.reshape(-1, 3)
+    dev = x.device
+    sdf, feat = mlp.run_chain(mlp.NET_FG_BASE, prec, P, x, spf, conds={0: fr["code_base"], 4: fr["code_base"]}, export_layer=8,
+                              freq_w=posenc_window(alpha, 10, dev))
+    sdf = sdf.view(shape[:-1] + (1,))
+    if get_density:
+        ibeta = P["logibeta"].exp()
+        out = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta  # VolSDF (nerf.py:186-192)
+    else:
+        out = sdf
+    if not with_color:
+        return out
+    rgb = mlp.run_chain(mlp.NET_FG_COLOR, prec, P, x, spf, conds={0: fr["code_color"], 3: fr["appr_code"]}, ext=feat,
+                        freq_w=posenc_window(alpha, 12, dev))
+    return torch.sigmoid(rgb).view(shape[:-1] + (3,)), out
+
+
+def vis_field(P, xyz, fr, prec):
+    """VisField.forward (visibility.py:53-63)."""
+    out = mlp.run_chain(mlp.NET_VIS, prec, P, xyz.reshape(-1, 3), _spf(xyz), conds={0: fr["code_vis"]})
+    return out.view(xyz.shape[:-1] + (1,))
+
+
+def compute_feat(P, xyz, prec):
+    """FeatureNeRF.compute_feat (feature.py:136-150)."""
+    f = mlp.run_chain(mlp.NET_FEAT, prec, P, xyz.reshape(-1, 3), _spf(xyz)).view(xyz.shape[:-1] + (16,))
+    return f / f.norm(dim=-1, keepdim=True)
+
+
+def global_match(P, feat_px, feat_canonical, xyz_canonical, perm):
+    """FeatureNeRF.global_match (feature.py:152-199): soft arg-max over <= 1024 host-drawn candidates."""
+    shape = feat_px.shape
+    fc = feat_canonical.reshape(-1, shape[-1])[perm]
+    xc = xyz_canonical.reshape(-1, 3)[perm]
+    prob = torch.softmax(feat_px.reshape(-1, shape[-1]) @ fc.t() * P["logsigma"].exp(), 1)
+    return (prob @ xc).view(shape[:-1] + (3,))
+
+
+def eikonal_subsample(P, xyz, code, rand_inds, alpha=None):
+    """NeRF.compute_eikonal (nerf.py:416-453) on the host-drawn 1/16 ray subset.  Needs d/dtheta of
+    |d sdf/dx| (double backward through the base MLP): this round it runs as plain device GEMMs under
+    torch autograd on the small subset; the tangent-mode chain kernel is listed as next in DESIGN.md."""
+    M, N, D, _ = xyz.shape
+    pts = xyz.reshape(-1, D, 3)
+    c = code[:, None].expand(M, N, code.shape[-1]).reshape(M * N, -1)
+    out = torch.zeros_like(pts[..., 0])
+    if rand_inds is None:
+        rand_inds = torch.arange(M * N, device=xyz.device)
+    with torch.enable_grad():
+        x = pts[rand_inds].detach().requires_grad_(True)
+        cc = c[rand_inds][:, None].expand(-1, D, -1)
+        sdf = _base_sdf_torch(P, x, cc, alpha)
+        (g,) = torch.autograd.grad(sdf, x, torch.ones_like(sdf), create_graph=True)
+    out = out.index_put((rand_inds,), (g.norm(2, dim=-1) - 1) ** 2)
+    return out.reshape(M, N, D, 1)
+
+
+def _posenc_torch(x, L, alpha):
+    freq = 2.0 ** torch.arange(L, dtype=x.dtype, device=x.device)
+    ang = freq[:, None] * x[..., None, :]
+    bands = torch.stack([torch.sin(ang), torch.cos(ang)], -2)
+    w = posenc_window(alpha, L, x.device)
+    if w is not None:
+        bands = bands * w[:, None, None]
+    return torch.cat([x, bands.reshape(x.shape[:-1] + (6 * L,))], -1)
+
+
+def _base_sdf_torch(P, x, code, alpha):
+    h0 = torch.cat([_posenc_torch(x, 10, alpha), code], -1)
+    out = h0
+    for i in range(8):
+        if i == 4:
+            out = torch.cat([h0, out], -1)
+        out = F.relu(F.linear(out, P[f"basefield.linear_{i+1}.0.weight"], P[f"basefield.linear_{i+1}.0.bias"]))
+    out = F.relu(F.linear(out, P["basefield.linear_final.0.weight"], P["basefield.linear_final.0.bias"]))
+    return F.linear(out, P["sdf.weight"], P["sdf.bias"])
+
+
+def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None, prec=mlp.PREC_F32):
+    """Training-mode Deformable.query_field for a SkinningWarp foreground (same contract as
+    oracle.lab4d_oracle.query_field_train)."""
+    cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
+    xyz_cam, dir_cam, deltas, depth, xyz_t, _ = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=n_depth)
+    xyz, bw_aux = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, prec)
+    fd = {}
+    vis = vis_field(P, xyz, fr, prec)
+    rgb, density = nerf_forward(P, xyz, fr, prec, alpha=alpha)
+    fd["rgb"], fd["density"], fd["density_fg"], fd["vis"] = rgb, density, density, vis
+    # flow: canonical points into the pair partner's camera (nerf.py:948-997)
+    nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam", "t_articulation", "rest_articulation"]})
+    xyz_next, _ = skinning_warp(P, xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"], fr["code_skin"], False, prec)
+    xyz_cam_next = rigid_apply(nxt["field2cam"][0], nxt["field2cam"][1], xyz_next)
+    hxy_next = pinhole_projection(Q.kmatinv(nxt["Kinv"]), xyz_cam_next)
+    flow = (hxy_next - hxy.unsqueeze(-2))[..., :2]
+    valid = xyz_cam_next[..., -1:] > 1e-6
+    if flow_thresh is not None:
+        valid = valid & (flow.norm(dim=-1, keepdim=True) < float(flow_thresh))
+    fd["flow"] = torch.cat([flow, valid.to(flow.dtype)], -1)
+    # cycle consistency (deformable.py:173-198)
+    xyz_cyc, cyc_aux = skinning_warp(P, xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], fr["code_skin"], False, prec)
+    fd["cyc_dist"] = (xyz_cyc - xyz_t).norm(2, -1, keepdim=True)
+    for k in ["skin_entropy", "delta_skin"]:
+        fd[k] = (cyc_aux[k] + bw_aux[k]) / 2
+    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha)
+    fd["xyz"] = xyz
+    fd["xyz_cam"] = xyz_cam
+    fd["depth"] = depth / P["logscale"].exp()
+    fd["feature"] = compute_feat(P, xyz, prec)
+    aux = {}
+    xyz_matches = global_match(P, fr["feature"], fd["feature"], xyz, rng["match_perm"])
+    xm_next, _ = skinning_warp(P, xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], fr["code_skin"],
+                               False, prec)
+    xyz_reproj = rigid_apply(fr["field2cam"][0], fr["field2cam"][1], xm_next)[:, :, 0]
+    aux["xyz_matches"] = xyz_matches
+    aux["xyz_reproj"] = xyz_reproj
+    aux["xy_reproj"] = pinhole_projection(Q.kmatinv(fr["Kinv"]), xyz_reproj)[..., :2]
+    fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
+    return fd, deltas, aux
+
+
+def render_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None, prec=mlp.PREC_F32):
+    """dvr_model.render_samples for field_type == "fg" (engine/model.py:328-361)."""
+    fd, deltas, aux = query_field_train(P, fr, hxy, rng, flow_thresh, n_depth, alpha, prec)
+    rendered = RU.render_pixel(fd, deltas)
+    aux_fg = dict(aux)
+    aux_fg.update(rendered)  # one field: the per-category render equals the composite (model.py:346-352)
+    rendered = dict(rendered)
+    rendered["xyz_matches"] = aux["xyz_matches"]
+    rendered["xyz_reproj"] = aux["xyz_reproj"]
+    return {"rendered": rendered, "aux_dict": {"fg": aux_fg}}
+
+
+# ---------------------------------------------------------------------------------------------------
+# losses (engine/model.py:401-611), per-ray element-wise glue
+# ---------------------------------------------------------------------------------------------------
+def mask_balance_wt(mask, vis2d, is_detected):
+    mask = mask.float()
+    vis2d = vis2d.float() * is_detected.float()[:, None, None]
+    if mask.sum() > 0 and (1 - mask).sum() > 0:
+        pos = vis2d.sum() / mask[vis2d > 0].sum()
+        neg = vis2d.sum() / (1 - mask[vis2d > 0]).sum()
+        return 0.5 * pos * mask + 0.5 * neg * (1 - mask)
+    return 1
+
+
+def losses_fg(results, batch, train_res, weights):
+    """compute_recon_loss + mask_losses + rendered regularisers + apply_loss_weights for field_type "fg"."""
+    r, a = results["rendered"], results["aux_dict"]["fg"]
+    L = {}
+    L["mask"] = (r["mask"] - batch["mask"].float()).pow(2) * mask_balance_wt(batch["mask"], batch["vis2d"], batch["is_detected"])
+    L["feature"] = (a["feature"] - batch["feature"]).norm(2, -1, keepdim=True)
+    L["feat_reproj"] = (a["xy_reproj"] - batch["hxy"][..., :2]).norm(2, -1, keepdim=True)
+    L["rgb"] = (r["rgb"] - batch["rgb"]).pow(2)
+    L["depth"] = (r["depth"] - batch["depth"]).norm(2, -1, keepdim=True)
+    L["flow"] = (r["flow"] - batch["flow"]).norm(2, -1, keepdim=True) * (batch["flow_uct"] > 0).float()
+    L["vis"] = a["vis"]
+    L["reg_gauss_mask"] = (a["gauss_mask"] - r["mask"].detach()).pow(2)
+    vis2d, mfg = batch["vis2d"].float(), batch["mask"].float()
+    det = batch["is_detected"].float()[:, None, None]
+    for k in list(L.keys()):
+        if k == "reg_gauss_mask":
+            continue
+        if k == "mask":
+            L[k] = L[k] * vis2d
+        elif k in ("feature", "feat_reproj"):
+            L[k] = L[k] * mfg
+        else:
+            L[k] = L[k] * (mfg * vis2d)
+        if k in ("mask", "feature", "feat_reproj"):
+            L[k] = L[k] * det
+    L["reg_eikonal"] = r["eikonal"]
+    L["reg_deform_cyc"] = a["cyc_dist"]
+    L["reg_delta_skin"] = a["delta_skin"]
+    L["reg_skin_entropy"] = a["skin_entropy"]
+    out = {}
+    for k, v in L.items():
+        v = v[v > 0].mean()
+        if k in ("flow", "feat_reproj"):
+            v = v / train_res
+        if weights is not None and k + "_wt" in weights:
+            v = v * weights[k + "_wt"]
+        out[k] = v
+    return out
+
+
+# lab4d/config.py:10-46 defaults
+DEFAULT_LOSS_WT = {
+    "mask_wt": 0.1, "rgb_wt": 0.1, "depth_wt": 1e-4, "flow_wt": 0.5, "vis_wt": 1e-2, "feature_wt": 1e-2, "feat_reproj_wt": 5e-2,
+    "reg_visibility_wt": 1e-4, "reg_eikonal_wt": 1e-3, "reg_deform_cyc_wt": 0.01, "reg_delta_skin_wt": 5e-3,
+    "reg_skin_entropy_wt": 5e-4, "reg_gauss_skin_wt": 1e-3, "reg_cam_prior_wt": 0.1, "reg_skel_prior_wt": 0.1,
+    "reg_gauss_mask_wt": 0.01, "reg_soft_deform_wt": 100.0,
+}
