@@ -158,3 +158,38 @@ def require_device(*tensors):
             raise RuntimeError("lab4d_amd ops need device (HIP) tensors; got a %s tensor -- there is no CPU path" % t.device)
         if not t.is_contiguous():
             raise RuntimeError("lab4d_amd ops need contiguous tensors")
+
+
+# --------------------------------------------------------------------------------------------------
+# optional per-kernel-family timing with HIP events on the launch stream (used by bench.py's roofline)
+# --------------------------------------------------------------------------------------------------
+PROF = None  # set to {} to enable: name -> list of (start_event, end_event, work)
+
+
+class timed:
+    """`with timed("mlp_fwd_base", flops): launch...` records HIP events around the launches on torch's
+    current stream (the stream the kernels are launched on)."""
+
+    def __init__(self, name, work=0.0):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if PROF is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROF is not None:
+            self.e.record()
+            PROF.setdefault(self.name, []).append((self.s, self.e, self.work))
+        return False
+
+
+def prof_summary():
+    """name -> (launches, total_ms, total_work). Call after torch.cuda.synchronize()."""
+    out = {}
+    for k, v in (PROF or {}).items():
+        out[k] = (len(v), sum(s.elapsed_time(e) for s, e, _ in v), sum(w for _, _, w in v))
+    return out

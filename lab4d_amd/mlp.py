@@ -52,6 +52,10 @@ _lib.register("lab4d_mlp_backward", [ctypes.POINTER(BwdArgs), vp])
 _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
 
+NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin"}
+# algorithmic MACs per sample (real layer shapes incl. conditioning columns)
+NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736}
+
 _DESC = {}
 
 
@@ -267,7 +271,8 @@ class MlpChain(Function):
             a.ext = ext.data_ptr()
         out = torch.empty(S, d.c_out, device=dev)
         a.out = out.data_ptr()
-        _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
+        with _lib.timed("mlp_fwd_%s" % NET_NAMES[net], 2.0 * S * NET_MACS[net]):
+            _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
         ctx.acts, ctx.emb, ctx.ext = acts, emb, ext
         ctx.params = params
@@ -318,7 +323,8 @@ class MlpChain(Function):
         if ctx.needs_input_grad[3]:
             d_x = torch.empty(ctx.x_shape, device=dev)
             a.d_x = d_x.data_ptr()
-        _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(a), _lib.stream()), "mlp_backward")
+        with _lib.timed("mlp_bwd_%s" % NET_NAMES[net], 2.0 * S * NET_MACS[net]):
+            _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(a), _lib.stream()), "mlp_backward")
         # weight / bias gradients
         M = (S + spf - 1) // spf
         grads_pf, grads_params = [], []
@@ -334,7 +340,8 @@ class MlpChain(Function):
                 dbk = torch.zeros(L.mout_pad, device=dev)
                 pfd = torch.zeros(M, L.mout_pad, device=dev) if need_pf else None
                 prev = ctx.acts[l - 1] if L.kin else None
-                _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, ld, spf, _lib.ptr(dz[l]), _lib.ptr(ctx.emb), _lib.ptr(prev),
+                with _lib.timed("mlp_wgrad", 2.0 * S * L.mout * (L.ke + L.kin)):
+                  _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, ld, spf, _lib.ptr(dz[l]), _lib.ptr(ctx.emb), _lib.ptr(prev),
                                                       _lib.ptr(dWk), _lib.ptr(dbk), _lib.ptr(pfd), M, _lib.stream()), "mlp_wgrad")
                 if need_w:
                     cm = col_map(net, l, dev).long()
