@@ -37,26 +37,32 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
   const typename P::store_t* ap[TM];
   const typename P::store_t* bp[TN];
   bool av_[TM], bv_[TN];
+  int bF[TN];  // feature rows of the buffer each B operand lives in (blocked layout stride)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int t = ob * TM + i;
     av_[i] = t < mo_tiles;
-    ap[i] = dz + (size_t)(32 * (av_[i] ? t : 0) + row) * ld;
+    ap[i] = dz + (size_t)(32 * (av_[i] ? t : 0) + row) * 64;
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int t = kb * TN + j;
     bv_[j] = t < nk_tiles;
     const int kr = 32 * (bv_[j] ? t : 0) + row;
-    bp[j] = kr < ke ? emb + (size_t)kr * ld : actp + (size_t)(kr - ke) * ld;
+    bp[j] = kr < ke ? emb + (size_t)kr * 64 : actp + (size_t)(kr - ke) * 64;
+    bF[j] = kr < ke ? ke : kin;
   }
   const int off = P::BF16 ? 8 * h : 4 * h;
+  const int moF = mo_tiles * 32;
   for (int s = s_begin; s < s_end; s += SPS) {
+    // blocked layout: sample s of feature row f lives at ((s/64)*F + f)*64 + s%64
+    const size_t blk = (size_t)(s >> 6);
+    const int in = (s & 63) + off;
     uint4 a4[TM], b4[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a4[i] = av_[i] ? *reinterpret_cast<const uint4*>(ap[i] + s + off) : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < TM; ++i) a4[i] = av_[i] ? *reinterpret_cast<const uint4*>(ap[i] + blk * block_stride(moF) + in) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b4[j] = bv_[j] ? *reinterpret_cast<const uint4*>(bp[j] + s + off) : make_uint4(0, 0, 0, 0);
+    for (int j = 0; j < TN; ++j) b4[j] = bv_[j] ? *reinterpret_cast<const uint4*>(bp[j] + blk * block_stride(bF[j]) + in) : make_uint4(0, 0, 0, 0);
     if (kb == 0 && db) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -117,15 +123,16 @@ __global__ void __launch_bounds__(256) k_rowsum_pf(const typename P::store_t* __
   if (job >= (long)mo_pad * nseg) return;
   const int o = (int)(job / nseg), seg = (int)(job % nseg);
   const long b = (long)seg * SEG, e = min((long)S, b + SEG);
-  const typename P::store_t* row = dz + (size_t)o * ld;
+  const typename P::store_t* row = dz + (size_t)o * 64;
   long i = b;
   while (i < e) {
     const int m = (int)(i / spf);
     const long fe = min(e, (long)(m + 1) * spf);
     float s = 0.f;
     for (long k = i + lane; k < fe; k += 64) {
-      if constexpr (P::BF16) s += bf2f(row[k]);
-      else s += row[k];
+      const size_t idx = (size_t)(k >> 6) * block_stride(mo_pad) + (k & 63);  // blocked [block][feature][64] (+skew)
+      if constexpr (P::BF16) s += bf2f(row[idx]);
+      else s += row[idx];
     }
     s = wave_sum(s);
     if (lane == 0) atomicAdd(pf_db + (size_t)m * mo_pad + o, s);

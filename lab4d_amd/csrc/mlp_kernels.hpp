@@ -49,7 +49,13 @@ __device__ __forceinline__ unsigned short f2bf(float x) {  // round to nearest e
   return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
-__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) { return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16); }
+// two fp32 -> packed bf16x2 with ONE v_cvt_pk_bf16_f32 (round-to-nearest-even in hardware).  The bit-twiddling
+// f2bf above costs ~7 VALU per value; with 64 conversions per M-tile it was as expensive as the tile's MFMAs.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+  const bf16x2_hw v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned int, v);
+}
 
 // feature (row) held by accumulator register r of lane-half h inside a 32-row tile
 __host__ __device__ __forceinline__ constexpr int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -100,39 +106,71 @@ __device__ __forceinline__ void tile_to_units(const f32x16_t& c, uint4* u) {
 }
 
 // ---- [feature][sample] tile IO in accumulator layout -------------------------------------------
-// bf16: lane n holds samples (s0+2n, s0+2n+1) packed in one dword ; fp32: sample s0+n.
+// A lane holds, per 4-feature group i, one dword per feature (bf16: samples (s0+2n, s0+2n+1) packed; fp32: sample
+// s0+n).  Storing those dwords one by one costs 16 four-byte store instructions per tile and is TA-issue-bound
+// (measured: the forward chain ran 2.3x slower with stores than without).  Instead the 4 lanes of a quad
+// (n = 4k+q) transpose their 4x4 dword block with two butterfly exchanges, after which lane q owns ONE feature
+// and 4 consecutive dwords (8 bf16 / 4 fp32 consecutive samples): one 16-byte store per group, 128-byte segments
+// per feature row.  Loads are the mirror image.
+__device__ __forceinline__ unsigned int quad_xor1(unsigned int v) { return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ unsigned int quad_xor2(unsigned int v) { return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ void quad_transpose(unsigned int (&a)[4], int q) {
+  {
+    const bool o = q & 1;
+    const unsigned int t0 = quad_xor1(o ? a[0] : a[1]), t1 = quad_xor1(o ? a[2] : a[3]);
+    a[0] = o ? t0 : a[0]; a[1] = o ? a[1] : t0; a[2] = o ? t1 : a[2]; a[3] = o ? a[3] : t1;
+  }
+  {
+    const bool o = q & 2;
+    const unsigned int t0 = quad_xor2(o ? a[0] : a[2]), t1 = quad_xor2(o ? a[1] : a[3]);
+    a[0] = o ? t0 : a[0]; a[2] = o ? a[2] : t0; a[1] = o ? t1 : a[1]; a[3] = o ? a[3] : t1;
+  }
+}
+
+// elements between consecutive 64-sample blocks: F*64 plus a 128-element skew.  Without the skew all concurrently
+// running waves (which march through their tiles in near lock-step) hit addresses that are equal modulo the block
+// size, i.e. the same HBM channel ("partition camping": measured 1.6x slower dgrad chain).
+__host__ __device__ __forceinline__ constexpr size_t block_stride(int F) { return (size_t)F * 64 + 128; }
+
 template <class P>
-__device__ __forceinline__ void store_tile(void* buf, int ld, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
-  const int n = lane & 31, h = lane >> 5;
-  if constexpr (P::BF16) {
-    unsigned int* p = reinterpret_cast<unsigned int*>(buf);
+__device__ __forceinline__ size_t tile_byte_offset(int F, int s0, int row, int k) {
+  return ((size_t)(s0 >> 6) * block_stride(F) + (size_t)row * 64 + (s0 & 63)) * sizeof(typename P::store_t) + 16 * (size_t)k;
+}
+
+template <class P>
+__device__ __forceinline__ void store_tile(void* buf, int F, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
+  const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
+  char* base = reinterpret_cast<char*>(buf);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const size_t row = (size_t)(32 * mt + drow(r, h));
-      p[(row * ld + s0) / 2 + n] = pack2bf(c[0][r], c[1][r]);
+  for (int i = 0; i < 4; ++i) {
+    unsigned int d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (P::BF16) d[j] = pack2bf(c[0][4 * i + j], c[1][4 * i + j]);
+      else d[j] = __float_as_uint(c[0][4 * i + j]);
     }
-  } else {
-    float* p = reinterpret_cast<float*>(buf);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p[(size_t)(32 * mt + drow(r, h)) * ld + s0 + n] = c[0][r];
+    quad_transpose(d, q);
+    *reinterpret_cast<uint4*>(base + tile_byte_offset<P>(F, s0, 32 * mt + 8 * i + 4 * h + q, k)) = make_uint4(d[0], d[1], d[2], d[3]);
   }
 }
 template <class P>
-__device__ __forceinline__ void load_tile(const void* buf, int ld, int s0, int mt, int lane, f32x16_t* c /*[NT]*/) {
-  const int n = lane & 31, h = lane >> 5;
-  if constexpr (P::BF16) {
-    const unsigned int* p = reinterpret_cast<const unsigned int*>(buf);
+__device__ __forceinline__ void load_tile(const void* buf, int F, int s0, int mt, int lane, f32x16_t* c /*[NT]*/) {
+  const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
+  const char* base = reinterpret_cast<const char*>(buf);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const size_t row = (size_t)(32 * mt + drow(r, h));
-      const unsigned int u = p[(row * ld + s0) / 2 + n];
-      c[0][r] = bf2f((unsigned short)(u & 0xffffu));
-      c[1][r] = bf2f((unsigned short)(u >> 16));
+  for (int i = 0; i < 4; ++i) {
+    const uint4 v = *reinterpret_cast<const uint4*>(base + tile_byte_offset<P>(F, s0, 32 * mt + 8 * i + 4 * h + q, k));
+    unsigned int d[4] = {v.x, v.y, v.z, v.w};
+    quad_transpose(d, q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (P::BF16) {
+        c[0][4 * i + j] = bf2f((unsigned short)(d[j] & 0xffffu));
+        c[1][4 * i + j] = bf2f((unsigned short)(d[j] >> 16));
+      } else {
+        c[0][4 * i + j] = __uint_as_float(d[j]);
+      }
     }
-  } else {
-    const float* p = reinterpret_cast<const float*>(buf);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c[0][r] = p[(size_t)(32 * mt + drow(r, h)) * ld + s0 + n];
   }
 }
 
@@ -218,14 +256,42 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       if constexpr (Net::EMB == 0) {
         const float x[3] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2]};
         if constexpr (P::BF16) {
+          // bf16 path: sin/cos(2^f x) by angle doubling from one accurate sincos per axis
+          // (sin 2a = 2 s c, cos 2a = 1 - 2 s^2).  The recurrence error doubles per octave (<= 2^11 * 6e-8 = 1.2e-4),
+          // far below the 4e-3 rounding of the bf16 operand it feeds; the fp32 path below keeps exact sincosf.
+          float sv[Net::NFREQ > 0 ? Net::NFREQ : 1][3], cv[Net::NFREQ > 0 ? Net::NFREQ : 1][3];
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            float sn, cs;
+            sincosf(x[ax], &sn, &cs);
+#pragma unroll
+            for (int f = 0; f < Net::NFREQ; ++f) {
+              sv[f][ax] = sn; cv[f][ax] = cs;
+              const float s2 = 2.f * sn * cs, c2 = 1.f - 2.f * sn * sn;
+              sn = s2; cs = c2;
+            }
+          }
 #pragma unroll
           for (int g = 0; g < UE; ++g) {
             unsigned int w[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {  // slots 16g + 8h + 2i, +1  = pair 8g + 4h + i
-              float v0, v1;
-              emb_pair<Net>(8 * g + 4 * h + i, x, a.freq_w, v0, v1);
-              w[i] = pack2bf(v0, v1);
+            for (int i = 0; i < 4; ++i) {  // slots 16g + 8h + 2i, +1  = pair 8g + 4h + i  (h selects one of two compile-time pairs)
+              float v0[2], v1[2];
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh) {
+                constexpr int L = Net::NFREQ;
+                const int pair = 8 * g + 4 * hh + i;  // compile-time after unrolling
+                if (pair < 3 * L) {
+                  const int f = pair / 3, ax = pair - 3 * f;
+                  const float wf = a.freq_w ? a.freq_w[f] : 1.0f;
+                  v0[hh] = sv[f < L ? f : 0][ax] * wf; v1[hh] = cv[f < L ? f : 0][ax] * wf;
+                } else {
+                  const int sl = 2 * pair - 6 * L;
+                  v0[hh] = sl < 3 ? x[sl < 3 ? sl : 0] : 0.f;
+                  v1[hh] = sl + 1 < 3 ? x[sl + 1 < 3 ? sl + 1 : 0] : 0.f;
+                }
+              }
+              w[i] = pack2bf(h ? v0[1] : v0[0], h ? v1[1] : v1[0]);
             }
             emb[t][g] = make_uint4(w[0], w[1], w[2], w[3]);
           }
@@ -266,28 +332,33 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         }
       }
     }
-    // store the embedding [slot][sample] for the backward / wgrad
+    // store the embedding [slot][sample] for the backward / wgrad (quad-transposed 16-byte stores, see store_tile)
     if (a.emb) {
-      if constexpr (P::BF16) {
-        unsigned int* p = reinterpret_cast<unsigned int*>(a.emb);
+      const int q = n & 3, kq = n >> 2;
+      char* base = reinterpret_cast<char*>(a.emb);
 #pragma unroll
-        for (int g = 0; g < UE; ++g) {
+      for (int g = 0; g < UE; ++g) {
+        if constexpr (P::BF16) {
+          // unit g: slots 16g + 8h + j (j = 0..7); emb[t][g] word (j>>1) half (j&1)
           const unsigned int w0[4] = {emb[0][g].x, emb[0][g].y, emb[0][g].z, emb[0][g].w};
           const unsigned int w1[4] = {emb[1][g].x, emb[1][g].y, emb[1][g].z, emb[1][g].w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const size_t row = 16 * g + 8 * h + j;
-            const unsigned int lo = (w0[j >> 1] >> (16 * (j & 1))) & 0xffffu, hi = (w1[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-            p[(row * a.ld + s0) / 2 + n] = lo | (hi << 16);
+          for (int half = 0; half < 2; ++half) {
+            unsigned int d[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int j = 4 * half + jj;
+              const unsigned int lo = (w0[j >> 1] >> (16 * (j & 1))) & 0xffffu, hi = (w1[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+              d[jj] = lo | (hi << 16);
+            }
+            quad_transpose(d, q);
+            *reinterpret_cast<uint4*>(base + tile_byte_offset<P>(KE, s0, 16 * g + 8 * h + 4 * half + q, kq)) = make_uint4(d[0], d[1], d[2], d[3]);
           }
-        }
-      } else {
-        float* p = reinterpret_cast<float*>(a.emb);
-#pragma unroll
-        for (int g = 0; g < UE; ++g) {
-          const unsigned int w[4] = {emb[0][g].x, emb[0][g].y, emb[0][g].z, emb[0][g].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) p[(size_t)(2 * (4 * g + e) + h) * a.ld + s0 + n] = __uint_as_float(w[e]);
+        } else {
+          // unit g: k-steps 4g+e, slot 2(4g+e) + h
+          unsigned int d[4] = {emb[0][g].x, emb[0][g].y, emb[0][g].z, emb[0][g].w};
+          quad_transpose(d, q);
+          *reinterpret_cast<uint4*>(base + tile_byte_offset<P>(KE, s0, 2 * (4 * g + q) + h, kq)) = make_uint4(d[0], d[1], d[2], d[3]);
         }
       }
     }
@@ -307,8 +378,14 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < GA; ++u) bin[t][u] = slab[(t * UW + u) * 64];
-#pragma nounroll
-      for (int mt = 0; mt < MT; ++mt) {
+      // Software-pipelined M-tile loop: the A groups of tile mt+1 are requested right after the MFMAs of tile mt
+      // have issued and BEFORE its activation stores.  vmcnt retires in order and counts stores too, so with the
+      // loads ahead of the stores in the queue the next tile never waits for a store acknowledgement.
+      auto load_tile_a = [&](int mt, uint4 (&A)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) A[g] = load_a(Wl, G, mt, g, lane);
+      };
+      auto body = [&](int mt, uint4 (&A)[G]) {
         f32x16_t acc[NT];
         // bias (+ per-frame bias): feature 32mt + 8i + 4h + (0..3)
 #pragma unroll
@@ -326,10 +403,12 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          const uint4 av = load_a(Wl, G, mt, g, lane);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], av, g < GE ? emb[t][g < GE ? g : 0] : bin[t][g >= GE ? g - GE : 0]);
+          for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], g < GE ? emb[t][g < GE ? g : 0] : bin[t][g >= GE ? g - GE : 0]);
         }
+        // A is consumed once the MFMAs have issued: request the next tile's groups now, ahead of this tile's
+        // stores in the (in-order) vmcnt queue; their L2 latency hides behind the epilogue below.
+        if (mt + 1 < MT) load_tile_a(mt + 1, A);
         if constexpr (ls.relu != 0) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -338,13 +417,13 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         }
         if constexpr (ls.add_ext != 0) {
           f32x16_t e[NT];
-          load_tile<P>(a.ext, a.ld, s0, mt, lane, e);
+          load_tile<P>(a.ext, 32 * MT, s0, mt, lane, e);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] += e[t][r];
         }
-        if (a.act[l]) store_tile<P>(a.act[l], a.ld, s0, mt, lane, acc);
+        if (a.act[l]) store_tile<P>(a.act[l], 32 * MT, s0, mt, lane, acc);
         if constexpr (l + 1 < Net::NL) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
@@ -363,7 +442,11 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
               if (f < Net::COUT && sidx[t] < a.S) a.out[(size_t)sidx[t] * Net::COUT + f] = acc[t][r];
             }
         }
-      }
+      };
+      uint4 A[G];
+      load_tile_a(0, A);
+#pragma nounroll
+      for (int mt = 0; mt < MT; ++mt) body(mt, A);
     });
   }
 }
@@ -406,7 +489,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
           const int f = drow(r, h);
           g[t][r] = (f < Net::COUT && sidx[t] < a.S) ? a.d_out[(size_t)sidx[t] * Net::COUT + f] : 0.f;
         }
-      if (a.dz[NL - 1]) store_tile<P>(a.dz[NL - 1], a.ld, s0, 0, lane, g);
+      if (a.dz[NL - 1]) store_tile<P>(a.dz[NL - 1], pad32(Net::L[NL - 1].mout), s0, 0, lane, g);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         uint4 u[P::UPT];
@@ -428,118 +511,123 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
 #pragma unroll
         for (int u = 0; u < GK; ++u) bin[t][u] = slab[(t * UW + u) * 64];
 
+      constexpr int MTT_ = MTE + ((l > 0 && MTA > 0) ? MTA : 0);
+      auto load_tile_a = [&](int mt, uint4 (&A)[GK]) {
+#pragma unroll
+        for (int g = 0; g < GK; ++g) A[g] = load_a(Wt, GK, mt, g, lane);
+      };
+      auto dgrad = [&](int mt_next, uint4 (&A)[GK], f32x16_t (&acc)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < GK; ++g) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], bin[t][g]);
+        }
+        if (mt_next < MTT_) load_tile_a(mt_next, A);  // prefetch the next row tile behind the epilogue
+      };
       // (a) gradient wrt the embedding slots -> input gradient
-      if constexpr (MTE > 0) {
-        if (a.d_x) {
-#pragma nounroll
-          for (int mt = 0; mt < MTE; ++mt) {
-            f32x16_t acc[NT];
+      auto body_emb = [&](int mt, uint4 (&A)[GK]) {
+        f32x16_t e[NT];
+        if constexpr (Net::EMB == 0) load_tile<P>(a.emb, Net::KE, s0, mt, lane, e);  // requested before the MFMAs
+        f32x16_t acc[NT];
+        dgrad(mt + 1, A, acc);
+        if constexpr (Net::EMB == 0) {
+          constexpr int L = Net::NFREQ;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int slot = 32 * mt + drow(r, h);
+              const float gv = acc[t][r];
+              if (slot < 6 * L) {
+                const int pair = slot >> 1, f = pair / 3, ax = pair - 3 * f;
+                // d/dx [w sin(2^f x)] = 2^f (w cos) ; d/dx [w cos(2^f x)] = -2^f (w sin): partner slot = register r^1
+                const float partner = e[t][r ^ 1];
+                const float c = ldexpf((r & 1) ? -partner : partner, f) * gv;
+                dx[t][0] += ax == 0 ? c : 0.f;
+                dx[t][1] += ax == 1 ? c : 0.f;
+                dx[t][2] += ax == 2 ? c : 0.f;
+              } else if (slot < 6 * L + 3) {
+                const int ax = slot - 6 * L;
+                dx[t][0] += ax == 0 ? gv : 0.f;
+                dx[t][1] += ax == 1 ? gv : 0.f;
+                dx[t][2] += ax == 2 ? gv : 0.f;
+              }
+            }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int c = 32 * mt + drow(r, h);
+              if (c < Net::CIN && sidx[t] < a.S) a.d_x[(size_t)sidx[t] * Net::CIN + c] = acc[t][r];
+            }
+        }
+      };
+      // (b) gradient wrt the previous layer's output -> masked dZ_{l-1}
+      auto body_act = [&](int j, uint4 (&A)[GK]) {
+        constexpr LS lp = Net::L[l > 0 ? l - 1 : 0];
+        f32x16_t y[NT], eg[NT], ex[NT];
+        // all HBM reads of this tile are requested before its MFMAs
+        if constexpr (lp.relu != 0) load_tile<P>(a.act[l > 0 ? l - 1 : 0], pad32(lp.mout), s0, j, lane, y);
+        if constexpr (lp.ext_grad != 0) load_tile<P>(a.ext_gin, pad32(lp.mout), s0, j, lane, eg);
+        if constexpr (lp.relu != 0 && lp.add_ext != 0) load_tile<P>(a.ext, pad32(lp.mout), s0, j, lane, ex);
+        f32x16_t acc[NT];
+        dgrad(MTE + j + 1, A, acc);
+        if constexpr (lp.ext_grad != 0) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += eg[t][r];
+        }
+        if constexpr (lp.add_ext != 0) {
+          if (a.ext_gout) store_tile<P>(a.ext_gout, pad32(lp.mout), s0, j, lane, acc);  // y = relu(z) + ext  ->  dL/dext = dL/dy
+        }
+        if constexpr (lp.relu != 0) {
+          if constexpr (lp.add_ext != 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#pragma unroll
-            for (int g = 0; g < GK; ++g) {
-              const uint4 av = load_a(Wt, GK, mt, g, lane);
-#pragma unroll
-              for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], av, bin[t][g]);
-            }
-            if constexpr (Net::EMB == 0) {
-              f32x16_t e[NT];
-              load_tile<P>(a.emb, a.ld, s0, mt, lane, e);
-              constexpr int L = Net::NFREQ;
-#pragma unroll
-              for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                  const int slot = 32 * mt + drow(r, h);
-                  const float gv = acc[t][r];
-                  if (slot < 6 * L) {
-                    const int pair = slot >> 1, f = pair / 3, ax = pair - 3 * f;
-                    // d/dx [w sin(2^f x)] = 2^f (w cos) ; d/dx [w cos(2^f x)] = -2^f (w sin): partner slot = register r^1
-                    const float partner = e[t][r ^ 1];
-                    const float c = ldexpf((r & 1) ? -partner : partner, f) * gv;
-                    dx[t][0] += ax == 0 ? c : 0.f;
-                    dx[t][1] += ax == 1 ? c : 0.f;
-                    dx[t][2] += ax == 2 ? c : 0.f;
-                  } else if (slot < 6 * L + 3) {
-                    const int ax = slot - 6 * L;
-                    dx[t][0] += ax == 0 ? gv : 0.f;
-                    dx[t][1] += ax == 1 ? gv : 0.f;
-                    dx[t][2] += ax == 2 ? gv : 0.f;
-                  }
-                }
-            } else {
-#pragma unroll
-              for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                  const int c = 32 * mt + drow(r, h);
-                  if (c < Net::CIN && sidx[t] < a.S) a.d_x[(size_t)sidx[t] * Net::CIN + c] = acc[t][r];
-                }
-            }
+              for (int r = 0; r < 16; ++r) y[t][r] -= ex[t][r];
           }
-        }
-      }
-      // (b) gradient wrt the previous layer's output -> masked dZ_{l-1}
-      if constexpr (l > 0 && MTA > 0) {
-        constexpr LS lp = Net::L[l - 1];
-#pragma nounroll
-        for (int j = 0; j < MTA; ++j) {
-          const int mt = MTE + j;
-          f32x16_t acc[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = y[t][r] > 0.f ? acc[t][r] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (sidx[t] >= a.S) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#pragma unroll
-          for (int g = 0; g < GK; ++g) {
-            const uint4 av = load_a(Wt, GK, mt, g, lane);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], av, bin[t][g]);
           }
-          if constexpr (lp.ext_grad != 0) {
-            f32x16_t e[NT];
-            load_tile<P>(a.ext_gin, a.ld, s0, j, lane, e);
+        if (a.dz[l > 0 ? l - 1 : 0]) store_tile<P>(a.dz[l > 0 ? l - 1 : 0], pad32(lp.mout), s0, j, lane, acc);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+          uint4 u[P::UPT];
+          tile_to_units<P>(acc[t], u);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[t][r] += e[t][r];
-          }
-          if constexpr (lp.add_ext != 0) {
-            if (a.ext_gout) store_tile<P>(a.ext_gout, a.ld, s0, j, lane, acc);  // y = relu(z) + ext  ->  dL/dext = dL/dy
-          }
-          if constexpr (lp.relu != 0) {
-            f32x16_t y[NT];
-            load_tile<P>(a.act[l - 1], a.ld, s0, j, lane, y);
-            if constexpr (lp.add_ext != 0) {
-              f32x16_t e[NT];
-              load_tile<P>(a.ext, a.ld, s0, j, lane, e);
-#pragma unroll
-              for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) y[t][r] -= e[t][r];
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[t][r] = y[t][r] > 0.f ? acc[t][r] : 0.f;
-          }
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            if (sidx[t] >= a.S) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            }
-          if (a.dz[l - 1]) store_tile<P>(a.dz[l - 1], a.ld, s0, j, lane, acc);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            uint4 u[P::UPT];
-            tile_to_units<P>(acc[t], u);
-#pragma unroll
-            for (int q = 0; q < P::UPT; ++q) slab[(t * UW + P::UPT * j + q) * 64] = u[q];
-          }
+          for (int q = 0; q < P::UPT; ++q) slab[(t * UW + P::UPT * j + q) * 64] = u[q];
         }
+      };
+      constexpr bool DO_ACT = (l > 0 && MTA > 0);
+      const bool do_emb = MTE > 0 && a.d_x != nullptr;
+      constexpr int MTT = MTE + (DO_ACT ? MTA : 0);  // row tiles of W^T visited: embedding tiles first
+      auto run_tile = [&](int mt, uint4 (&A)[GK]) {
+        if (mt < MTE) {
+          if (do_emb) body_emb(mt, A);
+          else if (mt + 1 < MTT) load_tile_a(mt + 1, A);
+        }
+        else if constexpr (DO_ACT) body_act(mt - MTE, A);
+      };
+      if constexpr (MTT > 0) {
+        uint4 A[GK];
+        load_tile_a(0, A);
+#pragma nounroll
+        for (int mt = 0; mt < MTT; ++mt) run_tile(mt, A);
       }
     });
 

@@ -150,7 +150,7 @@ def global_match(P, feat_px, feat_canonical, xyz_canonical, perm):
     return (prob @ xc).view(shape[:-1] + (3,))
 
 
-def eikonal_subsample(P, xyz, code, rand_inds, alpha=None):
+def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, bf16=False):
     """NeRF.compute_eikonal (nerf.py:416-453) on the host-drawn 1/16 ray subset.  Needs d/dtheta of
     |d sdf/dx| (double backward through the base MLP): this round it runs as plain device GEMMs under
     torch autograd on the small subset; the tangent-mode chain kernel is listed as next in DESIGN.md."""
@@ -160,11 +160,12 @@ def eikonal_subsample(P, xyz, code, rand_inds, alpha=None):
     out = torch.zeros_like(pts[..., 0])
     if rand_inds is None:
         rand_inds = torch.arange(M * N, device=xyz.device)
-    with torch.enable_grad():
+    with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
         x = pts[rand_inds].detach().requires_grad_(True)
         cc = c[rand_inds][:, None].expand(-1, D, -1)
         sdf = _base_sdf_torch(P, x, cc, alpha)
         (g,) = torch.autograd.grad(sdf, x, torch.ones_like(sdf), create_graph=True)
+    g = g.float()
     out = out.index_put((rand_inds,), (g.norm(2, dim=-1) - 1) ** 2)
     return out.reshape(M, N, D, 1)
 
@@ -215,7 +216,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     fd["cyc_dist"] = (xyz_cyc - xyz_t).norm(2, -1, keepdim=True)
     for k in ["skin_entropy", "delta_skin"]:
         fd[k] = (cyc_aux[k] + bw_aux[k]) / 2
-    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha)
+    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha, bf16=(prec == mlp.PREC_BF16))
     fd["xyz"] = xyz
     fd["xyz_cam"] = xyz_cam
     fd["depth"] = depth / P["logscale"].exp()

@@ -202,10 +202,15 @@ def s_pad_of(S):
     return (S + 63) // 64 * 64
 
 
+def buf_numel(F, S_pad):
+    """Elements of a stored-activation buffer: (S_pad/64) blocks of F*64 (+128 skew) elements (mlp_kernels.hpp block_stride)."""
+    return (S_pad // 64) * (F * 64 + 128)
+
+
 def ld_of(S_pad, prec):
     """Row stride of the [feature][sample] buffers.  +4352 bytes per row (17 x 256 B): with a power-of-two
     stride every feature row of a tile lands in the same HBM channel (measured 1 TB/s instead of >4)."""
-    return S_pad + (2176 if prec == PREC_BF16 else 1088)
+    return S_pad  # blocked [sample-block][feature][64] layout: no row-stride padding needed
 
 
 class MlpChain(Function):
@@ -258,11 +263,11 @@ class MlpChain(Function):
                 pf_used[l] = pf
                 keep.append(pf)
             if (need_grad and l + 1 < NL) or l == export_layer:
-                acts[l] = torch.empty(L.mout_pad, ld, dtype=sdt, device=dev)
+                acts[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
                 a.act[l] = acts[l].data_ptr()
         emb = None
         if need_grad:
-            emb = torch.empty(d.ke, ld, dtype=sdt, device=dev)
+            emb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
             a.emb = emb.data_ptr()
         if ext is not None:
             ext = ext.contiguous()
@@ -302,11 +307,11 @@ class MlpChain(Function):
             keep.append(pw)
             if ctx.acts[l] is not None:
                 a.act[l] = ctx.acts[l].data_ptr()
-            dz[l] = torch.empty(L.mout_pad, ld, dtype=sdt, device=dev)
+            dz[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
             a.dz[l] = dz[l].data_ptr()
             if L.ext_grad:
                 if d_export is None:
-                    d_export = torch.zeros(L.mout_pad, ld, dtype=sdt, device=dev)
+                    d_export = torch.zeros(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
                 d_export = d_export.contiguous()
                 a.ext_gin = d_export.data_ptr()
         if ctx.emb is not None:
