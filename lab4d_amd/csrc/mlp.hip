@@ -5,20 +5,24 @@
 namespace lab4d {
 
 // =================================================================================================
-// weight gradient: dW[o][k] += sum_s dz[o][s] X[k][s]   (both operands [feature][sample])
+// weight gradient: dW[o][k] += sum_s dz[o][s] X[k][s]   (both operands stored [block][feature][64 samples])
 // =================================================================================================
+// A workgroup (4 waves) owns one (TM x 4)-tile block of dW and one chunk of samples.  The 4 waves take the
+// 16-sample (bf16) / 8-sample (fp32) steps of the chunk round-robin, so together they consume every 128-byte line
+// exactly once; each wave keeps its TM x 4 accumulator tiles in registers, prefetches the operands of its next
+// step while the MFMAs of the current one run, and at the end the 4 partial blocks are summed through LDS
+// (ds_add_f32) so that only one set of global atomics per workgroup is issued.
 template <class P, int TM>
 __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __restrict__ dz, const typename P::store_t* __restrict__ emb,
                                                     const typename P::store_t* __restrict__ actp, int mo_tiles, int ke, int kin,
-                                                    int S_pad, int ld, int chunk, float* __restrict__ dW, float* __restrict__ db) {
+                                                    int S_pad, int chunk, float* __restrict__ dW, float* __restrict__ db) {
   constexpr int TN = 4;
   constexpr int SPS = P::BF16 ? 16 : 8;  // samples per step
-  const int lane = threadIdx.x & 63, row = lane & 31, h = lane >> 5;
+  __shared__ float red[TM * TN * 16 * 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
   const int K = ke + kin, nk_tiles = K / 32;
   const int ob_n = (mo_tiles + TM - 1) / TM, kb_n = (nk_tiles + TN - 1) / TN;
-  const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nchunks = (S_pad + chunk - 1) / chunk;
-  if (job >= ob_n * kb_n * nchunks) return;
+  const int job = blockIdx.x;
   const int c = job / (ob_n * kb_n), rem = job - c * (ob_n * kb_n);
   const int ob = rem / kb_n, kb = rem - ob * kb_n;
   const int s_begin = c * chunk, s_end = min(S_pad, s_begin + chunk);
@@ -54,15 +58,16 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
   }
   const int off = P::BF16 ? 8 * h : 4 * h;
   const int moF = mo_tiles * 32;
-  for (int s = s_begin; s < s_end; s += SPS) {
-    // blocked layout: sample s of feature row f lives at ((s/64)*F + f)*64 + s%64
+  auto load_step = [&](int s, uint4 (&a4)[TM], uint4 (&b4)[TN]) {
+    // blocked layout: sample s of feature row f lives at (s/64)*block_stride(F) + f*64 + s%64
     const size_t blk = (size_t)(s >> 6);
     const int in = (s & 63) + off;
-    uint4 a4[TM], b4[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) a4[i] = av_[i] ? *reinterpret_cast<const uint4*>(ap[i] + blk * block_stride(moF) + in) : make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) b4[j] = bv_[j] ? *reinterpret_cast<const uint4*>(bp[j] + blk * block_stride(bF[j]) + in) : make_uint4(0, 0, 0, 0);
+  };
+  auto compute = [&](const uint4 (&a4)[TM], const uint4 (&b4)[TN]) {
     if (kb == 0 && db) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -78,36 +83,57 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if constexpr (P::BF16) {
-          bf16x8_t x, y;
-          __builtin_memcpy(&x, &a4[i], 16);
-          __builtin_memcpy(&y, &b4[j], 16);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0);
-        } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4[i].x), __uint_as_float(b4[j].x), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4[i].y), __uint_as_float(b4[j].y), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4[i].z), __uint_as_float(b4[j].z), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4[i].w), __uint_as_float(b4[j].w), acc[i][j], 0, 0, 0);
-        }
-      }
+      for (int j = 0; j < TN; ++j) mma_unit<P>(acc[i][j], a4[i], b4[j]);
+  };
+  // software pipeline, depth 1, two statically-named buffers
+  const int step = 4 * SPS;
+  int s = s_begin + wid * SPS;
+  uint4 a0[TM], b0[TN], a1[TM], b1[TN];
+  if (s < s_end) load_step(s, a0, b0);
+  while (s < s_end) {
+    const int s1 = s + step;
+    if (s1 < s_end) load_step(s1, a1, b1);
+    compute(a0, b0);
+    if (s1 >= s_end) break;
+    const int s2 = s1 + step;
+    if (s2 < s_end) load_step(s2, a0, b0);
+    compute(a1, b1);
+    s = s2;
   }
+  // ---- cross-wave reduction through LDS, then one set of global atomics per workgroup ----
+  if (wid == 0) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    if (!av_[i]) continue;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      if (!bv_[j]) continue;
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = 32 * (ob * TM + i) + drow(r, h);
-        const int k = 32 * (kb * TN + j) + row;
-        atomicAdd(dW + (size_t)o * K + k, acc[i][j][r]);
-      }
+        for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (wid != 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(&red[((i * TN + j) * 16 + r) * 64 + lane], acc[i][j][r]);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < TM * TN * 16 * 64; e += 256) {
+    const int l2 = e & 63, r = (e >> 6) & 15, ij = e >> 10;
+    const int i = ij / TN, j = ij - i * TN;
+    const int to = ob * TM + i, tk = kb * TN + j;
+    if (to < mo_tiles && tk < nk_tiles) {
+      const int o = 32 * to + drow(r, l2 >> 5);
+      const int k = 32 * tk + (l2 & 31);
+      atomicAdd(dW + (size_t)o * K + k, red[e]);
     }
-    if (kb == 0 && db) {
+  }
+  if (kb == 0 && db) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
       const float v = rs[i] + __shfl_xor(rs[i], 32, 64);
-      if (h == 0) atomicAdd(db + 32 * (ob * TM + i) + row, v);
+      if (h == 0 && av_[i]) atomicAdd(db + 32 * (ob * TM + i) + row, v);
     }
   }
 }
@@ -294,15 +320,15 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   const int mo_tiles = L.mout_pad / 32, nk_tiles = (L.ke + L.kin) / 32;
   const int TM = mo_tiles >= 4 ? 4 : (mo_tiles >= 2 ? 2 : 1);
   const int ob_n = div_up(mo_tiles, TM), kb_n = div_up(nk_tiles, 4);
-  // ~2048 wave jobs in total; chunks are multiples of 64 samples
-  int nchunks = 2048 / (ob_n * kb_n); if (nchunks < 1) nchunks = 1;
-  int chunk = div_up(div_up(S_pad, nchunks), 64) * 64; if (chunk < 256) chunk = 256;
+  // ~1024 workgroups in total (4 per CU); chunks are multiples of 256 samples (one 64-sample step per wave)
+  int nchunks = 1024 / (ob_n * kb_n); if (nchunks < 1) nchunks = 1;
+  int chunk = div_up(div_up(S_pad, nchunks), 256) * 256; if (chunk < 1024) chunk = 1024;
   nchunks = div_up(S_pad, chunk);
   const int jobs = ob_n * kb_n * nchunks;
-  const dim3 grid(div_up(jobs, 4)), block(256);
+  const dim3 grid(jobs), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define WG(P, TMV) hipLaunchKernelGGL((k_mlp_wgrad<P, TMV>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
-                                      (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, ld, chunk, dW, db)
+                                      (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, dW, db)
   if (precision == LAB4D_PREC_BF16) { if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
   else if (precision == LAB4D_PREC_F32) { if (TM == 4) WG(PF32, 4); else if (TM == 2) WG(PF32, 2); else WG(PF32, 1); }
   else { set_error("mlp_wgrad: bad precision %d", precision); return LAB4D_EINVAL; }
