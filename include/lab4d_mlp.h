@@ -116,7 +116,7 @@ int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream);
 /* Weight / bias gradients of one layer: dW[o][k] = sum_s dz[o][s] * X[k][s], db[o] = sum_s dz[o][s],
  * X = [emb (ke rows) ; act_prev (kin rows)].  dW: (mout_pad, ke+kin) fp32 row-major, db: (mout_pad);
  * both are ACCUMULATED into (atomicAdd) -- zero-fill first.  pf_db: (M, mout_pad) per-frame bias
- * gradient or NULL. */
+ * gradient or NULL (accumulated, zero-fill first).  When pf_db is given, db is NOT written: db = sum_m pf_db[m]. */
 int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int ld, int spf, const void* dz, const void* emb,
                     const void* act_prev, float* dW, float* db, float* pf_db, int M, void* stream);
 

@@ -19,7 +19,9 @@
  * art_r, art_d: (M,B,4) real / dual parts of the bone-to-object dual quaternions; gauss: (B,3). */
 int lab4d_bone_coords_forward(const float* xyz, const float* art_r, const float* art_d, const float* gauss, int S,
                               int spf, int M, int B, float* xyz_bone, void* stream);
-/* g_bone (S,3B) -> g_xyz (S,3) written; g_art_r, g_art_d (M,B,4), g_gauss (B,3) accumulated (zero-fill first). */
+/* g_bone (S,3B) -> g_xyz (S,3) written; g_art_r, g_art_d (M,B,4), g_gauss (B,3) accumulated (zero-fill first).
+ * The three parameter gradients may be NULL: the host then derives them from lab4d_gram_per_frame(g_bone, [xyz,1])
+ * (the bone transform is affine in the point), which reads g_bone once instead of once per bone. */
 int lab4d_bone_coords_backward(const float* xyz, const float* art_r, const float* art_d, const float* gauss,
                                const float* g_bone, int S, int spf, int M, int B, float* g_xyz, float* g_art_r,
                                float* g_art_d, float* g_gauss, void* stream);
@@ -31,18 +33,24 @@ int lab4d_skin_blend_forward(const float* xyz, const float* xyz_bone, const floa
                              const float* se3_d, int S, int spf, int M, int B, float* out, float* entropy,
                              float* dskin, void* stream);
 /* Adjoint.  g_ent / g_dskin may be NULL.  Writes g_xyz (S,3), g_bone (S,3B), g_raw (S,B); accumulates
- * g_se3_r, g_se3_d (M,B,4) (zero-fill first).  `work` is scratch of S*(B+8) floats. */
+ * g_se3 (M,B,8) = [d/d se3_r (4) | d/d se3_d (4)] (zero-fill first).  `work` is scratch of S*(B+8) floats. */
 int lab4d_skin_blend_backward(const float* xyz, const float* xyz_bone, const float* delta_raw, const float* se3_r,
                               const float* se3_d, const float* g_out, const float* g_ent, const float* g_dskin,
                               int S, int spf, int M, int B, float* g_xyz, float* g_bone, float* g_raw,
-                              float* g_se3_r, float* g_se3_d, float* work, void* stream);
+                              float* g_se3, float* work, void* stream);
 
 /* Gaussian-bone density  max_b exp(-0.5 |x - c_b|^2 / 0.01^2) * ibeta  (nnutils/deformable.py:329-356,
- * warping.py:355-387, utils/transforms.py:28-40).  centres: (B,3).  best: (S) int32 arg-min bone (saved for
+ * warping.py:355-387, utils/transforms.py:28-40).  centres: (B,3); ibeta: device scalar (no host sync).
+ * best: (S) int32 arg-min bone (saved for
  * the adjoint).  Backward writes g_xyz (S,3) and accumulates g_centres (B,3), g_ibeta (1). */
-int lab4d_gauss_density_forward(const float* xyz, const float* centres, int B, float ibeta, int S, float* out,
+int lab4d_gauss_density_forward(const float* xyz, const float* centres, int B, const float* ibeta, int S, float* out,
                                 int* best, void* stream);
-int lab4d_gauss_density_backward(const float* xyz, const float* centres, int B, float ibeta, const int* best,
+int lab4d_gauss_density_backward(const float* xyz, const float* centres, int B, const float* ibeta, const int* best,
                                  const float* g, int S, float* g_xyz, float* g_centres, float* g_ibeta, void* stream);
+
+/* Per-frame tall-skinny product out[m][i][j] += sum_{s in frame m} A[s][i] * Bm[s][j]  (A: (S,CA<=80), Bm: (S,CB<=8),
+ * out: (M,CA,CB), accumulated).  All per-frame parameter gradients of the skinning warp reduce to this form
+ * (bone transforms are affine in the point, the blended dual quaternion is linear in the skin weights). */
+int lab4d_gram_per_frame(const float* A, int CA, const float* Bm, int CB, int S, int spf, int M, float* out, void* stream);
 
 #endif /* LAB4D_SKIN_H */

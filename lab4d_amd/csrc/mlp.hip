@@ -15,7 +15,7 @@ namespace lab4d {
 template <class P, int TM>
 __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __restrict__ dz, const typename P::store_t* __restrict__ emb,
                                                     const typename P::store_t* __restrict__ actp, int mo_tiles, int ke, int kin,
-                                                    int S_pad, int chunk, float* __restrict__ dW, float* __restrict__ db) {
+                                                    int S_pad, int chunk, int spf, int cpf, float* __restrict__ dW, float* __restrict__ db) {
   constexpr int TN = 4;
   constexpr int SPS = P::BF16 ? 16 : 8;  // samples per step
   __shared__ float red[TM * TN * 16 * 64];
@@ -25,7 +25,19 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
   const int job = blockIdx.x;
   const int c = job / (ob_n * kb_n), rem = job - c * (ob_n * kb_n);
   const int ob = rem / kb_n, kb = rem - ob * kb_n;
-  const int s_begin = c * chunk, s_end = min(S_pad, s_begin + chunk);
+  // cpf > 0: chunks are laid out per frame (cpf chunks per frame) and `db` is the per-frame bias gradient (M, mo_pad)
+  int s_begin, s_end;
+  if (cpf > 0) {
+    const int m = c / cpf, lc = c - m * cpf;
+    s_begin = m * spf + lc * chunk;
+    s_end = min(min(S_pad, (m + 1) * spf), s_begin + chunk);
+    if (db) db += (size_t)m * (mo_tiles * 32);
+    // the last frame also owns the zero-padded tail samples
+    if (s_end == (m + 1) * spf && S_pad - s_end < 64 && S_pad > s_end) s_end = S_pad;
+  } else {
+    s_begin = c * chunk;
+    s_end = min(S_pad, s_begin + chunk);
+  }
 
   f32x16_t acc[TM][TN];
 #pragma unroll
@@ -323,18 +335,29 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   // ~1024 workgroups in total (4 per CU); chunks are multiples of 256 samples (one 64-sample step per wave)
   int nchunks = 1024 / (ob_n * kb_n); if (nchunks < 1) nchunks = 1;
   int chunk = div_up(div_up(S_pad, nchunks), 256) * 256; if (chunk < 1024) chunk = 1024;
-  nchunks = div_up(S_pad, chunk);
+  // per-frame bias gradient folded into this kernel when frames are 256-sample aligned: chunks never straddle a
+  // frame and the row sums of dz go straight to pf_db (saves a second pass over dz)
+  const bool fold_pf = pf_db != nullptr && spf % 256 == 0 && M > 0 && (long)M * spf >= S;
+  int cpf = 0;
+  if (fold_pf) {
+    if (chunk > spf) chunk = spf;
+    cpf = div_up(spf, chunk);
+    nchunks = cpf * M;
+  } else {
+    nchunks = div_up(S_pad, chunk);
+  }
   const int jobs = ob_n * kb_n * nchunks;
   const dim3 grid(jobs), block(256);
+  float* db_arg = fold_pf ? pf_db : db;
   hipStream_t st = (hipStream_t)stream;
 #define WG(P, TMV) hipLaunchKernelGGL((k_mlp_wgrad<P, TMV>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
-                                      (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, dW, db)
+                                      (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
   if (precision == LAB4D_PREC_BF16) { if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
   else if (precision == LAB4D_PREC_F32) { if (TM == 4) WG(PF32, 4); else if (TM == 2) WG(PF32, 2); else WG(PF32, 1); }
   else { set_error("mlp_wgrad: bad precision %d", precision); return LAB4D_EINVAL; }
 #undef WG
   if (int e = check_launch("mlp_wgrad")) return e;
-  if (pf_db) {
+  if (pf_db && !fold_pf) {
     LAB4D_REQUIRE(M > 0 && spf > 0, "mlp_wgrad: pf_db needs M and spf");
     const int nseg = div_up(S, 4096);
     const long jobs2 = (long)L.mout_pad * nseg;

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(const float* __restrict__ xyz
   }
 }
 
-// per-sample part of the adjoint.  work[s] = [c_b = p_b*sign_b (B) | g_rw (4) | g_dw (4)] for the per-frame reduction.
+// per-sample part of the adjoint.  work = [coef (S,B): p_b*sign_b][gw (S,8): g_rw | g_dw] feeds the per-frame Gram reduction.
 template <int B>
 __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz, const float* __restrict__ bone, const float* __restrict__ raw,
                                                     const float* __restrict__ sr, const float* __restrict__ sd, const float* __restrict__ g_out,
@@ -234,9 +234,10 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz
     grw[2] = i * (gn_v.y - v.y * qg) - v.y * i * dg;
     grw[3] = i * (gn_v.z - v.z * qg) - v.z * i * dg;
     gdw[0] = i * gd_w; gdw[1] = i * gd_v.x; gdw[2] = i * gd_v.y; gdw[3] = i * gd_v.z;
-    float* wk = work + s * (B + 8);
+    float* wk = work + s * B;            // coef[s][b] = p_b * sign_b
+    float* wg = work + S * B + s * 8;    // [g_rw (4) | g_dw (4)]
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { wk[B + k] = grw[k]; wk[B + 4 + k] = gdw[k]; }
+    for (int k = 0; k < 4; ++k) { wg[k] = grw[k]; wg[4 + k] = gdw[k]; }
     // softmax / entropy / delta adjoint
     float gp[B];
     float pg = 0.f;
@@ -262,23 +263,38 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz
   }
 }
 
-// g_se3[m][b][c] += sum_{s in frame m} coef[s][b] * gw[s][c]: block = (frame, chunk); thread = (b, c)
-template <int B>
-__global__ void __launch_bounds__(256) k_blend_bwd_reduce(const float* __restrict__ work, long S, int spf, int chunk, float* __restrict__ g_sr,
-                                                           float* __restrict__ g_sd) {
+// ---------------------------------------------------------------------------------------------
+// per-frame "skinny Gram" reduction:  out[m][i][j] += sum_{s in frame m} A[s][i] * Bm[s][j]
+//   A: (S, CA) row-major, CA <= 80 ; Bm: (S, CB) row-major, CB <= 8.
+// Used for the per-frame parameter gradients of the skinning warp: every per-(sample,bone) gradient is linear in
+// a handful of per-sample vectors, so the whole reduction over the samples of a frame is one tall-skinny product.
+// Block = (frame, 1024-sample chunk): 128-sample tiles of A and Bm are staged through LDS with coalesced loads,
+// thread (i,j) accumulates its output over the tile from LDS (conflict-free: consecutive i -> consecutive banks).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(640) k_gram_pf(const float* __restrict__ A, int CA, const float* __restrict__ Bm, int CB, long S, int spf,
+                                                  int chunk, float* __restrict__ out) {
+  constexpr int TS = 128;
+  extern __shared__ float sm[];  // TS*CA + TS*CB
+  float* sa = sm;
+  float* sb = sm + TS * CA;
   const int m = blockIdx.y;
   const long f0 = (long)m * spf, f1 = min(S, f0 + spf);
   const long c0 = f0 + (long)blockIdx.x * chunk, c1 = min(f1, c0 + chunk);
+  if (c0 >= c1) return;
   const int t = threadIdx.x;
-  if (t >= B * 8 || c0 >= c1) return;
-  const int b = t >> 3, c = t & 7;
+  const int i = t / CB, j = t - i * CB;
+  const bool active = t < CA * CB;
   float acc = 0.f;
-  for (long s = c0; s < c1; ++s) {
-    const float* wk = work + s * (B + 8);
-    acc += wk[b] * wk[B + c];
+  for (long s0 = c0; s0 < c1; s0 += TS) {
+    const int n = (int)min((long)TS, c1 - s0);
+    for (int e = t; e < n * CA; e += blockDim.x) sa[e] = A[s0 * CA + e];
+    for (int e = t; e < n * CB; e += blockDim.x) sb[e] = Bm[s0 * CB + e];
+    __syncthreads();
+    if (active)
+      for (int k = 0; k < n; ++k) acc += sa[k * CA + i] * sb[k * CB + j];
+    __syncthreads();
   }
-  if (c < 4) atomicAdd(g_sr + ((size_t)m * B + b) * 4 + c, acc);
-  else atomicAdd(g_sd + ((size_t)m * B + b) * 4 + (c - 4), acc);
+  if (active) atomicAdd(out + ((size_t)m * CA + i) * CB + j, acc);
 }
 
 }  // namespace lab4d
@@ -330,19 +346,16 @@ extern "C" int lab4d_skin_blend_forward(const float* xyz, const float* bone, con
 
 extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* bone, const float* raw, const float* sr, const float* sd, const float* g_out,
                                          const float* g_ent, const float* g_dskin, int S, int spf, int M, int B, float* g_xyz, float* g_bone,
-                                         float* g_raw, float* g_sr, float* g_sd, float* work, void* stream) {
+                                         float* g_raw, float* g_se3, float* work, void* stream) {
   LAB4D_REQUIRE(xyz && bone && raw && sr && sd && g_out && g_xyz && g_bone && g_raw && work, "skin_blend_backward: null pointer");
   LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "skin_blend_backward: M*spf < S");
   if (S == 0) return LAB4D_OK;
   hipStream_t st = (hipStream_t)stream;
   SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB>), dim3(sgrid(S)), dim3(256), 0, st, xyz, bone, raw, sr, sd, g_out, g_ent, g_dskin, (long)S, spf,
                                       g_xyz, g_bone, g_raw, work));
-  if (g_sr && g_sd) {
-    const int chunk = 2048;
-    const dim3 grid(div_up(spf, chunk), M);
-    SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd_reduce<NB>), grid, dim3(256), 0, st, work, (long)S, spf, chunk, g_sr, g_sd));
-  }
-  return check_launch("skin_blend_backward");
+  if (int e = check_launch("skin_blend_backward")) return e;
+  if (g_se3) return lab4d_gram_per_frame(work, B, work + (size_t)S * B, 8, S, spf, M, g_se3, stream);
+  return LAB4D_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,8 +363,9 @@ extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* bone, co
 //   (deformable.py:329-356, warping.py:355-387, transforms.py:28-40; centres = frame-0 rest bones)
 // ---------------------------------------------------------------------------------------------
 namespace lab4d {
-__global__ void __launch_bounds__(256) k_gauss_density_fwd(const float* __restrict__ xyz, const float* __restrict__ centres, int B, float ibeta,
-                                                            long S, float* __restrict__ out, int* __restrict__ best) {
+__global__ void __launch_bounds__(256) k_gauss_density_fwd(const float* __restrict__ xyz, const float* __restrict__ centres, int B,
+                                                            const float* __restrict__ ibeta_p, long S, float* __restrict__ out, int* __restrict__ best) {
+  const float ibeta = *ibeta_p;
   for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
     const V3 x = ldv3(xyz + s * 3);
     float dmin = INFINITY;
@@ -366,10 +380,11 @@ __global__ void __launch_bounds__(256) k_gauss_density_fwd(const float* __restri
   }
 }
 // g_xyz (S,3) written; g_centres (B,3) and g_ibeta (1) accumulated
-__global__ void __launch_bounds__(256) k_gauss_density_bwd(const float* __restrict__ xyz, const float* __restrict__ centres, int B, float ibeta,
-                                                            const int* __restrict__ best, const float* __restrict__ g, long S,
+__global__ void __launch_bounds__(256) k_gauss_density_bwd(const float* __restrict__ xyz, const float* __restrict__ centres, int B,
+                                                            const float* __restrict__ ibeta_p, const int* __restrict__ best, const float* __restrict__ g, long S,
                                                             float* __restrict__ g_xyz, float* __restrict__ g_centres, float* __restrict__ g_ibeta) {
   extern __shared__ float acc[];  // 3B + 1
+  const float ibeta = *ibeta_p;
   for (int i = threadIdx.x; i < 3 * B + 1; i += blockDim.x) acc[i] = 0.f;
   __syncthreads();
   for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
@@ -388,13 +403,13 @@ __global__ void __launch_bounds__(256) k_gauss_density_bwd(const float* __restri
 }
 }  // namespace lab4d
 
-extern "C" int lab4d_gauss_density_forward(const float* xyz, const float* centres, int B, float ibeta, int S, float* out, int* best, void* stream) {
-  LAB4D_REQUIRE(xyz && centres && out, "gauss_density_forward: null pointer");
+extern "C" int lab4d_gauss_density_forward(const float* xyz, const float* centres, int B, const float* ibeta, int S, float* out, int* best, void* stream) {
+  LAB4D_REQUIRE(xyz && centres && out && ibeta, "gauss_density_forward: null pointer");
   if (S == 0) return LAB4D_OK;
   hipLaunchKernelGGL(lab4d::k_gauss_density_fwd, dim3(sgrid(S)), dim3(256), 0, (hipStream_t)stream, xyz, centres, B, ibeta, (long)S, out, best);
   return check_launch("gauss_density_forward");
 }
-extern "C" int lab4d_gauss_density_backward(const float* xyz, const float* centres, int B, float ibeta, const int* best, const float* g, int S,
+extern "C" int lab4d_gauss_density_backward(const float* xyz, const float* centres, int B, const float* ibeta, const int* best, const float* g, int S,
                                             float* g_xyz, float* g_centres, float* g_ibeta, void* stream) {
   LAB4D_REQUIRE(xyz && centres && best && g && g_centres, "gauss_density_backward: null pointer");
   LAB4D_REQUIRE(B <= 64, "gauss_density_backward: B too large");
@@ -403,4 +418,15 @@ extern "C" int lab4d_gauss_density_backward(const float* xyz, const float* centr
   hipLaunchKernelGGL(lab4d::k_gauss_density_bwd, dim3(grid), dim3(256), (3 * B + 1) * sizeof(float), (hipStream_t)stream, xyz, centres, B, ibeta, best, g,
                      (long)S, g_xyz, g_centres, g_ibeta);
   return check_launch("gauss_density_backward");
+}
+
+extern "C" int lab4d_gram_per_frame(const float* A, int CA, const float* Bm, int CB, int S, int spf, int M, float* out, void* stream) {
+  LAB4D_REQUIRE(A && Bm && out, "gram_per_frame: null pointer");
+  LAB4D_REQUIRE(CA >= 1 && CA <= 80 && CB >= 1 && CB <= 8, "gram_per_frame: need CA <= 80, CB <= 8 (got %d, %d)", CA, CB);
+  LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "gram_per_frame: M*spf < S");
+  if (S == 0) return LAB4D_OK;
+  const int chunk = 1024;
+  const dim3 grid(div_up(spf, chunk), M);
+  hipLaunchKernelGGL(lab4d::k_gram_pf, grid, dim3(640), 128 * (CA + CB) * sizeof(float), (hipStream_t)stream, A, CA, Bm, CB, (long)S, spf, chunk, out);
+  return check_launch("gram_per_frame");
 }

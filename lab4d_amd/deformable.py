@@ -21,8 +21,8 @@ from . import render_utils as RU
 from .warping import skinning_warp
 
 vp, ci, cf = _lib.vp, _lib.ci, _lib.cf
-_lib.register("lab4d_gauss_density_forward", [vp, vp, ci, cf, ci, vp, vp, vp])
-_lib.register("lab4d_gauss_density_backward", [vp, vp, ci, cf, vp, vp, ci, vp, vp, vp, vp])
+_lib.register("lab4d_gauss_density_forward", [vp, vp, ci, vp, ci, vp, vp, vp])
+_lib.register("lab4d_gauss_density_backward", [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp])
 
 
 def flip_pair(x):
@@ -71,22 +71,21 @@ class GaussDensity(Function):
         S, B = xyz.shape[0], centres.shape[0]
         out = torch.empty(S, 1, device=xyz.device)
         best = torch.empty(S, dtype=torch.int32, device=xyz.device)
-        ib = float(ibeta)
-        _lib.check(_lib.lib().lab4d_gauss_density_forward(_lib.ptr(xyz), _lib.ptr(centres), B, ib, S, _lib.ptr(out), _lib.ptr(best), _lib.stream()),
-                   "gauss_density_forward")
-        ctx.save_for_backward(xyz, centres, best)
-        ctx.ib = ib
+        ib = ibeta.detach().reshape(1).float().contiguous()  # stays on the device: no host sync (graph-capturable)
+        _lib.check(_lib.lib().lab4d_gauss_density_forward(_lib.ptr(xyz), _lib.ptr(centres), B, _lib.ptr(ib), S, _lib.ptr(out), _lib.ptr(best),
+                                                          _lib.stream()), "gauss_density_forward")
+        ctx.save_for_backward(xyz, centres, best, ib)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        xyz, centres, best = ctx.saved_tensors
+        xyz, centres, best, ib = ctx.saved_tensors
         g = g.contiguous()
         gx = torch.empty_like(xyz)
         gc = torch.zeros_like(centres)
         gi = torch.zeros(1, device=xyz.device)
-        _lib.check(_lib.lib().lab4d_gauss_density_backward(_lib.ptr(xyz), _lib.ptr(centres), centres.shape[0], ctx.ib, _lib.ptr(best), _lib.ptr(g),
+        _lib.check(_lib.lib().lab4d_gauss_density_backward(_lib.ptr(xyz), _lib.ptr(centres), centres.shape[0], _lib.ptr(ib), _lib.ptr(best), _lib.ptr(g),
                                                            xyz.shape[0], _lib.ptr(gx), _lib.ptr(gc), _lib.ptr(gi), _lib.stream()),
                    "gauss_density_backward")
         return gx, gc, gi
@@ -249,13 +248,16 @@ def render_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None, prec
 # losses (engine/model.py:401-611), per-ray element-wise glue
 # ---------------------------------------------------------------------------------------------------
 def mask_balance_wt(mask, vis2d, is_detected):
+    """dvr_model.get_mask_balance_wt (model.py:401-424) without host synchronisation (branch -> torch.where)."""
     mask = mask.float()
     vis2d = vis2d.float() * is_detected.float()[:, None, None]
-    if mask.sum() > 0 and (1 - mask).sum() > 0:
-        pos = vis2d.sum() / mask[vis2d > 0].sum()
-        neg = vis2d.sum() / (1 - mask[vis2d > 0]).sum()
-        return 0.5 * pos * mask + 0.5 * neg * (1 - mask)
-    return 1
+    vis = (vis2d > 0).float()
+    npos, nneg = (mask * vis).sum(), ((1 - mask) * vis).sum()
+    pos = vis2d.sum() / npos.clamp_min(1e-12)
+    neg = vis2d.sum() / nneg.clamp_min(1e-12)
+    wt = 0.5 * pos * mask + 0.5 * neg * (1 - mask)
+    both = (mask.sum() > 0) & ((1 - mask).sum() > 0)
+    return torch.where(both, wt, torch.ones_like(wt))
 
 
 def losses_fg(results, batch, train_res, weights):
@@ -289,7 +291,8 @@ def losses_fg(results, batch, train_res, weights):
     L["reg_skin_entropy"] = a["skin_entropy"]
     out = {}
     for k, v in L.items():
-        v = v[v > 0].mean()
+        pos = (v > 0).to(v.dtype)
+        v = (v * pos).sum() / pos.sum()  # == v[v > 0].mean() (model.py:602) without the host sync of boolean indexing
         if k in ("flow", "feat_reproj"):
             v = v / train_res
         if weights is not None and k + "_wt" in weights:

@@ -157,6 +157,21 @@ def col_map(net, layer, device):
     return _COLMAP[key]
 
 
+ALWAYS_PACK = False  # set while capturing a hipGraph: the pack kernels must be part of the graph (weights change between replays)
+_COLIDX = {}
+
+
+def col_index(net, layer, device):
+    """(kernel columns, reference columns) LongTensors of the valid entries of col_map -- built once on the host so the
+    scatter of a weight gradient back into reference layout needs no boolean indexing (no device->host sync)."""
+    key = (net, layer, str(device))
+    if key not in _COLIDX:
+        cm = col_map(net, layer, device).cpu()
+        k = torch.nonzero(cm >= 0).flatten()
+        _COLIDX[key] = (k.to(device), cm[k].long().to(device))
+    return _COLIDX[key]
+
+
 _PACK_CACHE = {}  # id(weight tensor) -> (weakref to it, {(net, layer, prec, transposed): (version, packed)})
 
 
@@ -173,7 +188,7 @@ def packed_weights(net, layer, prec, W, transposed):
         weakref.finalize(W, _PACK_CACHE.pop, id(W), None)
     per = ent[1]
     hit = per.get(key)
-    if hit is not None and hit[0] == ver and hit[1].device == W.device:
+    if hit is not None and hit[0] == ver and hit[1].device == W.device and not ALWAYS_PACK:
         return hit[1]
     d = describe(net)
     L = d.layers[layer]
@@ -183,13 +198,15 @@ def packed_weights(net, layer, prec, W, transposed):
     cm = col_map(net, layer, W.device)
     _lib.check(_lib.lib().lab4d_mlp_pack(net, layer, prec, 1 if transposed else 0, _lib.ptr(Wc), Wc.shape[1], _lib.ptr(cm),
                                          _lib.ptr(out), _lib.stream()), "mlp_pack")
-    per[key] = (ver, out)
+    if not ALWAYS_PACK:
+        per[key] = (ver, out)
     return out
 
 
 def clear_caches():
     _PACK_CACHE.clear()
     _COLMAP.clear()
+    _COLIDX.clear()
 
 
 def pf_bias_of(net, layer, W, cond):
@@ -349,12 +366,11 @@ class MlpChain(Function):
                   _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, ld, spf, _lib.ptr(dz[l]), _lib.ptr(ctx.emb), _lib.ptr(prev),
                                                       _lib.ptr(dWk), _lib.ptr(dbk), _lib.ptr(pfd), M, _lib.stream()), "mlp_wgrad")
                 if need_w:
-                    cm = col_map(net, l, dev).long()
-                    valid = cm >= 0
+                    kcols, rcols = col_index(net, l, dev)
                     gW = torch.zeros_like(Ws[l], dtype=torch.float32)
-                    gW[:, cm[valid]] = dWk[:L.mout][:, valid]
+                    gW[:, rcols] = dWk[:L.mout][:, kcols]
                 if need_b:
-                    gb = dbk[:L.mout].reshape(bs[l].shape)
+                    gb = (pfd.sum(0) if need_pf else dbk)[:L.mout].reshape(bs[l].shape)
                 if need_pf:
                     grads_pf.append(pfd)
             grads_params += [gW, gb]

@@ -12,7 +12,8 @@ vp, ci = _lib.vp, _lib.ci
 _lib.register("lab4d_bone_coords_forward", [vp] * 4 + [ci] * 4 + [vp, vp])
 _lib.register("lab4d_bone_coords_backward", [vp] * 5 + [ci] * 4 + [vp] * 4 + [vp])
 _lib.register("lab4d_skin_blend_forward", [vp] * 5 + [ci] * 4 + [vp] * 3 + [vp])
-_lib.register("lab4d_skin_blend_backward", [vp] * 8 + [ci] * 4 + [vp] * 6 + [vp])
+_lib.register("lab4d_skin_blend_backward", [vp] * 8 + [ci] * 4 + [vp] * 5 + [vp])
+_lib.register("lab4d_gram_per_frame", [vp, ci, vp, ci, ci, ci, ci, vp, vp])
 
 
 class BoneCoords(Function):
@@ -37,10 +38,24 @@ class BoneCoords(Function):
         S, (M, B) = xyz.shape[0], art_r.shape[:2]
         g = g.contiguous()
         gx = torch.empty_like(xyz)
-        gar, gad, gg = torch.zeros_like(art_r), torch.zeros_like(art_d), torch.zeros_like(gauss)
         _lib.check(_lib.lib().lab4d_bone_coords_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(g), S, ctx.spf,
-                                                         M, B, _lib.ptr(gx), _lib.ptr(gar), _lib.ptr(gad), _lib.ptr(gg), _lib.stream()),
-                   "bone_coords_backward")
+                                                         M, B, _lib.ptr(gx), None, None, None, _lib.stream()), "bone_coords_backward")
+        # parameter gradients: out[s,b,:] = (R_b x_s + t_b) / gauss_b is affine in x_s, so
+        #   L = sum_s <g, out> = sum_{m,b,k,j} A[m,b,k,j] / gauss[b,k] * G[m,b,k,j],  G = sum_{s in m} g[s,b,k] [x_s,1]_j
+        # G is one per-frame tall-skinny product on the device; the (M,B)-sized chain rule runs under torch autograd.
+        xh = torch.cat([xyz, torch.ones_like(xyz[:, :1])], -1)
+        G = torch.zeros(M, 3 * B, 4, device=xyz.device)
+        _lib.check(_lib.lib().lab4d_gram_per_frame(_lib.ptr(g), 3 * B, _lib.ptr(xh), 4, S, ctx.spf, M, _lib.ptr(G), _lib.stream()), "gram_per_frame")
+        G = G.view(M, B, 3, 4)
+        with torch.enable_grad():
+            r, d, gs = art_r.detach().requires_grad_(True), art_d.detach().requires_grad_(True), gauss.detach().requires_grad_(True)
+            qi = Q.quaternion_conjugate(r)                                     # inverse bone rotation
+            t = 2 * Q.quaternion_mul(Q.quaternion_conjugate(d), r)[..., 1:]    # inverse bone translation (M,B,3)
+            eye = torch.eye(3, device=xyz.device).view(1, 1, 3, 3)
+            Rt = Q.quaternion_apply(qi[:, :, None, :], eye)                    # (M,B,j,k) = R[k][j]
+            Amat = torch.cat([Rt.transpose(-1, -2), t[..., None]], -1)         # (M,B,k,4)
+            L = (Amat / gs.view(1, B, 3, 1) * G).sum()
+            gar, gad, gg = torch.autograd.grad(L, [r, d, gs])
         return gx, gar, gad, gg, None
 
 
@@ -70,13 +85,13 @@ class SkinBlend(Function):
         g_ent = g_ent.contiguous() if g_ent is not None else None
         g_dsk = g_dsk.contiguous() if g_dsk is not None else None
         gx, gb, gr = torch.empty_like(xyz), torch.empty_like(bone), torch.empty_like(raw)
-        gsr, gsd = torch.zeros_like(se3_r), torch.zeros_like(se3_d)
-        work = torch.empty(S, B + 8, device=xyz.device)
+        gse3 = torch.zeros(M, B, 8, device=xyz.device)
+        work = torch.empty(S * (B + 8), device=xyz.device)
         _lib.check(_lib.lib().lab4d_skin_blend_backward(_lib.ptr(xyz), _lib.ptr(bone), _lib.ptr(raw), _lib.ptr(se3_r), _lib.ptr(se3_d),
                                                         _lib.ptr(g_out), _lib.ptr(g_ent), _lib.ptr(g_dsk), S, ctx.spf, M, B, _lib.ptr(gx),
-                                                        _lib.ptr(gb), _lib.ptr(gr), _lib.ptr(gsr), _lib.ptr(gsd), _lib.ptr(work), _lib.stream()),
+                                                        _lib.ptr(gb), _lib.ptr(gr), _lib.ptr(gse3), _lib.ptr(work), _lib.stream()),
                    "skin_blend_backward")
-        return gx, gb, gr, gsr, gsd, None
+        return gx, gb, gr, gse3[..., :4].contiguous(), gse3[..., 4:].contiguous(), None
 
 
 def get_gauss(P):

@@ -81,7 +81,8 @@ def cosine(a, b):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("name,cin,shape", [("vis", 3, (2, 5, 16)), ("skin", 75, (2, 3, 24)), ("feat", 3, (2, 7, 8)), ("base", 3, (2, 9, 8))])
+@pytest.mark.parametrize("name,cin,shape", [("vis", 3, (2, 5, 16)), ("skin", 75, (2, 3, 24)), ("feat", 3, (2, 7, 8)), ("base", 3, (2, 9, 8)),
+                                            ("vis", 3, (2, 16, 16)), ("base", 3, (3, 32, 8))])  # spf % 256 == 0: per-frame bias grads folded into wgrad
 def test_chain_forward_backward(name, cin, shape, prec):
     M, N, D = shape
     P, fr, xyz, g = setup(3, M, N, D)
