@@ -92,7 +92,8 @@ typedef struct {
   const void* W[LAB4D_MLP_MAX_LAYERS];        /* packed forward weights                                    */
   const float* bias[LAB4D_MLP_MAX_LAYERS];    /* (mout_pad) fp32                                           */
   const float* pf_bias[LAB4D_MLP_MAX_LAYERS]; /* (M, mout_pad) fp32 or NULL                                */
-  void* act[LAB4D_MLP_MAX_LAYERS];  /* [mout_pad][ld] stored post-activation or NULL (not stored)       */
+  void* act[LAB4D_MLP_MAX_LAYERS];  /* stored post-activation (blocked [64-sample block][mout_pad][64] + skew) or NULL */
+  void* mask[LAB4D_MLP_MAX_LAYERS]; /* ReLU sign bits, uint32 [S_pad/TILE][mout_pad/32][64] (TILE = 64 bf16 / 32 fp32), or NULL */
   void* emb;                        /* [ke][ld] stored embedding or NULL                                */
   const void* ext;                  /* [mout_pad][ld] tensor added at the add_ext layer                 */
   float* out;                       /* (S, c_out) raw head output, fp32                                    */
@@ -102,9 +103,10 @@ int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream);
 typedef struct {
   int net, precision, S, S_pad, ld, spf;
   const void* WT[LAB4D_MLP_MAX_LAYERS];        /* packed transposed weights                                */
-  const void* act[LAB4D_MLP_MAX_LAYERS];       /* stored post-activations from the forward                 */
+  const void* act[LAB4D_MLP_MAX_LAYERS];       /* stored post-activations from the forward (unused by the dgrad chain) */
+  const void* mask[LAB4D_MLP_MAX_LAYERS];      /* ReLU sign bits written by the forward                    */
   const void* emb;                             /* stored embedding (posenc Jacobian)                       */
-  const void* ext;                             /* forward `ext` (to recover relu(z) = y - ext)             */
+  const void* ext;                             /* unused (kept for ABI stability)                          */
   const float* d_out;                          /* (S, c_out) gradient of the head output                   */
   const void* ext_gin;                         /* [mout_pad][ld] gradient added at the ext_grad layer   */
   void* ext_gout;                              /* [mout_pad][ld] gradient wrt `ext` (written) or NULL   */

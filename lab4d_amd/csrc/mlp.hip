@@ -150,6 +150,127 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
   }
 }
 
+// Large layers (>= 8 row tiles): a workgroup owns an 8 x 8 block of 32x32 output tiles (256 x 256), its 4 waves are
+// arranged 2 x 2 with a 4 x 4 tile sub-block each and ALL walk the same samples in the same order: the two waves of
+// a row share their dz tiles and the two of a column share their X tiles through the CU's L1 (same lines requested
+// at the same time), which halves the L2 -> L1 traffic of the 4x4-per-wave scheme above; every output tile has a
+// single owner, so no cross-wave reduction is needed.
+template <class P>
+__global__ void __launch_bounds__(256) k_mlp_wgrad_big(const typename P::store_t* __restrict__ dz, const typename P::store_t* __restrict__ emb,
+                                                        const typename P::store_t* __restrict__ actp, int mo_tiles, int ke, int kin,
+                                                        int S_pad, int chunk, int spf, int cpf, float* __restrict__ dW, float* __restrict__ db) {
+  constexpr int TM = 4, TN = 4;
+  constexpr int SPS = P::BF16 ? 16 : 8;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int K = ke + kin, nk_tiles = K / 32;
+  const int ob_n = (mo_tiles + 7) / 8, kb_n = (nk_tiles + 7) / 8;
+  const int job = blockIdx.x;
+  const int c = job / (ob_n * kb_n), rem = job - c * (ob_n * kb_n);
+  const int ob = rem / kb_n, kb = rem - ob * kb_n;
+  int s_begin, s_end;
+  if (cpf > 0) {
+    const int m = c / cpf, lc = c - m * cpf;
+    s_begin = m * spf + lc * chunk;
+    s_end = min(min(S_pad, (m + 1) * spf), s_begin + chunk);
+    if (db) db += (size_t)m * (mo_tiles * 32);
+  } else {
+    s_begin = c * chunk;
+    s_end = min(S_pad, s_begin + chunk);
+  }
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float rs[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rs[i] = 0.f;
+  const typename P::store_t* ap[TM];
+  const typename P::store_t* bp[TN];
+  bool av_[TM], bv_[TN];
+  int bF[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int t = ob * 8 + wr * 4 + i;
+    av_[i] = t < mo_tiles;
+    ap[i] = dz + (size_t)(32 * (av_[i] ? t : 0) + row) * 64;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int t = kb * 8 + wc * 4 + j;
+    bv_[j] = t < nk_tiles;
+    const int kr = 32 * (bv_[j] ? t : 0) + row;
+    bp[j] = kr < ke ? emb + (size_t)kr * 64 : actp + (size_t)(kr - ke) * 64;
+    bF[j] = kr < ke ? ke : kin;
+  }
+  const bool any = (av_[0] && bv_[0]);
+  const bool do_db = (kb == 0 && wc == 0 && db != nullptr);
+  const int off = P::BF16 ? 8 * h : 4 * h;
+  const int moF = mo_tiles * 32;
+  auto load_step = [&](int s, uint4 (&a4)[TM], uint4 (&b4)[TN]) {
+    const size_t blk = (size_t)(s >> 6);
+    const int in = (s & 63) + off;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a4[i] = av_[i] ? *reinterpret_cast<const uint4*>(ap[i] + blk * block_stride(moF) + in) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b4[j] = bv_[j] ? *reinterpret_cast<const uint4*>(bp[j] + blk * block_stride(bF[j]) + in) : make_uint4(0, 0, 0, 0);
+  };
+  auto compute = [&](const uint4 (&a4)[TM], const uint4 (&b4)[TN]) {
+    if (do_db) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (P::BF16) {
+          const unsigned int w[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rs[i] += bf2f((unsigned short)(w[q] & 0xffffu)) + bf2f((unsigned short)(w[q] >> 16));
+        } else {
+          rs[i] += __uint_as_float(a4[i].x) + __uint_as_float(a4[i].y) + __uint_as_float(a4[i].z) + __uint_as_float(a4[i].w);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) mma_unit<P>(acc[i][j], a4[i], b4[j]);
+  };
+  if (any) {
+    int s = s_begin;
+    uint4 a0[TM], b0[TN], a1[TM], b1[TN];
+    if (s < s_end) load_step(s, a0, b0);
+    while (s < s_end) {
+      const int s1 = s + SPS;
+      if (s1 < s_end) load_step(s1, a1, b1);
+      compute(a0, b0);
+      if (s1 >= s_end) break;
+      const int s2 = s1 + SPS;
+      if (s2 < s_end) load_step(s2, a0, b0);
+      compute(a1, b1);
+      s = s2;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (!av_[i]) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!bv_[j]) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = 32 * (ob * 8 + wr * 4 + i) + drow(r, h);
+          const int k = 32 * (kb * 8 + wc * 4 + j) + row;
+          atomicAdd(dW + (size_t)o * K + k, acc[i][j][r]);
+        }
+      }
+      if (do_db) {
+        const float v = rs[i] + __shfl_xor(rs[i], 32, 64);
+        if (h == 0) atomicAdd(db + 32 * (ob * 8 + wr * 4 + i) + row, v);
+      }
+    }
+  }
+}
+
 // per-frame bias gradient: pf_db[m][o] += sum_{s in frame m} dz[o][s].  One wave per (row o, 4096-sample
 // segment); a segment that straddles frames flushes at the boundary.  pf_db is zero-filled by the caller.
 template <class P>
@@ -289,7 +410,7 @@ extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
       LAB4D_REQUIRE(a->W[l] && a->bias[l], "mlp_forward: layer %d weights/bias missing", l);
       LAB4D_REQUIRE(!Net::L[l].pf || a->pf_bias[l], "mlp_forward: layer %d needs a per-frame bias", l);
       LAB4D_REQUIRE(!Net::L[l].add_ext || a->ext, "mlp_forward: layer %d needs ext", l);
-      k.W[l] = a->W[l]; k.bias[l] = a->bias[l]; k.pf_bias[l] = a->pf_bias[l]; k.act[l] = a->act[l];
+      k.W[l] = a->W[l]; k.bias[l] = a->bias[l]; k.pf_bias[l] = a->pf_bias[l]; k.act[l] = a->act[l]; k.mask[l] = (unsigned int*)a->mask[l];
     }
     return launch_mlp_fwd<Net>(a->precision, k, a->S, (hipStream_t)stream);
   });
@@ -309,10 +430,9 @@ extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
     LAB4D_REQUIRE(!(a->d_x && Net::EMB == 0) || a->emb, "mlp_backward: d_x needs the stored embedding");
     for (int l = 0; l < Net::NL; ++l) {
       LAB4D_REQUIRE(a->WT[l], "mlp_backward: layer %d transposed weights missing", l);
-      LAB4D_REQUIRE(!(Net::L[l].relu && l + 1 < Net::NL) || a->act[l], "mlp_backward: layer %d stored activation missing", l);
+      LAB4D_REQUIRE(!(Net::L[l].relu && l + 1 < Net::NL) || a->mask[l], "mlp_backward: layer %d ReLU mask missing", l);
       LAB4D_REQUIRE(!Net::L[l].ext_grad || a->ext_gin, "mlp_backward: layer %d needs ext_gin", l);
-      LAB4D_REQUIRE(!Net::L[l].add_ext || a->ext, "mlp_backward: layer %d needs ext", l);
-      k.WT[l] = a->WT[l]; k.act[l] = a->act[l]; k.dz[l] = a->dz[l];
+      k.WT[l] = a->WT[l]; k.act[l] = a->act[l]; k.mask[l] = (const unsigned int*)a->mask[l]; k.dz[l] = a->dz[l];
     }
     return launch_mlp_bwd<Net>(a->precision, k, a->S, (hipStream_t)stream);
   });
@@ -330,8 +450,9 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   LAB4D_REQUIRE(S_pad % 64 == 0 && S_pad >= S && ld >= S_pad && ld % 8 == 0, "mlp_wgrad: bad S_pad/ld");
   if (S == 0) return LAB4D_OK;
   const int mo_tiles = L.mout_pad / 32, nk_tiles = (L.ke + L.kin) / 32;
+  const bool big = mo_tiles >= 8;  // 256-wide layers: 8x8-tile workgroup blocks (k_mlp_wgrad_big)
   const int TM = mo_tiles >= 4 ? 4 : (mo_tiles >= 2 ? 2 : 1);
-  const int ob_n = div_up(mo_tiles, TM), kb_n = div_up(nk_tiles, 4);
+  const int ob_n = big ? div_up(mo_tiles, 8) : div_up(mo_tiles, TM), kb_n = big ? div_up(nk_tiles, 8) : div_up(nk_tiles, 4);
   // ~1024 workgroups in total (4 per CU); chunks are multiples of 256 samples (one 64-sample step per wave)
   int nchunks = 1024 / (ob_n * kb_n); if (nchunks < 1) nchunks = 1;
   int chunk = div_up(div_up(S_pad, nchunks), 256) * 256; if (chunk < 1024) chunk = 1024;
@@ -352,9 +473,12 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   hipStream_t st = (hipStream_t)stream;
 #define WG(P, TMV) hipLaunchKernelGGL((k_mlp_wgrad<P, TMV>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
                                       (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
-  if (precision == LAB4D_PREC_BF16) { if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
-  else if (precision == LAB4D_PREC_F32) { if (TM == 4) WG(PF32, 4); else if (TM == 2) WG(PF32, 2); else WG(PF32, 1); }
+#define WGB(P) hipLaunchKernelGGL((k_mlp_wgrad_big<P>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
+                                  (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
+  if (precision == LAB4D_PREC_BF16) { if (big) WGB(PBF16); else if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
+  else if (precision == LAB4D_PREC_F32) { if (big) WGB(PF32); else if (TM == 4) WG(PF32, 4); else if (TM == 2) WG(PF32, 2); else WG(PF32, 1); }
   else { set_error("mlp_wgrad: bad precision %d", precision); return LAB4D_EINVAL; }
+#undef WGB
 #undef WG
   if (int e = check_launch("mlp_wgrad")) return e;
   if (pf_db && !fold_pf) {

@@ -36,13 +36,13 @@ class NetDesc(ctypes.Structure):
 
 class FwdArgs(ctypes.Structure):
     _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("S_pad", ci), ("ld", ci), ("spf", ci), ("x", vp), ("freq_w", vp),
-                ("W", vp * MAXL), ("bias", vp * MAXL), ("pf_bias", vp * MAXL), ("act", vp * MAXL), ("emb", vp), ("ext", vp),
-                ("out", vp)]
+                ("W", vp * MAXL), ("bias", vp * MAXL), ("pf_bias", vp * MAXL), ("act", vp * MAXL), ("mask", vp * MAXL), ("emb", vp),
+                ("ext", vp), ("out", vp)]
 
 
 class BwdArgs(ctypes.Structure):
     _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("S_pad", ci), ("ld", ci), ("spf", ci), ("WT", vp * MAXL), ("act", vp * MAXL),
-                ("emb", vp), ("ext", vp), ("d_out", vp), ("ext_gin", vp), ("ext_gout", vp), ("dz", vp * MAXL), ("d_x", vp)]
+                ("mask", vp * MAXL), ("emb", vp), ("ext", vp), ("d_out", vp), ("ext_gin", vp), ("ext_gout", vp), ("dz", vp * MAXL), ("d_x", vp)]
 
 
 _lib.register("lab4d_mlp_describe", [ci, ctypes.POINTER(NetDesc)])
@@ -259,6 +259,7 @@ class MlpChain(Function):
             a.freq_w = freq_w.data_ptr()
         keep = []
         acts = [None] * NL
+        masks = [None] * NL
         pf_i = 0
         pf_used = [None] * NL
         for l in range(NL):
@@ -282,6 +283,10 @@ class MlpChain(Function):
             if (need_grad and l + 1 < NL) or l == export_layer:
                 acts[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
                 a.act[l] = acts[l].data_ptr()
+            if need_grad and L.relu and l + 1 < NL:
+                tile = 64 if prec == PREC_BF16 else 32
+                masks[l] = torch.empty((S_pad // tile) * (L.mout_pad // 32) * 64, dtype=torch.int32, device=dev)
+                a.mask[l] = masks[l].data_ptr()
         emb = None
         if need_grad:
             emb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
@@ -296,7 +301,7 @@ class MlpChain(Function):
         with _lib.timed("mlp_fwd_%s" % NET_NAMES[net], 2.0 * S * NET_MACS[net]):
             _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
-        ctx.acts, ctx.emb, ctx.ext = acts, emb, ext
+        ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
         ctx.params = params
         ctx.x_shape = x.shape
         if export_layer is not None and export_layer >= 0:
@@ -324,6 +329,8 @@ class MlpChain(Function):
             keep.append(pw)
             if ctx.acts[l] is not None:
                 a.act[l] = ctx.acts[l].data_ptr()
+            if ctx.masks[l] is not None:
+                a.mask[l] = ctx.masks[l].data_ptr()
             dz[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
             a.dz[l] = dz[l].data_ptr()
             if L.ext_grad:
