@@ -268,7 +268,7 @@ class MlpChain(Function):
             a.W[l] = pw.data_ptr()
             b = bs[l].detach().float()
             if b.numel() != L.mout_pad:
-                b = torch.cat([b, torch.zeros(L.mout_pad - b.numel(), device=dev)])
+                b = torch.nn.functional.pad(b, (0, L.mout_pad - b.numel()))
             b = b.contiguous()
             a.bias[l] = b.data_ptr()
             keep += [pw, b]
@@ -357,6 +357,13 @@ class MlpChain(Function):
         # weight / bias gradients
         M = (S + spf - 1) // spf
         grads_pf, grads_params = [], []
+        # one zero-filled arena for every accumulated output of the wgrad launches (one fill instead of ~3 per layer)
+        sizes = []
+        for l in range(NL):
+            L = d.layers[l]
+            sizes.append((L.mout_pad * (L.ke + L.kin), L.mout_pad, M * L.mout_pad if L.pf_bias else 0))
+        arena = torch.zeros(sum(sum(t) for t in sizes), device=dev)
+        aoff = 0
         for l in range(NL):
             L = d.layers[l]
             K = L.ke + L.kin
@@ -365,9 +372,10 @@ class MlpChain(Function):
             need_pf = bool(L.pf_bias)
             gW = gb = None
             if need_w or need_b or need_pf:
-                dWk = torch.zeros(L.mout_pad, K, device=dev)
-                dbk = torch.zeros(L.mout_pad, device=dev)
-                pfd = torch.zeros(M, L.mout_pad, device=dev) if need_pf else None
+                n0, n1, n2 = sizes[l]
+                dWk = arena[aoff:aoff + n0].view(L.mout_pad, K)
+                dbk = arena[aoff + n0:aoff + n0 + n1]
+                pfd = arena[aoff + n0 + n1:aoff + n0 + n1 + n2].view(M, L.mout_pad) if need_pf else None
                 prev = ctx.acts[l - 1] if L.kin else None
                 with _lib.timed("mlp_wgrad", 2.0 * S * L.mout * (L.ke + L.kin)):
                   _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, ld, spf, _lib.ptr(dz[l]), _lib.ptr(ctx.emb), _lib.ptr(prev),
@@ -380,6 +388,7 @@ class MlpChain(Function):
                     gb = (pfd.sum(0) if need_pf else dbk)[:L.mout].reshape(bs[l].shape)
                 if need_pf:
                     grads_pf.append(pfd)
+            aoff += sum(sizes[l])
             grads_params += [gW, gb]
         return (None, None, None, d_x, ext_g, None, None, None, *grads_pf, *grads_params)
 

@@ -4,6 +4,8 @@ lab4d/utils/quat_transform.py that the field code applies to per-frame quantitie
 per-sample goes through the HIP kernels instead."""
 import torch
 
+from . import quaternion as _hipq
+
 
 def _pad_w(a):
     if a.shape[-1] == 3:
@@ -12,7 +14,12 @@ def _pad_w(a):
 
 
 def quaternion_mul(a, b):
-    """quat_transform.py:62-81 (3-vector operands are pure quaternions, quaternion.cu:46-57)."""
+    """quat_transform.py:62-81 / 106-113: on device tensors this is ONE launch of the dqtorch-replacement kernel
+    (double-differentiable), exactly like the reference dispatches to its CUDA kernel; a 3-vector operand is a pure
+    quaternion (quaternion.cu:46-57)."""
+    if a.is_cuda and a.shape[:-1] == b.shape[:-1]:
+        out_shape = a.shape[:-1] + (4,)
+        return _hipq.quaternion_mul(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])).view(out_shape)
     a, b = torch.broadcast_tensors(_pad_w(a), _pad_w(b))
     aw, ax, ay, az = a.unbind(-1)
     bw, bx, by, bz = b.unbind(-1)
@@ -21,6 +28,8 @@ def quaternion_mul(a, b):
 
 
 def quaternion_conjugate(q):
+    if q.is_cuda:
+        return _hipq.quaternion_conjugate(q.reshape(-1, 4)).view(q.shape)
     return torch.cat((q[..., :1], -q[..., 1:]), -1)
 
 
