@@ -308,3 +308,82 @@ DEFAULT_LOSS_WT = {
     "reg_skin_entropy_wt": 5e-4, "reg_gauss_skin_wt": 1e-3, "reg_cam_prior_wt": 0.1, "reg_skel_prior_wt": 0.1,
     "reg_gauss_mask_wt": 0.01, "reg_soft_deform_wt": 100.0,
 }
+
+
+# ---------------------------------------------------------------------------------------------------
+# evaluation graph: importance sampling, valid-mask, normals   (nerf.py:455-528, 605-636, 686-738, 769-819)
+# ---------------------------------------------------------------------------------------------------
+def extend_aabb(aabb, factor=0.1):
+    """geom_utils.py:409-422."""
+    ext = (aabb[1] - aabb[0]) * factor
+    return torch.stack([aabb[0] - ext, aabb[1] + ext], 0)
+
+
+def check_inside_aabb(xyz, aabb):
+    """geom_utils.py:506-517 (strict inequalities)."""
+    return ((xyz > aabb[:1]) & (xyz < aabb[1:])).all(-1)
+
+
+def get_valid_idx(P, xyz, xyz_t, t_articulation):
+    """NeRF.get_valid_idx (nerf.py:495-528): bool (M,N,D)."""
+    valid = check_inside_aabb(xyz, extend_aabb(P["aabb"]))
+    _, tb = Q.dual_quaternion_to_quaternion_translation(t_articulation)
+    tb = tb[0]
+    t_aabb = extend_aabb(torch.stack([tb.min(0)[0], tb.max(0)[0]], 0), factor=1.0)
+    return valid & check_inside_aabb(xyz_t, t_aabb)
+
+
+@torch.no_grad()
+def importance_sampling(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
+    """NeRF.importance_sampling (nerf.py:686-738): n/2 uniform samples -> density -> weights -> inverse-CDF samples
+    (sample_pdf, det=True) -> merge-sort -> 64 depths.  Returns (xyz_cam, dir_cam, deltas, depth, xyz_t), inds."""
+    nc = n_depth // 2
+    cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
+    xyz_cam, _, deltas, depth, xyz_t, _ = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=nc)
+    xyz, _ = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, prec)
+    density = nerf_forward(P, xyz, fr, prec, with_color=False, alpha=alpha)
+    weights, _ = RU.compute_weights(density, deltas)
+    depth_mid = (0.5 * (depth[:, :, :-1] + depth[:, :, 1:])).reshape(-1, nc - 1)
+    new, inds = RU.sample_pdf(depth_mid, weights.reshape(-1, nc)[:, 1:-1].contiguous(), nc, det=True, return_inds=True)
+    depth_all = RU.sort_depth(depth.reshape(-1, nc), new).view(depth.shape[0], depth.shape[1], n_depth, 1)
+    return RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, depth=depth_all), inds
+
+
+def query_field_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
+    """Eval-mode Deformable.query_field (train-only fields return {}, decorator.py:4-17)."""
+    (xyz_cam, dir_cam, deltas, depth, _, _), inds = importance_sampling(P, fr, hxy, n_depth, alpha, prec)
+    # normals need d sdf / d xyz_cam through the rigid transform and the warp (nerf.py:455-493): one first-order
+    # backward pass through the same kernels, so the forward below is run under autograd with xyz_cam as the leaf.
+    with torch.enable_grad():
+        xc = xyz_cam.detach().requires_grad_(True)
+        qi, ti = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
+        xyz_t = rigid_apply(qi, ti, xc)
+        xyz, _ = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, prec)
+        rgb, sdf = nerf_forward(P, xyz, fr, prec, get_density=False, alpha=alpha)
+        (g,) = torch.autograd.grad(sdf, xc, torch.ones_like(sdf))
+    with torch.no_grad():
+        xyz, xyz_t, rgb, sdf = xyz.detach(), xyz_t.detach(), rgb.detach(), sdf.detach()
+        ibeta = P["logibeta"].exp()
+        density = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta
+        vis = vis_field(P, xyz, fr, prec)
+        valid = get_valid_idx(P, xyz, xyz_t, fr["t_articulation"])
+        # query_nerf (nerf.py:782-819) evaluates the field on the valid samples only and scatters into zeros; here the
+        # field is evaluated everywhere and masked (same result; the compaction itself is future work, DESIGN.md s.7)
+        rgb = rgb * valid[..., None]
+        density = density * valid[..., None]
+        fd = {"rgb": rgb, "density": density, "density_fg": density, "vis": vis}
+        fd["eikonal"] = (g.norm(2, dim=-1, keepdim=True) - 1) ** 2
+        fd["normal"] = F.normalize(g, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=g.device)
+        fd["xyz"] = xyz
+        fd["xyz_cam"] = xyz_cam
+        fd["depth"] = depth / P["logscale"].exp()
+        fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
+    return fd, deltas, {"valid": valid, "inds": inds}
+
+
+@torch.no_grad()
+def render_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
+    """dvr_model.render (eval) for field_type == "fg"."""
+    fd, deltas, dbg = query_field_eval(P, fr, hxy, n_depth, alpha, prec)
+    out = RU.render_pixel(fd, deltas)
+    return {"rendered": out, "aux_dict": {"fg": dict(out)}, "debug": dbg}
