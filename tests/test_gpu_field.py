@@ -116,3 +116,19 @@ def test_eval_graph_matches_reference_goldens(golden_dir):
     # rendered channel must still match the reference render at 1e-4 (fp32 path)
     for k, v in g["rendered"].items():
         assert rel(out["rendered"][k], v) < 2e-4, f"rendered.{k}: {rel(out['rendered'][k], v):.3e}"
+
+
+def test_render_samples_chunk_equals_unchunked_eval(golden_dir):
+    """Chunking along N is invisible in eval mode (model.py:259-326), apart from the global mean(T) normaliser of `vis`."""
+    from lab4d_amd import model
+    g, P = load_case(golden_dir, "eval_small.pt")
+    Pd = synthetic.to_device(P, DEV)
+    sd = synthetic.to_device(dict(g["frames"]), DEV)
+    sd["hxy"] = g["hxy"].to(DEV)
+    full = model.render_samples(Pd, sd, training=False, n_depth=g["meta"]["D"])
+    chunked = model.render_samples_chunk(Pd, sd, chunk_size=6, training=False, n_depth=g["meta"]["D"])
+    for k, v in full["rendered"].items():
+        if k == "vis":
+            continue
+        assert chunked["rendered"][k].shape == v.shape
+        assert rel(chunked["rendered"][k].cpu(), v.cpu()) < 1e-5, k
