@@ -100,6 +100,15 @@ typedef struct {
 } lab4d_mlp_fwd_args;
 int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream);
 
+/* Tangent-mode forward of LAB4D_NET_FG_BASE for the eikonal term (nnutils/nerf.py:416-453, utils/torch_utils.py:4-27).
+ * The SDF network is piecewise linear in its embedding e(x), so with v = d sdf / d e (the dgrad chain with d_out = 1),
+ *   g = d sdf / d x = J_e(x)^T v        and        d L(g) / d theta = d/d theta [ u^T v(theta) ],  u = J_e(x) dL/dg.
+ * u^T v is the output of the bias-free network with the primal's ReLU pattern applied to the input u, so its weight
+ * gradient is dz(primal dgrad, d_out = 1) (x) t_{l-1}: run this entry point with x = u (S, ke) (embedding-slot order) and
+ * mask[l] = the primal's sign bits, then lab4d_mlp_wgrad with the primal dz and the tangent act / emb stored here.
+ * bias / pf_bias / ext are ignored. */
+int lab4d_mlp_forward_tangent(const lab4d_mlp_fwd_args* a, void* stream);
+
 typedef struct {
   int net, precision, S, S_pad, ld, spf;
   const void* WT[LAB4D_MLP_MAX_LAYERS];        /* packed transposed weights                                */

@@ -233,7 +233,10 @@ struct Slab {
 // =================================================================================================
 // forward chain
 // =================================================================================================
-template <class Net, class P>
+// TAN = tangent mode (eikonal term, nerf.py:416-453): the input is a raw (S, KE) tangent vector in embedding-slot order,
+// layers have no bias, and ReLU is replaced by the sign bits the primal pass stored (the network is piecewise linear, so
+// d/dtheta of the directional derivative of sdf is an ordinary backward pass of this masked linear network).
+template <class Net, class P, bool TAN = false>
 __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
   constexpr int NT = P::NT, TILE = P::TILE, KE = Net::KE, UE = KE / P::FPG, UW = Slab<Net, P>::UW;
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
@@ -255,7 +258,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int s = sidx[t] < a.S ? sidx[t] : a.S - 1;
-      if constexpr (Net::EMB == 0) {
+      if constexpr (Net::EMB == 0 && !TAN) {
         const float x[3] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2]};
         if constexpr (P::BF16) {
           // bf16 path: sin/cos(2^f x) by angle doubling from one accurate sincos per axis
@@ -310,8 +313,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
             emb[t][g] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
           }
         }
-      } else {  // raw channels
-        const float* xr = a.x + (size_t)s * Net::CIN;
+      } else {  // raw channels (tangent mode: KE slots)
+        constexpr int CINR = TAN ? KE : Net::CIN;
+        const float* xr = a.x + (size_t)s * CINR;
 #pragma unroll
         for (int g = 0; g < UE; ++g) {
           if constexpr (P::BF16) {
@@ -319,7 +323,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const int c = 16 * g + 8 * h + j;
-              v[j] = c < Net::CIN ? xr[c] : 0.f;
+              v[j] = c < CINR ? xr[c] : 0.f;
             }
             emb[t][g] = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
           } else {
@@ -327,7 +331,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int c = 2 * (4 * g + e) + h;
-              v[e] = c < Net::CIN ? xr[c] : 0.f;
+              v[e] = c < CINR ? xr[c] : 0.f;
             }
             emb[t][g] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
           }
@@ -396,7 +400,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             float4 v = b4;
-            if constexpr (ls.pf != 0) {
+            if constexpr (TAN) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (ls.pf != 0 && !TAN) {
               const float4 p4 = *reinterpret_cast<const float4*>(pfl + (size_t)frame[t] * (32 * MT) + 32 * mt + 8 * i + 4 * h);
               v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
             }
@@ -414,17 +419,25 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         if constexpr (ls.relu != 0) {
           // ReLU + its sign bits (1 dword per lane per tile): the backward masks with these instead of re-reading
           // the whole activation tile (16x less traffic, 31 fewer live registers)
-          unsigned int bits = 0;
+          if constexpr (TAN) {
+            const unsigned int bits = a.mask[l][((size_t)tile * MT + mt) * 64 + lane];
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              bits |= (acc[t][r] > 0.f ? 1u : 0u) << (16 * t + r);
-              acc[t][r] = fmaxf(acc[t][r], 0.f);
-            }
-          if (a.mask[l]) a.mask[l][((size_t)tile * MT + mt) * 64 + lane] = bits;
+              for (int r = 0; r < 16; ++r) acc[t][r] = ((bits >> (16 * t + r)) & 1u) ? acc[t][r] : 0.f;
+          } else {
+            unsigned int bits = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                bits |= (acc[t][r] > 0.f ? 1u : 0u) << (16 * t + r);
+                acc[t][r] = fmaxf(acc[t][r], 0.f);
+              }
+            if (a.mask[l]) a.mask[l][((size_t)tile * MT + mt) * 64 + lane] = bits;
+          }
         }
-        if constexpr (ls.add_ext != 0) {
+        if constexpr (ls.add_ext != 0 && !TAN) {
           f32x16_t e[NT];
           load_tile<P>(a.ext, 32 * MT, s0, mt, lane, e);
 #pragma unroll
@@ -448,7 +461,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int f = 32 * mt + drow(r, h);
-              if (f < Net::COUT && sidx[t] < a.S) a.out[(size_t)sidx[t] * Net::COUT + f] = acc[t][r];
+              if (f < Net::COUT && sidx[t] < a.S && a.out) a.out[(size_t)sidx[t] * Net::COUT + f] = acc[t][r];
             }
         }
       };
@@ -656,6 +669,8 @@ template <class Net>
 int launch_mlp_fwd(int precision, const FwdK& k, int S, hipStream_t st);
 template <class Net>
 int launch_mlp_bwd(int precision, const BwdK& k, int S, hipStream_t st);
+template <class Net>
+int launch_mlp_fwd_tangent(int precision, const FwdK& k, int S, hipStream_t st);
 
 inline int mlp_grid(int ntiles) {
   int g = (ntiles + 3) / 4;

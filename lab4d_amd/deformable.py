@@ -149,45 +149,19 @@ def global_match(P, feat_px, feat_canonical, xyz_canonical, perm):
     return (prob @ xc).view(shape[:-1] + (3,))
 
 
-def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, bf16=False):
-    """NeRF.compute_eikonal (nerf.py:416-453) on the host-drawn 1/16 ray subset.  Needs d/dtheta of
-    |d sdf/dx| (double backward through the base MLP): this round it runs as plain device GEMMs under
-    torch autograd on the small subset; the tangent-mode chain kernel is listed as next in DESIGN.md."""
+def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32):
+    """NeRF.compute_eikonal (nerf.py:416-453) on the host-drawn 1/16 ray subset: (|d sdf/dx| - 1)^2 with gradients to the
+    basefield / sdf weights, via the primal + tangent-mode chain kernels (mlp.EikonalSdf) -- no second-order autograd."""
     M, N, D, _ = xyz.shape
-    pts = xyz.reshape(-1, D, 3)
-    c = code[:, None].expand(M, N, code.shape[-1]).reshape(M * N, -1)
-    out = torch.zeros_like(pts[..., 0])
+    pts = xyz.reshape(M * N, D, 3)
+    out = torch.zeros(M * N, D, device=xyz.device)
     if rand_inds is None:
         rand_inds = torch.arange(M * N, device=xyz.device)
-    with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
-        x = pts[rand_inds].detach().requires_grad_(True)
-        cc = c[rand_inds][:, None].expand(-1, D, -1)
-        sdf = _base_sdf_torch(P, x, cc, alpha)
-        (g,) = torch.autograd.grad(sdf, x, torch.ones_like(sdf), create_graph=True)
-    g = g.float()
-    out = out.index_put((rand_inds,), (g.norm(2, dim=-1) - 1) ** 2)
+    ray_code = code[torch.div(rand_inds, N, rounding_mode="floor")]
+    x = pts[rand_inds].detach().reshape(-1, 3)
+    e = mlp.eikonal_sdf(P, x, ray_code, D, prec, freq_w=posenc_window(alpha, 10, xyz.device))
+    out = out.index_put((rand_inds,), e.view(-1, D))
     return out.reshape(M, N, D, 1)
-
-
-def _posenc_torch(x, L, alpha):
-    freq = 2.0 ** torch.arange(L, dtype=x.dtype, device=x.device)
-    ang = freq[:, None] * x[..., None, :]
-    bands = torch.stack([torch.sin(ang), torch.cos(ang)], -2)
-    w = posenc_window(alpha, L, x.device)
-    if w is not None:
-        bands = bands * w[:, None, None]
-    return torch.cat([x, bands.reshape(x.shape[:-1] + (6 * L,))], -1)
-
-
-def _base_sdf_torch(P, x, code, alpha):
-    h0 = torch.cat([_posenc_torch(x, 10, alpha), code], -1)
-    out = h0
-    for i in range(8):
-        if i == 4:
-            out = torch.cat([h0, out], -1)
-        out = F.relu(F.linear(out, P[f"basefield.linear_{i+1}.0.weight"], P[f"basefield.linear_{i+1}.0.bias"]))
-    out = F.relu(F.linear(out, P["basefield.linear_final.0.weight"], P["basefield.linear_final.0.bias"]))
-    return F.linear(out, P["sdf.weight"], P["sdf.bias"])
 
 
 def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None, prec=mlp.PREC_F32):
@@ -215,7 +189,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     fd["cyc_dist"] = (xyz_cyc - xyz_t).norm(2, -1, keepdim=True)
     for k in ["skin_entropy", "delta_skin"]:
         fd[k] = (cyc_aux[k] + bw_aux[k]) / 2
-    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha, bf16=(prec == mlp.PREC_BF16))
+    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha, prec)
     fd["xyz"] = xyz
     fd["xyz_cam"] = xyz_cam
     fd["depth"] = depth / P["logscale"].exp()

@@ -49,6 +49,7 @@ _lib.register("lab4d_mlp_describe", [ci, ctypes.POINTER(NetDesc)])
 _lib.register("lab4d_mlp_pack", [ci, ci, ci, ci, vp, ci, vp, vp, vp])
 _lib.register("lab4d_mlp_forward", [ctypes.POINTER(FwdArgs), vp])
 _lib.register("lab4d_mlp_backward", [ctypes.POINTER(BwdArgs), vp])
+_lib.register("lab4d_mlp_forward_tangent", [ctypes.POINTER(FwdArgs), vp])
 _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
 
@@ -406,3 +407,146 @@ def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_la
     for l in range(d.n_layers):
         params += [P[bd[l].wname], P[bd[l].bname]]
     return MlpChain.apply(net, prec, spf, x, ext, freq_w, -1 if export_layer is None else export_layer, len(pfs), *pfs, *params)
+
+
+
+class EikonalSdf(Function):
+    """e[s] = (|d sdf / d x_s| - 1)^2 for detached points x (S,3): NeRF.compute_eikonal / torch_utils.compute_gradient
+    (nerf.py:416-453, torch_utils.py:4-27) without second-order autograd.  Forward = primal chain + dgrad chain with
+    d_out = 1 (gives g = d sdf/dx and the backward signals dz_l).  Backward = tangent-mode forward of u = J_e(x) dL/dg
+    through the same ReLU pattern, then the ordinary wgrad kernel on (dz_l, tangent activations): see
+    lab4d_mlp_forward_tangent in include/lab4d_mlp.h for the derivation."""
+
+    @staticmethod
+    def forward(ctx, prec, spf, x, freq_w, pf0, pf4, *params):
+        net = NET_FG_BASE
+        d = describe(net)
+        NL = d.n_layers
+        Ws, bs = params[0::2], params[1::2]
+        x = x.detach().contiguous()
+        _lib.require_device(x)
+        S = x.shape[0]
+        S_pad = s_pad_of(S)
+        dev, sdt = x.device, store_dtype(prec)
+        tile = 64 if prec == PREC_BF16 else 32
+        a = FwdArgs()
+        a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, S_pad, int(spf)
+        a.x = x.data_ptr()
+        fw = None
+        if freq_w is not None:
+            fw = freq_w.detach().contiguous().float()
+            a.freq_w = fw.data_ptr()
+        keep, masks, packed = [], [None] * NL, []
+        pfs = {0: pf0.detach().contiguous().float(), 4: pf4.detach().contiguous().float()}
+        for l in range(NL):
+            L = d.layers[l]
+            pw = packed_weights(net, l, prec, Ws[l], False)
+            packed.append(pw)
+            a.W[l] = pw.data_ptr()
+            b = bs[l].detach().float()
+            if b.numel() != L.mout_pad:
+                b = torch.nn.functional.pad(b, (0, L.mout_pad - b.numel()))
+            b = b.contiguous()
+            keep.append(b)
+            a.bias[l] = b.data_ptr()
+            if L.pf_bias:
+                a.pf_bias[l] = pfs[l].data_ptr()
+            if L.relu and l + 1 < NL:
+                masks[l] = torch.empty((S_pad // tile) * (L.mout_pad // 32) * 64, dtype=torch.int32, device=dev)
+                a.mask[l] = masks[l].data_ptr()
+        emb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
+        a.emb = emb.data_ptr()
+        sdf = torch.empty(S, 1, device=dev)
+        a.out = sdf.data_ptr()
+        _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(eikonal primal)")
+        bk = BwdArgs()
+        bk.net, bk.precision, bk.S, bk.S_pad, bk.ld, bk.spf = net, prec, S, S_pad, S_pad, int(spf)
+        dz = [None] * NL
+        for l in range(NL):
+            L = d.layers[l]
+            pt = packed_weights(net, l, prec, Ws[l], True)
+            keep.append(pt)
+            bk.WT[l] = pt.data_ptr()
+            if masks[l] is not None:
+                bk.mask[l] = masks[l].data_ptr()
+            dz[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
+            bk.dz[l] = dz[l].data_ptr()
+            if L.ext_grad:
+                zg = torch.zeros(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
+                keep.append(zg)
+                bk.ext_gin = zg.data_ptr()
+        bk.emb = emb.data_ptr()
+        ones = torch.ones(S, 1, device=dev)
+        bk.d_out = ones.data_ptr()
+        g = torch.empty(S, 3, device=dev)
+        bk.d_x = g.data_ptr()
+        _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(bk), _lib.stream()), "mlp_backward(eikonal primal)")
+        gn = g.norm(2, dim=-1, keepdim=True)
+        ctx.meta = (prec, int(spf), S, S_pad)
+        ctx.saved = (x, fw, g, gn, dz, masks, packed)
+        ctx.params = params
+        return (gn - 1) ** 2
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ge):
+        prec, spf, S, S_pad = ctx.meta
+        x, fw, g, gn, dz, masks, packed = ctx.saved
+        net = NET_FG_BASE
+        d = describe(net)
+        NL, L0 = d.n_layers, d.n_freq
+        Ws = ctx.params[0::2]
+        dev, sdt = x.device, store_dtype(prec)
+        # dL/dg, then u = J_e(x) dL/dg in embedding-slot order [ (f, a, {sin,cos}) pairs | x | pad ]
+        dLdg = ge * 2 * (gn - 1) / gn * g
+        freq = 2.0 ** torch.arange(L0, dtype=torch.float32, device=dev)
+        wf = freq if fw is None else freq * fw
+        ang = x[:, None, :] * freq[None, :, None]
+        u = torch.stack([wf[None, :, None] * torch.cos(ang) * dLdg[:, None, :], -wf[None, :, None] * torch.sin(ang) * dLdg[:, None, :]], -1)
+        u = torch.cat([u.reshape(S, 6 * L0), dLdg, torch.zeros(S, d.ke - 6 * L0 - 3, device=dev)], -1).contiguous()
+        a = FwdArgs()
+        a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, S_pad, spf
+        a.x = u.data_ptr()
+        tact = [None] * NL
+        for l in range(NL):
+            L = d.layers[l]
+            a.W[l] = packed[l].data_ptr()
+            if masks[l] is not None:
+                a.mask[l] = masks[l].data_ptr()
+            if l + 1 < NL:
+                tact[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
+                a.act[l] = tact[l].data_ptr()
+        temb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
+        a.emb = temb.data_ptr()
+        _lib.check(_lib.lib().lab4d_mlp_forward_tangent(ctypes.byref(a), _lib.stream()), "mlp_forward_tangent")
+        sizes = [d.layers[l].mout_pad * (d.layers[l].ke + d.layers[l].kin) for l in range(NL)]
+        arena = torch.zeros(sum(sizes), device=dev)
+        off = 0
+        grads = []
+        for l in range(NL):
+            L = d.layers[l]
+            gW = None
+            if ctx.needs_input_grad[6 + 2 * l]:
+                dWk = arena[off:off + sizes[l]].view(L.mout_pad, L.ke + L.kin)
+                prev = tact[l - 1] if L.kin else None
+                with _lib.timed("mlp_wgrad", 2.0 * S * L.mout * (L.ke + L.kin)):
+                    _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, S_pad, spf, _lib.ptr(dz[l]), _lib.ptr(temb), _lib.ptr(prev),
+                                                          _lib.ptr(dWk), None, None, 0, _lib.stream()), "mlp_wgrad(eikonal)")
+                kcols, rcols = col_index(net, l, dev)
+                gW = torch.zeros_like(Ws[l], dtype=torch.float32)
+                gW[:, rcols] = dWk[:L.mout][:, kcols]
+            off += sizes[l]
+            grads += [gW, None]
+        return (None, None, None, None, None, None, *grads)
+
+
+def eikonal_sdf(P, x, ray_code, spf, prec, freq_w=None, prefix=""):
+    """(|d sdf/dx| - 1)^2 at detached points x (S,3); ray_code (S/spf, 32) = instance code of the ray each group of `spf`
+    consecutive samples belongs to."""
+    bd = bindings(NET_FG_BASE, prefix)
+    pf0 = pf_bias_of(NET_FG_BASE, 0, P[bd[0].wname], ray_code)
+    pf4 = pf_bias_of(NET_FG_BASE, 4, P[bd[4].wname], ray_code)
+    params = []
+    for l in range(describe(NET_FG_BASE).n_layers):
+        params += [P[bd[l].wname], P[bd[l].bname]]
+    return EikonalSdf.apply(prec, spf, x, freq_w, pf0, pf4, *params)

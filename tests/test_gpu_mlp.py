@@ -176,3 +176,33 @@ def test_chain_full_size_linearity_property():
     b = mlp.run_chain(mlp.NET_VIS, 1, P2, x, S, conds={0: code})
     assert a.shape == (S, 1)
     assert float(((b - a) - 0.5).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("prec,tol", [(0, 2e-3), (1, 0.35)])
+def test_eikonal_value_and_weight_gradients(prec, tol):
+    """(|d sdf/dx| - 1)^2 and its gradient wrt every basefield / sdf weight (second-order in the reference:
+    torch_utils.compute_gradient with create_graph=True) through the primal + tangent-mode kernels."""
+    from lab4d_amd import deformable as DF
+    M, N, D = 2, 8, 8
+    P, fr, xyz, g = setup(11, M, N, D)
+    inds = torch.tensor([1, 5, 6, 12])
+    w = torch.rand(M, N, D, 1, generator=g)
+    keys = ["basefield.linear_1.0.weight", "basefield.linear_2.0.weight", "basefield.linear_5.0.weight", "basefield.linear_8.0.weight",
+            "basefield.linear_final.0.weight", "sdf.weight"]
+
+    def run(dev):
+        Pl = {k: (v.to(dev).clone().requires_grad_(True) if v.dtype.is_floating_point else v.to(dev)) for k, v in P.items()}
+        code = fr["code_base"].to(dev)
+        if dev == "cpu":
+            e = O.compute_eikonal(Pl, xyz, code, inds)
+        else:
+            e = DF.eikonal_subsample(Pl, xyz.to(dev), code, inds.to(dev), prec=prec)
+        gs = torch.autograd.grad((e * w.to(dev)).sum(), [Pl[k] for k in keys])
+        return e, gs
+
+    re, rg = run("cpu")
+    de, dg = run(DEV)
+    assert rel_err(de, re) < (1e-3 if prec == 0 else 0.2), rel_err(de, re)
+    for k, a, b in zip(keys, dg, rg):
+        assert rel_err(a, b) < tol, f"{k}: {rel_err(a, b):.3e}"
+        assert cosine(a, b) > 0.97, f"{k}: cosine {cosine(a, b):.4f}"
