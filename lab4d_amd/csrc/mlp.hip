@@ -271,6 +271,137 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_big(const typename P::store_t
   }
 }
 
+// bf16, 256 output rows: LDS-DMA double-buffered version.  In the blocked activation layout one 64-sample block of all
+// 256 feature rows is ONE contiguous 32 KiB region, so a stage (A = dz block, B = X block) is filled by 64 lane-linear
+// 1-KiB `global_load_lds_dwordx4` transfers with no VGPR round trip; two 64-KiB stages ping-pong in LDS, the next block
+// streams in while the 4 waves (2x2, 4x4 tiles each) run 64 MFMAs each on the current one.  The kernel is HBM-bound by
+// ~4x (64 KiB per 2048 MFMA-cycles per CU), so one barrier per block and the un-swizzled LDS image are not the limiter.
+__device__ __forceinline__ void dma_1k(const void* gsrc_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned int*)gsrc_lane,
+                                   (__attribute__((address_space(3))) unsigned int*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __restrict__ dz, const unsigned short* __restrict__ emb,
+                                                        const unsigned short* __restrict__ actp, int ke, int kin, int S_pad, int chunk,
+                                                        int spf, int cpf, float* __restrict__ dW, float* __restrict__ db) {
+  using P = PBF16;
+  constexpr int TM = 4, TN = 4, MO = 256;
+  constexpr int STAGE = 65536;  // bytes: A 32 KiB + B 32 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int K = ke + kin;
+  const int kb_n = (K + 255) / 256;
+  const int job = blockIdx.x;
+  const int c = job / kb_n, kb = job - c * kb_n;
+  int s_begin, s_end;
+  if (cpf > 0) {
+    const int m = c / cpf, lc = c - m * cpf;
+    s_begin = m * spf + lc * chunk;
+    s_end = min(min(S_pad, (m + 1) * spf), s_begin + chunk);
+    if (db) db += (size_t)m * MO;
+  } else {
+    s_begin = c * chunk;
+    s_end = min(S_pad, s_begin + chunk);
+  }
+  // B rows [k0, k0+nb) of X = [emb (ke rows) ; act (kin rows)]: up to two contiguous segments per 64-sample block
+  const int k0 = kb * 256, nb = min(256, K - k0);
+  const int n1 = k0 < ke ? min(nb, ke - k0) : 0;         // rows taken from emb, starting at row k0
+  const int n2 = nb - n1;                                // rows taken from act, starting at row max(k0, ke) - ke
+  const int r2 = (k0 > ke ? k0 : ke) - ke;
+  bool bv_[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv_[j] = (wc * 4 + j) * 32 < nb;
+  const bool do_db = (kb == 0 && wc == 0 && db != nullptr);
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float rs[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rs[i] = 0.f;
+
+  auto issue = [&](int blk, int buf) {
+    unsigned char* st = lds + buf * STAGE;
+    // A: 32 KiB = 32 pieces of 1 KiB, wave w takes pieces w, w+4, ...
+    const unsigned char* ga = reinterpret_cast<const unsigned char*>(dz + (size_t)blk * block_stride(MO));
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int piece = wid + 4 * p;
+      dma_1k(ga + piece * 1024 + lane * 16, st + piece * 1024);
+    }
+    unsigned char* sb = st + 32768;
+    const int np1 = n1 / 8, np2 = n2 / 8;  // 1-KiB pieces (8 rows of 128 B each)
+    if (n1 > 0) {
+      const unsigned char* g1 = reinterpret_cast<const unsigned char*>(emb + (size_t)blk * block_stride(ke) + (size_t)k0 * 64);
+      for (int piece = wid; piece < np1; piece += 4) dma_1k(g1 + piece * 1024 + lane * 16, sb + piece * 1024);
+    }
+    if (n2 > 0) {
+      const unsigned char* g2 = reinterpret_cast<const unsigned char*>(actp + (size_t)blk * block_stride(kin) + (size_t)r2 * 64);
+      unsigned char* sb2 = sb + n1 * 128;
+      for (int piece = wid; piece < np2; piece += 4) dma_1k(g2 + piece * 1024 + lane * 16, sb2 + piece * 1024);
+    }
+  };
+  auto compute = [&](int buf) {
+    const unsigned char* sa = lds + buf * STAGE;
+    const unsigned char* sb = sa + 32768;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      uint4 a4[TM], b4[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const uint4*>(sa + ((wr * 4 + i) * 32 + row) * 128 + sub * 32 + 16 * h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b4[j] = bv_[j] ? *reinterpret_cast<const uint4*>(sb + ((wc * 4 + j) * 32 + row) * 128 + sub * 32 + 16 * h) : make_uint4(0, 0, 0, 0);
+      if (do_db) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const unsigned int w[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rs[i] += bf2f((unsigned short)(w[q] & 0xffffu)) + bf2f((unsigned short)(w[q] >> 16));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_unit<P>(acc[i][j], a4[i], b4[j]);
+    }
+  };
+  const int b_begin = s_begin >> 6, b_end = s_end >> 6;
+  if (b_begin < b_end) {
+    issue(b_begin, 0);
+    __syncthreads();  // (the compiler drains the DMA with vmcnt(0) ahead of the barrier)
+    int buf = 0;
+    for (int b = b_begin; b < b_end; ++b) {
+      if (b + 1 < b_end) issue(b + 1, buf ^ 1);
+      compute(buf);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (!bv_[j]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = 32 * (wr * 4 + i) + drow(r, h);
+        const int k = k0 + 32 * (wc * 4 + j) + row;
+        atomicAdd(dW + (size_t)o * K + k, acc[i][j][r]);
+      }
+    }
+    if (do_db) {
+      const float v = rs[i] + __shfl_xor(rs[i], 32, 64);
+      if (h == 0) atomicAdd(db + 32 * (wr * 4 + i) + row, v);
+    }
+  }
+}
+
 // per-frame bias gradient: pf_db[m][o] += sum_{s in frame m} dz[o][s].  One wave per (row o, 4096-sample
 // segment); a segment that straddles frames flushes at the boundary.  pf_db is zero-filled by the caller.
 template <class P>
@@ -450,7 +581,8 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   LAB4D_REQUIRE(S_pad % 64 == 0 && S_pad >= S && ld >= S_pad && ld % 8 == 0, "mlp_wgrad: bad S_pad/ld");
   if (S == 0) return LAB4D_OK;
   const int mo_tiles = L.mout_pad / 32, nk_tiles = (L.ke + L.kin) / 32;
-  const bool big = mo_tiles >= 8;  // 256-wide layers: 8x8-tile workgroup blocks (k_mlp_wgrad_big)
+  const bool big = mo_tiles >= 8;  // 256-wide layers: 8x8-tile workgroup blocks (k_mlp_wgrad_big / k_mlp_wgrad_dma)
+  const bool dma = precision == LAB4D_PREC_BF16 && mo_tiles == 8;
   const int TM = mo_tiles >= 4 ? 4 : (mo_tiles >= 2 ? 2 : 1);
   const int ob_n = big ? div_up(mo_tiles, 8) : div_up(mo_tiles, TM), kb_n = big ? div_up(nk_tiles, 8) : div_up(nk_tiles, 4);
   // ~1024 workgroups in total (4 per CU); chunks are multiples of 256 samples (one 64-sample step per wave)
@@ -475,7 +607,10 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
                                       (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
 #define WGB(P) hipLaunchKernelGGL((k_mlp_wgrad_big<P>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
                                   (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
-  if (precision == LAB4D_PREC_BF16) { if (big) WGB(PBF16); else if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
+  if (dma)
+    hipLaunchKernelGGL(k_mlp_wgrad_dma, grid, block, 0, st, (const unsigned short*)dz, (const unsigned short*)emb, (const unsigned short*)act_prev,
+                       L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg);
+  else if (precision == LAB4D_PREC_BF16) { if (big) WGB(PBF16); else if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
   else if (precision == LAB4D_PREC_F32) { if (big) WGB(PF32); else if (TM == 4) WG(PF32, 4); else if (TM == 2) WG(PF32, 2); else WG(PF32, 1); }
   else { set_error("mlp_wgrad: bad precision %d", precision); return LAB4D_EINVAL; }
 #undef WGB
