@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=128)
-    ap.add_argument("--chunk-rows", type=int, default=16, help="image rows per frame per chunk (16 rows x 512 = 8192 rays/frame)")
+    ap.add_argument("--chunk-rows", type=int, default=32, help="image rows per frame per chunk (32 rows x 512 = 16384 rays/frame; ~150 GiB of HBM)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
@@ -262,6 +262,7 @@ def main():
             "config": {"workload": "cat-pikachu fg NeRF (Deformable skel-quad, 25 bones), %dx%d frame pair, %d samples/ray, training graph fwd+bwd+AdamW"
                                    % (res, res, spp), "rays_per_step": rays_per_step, "chunk_rays": 2 * a.chunk_rows * res,
                        "parallelism": "ray-band x%d, RCCL grad all-reduce" % world, "launch": "hipGraph replay per chunk" if graph is not None else "eager"},
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "whole_graph_tflops": round(value * spp * FLOP_PER_SAMPLE / 1e12, 2),
             "whole_graph_frac_of_peak": round(value * spp * FLOP_PER_SAMPLE / peak, 4),
             "roofline": roofline,

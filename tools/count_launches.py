@@ -1,0 +1,30 @@
+"""Count device kernel launches per autograd-function / op name over one eager chunk (fwd+bwd)."""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from lab4d_amd import deformable as DF, mlp
+dev = torch.device("cuda")
+P, fr = bench.make_problem(512, dev)
+hxy, batch = bench.chunk_inputs(512, 0, 16, dev, 1)
+gen = torch.Generator(device=dev).manual_seed(0)
+M, N = hxy.shape[:2]
+rng = bench.draw_rng(M, N, M * N * 128, dev, gen)
+for _ in range(2):
+    bench.train_chunk(DF, P, fr, hxy, batch, rng, 128, 512, mlp.PREC_BF16)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    bench.train_chunk(DF, P, fr, hxy, batch, rng, 128, 512, mlp.PREC_BF16)
+    torch.cuda.synchronize()
+ev = prof.key_averages()
+rows = []
+for e in ev:
+    if e.device_type == torch.autograd.DeviceType.CUDA:
+        continue
+    rows.append((e.key, e.count, e.self_device_time_total))
+rows.sort(key=lambda r: -r[1])
+tot = 0
+print("top CPU-side ops by call count (aten ops launching kernels):")
+for k, c, t in rows[:45]:
+    print(f"{k[:60]:60s} {c:6d} {t/1e3:9.2f} ms self device")
