@@ -245,16 +245,28 @@ def main():
 
     if rank == 0:
         peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32
-        # dominant kernel family = the one with the largest event-measured time over the timed region
+        # dominant kernel = the kernel symbol with the largest event-measured time
         dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
         roofline = None
         if dom:
-            name, (launches, ms, work) = dom
-            ach = work / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-                        "frac": round(ach * 1e12 / peak, 4), "traffic": None, "launches": launches, "avg_ms": round(ms / launches, 4),
-                        "measured": prof_src,
-                        "families_ms_per_step": {k: round(v[1] / n_prof_chunks * len(inputs), 2) for k, v in sorted(prof.items())}}
+            name, (launches, ms, flops, nbytes) = dom
+            hbm_bound = name.startswith("k_mlp_wgrad")  # 64 KiB of operands per 2048 MFMA-cycles per CU: HBM needs ~4x the MFMA time
+            pmc = {}
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pmc_path):
+                pmc = json.load(open(pmc_path))
+            traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
+            if hbm_bound:
+                ach = nbytes / (ms * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(ach / 8000.0, 4), "traffic": traffic}
+            else:
+                ach = flops / (ms * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                            "frac": round(ach * 1e12 / peak, 4), "traffic": traffic}
+            roofline.update({"launches": launches, "avg_ms": round(ms / launches, 4), "algorithmic_per_launch": {"flop": flops / launches, "bytes": nbytes / launches},
+                             "traffic_source": pmc.get("_source") if traffic else None, "measured": prof_src,
+                             "kernels_ms_per_step": {k: round(v[1] / n_prof_chunks * len(inputs), 2) for k, v in sorted(prof.items())}})
         out = {
             "metric": "rendered rays/sec (fwd+bwd) at 512^2 x 128 samples", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),

@@ -188,8 +188,10 @@ class timed:
 
 
 def prof_summary():
-    """name -> (launches, total_ms, total_work). Call after torch.cuda.synchronize()."""
+    """name -> (launches, total_ms, total_flops, total_bytes). Call after torch.cuda.synchronize()."""
     out = {}
     for k, v in (PROF or {}).items():
-        out[k] = (len(v), sum(s.elapsed_time(e) for s, e, _ in v), sum(w for _, _, w in v))
+        fl = sum((w[0] if isinstance(w, tuple) else w) for _, _, w in v)
+        by = sum((w[1] if isinstance(w, tuple) else 0.0) for _, _, w in v)
+        out[k] = (len(v), sum(s.elapsed_time(e) for s, e, _ in v), fl, by)
     return out

@@ -57,6 +57,28 @@ NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin"}
 # algorithmic MACs per sample (real layer shapes incl. conditioning columns)
 NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736}
 
+
+
+KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin"}  # template argument names in csrc/mlp_nets.hpp
+
+
+def wgrad_kernel_name(L, prec):
+    """Which kernel lab4d_mlp_wgrad dispatches to for this layer (mirrors the dispatch in csrc/mlp.hip)."""
+    if prec == PREC_BF16 and L.mout_pad == 256:
+        return "k_mlp_wgrad_dma"
+    if L.mout_pad >= 256:
+        return "k_mlp_wgrad_big"
+    return "k_mlp_wgrad<%d>" % (4 if L.mout_pad >= 128 else (2 if L.mout_pad >= 64 else 1))
+
+
+def wgrad_work(L, S_pad, prec):
+    """(algorithmic FLOPs, algorithmic HBM bytes) of one wgrad launch: 2*mout*K MAC-flops per sample; both operands
+    ([mout_pad + K] feature rows of S_pad samples) are read once, the (mout_pad, K) fp32 result is written once."""
+    K = L.ke + L.kin
+    esize = 2 if prec == PREC_BF16 else 4
+    return (2.0 * S_pad * L.mout * K, float((L.mout_pad + K) * S_pad * esize + L.mout_pad * K * 4))
+
+
 _DESC = {}
 
 
@@ -299,7 +321,7 @@ class MlpChain(Function):
             a.ext = ext.data_ptr()
         out = torch.empty(S, d.c_out, device=dev)
         a.out = out.data_ptr()
-        with _lib.timed("mlp_fwd_%s" % NET_NAMES[net], 2.0 * S * NET_MACS[net]):
+        with _lib.timed("k_mlp_fwd<%s>" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], 0.0)):
             _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
         ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
@@ -353,7 +375,7 @@ class MlpChain(Function):
         if ctx.needs_input_grad[3]:
             d_x = torch.empty(ctx.x_shape, device=dev)
             a.d_x = d_x.data_ptr()
-        with _lib.timed("mlp_bwd_%s" % NET_NAMES[net], 2.0 * S * NET_MACS[net]):
+        with _lib.timed("k_mlp_bwd<%s>" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], 0.0)):
             _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(a), _lib.stream()), "mlp_backward")
         # weight / bias gradients
         M = (S + spf - 1) // spf
@@ -378,7 +400,7 @@ class MlpChain(Function):
                 dbk = arena[aoff + n0:aoff + n0 + n1]
                 pfd = arena[aoff + n0 + n1:aoff + n0 + n1 + n2].view(M, L.mout_pad) if need_pf else None
                 prev = ctx.acts[l - 1] if L.kin else None
-                with _lib.timed("mlp_wgrad", 2.0 * S * L.mout * (L.ke + L.kin)):
+                with _lib.timed(wgrad_kernel_name(L, prec), wgrad_work(L, S_pad, prec)):
                   _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, ld, spf, _lib.ptr(dz[l]), _lib.ptr(ctx.emb), _lib.ptr(prev),
                                                       _lib.ptr(dWk), _lib.ptr(dbk), _lib.ptr(pfd), M, _lib.stream()), "mlp_wgrad")
                 if need_w:
@@ -529,7 +551,7 @@ class EikonalSdf(Function):
             if ctx.needs_input_grad[6 + 2 * l]:
                 dWk = arena[off:off + sizes[l]].view(L.mout_pad, L.ke + L.kin)
                 prev = tact[l - 1] if L.kin else None
-                with _lib.timed("mlp_wgrad", 2.0 * S * L.mout * (L.ke + L.kin)):
+                with _lib.timed(wgrad_kernel_name(L, prec) + "@eik", wgrad_work(L, S_pad, prec)):
                     _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, S_pad, spf, _lib.ptr(dz[l]), _lib.ptr(temb), _lib.ptr(prev),
                                                           _lib.ptr(dWk), None, None, 0, _lib.stream()), "mlp_wgrad(eikonal)")
                 kcols, rcols = col_index(net, l, dev)
