@@ -91,7 +91,9 @@ typedef struct {
   const float* freq_w;   /* (n_freq) annealing window weights or NULL (all ones)                           */
   const void* W[LAB4D_MLP_MAX_LAYERS];        /* packed forward weights                                    */
   const float* bias[LAB4D_MLP_MAX_LAYERS];    /* (mout_pad) fp32                                           */
-  const float* pf_bias[LAB4D_MLP_MAX_LAYERS]; /* (M, mout_pad) fp32 or NULL                                */
+  const float* pf_bias[LAB4D_MLP_MAX_LAYERS]; /* (M, mout_pad) fp32 per-frame bias of the pf_bias layers.  It REPLACES bias[l]
+                                                 there (the host adds the shared bias into every row: the kernel fetches
+                                                 one bias vector per tile, not two)                                   */
   void* act[LAB4D_MLP_MAX_LAYERS];  /* stored post-activation (blocked [64-sample block][mout_pad][64] + skew) or NULL */
   void* mask[LAB4D_MLP_MAX_LAYERS]; /* ReLU sign bits, uint32 [S_pad/TILE][mout_pad/32][64] (TILE = 64 bf16 / 32 fp32), or NULL */
   void* emb;                        /* [ke][ld] stored embedding or NULL                                */

@@ -16,12 +16,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
-SO_PATH = os.path.join(HERE, "liblab4d_hip.so")
-BUILD_DIR = os.path.join(HERE, "build")
+SO_PATH = os.environ.get("LAB4D_SO_PATH", os.path.join(HERE, "liblab4d_hip.so"))  # override: kernel experiments only
+BUILD_DIR = os.environ.get("LAB4D_BUILD_DIR", os.path.join(HERE, "build"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
-          "-Wno-unused-value", "-Wno-pass-failed"]
+          "-Wno-unused-value", "-Wno-pass-failed"] + os.environ.get("LAB4D_HIPCC_EXTRA", "").split()
 
 
 def sources():

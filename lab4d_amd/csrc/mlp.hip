@@ -541,6 +541,11 @@ extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
       LAB4D_REQUIRE(a->W[l] && a->bias[l], "mlp_forward: layer %d weights/bias missing", l);
       LAB4D_REQUIRE(!Net::L[l].pf || a->pf_bias[l], "mlp_forward: layer %d needs a per-frame bias", l);
       LAB4D_REQUIRE(!Net::L[l].add_ext || a->ext, "mlp_forward: layer %d needs ext", l);
+      // training mode (emb given): the kernel stores every hidden activation and ReLU mask unconditionally
+      if (a->emb && l + 1 < Net::NL) {
+        LAB4D_REQUIRE(a->act[l], "mlp_forward: training mode (emb != NULL) needs act[%d]", l);
+        LAB4D_REQUIRE(!Net::L[l].relu || a->mask[l], "mlp_forward: training mode (emb != NULL) needs mask[%d]", l);
+      }
       k.W[l] = a->W[l]; k.bias[l] = a->bias[l]; k.pf_bias[l] = a->pf_bias[l]; k.act[l] = a->act[l]; k.mask[l] = (unsigned int*)a->mask[l];
     }
     return launch_mlp_fwd<Net>(a->precision, k, a->S, (hipStream_t)stream);
@@ -563,6 +568,8 @@ extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
       LAB4D_REQUIRE(a->WT[l], "mlp_backward: layer %d transposed weights missing", l);
       LAB4D_REQUIRE(!(Net::L[l].relu && l + 1 < Net::NL) || a->mask[l], "mlp_backward: layer %d ReLU mask missing", l);
       LAB4D_REQUIRE(!Net::L[l].ext_grad || a->ext_gin, "mlp_backward: layer %d needs ext_gin", l);
+      LAB4D_REQUIRE(a->dz[l], "mlp_backward: dz[%d] missing (every layer's dZ is written)", l);
+      LAB4D_REQUIRE(!Net::L[l].add_ext || a->ext_gout, "mlp_backward: layer %d needs ext_gout", l);
       k.WT[l] = a->WT[l]; k.act[l] = a->act[l]; k.mask[l] = (const unsigned int*)a->mask[l]; k.dz[l] = a->dz[l];
     }
     return launch_mlp_bwd<Net>(a->precision, k, a->S, (hipStream_t)stream);
@@ -635,7 +642,7 @@ extern "C" int lab4d_mlp_forward_tangent(const lab4d_mlp_fwd_args* a, void* stre
   LAB4D_REQUIRE(a, "mlp_forward_tangent: null args");
   LAB4D_REQUIRE(a->net == LAB4D_NET_FG_BASE, "mlp_forward_tangent: only the basefield/sdf network has an eikonal term (got net %d)", a->net);
   LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0, "mlp_forward_tangent: bad sizes");
-  LAB4D_REQUIRE(a->x, "mlp_forward_tangent: null x");
+  LAB4D_REQUIRE(a->x && a->emb, "mlp_forward_tangent: null x / emb");
   if (a->S == 0) return LAB4D_OK;
   using Net = NetFgBase;
   FwdK k;
@@ -644,6 +651,7 @@ extern "C" int lab4d_mlp_forward_tangent(const lab4d_mlp_fwd_args* a, void* stre
   for (int l = 0; l < Net::NL; ++l) {
     LAB4D_REQUIRE(a->W[l], "mlp_forward_tangent: layer %d weights missing", l);
     LAB4D_REQUIRE(!(Net::L[l].relu) || a->mask[l], "mlp_forward_tangent: layer %d primal ReLU mask missing", l);
+    LAB4D_REQUIRE(l + 1 == Net::NL || a->act[l], "mlp_forward_tangent: act[%d] missing", l);
     k.W[l] = a->W[l]; k.bias[l] = a->bias[l] ? a->bias[l] : (const float*)a->W[l]; k.act[l] = a->act[l]; k.mask[l] = (unsigned int*)a->mask[l];
   }
   return launch_mlp_fwd_tangent<Net>(a->precision, k, a->S, (hipStream_t)stream);

@@ -21,6 +21,7 @@
 // just dynamically-indexable register space.  The next layer reloads its inputs from the slab.
 // Weights stream from L2 as pre-packed, lane-linear 1-KiB A-groups (global_load_dwordx4).
 #pragma once
+#include <cstddef>
 #include <type_traits>
 
 #include "common.hpp"
@@ -68,10 +69,44 @@ __device__ __forceinline__ void sfor(F&& f) {
   }
 }
 
-// 16-byte A group load: the packed block of (mt, g) is 1 KiB, lane-linear.
-__device__ __forceinline__ uint4 load_a(const void* base, int G, int mt, int g, int lane) {
-  return *(reinterpret_cast<const uint4*>(base) + ((size_t)(mt * G + g) * 64 + lane));
+#define GLOBAL_AS __attribute__((address_space(1)))
+// plain clang vectors for accesses through address-space-qualified pointers (HIP's uint4/float4 are classes whose
+// copy constructors only bind generic references)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 gld16(const GLOBAL_AS void* p) {
+  const u32x4_t v = *(const GLOBAL_AS u32x4_t*)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ void gst16(GLOBAL_AS void* p, unsigned int x, unsigned int y, unsigned int z, unsigned int w) {
+  u32x4_t v = {x, y, z, w};
+  *(GLOBAL_AS u32x4_t*)p = v;
+}
+
+// 16-byte A group load: the packed block of (mt, g) is 1 KiB, lane-linear.
+// `base`, G and mt are wave-uniform: the tile base stays in SGPRs and the load uses the saddr + 32-bit lane offset +
+// immediate form (64-bit per-lane addresses cost two VGPRs per group and, under the register pressure of this kernel,
+// were being spilled to scratch and reloaded one by one).
+__device__ __forceinline__ uint4 load_a(const GLOBAL_AS void* base, int G, int mt, int g, int lane) {
+  const GLOBAL_AS char* tile = (const GLOBAL_AS char*)base + (size_t)(unsigned)(mt * G) * 1024u;
+  return gld16(tile + (unsigned)(g * 1024 + lane * 16));
+}
+
+// Kernel arguments are read from the kernarg segment at the point of use.  Left to itself the compiler hoists the ~60
+// pointer loads of the argument block to the kernel entry, runs out of SGPRs and parks them in scratch (94 scratch
+// stores at entry, reloads on every layer's critical path).  The empty asm makes the segment pointer opaque per use.
+template <class T>
+__device__ __forceinline__ GLOBAL_AS typename std::remove_pointer<T>::type* karg(size_t byte_off) {
+  static_assert(std::is_pointer<T>::value, "karg: pointer arguments only");
+  typedef __attribute__((address_space(4))) const char* kptr_t;  // constant address space: scalar loads
+  kptr_t p = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  T v = *(__attribute__((address_space(4))) const T*)(p + byte_off);
+  // a pointer loaded from memory is a generic (flat) pointer to the compiler; the result type carries the global address
+  // space explicitly, otherwise every access through it becomes a flat_load/flat_store with 64-bit per-lane addressing
+  return (GLOBAL_AS typename std::remove_pointer<T>::type*)v;
+}
+#define KARG_PTR(Struct, T, field, idx) karg<T>(offsetof(Struct, field) + sizeof(void*) * (size_t)(idx))
 
 // acc += A(group) * B(unit)
 template <class P>
@@ -136,11 +171,22 @@ template <class P>
 __device__ __forceinline__ size_t tile_byte_offset(int F, int s0, int row, int k) {
   return ((size_t)(s0 >> 6) * block_stride(F) + (size_t)row * 64 + (s0 & 63)) * sizeof(typename P::store_t) + 16 * (size_t)k;
 }
+// the same offset split for saddr addressing: wave-uniform part (tile + first row of the 32-row M-tile) ...
+template <class P>
+__device__ __forceinline__ size_t tile_base_offset(int F, int s0, int row0) {
+  return ((size_t)(s0 >> 6) * block_stride(F) + (size_t)row0 * 64 + (s0 & 63)) * sizeof(typename P::store_t);
+}
+// ... and the per-lane part (row within the tile, 16-byte column k): < 32*64*4 + 128 bytes
+template <class P>
+__device__ __forceinline__ unsigned tile_lane_offset(int row, int k) {
+  return (unsigned)(row * 64) * (unsigned)sizeof(typename P::store_t) + 16u * (unsigned)k;
+}
 
 template <class P>
-__device__ __forceinline__ void store_tile(void* buf, int F, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
+__device__ __forceinline__ void store_tile(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
   const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
-  char* base = reinterpret_cast<char*>(buf);
+  GLOBAL_AS char* base = (GLOBAL_AS char*)buf + tile_base_offset<P>(F, s0, 32 * mt);
+  const unsigned lo = tile_lane_offset<P>(4 * h + q, k);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     unsigned int d[4];
@@ -150,16 +196,17 @@ __device__ __forceinline__ void store_tile(void* buf, int F, int s0, int mt, int
       else d[j] = __float_as_uint(c[0][4 * i + j]);
     }
     quad_transpose(d, q);
-    *reinterpret_cast<uint4*>(base + tile_byte_offset<P>(F, s0, 32 * mt + 8 * i + 4 * h + q, k)) = make_uint4(d[0], d[1], d[2], d[3]);
+    gst16(base + (lo + tile_lane_offset<P>(8 * i, 0)), d[0], d[1], d[2], d[3]);
   }
 }
 template <class P>
-__device__ __forceinline__ void load_tile(const void* buf, int F, int s0, int mt, int lane, f32x16_t* c /*[NT]*/) {
+__device__ __forceinline__ void load_tile(const GLOBAL_AS void* buf, int F, int s0, int mt, int lane, f32x16_t* c /*[NT]*/) {
   const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
-  const char* base = reinterpret_cast<const char*>(buf);
+  const GLOBAL_AS char* base = (const GLOBAL_AS char*)buf + tile_base_offset<P>(F, s0, 32 * mt);
+  const unsigned lo = tile_lane_offset<P>(4 * h + q, k);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const uint4 v = *reinterpret_cast<const uint4*>(base + tile_byte_offset<P>(F, s0, 32 * mt + 8 * i + 4 * h + q, k));
+    const uint4 v = gld16(base + (lo + tile_lane_offset<P>(8 * i, 0)));
     unsigned int d[4] = {v.x, v.y, v.z, v.w};
     quad_transpose(d, q);
 #pragma unroll
@@ -223,6 +270,60 @@ __device__ __forceinline__ void emb_pair(int pair, const float* x, const float* 
   }
 }
 
+// ---- layer kinds ----------------------------------------------------------------------------------
+// Layers of identical shape share ONE copy of the layer code, executed from a runtime loop over the layers: the fully
+// unrolled chain (10 layer bodies, 70-120 KB of code) does not fit the 64 KB instruction cache two CUs share, and with
+// every wave at a different layer the cache thrashed (measured: the training-mode forward ran 1.4x faster with the
+// seven 256x256 layers sharing their code).  A kind is named by its first ("representative") layer.
+template <class Net>
+constexpr bool fwd_same(int a, int b) {
+  const LS x = Net::L[a], y = Net::L[b];
+  return x.ke == y.ke && x.kin == y.kin && x.mout == y.mout && x.relu == y.relu && x.pf == y.pf && x.add_ext == y.add_ext &&
+         ((a == Net::NL - 1) == (b == Net::NL - 1));
+}
+template <class Net>
+constexpr int fwd_rep(int l) {
+  for (int j = 0; j < l; ++j)
+    if (fwd_same<Net>(j, l)) return j;
+  return l;
+}
+template <class Net>
+constexpr unsigned fwd_members(int r) {  // bit l set: layer l runs the code of representative r
+  unsigned m = 0;
+  for (int l = 0; l < Net::NL; ++l)
+    if (fwd_rep<Net>(l) == r) m |= 1u << l;
+  return m;
+}
+template <class Net>
+constexpr bool fwd_any_export(int r) {
+  for (int l = 0; l < Net::NL; ++l)
+    if (fwd_rep<Net>(l) == r && Net::L[l].ext_grad) return true;
+  return false;
+}
+// backward: the body of layer l depends on its own shape and on the layer below (mask / ext of its output)
+template <class Net>
+constexpr bool bwd_same(int a, int b) {
+  if ((a == 0) != (b == 0)) return false;
+  const LS x = Net::L[a], y = Net::L[b];
+  if (!(x.ke == y.ke && x.kin == y.kin && x.mout == y.mout)) return false;
+  if (a == 0) return true;
+  const LS xp = Net::L[a - 1], yp = Net::L[b - 1];
+  return xp.relu == yp.relu && xp.ext_grad == yp.ext_grad && xp.add_ext == yp.add_ext && xp.mout == yp.mout;
+}
+template <class Net>
+constexpr int bwd_rep(int l) {
+  for (int j = Net::NL - 1; j > l; --j)
+    if (bwd_same<Net>(j, l)) return j;
+  return l;
+}
+template <class Net>
+constexpr unsigned bwd_members(int r) {
+  unsigned m = 0;
+  for (int l = 0; l < Net::NL; ++l)
+    if (bwd_rep<Net>(l) == r) m |= 1u << l;
+  return m;
+}
+
 template <class Net, class P>
 struct Slab {
   static constexpr int W = net_wmax<Net>();
@@ -236,13 +337,20 @@ struct Slab {
 // TAN = tangent mode (eikonal term, nerf.py:416-453): the input is a raw (S, KE) tangent vector in embedding-slot order,
 // layers have no bias, and ReLU is replaced by the sign bits the primal pass stored (the network is piecewise linear, so
 // d/dtheta of the directional derivative of sdf is an ordinary backward pass of this masked linear network).
-template <class Net, class P, bool TAN = false>
+// ST = training mode: the embedding, every hidden post-activation and every ReLU sign mask are stored unconditionally
+// (all pointers non-NULL, checked by the host).  It is a template parameter, not a runtime test, because a store inside
+// a runtime branch makes the compiler's s_waitcnt vmcnt(N) bookkeeping assume the store-free path: the wait for the
+// prefetched A groups of the next tile then also waits for this tile's activation stores (a full HBM round trip per tile).
+template <class Net, class P, bool TAN = false, bool ST = false>
 __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
   constexpr int NT = P::NT, TILE = P::TILE, KE = Net::KE, UE = KE / P::FPG, UW = Slab<Net, P>::UW;
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
-  uint4* slab = slab_all + (threadIdx.x >> 6) * Slab<Net, P>::UNITS_PER_WAVE + lane;  // + (t*UW + u)*64
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  // the wave index is the same in all lanes, but the compiler only knows that after a readfirstlane: with it the tile
+  // index and every tile base address are scalar (SGPR) values instead of 64-bit per-lane VGPR pairs
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint4* slab = slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE + lane;  // + (t*UW + u)*64
+  const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
 
   for (int tile = wave; tile < a.ntiles; tile += nwaves) {
     const int s0 = tile * TILE;
@@ -339,9 +447,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       }
     }
     // store the embedding [slot][sample] for the backward / wgrad (quad-transposed 16-byte stores, see store_tile)
-    if (a.emb) {
+    if constexpr (ST) {
       const int q = n & 3, kq = n >> 2;
-      char* base = reinterpret_cast<char*>(a.emb);
+      GLOBAL_AS char* base = (GLOBAL_AS char*)a.emb + tile_base_offset<P>(KE, s0, 0);
 #pragma unroll
       for (int g = 0; g < UE; ++g) {
         if constexpr (P::BF16) {
@@ -358,26 +466,34 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
               d[jj] = lo | (hi << 16);
             }
             quad_transpose(d, q);
-            *reinterpret_cast<uint4*>(base + tile_byte_offset<P>(KE, s0, 16 * g + 8 * h + 4 * half + q, kq)) = make_uint4(d[0], d[1], d[2], d[3]);
+            gst16(base + tile_lane_offset<P>(16 * g + 8 * h + 4 * half + q, kq), d[0], d[1], d[2], d[3]);
           }
         } else {
           // unit g: k-steps 4g+e, slot 2(4g+e) + h
           unsigned int d[4] = {emb[0][g].x, emb[0][g].y, emb[0][g].z, emb[0][g].w};
           quad_transpose(d, q);
-          *reinterpret_cast<uint4*>(base + tile_byte_offset<P>(KE, s0, 2 * (4 * g + q) + h, kq)) = make_uint4(d[0], d[1], d[2], d[3]);
+          gst16(base + tile_lane_offset<P>(2 * (4 * g + q) + h, kq), d[0], d[1], d[2], d[3]);
         }
       }
     }
 
     // ---- layers ----
-    sfor<0, Net::NL>([&](auto li) {
-      constexpr int l = decltype(li)::value;
-      constexpr LS ls = Net::L[l];
+#pragma nounroll
+    for (int l = 0; l < Net::NL; ++l)
+    sfor<0, Net::NL>([&](auto ri) {
+      constexpr int R = decltype(ri)::value;  // representative layer of a kind (see fwd_rep)
+      if constexpr (fwd_rep<Net>(R) != R) return;
+      constexpr unsigned MEMBERS = fwd_members<Net>(R);  // forced compile-time (otherwise evaluated by the wave!)
+      if (!((MEMBERS >> l) & 1u)) return;
+      constexpr LS ls = Net::L[R];
+      constexpr bool LAST = (R == Net::NL - 1);
       constexpr int MT = pad32(ls.mout) / 32;
       constexpr int GE = ls.ke / P::FPG, GA = ls.kin / P::FPG, G = GE + GA;
-      const void* Wl = a.W[l];
-      const float* bl = a.bias[l];
-      const float* pfl = a.pf_bias[l];
+      const GLOBAL_AS void* Wl = KARG_PTR(FwdK, const void*, W, l);
+      const GLOBAL_AS float* bl = KARG_PTR(FwdK, const float*, bias, l);
+      const GLOBAL_AS float* pfl = KARG_PTR(FwdK, const float*, pf_bias, l);
+      GLOBAL_AS unsigned int* maskl = KARG_PTR(FwdK, unsigned int*, mask, l);
+      GLOBAL_AS void* actl = KARG_PTR(FwdK, void*, act, l);
       // inputs from the previous layer: slab -> registers
       uint4 bin[NT][GA > 0 ? GA : 1];
 #pragma unroll
@@ -391,62 +507,80 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
 #pragma unroll
         for (int g = 0; g < G; ++g) A[g] = load_a(Wl, G, mt, g, lane);
       };
-      auto body = [&](int mt, uint4 (&A)[G]) {
-        f32x16_t acc[NT];
-        // bias (+ per-frame bias): feature 32mt + 8i + 4h + (0..3)
+      // bias (+ per-frame bias) of one M-tile in accumulator layout: feature 32mt + 8i + 4h + (0..3).  Like the A groups it
+      // is requested one tile ahead (right after the MFMAs issue, BEFORE the epilogue's stores): a bias load at the top
+      // of the tile would sit behind those stores in the in-order vmcnt queue and cost a full store round trip per tile.
+      constexpr int NB = (ls.pf != 0 && !TAN) ? NT : 1;
+      auto load_bias = [&](int mt, f32x16_t (&bv)[NB]) {
+        if constexpr (TAN) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bl + 32 * mt + 8 * i + 4 * h);
+          for (int r = 0; r < 16; ++r) bv[0][r] = 0.f;
+        } else {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            float4 v = b4;
-            if constexpr (TAN) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (ls.pf != 0 && !TAN) {
-              const float4 p4 = *reinterpret_cast<const float4*>(pfl + (size_t)frame[t] * (32 * MT) + 32 * mt + 8 * i + 4 * h);
-              v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+          for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              // pf layers: the per-frame table already contains the shared bias (host contract, lab4d_mlp.h)
+              const GLOBAL_AS float* src = (ls.pf != 0) ? pfl + (size_t)frame[t] * (32 * MT) : bl;
+              const f32x4_t v = *(const GLOBAL_AS f32x4_t*)(src + 32 * mt + 8 * i + 4 * h);
+              bv[t][4 * i + 0] = v.x; bv[t][4 * i + 1] = v.y; bv[t][4 * i + 2] = v.z; bv[t][4 * i + 3] = v.w;
             }
-            acc[t][4 * i + 0] = v.x; acc[t][4 * i + 1] = v.y; acc[t][4 * i + 2] = v.z; acc[t][4 * i + 3] = v.w;
-          }
         }
+      };
+      // ---- MFMA phase of one M-tile: acc = bias + W[mt] x.  `pre` = tile whose A groups / bias are requested behind it
+      // (each group's registers are re-loaded as soon as its MFMAs have issued), or -1.
+      auto mfma_tile = [&](auto has_pre, int pre, uint4 (&A)[G], f32x16_t (&bv)[NB], f32x16_t (&acc)[NT]) {
+        constexpr bool PRE = decltype(has_pre)::value;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = bv[NB == 1 ? 0 : t];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], g < GE ? emb[t][g < GE ? g : 0] : bin[t][g >= GE ? g - GE : 0]);
+          if constexpr (PRE) A[g] = load_a(Wl, G, pre, g, lane);
         }
-        // A is consumed once the MFMAs have issued: request the next tile's groups now, ahead of this tile's
-        // stores in the (in-order) vmcnt queue; their L2 latency hides behind the epilogue below.
-        if (mt + 1 < MT) load_tile_a(mt + 1, A);
+        if constexpr (PRE) load_bias(pre, bv);
+      };
+      // ---- epilogue of one M-tile: ReLU (+ sign mask), ext add, activation store, hand-over to the next layer
+      auto epilogue = [&](int mt, f32x16_t (&acc)[NT]) {
         if constexpr (ls.relu != 0) {
           // ReLU + its sign bits (1 dword per lane per tile): the backward masks with these instead of re-reading
           // the whole activation tile (16x less traffic, 31 fewer live registers)
           if constexpr (TAN) {
-            const unsigned int bits = a.mask[l][((size_t)tile * MT + mt) * 64 + lane];
+            const unsigned int bits = maskl[((size_t)tile * MT + mt) * 64 + lane];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[t][r] = ((bits >> (16 * t + r)) & 1u) ? acc[t][r] : 0.f;
           } else {
-            unsigned int bits = 0;
+            if constexpr (ST && !LAST) {
+              unsigned int bits = 0;
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bits |= (acc[t][r] > 0.f ? 1u : 0u) << (16 * t + r);
+              maskl[((size_t)tile * MT + mt) * 64 + lane] = bits;
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                bits |= (acc[t][r] > 0.f ? 1u : 0u) << (16 * t + r);
-                acc[t][r] = fmaxf(acc[t][r], 0.f);
-              }
-            if (a.mask[l]) a.mask[l][((size_t)tile * MT + mt) * 64 + lane] = bits;
+              for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
           }
         }
         if constexpr (ls.add_ext != 0 && !TAN) {
           f32x16_t e[NT];
-          load_tile<P>(a.ext, 32 * MT, s0, mt, lane, e);
+          load_tile<P>((const GLOBAL_AS void*)a.ext, 32 * MT, s0, mt, lane, e);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] += e[t][r];
         }
-        if (a.act[l]) store_tile<P>(a.act[l], 32 * MT, s0, mt, lane, acc);
-        if constexpr (l + 1 < Net::NL) {
+        if constexpr (ST) {
+          if constexpr (!LAST) store_tile<P>(actl, 32 * MT, s0, mt, lane, acc);
+        } else if constexpr (fwd_any_export<Net>(R)) {
+          if (actl) store_tile<P>(actl, 32 * MT, s0, mt, lane, acc);  // inference: only the layer another net consumes
+        }
+        if constexpr (!LAST) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             uint4 u[P::UPT];
@@ -465,10 +599,33 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
             }
         }
       };
+      // Software pipeline over the M-tiles (one wave per SIMD: nothing else hides the epilogue): step k issues the
+      // MFMAs of tile k+1 into the second accumulator set and, in the same basic block, runs the epilogue of tile k, so
+      // the VALU / LDS / store work of one tile overlaps the matrix pipe of the next.  Accumulator sets alternate, hence
+      // the pair loop; MT is a compile-time constant so the tail is resolved statically.
       uint4 A[G];
+      f32x16_t bv[NB];
+      f32x16_t acc0[NT], acc1[NT];
       load_tile_a(0, A);
+      load_bias(0, bv);
+      mfma_tile(std::bool_constant<(MT > 1)>{}, 1, A, bv, acc0);
+      constexpr int NSTEP = MT - 1, NPAIR = NSTEP / 2;
+      if constexpr (NPAIR > 0) {
 #pragma nounroll
-      for (int mt = 0; mt < MT; ++mt) body(mt, A);
+        for (int k = 0; k < 2 * NPAIR; k += 2) {
+          mfma_tile(std::true_type{}, k + 2 < MT ? k + 2 : MT - 1, A, bv, acc1);  // tile k+1 (its A arrived during the previous step)
+          epilogue(k, acc0);
+          mfma_tile(std::true_type{}, k + 3 < MT ? k + 3 : MT - 1, A, bv, acc0);  // tile k+2
+          epilogue(k + 1, acc1);
+        }
+      }
+      if constexpr (NSTEP % 2 == 1) {
+        mfma_tile(std::false_type{}, 0, A, bv, acc1);  // tile MT-1
+        epilogue(MT - 2, acc0);
+        epilogue(MT - 1, acc1);
+      } else {
+        epilogue(MT - 1, acc0);
+      }
     });
   }
 }
@@ -489,8 +646,9 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
   constexpr int NT = P::NT, TILE = P::TILE, NL = Net::NL, UW = Slab<Net, P>::UW;
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
-  uint4* slab = slab_all + (threadIdx.x >> 6) * Slab<Net, P>::UNITS_PER_WAVE + lane;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint4* slab = slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE + lane;
+  const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
 
   for (int tile = wave; tile < a.ntiles; tile += nwaves) {
     const int s0 = tile * TILE;
@@ -511,7 +669,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
           const int f = drow(r, h);
           g[t][r] = (f < Net::COUT && sidx[t] < a.S) ? a.d_out[(size_t)sidx[t] * Net::COUT + f] : 0.f;
         }
-      if (a.dz[NL - 1]) store_tile<P>(a.dz[NL - 1], pad32(Net::L[NL - 1].mout), s0, 0, lane, g);
+      store_tile<P>((GLOBAL_AS void*)a.dz[NL - 1], pad32(Net::L[NL - 1].mout), s0, 0, lane, g);  // every dz[l] is required (host-checked): no stores in runtime branches
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         uint4 u[P::UPT];
@@ -526,7 +684,9 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
       constexpr LS ls = Net::L[l];
       constexpr int GK = pad32(ls.mout) / P::FPG;        // K units = out features of layer l
       constexpr int MTE = ls.ke / 32, MTA = ls.kin / 32;  // row tiles: embedding slots, then previous activation
-      const void* Wt = a.WT[l];
+      const GLOBAL_AS void* Wt = KARG_PTR(BwdK, const void*, WT, l);
+      const GLOBAL_AS unsigned int* maskp = KARG_PTR(BwdK, const unsigned int*, mask, l > 0 ? l - 1 : 0);
+      GLOBAL_AS void* dzp = KARG_PTR(BwdK, void*, dz, l > 0 ? l - 1 : 0);
       uint4 bin[NT][GK];
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -553,7 +713,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
       // (a) gradient wrt the embedding slots -> input gradient
       auto body_emb = [&](int mt, uint4 (&A)[GK]) {
         f32x16_t e[NT];
-        if constexpr (Net::EMB == 0) load_tile<P>(a.emb, Net::KE, s0, mt, lane, e);  // requested before the MFMAs
+        if constexpr (Net::EMB == 0) load_tile<P>((const GLOBAL_AS void*)a.emb, Net::KE, s0, mt, lane, e);  // requested before the MFMAs
         f32x16_t acc[NT];
         dgrad(mt + 1, A, acc);
         if constexpr (Net::EMB == 0) {
@@ -595,8 +755,8 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
         f32x16_t eg[NT];
         // all HBM reads of this tile are requested before its MFMAs
         unsigned int bits = 0xffffffffu;
-        if constexpr (lp.relu != 0) bits = a.mask[l > 0 ? l - 1 : 0][((size_t)tile * (pad32(lp.mout) / 32) + j) * 64 + lane];
-        if constexpr (lp.ext_grad != 0) load_tile<P>(a.ext_gin, pad32(lp.mout), s0, j, lane, eg);
+        if constexpr (lp.relu != 0) bits = maskp[((size_t)tile * (pad32(lp.mout) / 32) + j) * 64 + lane];
+        if constexpr (lp.ext_grad != 0) load_tile<P>((const GLOBAL_AS void*)a.ext_gin, pad32(lp.mout), s0, j, lane, eg);
         f32x16_t acc[NT];
         dgrad(MTE + j + 1, A, acc);
         if constexpr (lp.ext_grad != 0) {
@@ -606,7 +766,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
             for (int r = 0; r < 16; ++r) acc[t][r] += eg[t][r];
         }
         if constexpr (lp.add_ext != 0) {
-          if (a.ext_gout) store_tile<P>(a.ext_gout, pad32(lp.mout), s0, j, lane, acc);  // y = relu(z) + ext  ->  dL/dext = dL/dy
+          store_tile<P>((GLOBAL_AS void*)a.ext_gout, pad32(lp.mout), s0, j, lane, acc);  // y = relu(z) + ext  ->  dL/dext = dL/dy
         }
         if constexpr (lp.relu != 0) {
 #pragma unroll
@@ -620,7 +780,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
           }
-        if (a.dz[l > 0 ? l - 1 : 0]) store_tile<P>(a.dz[l > 0 ? l - 1 : 0], pad32(lp.mout), s0, j, lane, acc);
+        store_tile<P>(dzp, pad32(lp.mout), s0, j, lane, acc);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           uint4 u[P::UPT];
@@ -685,10 +845,12 @@ inline int mlp_grid(int ntiles) {
     FwdK k = k0;                                                                                                          \
     if (precision == LAB4D_PREC_BF16) {                                                                                   \
       k.ntiles = k.S_pad / PBF16::TILE; /* padded tail tiles are processed too: they zero-fill dz */                                                                                  \
-      hipLaunchKernelGGL((k_mlp_fwd<Net, PBF16>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);                         \
+      if (k.emb) hipLaunchKernelGGL((k_mlp_fwd<Net, PBF16, false, true>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);  \
+      else hipLaunchKernelGGL((k_mlp_fwd<Net, PBF16, false, false>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);       \
     } else if (precision == LAB4D_PREC_F32) {                                                                             \
       k.ntiles = k.S_pad / PF32::TILE;                                                                                   \
-      hipLaunchKernelGGL((k_mlp_fwd<Net, PF32>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);                          \
+      if (k.emb) hipLaunchKernelGGL((k_mlp_fwd<Net, PF32, false, true>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);   \
+      else hipLaunchKernelGGL((k_mlp_fwd<Net, PF32, false, false>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);        \
     } else {                                                                                                              \
       set_error("mlp_forward: bad precision %d", precision);                                                              \
       return LAB4D_EINVAL;                                                                                                \

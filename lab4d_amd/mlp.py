@@ -296,7 +296,7 @@ class MlpChain(Function):
             a.bias[l] = b.data_ptr()
             keep += [pw, b]
             if L.pf_bias:
-                pf = pfs[pf_i].detach().contiguous().float()
+                pf = (pfs[pf_i].detach().float() + b[None]).contiguous()  # kernel contract: the per-frame table includes the bias
                 pf_i += 1
                 if pf.shape[1] != L.mout_pad:
                     raise RuntimeError("per-frame bias of layer %d must have %d columns" % (l, L.mout_pad))
@@ -366,9 +366,8 @@ class MlpChain(Function):
         ext_g = None
         if ctx.ext is not None:
             a.ext = ctx.ext.data_ptr()
-            if ctx.needs_input_grad[4]:
-                ext_g = torch.empty_like(ctx.ext)
-                a.ext_gout = ext_g.data_ptr()
+            ext_g = torch.empty_like(ctx.ext)  # always written by the kernel (no stores in runtime branches)
+            a.ext_gout = ext_g.data_ptr()
         d_out = d_out.contiguous().float()
         a.d_out = d_out.data_ptr()
         d_x = None
@@ -472,12 +471,20 @@ class EikonalSdf(Function):
             keep.append(b)
             a.bias[l] = b.data_ptr()
             if L.pf_bias:
-                a.pf_bias[l] = pfs[l].data_ptr()
+                pfb = (pfs[l].detach().float() + b[None]).contiguous()
+                keep.append(pfb)
+                a.pf_bias[l] = pfb.data_ptr()
             if L.relu and l + 1 < NL:
                 masks[l] = torch.empty((S_pad // tile) * (L.mout_pad // 32) * 64, dtype=torch.int32, device=dev)
                 a.mask[l] = masks[l].data_ptr()
         emb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
         a.emb = emb.data_ptr()
+        # training-mode forward stores every hidden activation; the primal ones are not needed here, so the buffers are
+        # the ones the tangent pass of backward() overwrites with the tangent activations
+        tact = [None] * NL
+        for l in range(NL - 1):
+            tact[l] = torch.empty(buf_numel(d.layers[l].mout_pad, S_pad), dtype=sdt, device=dev)
+            a.act[l] = tact[l].data_ptr()
         sdf = torch.empty(S, 1, device=dev)
         a.out = sdf.data_ptr()
         _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(eikonal primal)")
@@ -505,7 +512,7 @@ class EikonalSdf(Function):
         _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(bk), _lib.stream()), "mlp_backward(eikonal primal)")
         gn = g.norm(2, dim=-1, keepdim=True)
         ctx.meta = (prec, int(spf), S, S_pad)
-        ctx.saved = (x, fw, g, gn, dz, masks, packed)
+        ctx.saved = (x, fw, g, gn, dz, masks, packed, tact)
         ctx.params = params
         return (gn - 1) ** 2
 
@@ -513,7 +520,7 @@ class EikonalSdf(Function):
     @once_differentiable
     def backward(ctx, ge):
         prec, spf, S, S_pad = ctx.meta
-        x, fw, g, gn, dz, masks, packed = ctx.saved
+        x, fw, g, gn, dz, masks, packed, tact = ctx.saved
         net = NET_FG_BASE
         d = describe(net)
         NL, L0 = d.n_layers, d.n_freq
@@ -529,14 +536,12 @@ class EikonalSdf(Function):
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, S_pad, spf
         a.x = u.data_ptr()
-        tact = [None] * NL
         for l in range(NL):
             L = d.layers[l]
             a.W[l] = packed[l].data_ptr()
             if masks[l] is not None:
                 a.mask[l] = masks[l].data_ptr()
             if l + 1 < NL:
-                tact[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
                 a.act[l] = tact[l].data_ptr()
         temb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
         a.emb = temb.data_ptr()
