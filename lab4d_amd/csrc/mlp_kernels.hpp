@@ -58,6 +58,14 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
   return __builtin_bit_cast(unsigned int, v);
 }
 
+// max(x, 0) in ONE v_max_f32: fmaxf() first canonicalises its argument (a second v_max) to quiet signalling NaNs, which an
+// MFMA result never is
+__device__ __forceinline__ float relu1(float x) {
+  float y;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
+
 // feature (row) held by accumulator register r of lane-half h inside a 32-row tile
 __host__ __device__ __forceinline__ constexpr int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -150,15 +158,17 @@ __device__ __forceinline__ void tile_to_units(const f32x16_t& c, uint4* u) {
 __device__ __forceinline__ unsigned int quad_xor1(unsigned int v) { return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }  // quad_perm [1,0,3,2]
 __device__ __forceinline__ unsigned int quad_xor2(unsigned int v) { return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }  // quad_perm [2,3,0,1]
 __device__ __forceinline__ void quad_transpose(unsigned int (&a)[4], int q) {
+  // written so that every select takes ONE DPP-permuted operand straight from a register: the DPP move then folds into
+  // the v_cndmask (v_cndmask_b32_dpp) and a 4x4 transpose costs 8 VALU ops instead of 16
   {
     const bool o = q & 1;
-    const unsigned int t0 = quad_xor1(o ? a[0] : a[1]), t1 = quad_xor1(o ? a[2] : a[3]);
-    a[0] = o ? t0 : a[0]; a[1] = o ? a[1] : t0; a[2] = o ? t1 : a[2]; a[3] = o ? a[3] : t1;
+    const unsigned int x0 = quad_xor1(a[0]), x1 = quad_xor1(a[1]), x2 = quad_xor1(a[2]), x3 = quad_xor1(a[3]);
+    a[0] = o ? x1 : a[0]; a[1] = o ? a[1] : x0; a[2] = o ? x3 : a[2]; a[3] = o ? a[3] : x2;
   }
   {
     const bool o = q & 2;
-    const unsigned int t0 = quad_xor2(o ? a[0] : a[2]), t1 = quad_xor2(o ? a[1] : a[3]);
-    a[0] = o ? t0 : a[0]; a[2] = o ? a[2] : t0; a[1] = o ? t1 : a[1]; a[3] = o ? a[3] : t1;
+    const unsigned int x0 = quad_xor2(a[0]), x1 = quad_xor2(a[1]), x2 = quad_xor2(a[2]), x3 = quad_xor2(a[3]);
+    a[0] = o ? x2 : a[0]; a[2] = o ? a[2] : x0; a[1] = o ? x3 : a[1]; a[3] = o ? a[3] : x1;
   }
 }
 
@@ -199,15 +209,21 @@ __device__ __forceinline__ void store_tile(GLOBAL_AS void* buf, int F, int s0, i
     gst16(base + (lo + tile_lane_offset<P>(8 * i, 0)), d[0], d[1], d[2], d[3]);
   }
 }
+// load_tile in two halves so that the four 16-byte loads can be issued one pipeline step ahead of their use
 template <class P>
-__device__ __forceinline__ void load_tile(const GLOBAL_AS void* buf, int F, int s0, int mt, int lane, f32x16_t* c /*[NT]*/) {
+__device__ __forceinline__ void load_tile_raw(const GLOBAL_AS void* buf, int F, int s0, int mt, int lane, uint4 (&raw)[4]) {
   const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
   const GLOBAL_AS char* base = (const GLOBAL_AS char*)buf + tile_base_offset<P>(F, s0, 32 * mt);
   const unsigned lo = tile_lane_offset<P>(4 * h + q, k);
 #pragma unroll
+  for (int i = 0; i < 4; ++i) raw[i] = gld16(base + (lo + tile_lane_offset<P>(8 * i, 0)));
+}
+template <class P>
+__device__ __forceinline__ void tile_from_raw(const uint4 (&raw)[4], int lane, f32x16_t* c /*[NT]*/) {
+  const int q = lane & 3;
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const uint4 v = gld16(base + (lo + tile_lane_offset<P>(8 * i, 0)));
-    unsigned int d[4] = {v.x, v.y, v.z, v.w};
+    unsigned int d[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
     quad_transpose(d, q);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -219,6 +235,12 @@ __device__ __forceinline__ void load_tile(const GLOBAL_AS void* buf, int F, int 
       }
     }
   }
+}
+template <class P>
+__device__ __forceinline__ void load_tile(const GLOBAL_AS void* buf, int F, int s0, int mt, int lane, f32x16_t* c /*[NT]*/) {
+  uint4 raw[4];
+  load_tile_raw<P>(buf, F, s0, mt, lane, raw);
+  tile_from_raw<P>(raw, lane, c);
 }
 
 // ---- kernel argument blocks (passed by value) ---------------------------------------------------
@@ -537,9 +559,19 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         for (int g = 0; g < G; ++g) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], g < GE ? emb[t][g < GE ? g : 0] : bin[t][g >= GE ? g - GE : 0]);
+#ifndef LAB4D_ABL_NOA
           if constexpr (PRE) A[g] = load_a(Wl, G, pre, g, lane);
+#endif
         }
         if constexpr (PRE) load_bias(pre, bv);
+      };
+      // ---- HBM inputs of an epilogue (tangent mode: the primal's sign bits; colour net: the basefield feature tile) are
+      // requested one pipeline step ahead, like the A groups
+      unsigned int tan_bits = 0;
+      uint4 ext_raw[4];
+      auto prefetch = [&](int mt) {
+        if constexpr (TAN && ls.relu != 0) tan_bits = maskl[((size_t)tile * MT + mt) * 64 + lane];
+        if constexpr (ls.add_ext != 0 && !TAN) load_tile_raw<P>((const GLOBAL_AS void*)a.ext, 32 * MT, s0, mt, lane, ext_raw);
       };
       // ---- epilogue of one M-tile: ReLU (+ sign mask), ext add, activation store, hand-over to the next layer
       auto epilogue = [&](int mt, f32x16_t (&acc)[NT]) {
@@ -547,7 +579,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
           // ReLU + its sign bits (1 dword per lane per tile): the backward masks with these instead of re-reading
           // the whole activation tile (16x less traffic, 31 fewer live registers)
           if constexpr (TAN) {
-            const unsigned int bits = maskl[((size_t)tile * MT + mt) * 64 + lane];
+            const unsigned int bits = tan_bits;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -564,12 +596,12 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+              for (int r = 0; r < 16; ++r) acc[t][r] = relu1(acc[t][r]);
           }
         }
         if constexpr (ls.add_ext != 0 && !TAN) {
           f32x16_t e[NT];
-          load_tile<P>((const GLOBAL_AS void*)a.ext, 32 * MT, s0, mt, lane, e);
+          tile_from_raw<P>(ext_raw, lane, e);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -608,6 +640,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       f32x16_t acc0[NT], acc1[NT];
       load_tile_a(0, A);
       load_bias(0, bv);
+      prefetch(0);
       mfma_tile(std::bool_constant<(MT > 1)>{}, 1, A, bv, acc0);
       constexpr int NSTEP = MT - 1, NPAIR = NSTEP / 2;
       if constexpr (NPAIR > 0) {
@@ -615,13 +648,16 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         for (int k = 0; k < 2 * NPAIR; k += 2) {
           mfma_tile(std::true_type{}, k + 2 < MT ? k + 2 : MT - 1, A, bv, acc1);  // tile k+1 (its A arrived during the previous step)
           epilogue(k, acc0);
+          prefetch(k + 1);
           mfma_tile(std::true_type{}, k + 3 < MT ? k + 3 : MT - 1, A, bv, acc0);  // tile k+2
           epilogue(k + 1, acc1);
+          prefetch(k + 2 < MT ? k + 2 : MT - 1);
         }
       }
       if constexpr (NSTEP % 2 == 1) {
         mfma_tile(std::false_type{}, 0, A, bv, acc1);  // tile MT-1
         epilogue(MT - 2, acc0);
+        prefetch(MT - 1);
         epilogue(MT - 1, acc1);
       } else {
         epilogue(MT - 1, acc0);
@@ -679,26 +715,31 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
       }
     }
 
-    sfor<0, NL>([&](auto li) {
-      constexpr int l = NL - 1 - decltype(li)::value;  // NL-1 .. 0
-      constexpr LS ls = Net::L[l];
+#pragma nounroll
+    for (int l = NL - 1; l >= 0; --l)
+    sfor<0, NL>([&](auto ri) {
+      constexpr int R = NL - 1 - decltype(ri)::value;  // representative layer of a kind (see bwd_rep), NL-1 .. 0
+      if constexpr (bwd_rep<Net>(R) != R) return;
+      constexpr unsigned MEMBERS = bwd_members<Net>(R);
+      if (!((MEMBERS >> l) & 1u)) return;
+      constexpr LS ls = Net::L[R];
+      constexpr LS lp = Net::L[R > 0 ? R - 1 : 0];
       constexpr int GK = pad32(ls.mout) / P::FPG;        // K units = out features of layer l
       constexpr int MTE = ls.ke / 32, MTA = ls.kin / 32;  // row tiles: embedding slots, then previous activation
+      constexpr bool DO_ACT = (R > 0 && MTA > 0);
+      const int lm1 = l > 0 ? l - 1 : 0;
       const GLOBAL_AS void* Wt = KARG_PTR(BwdK, const void*, WT, l);
-      const GLOBAL_AS unsigned int* maskp = KARG_PTR(BwdK, const unsigned int*, mask, l > 0 ? l - 1 : 0);
-      GLOBAL_AS void* dzp = KARG_PTR(BwdK, void*, dz, l > 0 ? l - 1 : 0);
+      const GLOBAL_AS unsigned int* maskp = KARG_PTR(BwdK, const unsigned int*, mask, lm1);
+      GLOBAL_AS void* dzp = KARG_PTR(BwdK, void*, dz, lm1);
       uint4 bin[NT][GK];
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < GK; ++u) bin[t][u] = slab[(t * UW + u) * 64];
 
-      constexpr int MTT_ = MTE + ((l > 0 && MTA > 0) ? MTA : 0);
-      auto load_tile_a = [&](int mt, uint4 (&A)[GK]) {
-#pragma unroll
-        for (int g = 0; g < GK; ++g) A[g] = load_a(Wt, GK, mt, g, lane);
-      };
-      auto dgrad = [&](int mt_next, uint4 (&A)[GK], f32x16_t (&acc)[NT]) {
+      // MFMA phase of one row tile of W^T: acc = W^T[mt] dz.  pre = row tile whose A groups are requested behind it.
+      auto mfma_tile = [&](auto has_pre, int pre, uint4 (&A)[GK], f32x16_t (&acc)[NT]) {
+        constexpr bool PRE = decltype(has_pre)::value;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -707,16 +748,57 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
         for (int g = 0; g < GK; ++g) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], bin[t][g]);
+          if constexpr (PRE) A[g] = load_a(Wt, GK, pre, g, lane);
         }
-        if (mt_next < MTT_) load_tile_a(mt_next, A);  // prefetch the next row tile behind the epilogue
+      };
+      // Software pipeline over N row tiles starting at tile0 (same scheme as the forward chain): step k issues the MFMAs
+      // of tile k+1 into the other accumulator set in the same basic block as the epilogue of tile k.
+      // pre(j) requests the HBM inputs of epi(j) (mask bits, stored embedding / external gradient tile) one step ahead.
+      auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi) {
+        constexpr int N = decltype(n_c)::value;
+        if constexpr (N > 0) {
+          uint4 A[GK];
+          f32x16_t acc0[NT], acc1[NT];
+#pragma unroll
+          for (int g = 0; g < GK; ++g) A[g] = load_a(Wt, GK, tile0, g, lane);
+          pre(0);
+          mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, A, acc0);
+          constexpr int NSTEP = N - 1, NPAIR = NSTEP / 2;
+          if constexpr (NPAIR > 0) {
+#pragma nounroll
+            for (int k = 0; k < 2 * NPAIR; k += 2) {
+              mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), A, acc1);
+              epi(k, acc0);
+              pre(k + 1);
+              mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), A, acc0);
+              epi(k + 1, acc1);
+              pre(k + 2 < N ? k + 2 : N - 1);
+            }
+          }
+          if constexpr (NSTEP % 2 == 1) {
+            mfma_tile(std::false_type{}, 0, A, acc1);
+            epi(N - 2, acc0);
+            pre(N - 1);
+            epi(N - 1, acc1);
+          } else {
+            epi(N - 1, acc0);
+          }
+        }
+      };
+      uint4 raw[4];            // prefetched tile: stored embedding (epi_emb) or external gradient (epi_act)
+      unsigned int mbits = 0;  // prefetched ReLU sign bits
+      auto pre_emb = [&](int mt) {
+        if constexpr (Net::EMB == 0) load_tile_raw<P>((const GLOBAL_AS void*)a.emb, Net::KE, s0, mt, lane, raw);
+      };
+      auto pre_act = [&](int j) {
+        if constexpr (lp.relu != 0) mbits = maskp[((size_t)tile * (pad32(lp.mout) / 32) + j) * 64 + lane];
+        if constexpr (lp.ext_grad != 0) load_tile_raw<P>((const GLOBAL_AS void*)a.ext_gin, pad32(lp.mout), s0, j, lane, raw);
       };
       // (a) gradient wrt the embedding slots -> input gradient
-      auto body_emb = [&](int mt, uint4 (&A)[GK]) {
-        f32x16_t e[NT];
-        if constexpr (Net::EMB == 0) load_tile<P>((const GLOBAL_AS void*)a.emb, Net::KE, s0, mt, lane, e);  // requested before the MFMAs
-        f32x16_t acc[NT];
-        dgrad(mt + 1, A, acc);
+      auto epi_emb = [&](int mt, f32x16_t (&acc)[NT]) {
         if constexpr (Net::EMB == 0) {
+          f32x16_t e[NT];
+          tile_from_raw<P>(raw, lane, e);
           constexpr int L = Net::NFREQ;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -750,16 +832,11 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
         }
       };
       // (b) gradient wrt the previous layer's output -> masked dZ_{l-1}
-      auto body_act = [&](int j, uint4 (&A)[GK]) {
-        constexpr LS lp = Net::L[l > 0 ? l - 1 : 0];
-        f32x16_t eg[NT];
-        // all HBM reads of this tile are requested before its MFMAs
-        unsigned int bits = 0xffffffffu;
-        if constexpr (lp.relu != 0) bits = maskp[((size_t)tile * (pad32(lp.mout) / 32) + j) * 64 + lane];
-        if constexpr (lp.ext_grad != 0) load_tile<P>((const GLOBAL_AS void*)a.ext_gin, pad32(lp.mout), s0, j, lane, eg);
-        f32x16_t acc[NT];
-        dgrad(MTE + j + 1, A, acc);
+      auto epi_act = [&](int j, f32x16_t (&acc)[NT]) {
+        const unsigned int bits = mbits;
         if constexpr (lp.ext_grad != 0) {
+          f32x16_t eg[NT];
+          tile_from_raw<P>(raw, lane, eg);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -789,22 +866,11 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
           for (int q = 0; q < P::UPT; ++q) slab[(t * UW + P::UPT * j + q) * 64] = u[q];
         }
       };
-      constexpr bool DO_ACT = (l > 0 && MTA > 0);
-      const bool do_emb = MTE > 0 && a.d_x != nullptr;
-      constexpr int MTT = MTE + (DO_ACT ? MTA : 0);  // row tiles of W^T visited: embedding tiles first
-      auto run_tile = [&](int mt, uint4 (&A)[GK]) {
-        if (mt < MTE) {
-          if (do_emb) body_emb(mt, A);
-          else if (mt + 1 < MTT) load_tile_a(mt + 1, A);
-        }
-        else if constexpr (DO_ACT) body_act(mt - MTE, A);
-      };
-      if constexpr (MTT > 0) {
-        uint4 A[GK];
-        load_tile_a(0, A);
-#pragma nounroll
-        for (int mt = 0; mt < MTT; ++mt) run_tile(mt, A);
+      // embedding row tiles come first in W^T; they are skipped when no input gradient is wanted
+      if constexpr (MTE > 0) {
+        if (a.d_x != nullptr) pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb);
       }
+      if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act);
     });
 
     if constexpr (Net::EMB == 0) {
