@@ -271,14 +271,24 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_big(const typename P::store_t
   }
 }
 
-// bf16, 256 output rows: LDS-DMA double-buffered version.  In the blocked activation layout one 64-sample block of all
-// 256 feature rows is ONE contiguous 32 KiB region, so a stage (A = dz block, B = X block) is filled by 64 lane-linear
-// 1-KiB `global_load_lds_dwordx4` transfers with no VGPR round trip; two 64-KiB stages ping-pong in LDS, the next block
-// streams in while the 4 waves (2x2, 4x4 tiles each) run 64 MFMAs each on the current one.  The kernel is HBM-bound by
-// ~4x (64 KiB per 2048 MFMA-cycles per CU), so one barrier per block and the un-swizzled LDS image are not the limiter.
+// bf16, 256 output rows: LDS-DMA ring.  In the blocked activation layout a 64-sample block of all 256 feature rows is one
+// contiguous 32 KiB region; a STAGE is one 32-sample half of such a block for both operands (A = dz, B = X: 2 x 16 KiB),
+// filled by 32 lane-linear 1-KiB `global_load_lds_dwordx4` transfers (8 per wave) with no VGPR round trip.  Four stages
+// ring through 128 KiB of LDS, so up to three stages (96 KiB per CU) are in flight while the 4 waves (2x2, 4x4 tiles
+// each) run 32 MFMAs each on the fourth.  The kernel is HBM-bound (64 KiB of operands per 2048 MFMA-cycles per CU), what
+// matters is bytes in flight: the first version (two 64 KiB stages, compiler-managed waits) had NO overlap at all --
+// the compiler cannot tell which LDS bytes a DMA writes, so it drained every DMA (s_waitcnt vmcnt(0)) before the first
+// ds_read of the other stage.  Here the LDS reads are inline asm (invisible to that analysis), the waits are explicit
+// counted vmcnt / lgkmcnt, and the barrier is the raw s_barrier (no fence).
 __device__ __forceinline__ void dma_1k(const void* gsrc_lane, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned int*)gsrc_lane,
                                    (__attribute__((address_space(3))) unsigned int*)lds_wave_base, 16, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_read16(unsigned addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
 }
 
 __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __restrict__ dz, const unsigned short* __restrict__ emb,
@@ -286,9 +296,9 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
                                                         int spf, int cpf, float* __restrict__ dW, float* __restrict__ db) {
   using P = PBF16;
   constexpr int TM = 4, TN = 4, MO = 256;
-  constexpr int STAGE = 65536;  // bytes: A 32 KiB + B 32 KiB
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
+  constexpr int STAGE = 32768, NSTAGE = 4;  // bytes: A 16 KiB + B 16 KiB (32 samples x 256 rows x 2 B each)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), row = lane & 31, h = lane >> 5;
   const int wr = wid >> 1, wc = wid & 1;
   const int K = ke + kin;
   const int kb_n = (K + 255) / 256;
@@ -304,10 +314,9 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
     s_begin = c * chunk;
     s_end = min(S_pad, s_begin + chunk);
   }
-  // B rows [k0, k0+nb) of X = [emb (ke rows) ; act (kin rows)]: up to two contiguous segments per 64-sample block
+  // B rows [k0, k0+nb) of X = [emb (ke rows) ; act (kin rows)]: n1 rows from emb (from row k0), then n2 rows from act
   const int k0 = kb * 256, nb = min(256, K - k0);
-  const int n1 = k0 < ke ? min(nb, ke - k0) : 0;         // rows taken from emb, starting at row k0
-  const int n2 = nb - n1;                                // rows taken from act, starting at row max(k0, ke) - ke
+  const int n1 = k0 < ke ? min(nb, ke - k0) : 0;
   const int r2 = (k0 > ke ? k0 : ke) - ke;
   bool bv_[TN];
 #pragma unroll
@@ -325,38 +334,53 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
 #pragma unroll
   for (int i = 0; i < TM; ++i) rs[i] = 0.f;
 
-  auto issue = [&](int blk, int buf) {
+  // LDS image of a stage operand: [256 rows][64 B]; row r keeps its 16-byte chunk c (4 per row) at slot c ^ ((r >> 2) & 3).
+  // The DMA writes lane-linear (a 1-KiB piece = 16 rows, position = lane), so the swizzle is applied to the SOURCE chunk
+  // a lane fetches; the 32-row x one-chunk ds_read_b128 pattern below then touches 16 distinct 4-bank slots per 16-lane
+  // group (un-swizzled: 86 % of the LDS-active cycles were bank-conflict cycles).
+  const int lane_src = (lane >> 2) * 128 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);  // within a 16-row piece of a block
+  // every wave issues exactly 8 transfers per stage (the counted waits below rely on it): B pieces past the end of a
+  // short B operand (nb < 256) re-fetch its last piece
+  const int nbp = nb / 16;
+  auto issue = [&](int st_idx, int buf) {
+    const int blk = (s_begin >> 6) + (st_idx >> 1), half = st_idx & 1;
     unsigned char* st = lds + buf * STAGE;
-    // A: 32 KiB = 32 pieces of 1 KiB, wave w takes pieces w, w+4, ...
-    const unsigned char* ga = reinterpret_cast<const unsigned char*>(dz + (size_t)blk * block_stride(MO));
+    const unsigned char* ga = reinterpret_cast<const unsigned char*>(dz + (size_t)blk * block_stride(MO)) + half * 64 + lane_src;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < 4; ++p) {
       const int piece = wid + 4 * p;
-      dma_1k(ga + piece * 1024 + lane * 16, st + piece * 1024);
+      dma_1k(ga + piece * 2048, st + piece * 1024);
     }
-    unsigned char* sb = st + 32768;
-    const int np1 = n1 / 8, np2 = n2 / 8;  // 1-KiB pieces (8 rows of 128 B each)
-    if (n1 > 0) {
-      const unsigned char* g1 = reinterpret_cast<const unsigned char*>(emb + (size_t)blk * block_stride(ke) + (size_t)k0 * 64);
-      for (int piece = wid; piece < np1; piece += 4) dma_1k(g1 + piece * 1024 + lane * 16, sb + piece * 1024);
-    }
-    if (n2 > 0) {
-      const unsigned char* g2 = reinterpret_cast<const unsigned char*>(actp + (size_t)blk * block_stride(kin) + (size_t)r2 * 64);
-      unsigned char* sb2 = sb + n1 * 128;
-      for (int piece = wid; piece < np2; piece += 4) dma_1k(g2 + piece * 1024 + lane * 16, sb2 + piece * 1024);
+    unsigned char* sb = st + 16384;
+    const unsigned char* g1 = reinterpret_cast<const unsigned char*>(emb + (size_t)blk * block_stride(ke) + (size_t)k0 * 64) + half * 64 + lane_src;
+    const unsigned char* g2 = reinterpret_cast<const unsigned char*>(actp + (size_t)blk * block_stride(kin) + (size_t)r2 * 64) + half * 64 + lane_src;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int q = wid + 4 * p;
+      q = q < nbp ? q : nbp - 1;
+      const int r0 = 16 * q;  // first row of the piece inside the B operand
+      const unsigned char* src = r0 < n1 ? g1 + (size_t)r0 * 128 : g2 + (size_t)(r0 - n1) * 128;
+      dma_1k(src, sb + q * 1024);
     }
   };
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  const unsigned f = (row >> 2) & 3;
+  const unsigned la0 = lds_base + (unsigned)((wr * 128 + row) * 64) + ((unsigned)(h ^ f) * 16u);          // sub-step 0: chunk h
+  const unsigned lb0 = lds_base + 16384u + (unsigned)((wc * 128 + row) * 64) + ((unsigned)(h ^ f) * 16u);
   auto compute = [&](int buf) {
-    const unsigned char* sa = lds + buf * STAGE;
-    const unsigned char* sb = sa + 32768;
+    const unsigned oa = la0 + (unsigned)buf * STAGE, ob = lb0 + (unsigned)buf * STAGE;
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      uint4 a4[TM], b4[TN];
+    for (int sub = 0; sub < 2; ++sub) {
+      // chunk 2*sub + h -> slot (2*sub + h) ^ f = slot(sub 0) ^ (2*sub): byte address ^ 32
+      const unsigned xa = oa ^ (unsigned)(32 * sub), xb = ob ^ (unsigned)(32 * sub);
+      u32x4_t a4[TM], b4[TN];
+      a4[0] = lds_read16<0>(xa); a4[1] = lds_read16<2048>(xa); a4[2] = lds_read16<4096>(xa); a4[3] = lds_read16<6144>(xa);
+      b4[0] = lds_read16<0>(xb); b4[1] = lds_read16<2048>(xb); b4[2] = lds_read16<4096>(xb); b4[3] = lds_read16<6144>(xb);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]), "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const uint4*>(sa + ((wr * 4 + i) * 32 + row) * 128 + sub * 32 + 16 * h);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b4[j] = bv_[j] ? *reinterpret_cast<const uint4*>(sb + ((wc * 4 + j) * 32 + row) * 128 + sub * 32 + 16 * h) : make_uint4(0, 0, 0, 0);
+      for (int j = 0; j < TN; ++j)  // column tiles past the end of a short B operand multiply zeros (branch-free)
+        if (!bv_[j]) b4[j] = u32x4_t{0u, 0u, 0u, 0u};
       if (do_db) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -368,19 +392,28 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma_unit<P>(acc[i][j], a4[i], b4[j]);
+        for (int j = 0; j < TN; ++j) {
+          bf16x8_t av, bv;
+          __builtin_memcpy(&av, &a4[i], 16);
+          __builtin_memcpy(&bv, &b4[j], 16);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+        }
     }
   };
-  const int b_begin = s_begin >> 6, b_end = s_end >> 6;
-  if (b_begin < b_end) {
-    issue(b_begin, 0);
-    __syncthreads();  // (the compiler drains the DMA with vmcnt(0) ahead of the barrier)
-    int buf = 0;
-    for (int b = b_begin; b < b_end; ++b) {
-      if (b + 1 < b_end) issue(b + 1, buf ^ 1);
-      compute(buf);
-      __syncthreads();
-      buf ^= 1;
+  const int N = ((s_end >> 6) - (s_begin >> 6)) * 2;  // 32-sample stages
+  if (N > 0) {
+    issue(0, 0);
+    if (N > 1) issue(1, 1);
+    if (N > 2) issue(2, 2);
+    for (int s = 0; s < N; ++s) {
+      // this wave's 8 transfers of stage s have landed once at most the later stages' transfers are outstanding
+      if (s + 2 < N) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (s + 1 < N) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everybody's part of stage s has landed AND everybody is done reading stage s-1 ...
+      asm volatile("" ::: "memory");
+      if (s + 3 < N) issue(s + 3, (s + 3) & 3);  // ... whose buffer stage s+3 overwrites
+      compute(s & 3);
     }
   }
 #pragma unroll

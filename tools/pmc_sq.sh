@@ -15,7 +15,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob('/tmp/sq_*/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name']
-        if 'k_mlp' not in k: continue
+        if "k_mlp_wgrad" not in k: continue
         k = re.sub(r'lab4d::', '', k.split('(')[0])[:70]
         acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
 for k in sorted(acc):
