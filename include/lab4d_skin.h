@@ -26,6 +26,13 @@ int lab4d_bone_coords_backward(const float* xyz, const float* art_r, const float
                                const float* g_bone, int S, int spf, int M, int B, float* g_xyz, float* g_art_r,
                                float* g_art_d, float* g_gauss, void* stream);
 
+/* Parameter gradients of lab4d_bone_coords_forward from the per-frame Gram matrix G (M,B,3,4) =
+ * lab4d_gram_per_frame(g_bone (S,3B), [xyz,1] (S,4)): g_art_r, g_art_d (M,B,4) written, g_gauss (B,3) accumulated
+ * (zero-fill first); any of the three may be NULL.  Replaces the reference's autograd through
+ * transforms.get_bone_coords / quaternion ops (lab4d/nnutils/skinning.py:126-140) for the (M,B)-sized parameters. */
+int lab4d_bone_params_from_gram(const float* art_r, const float* art_d, const float* gauss, const float* G, int M, int B,
+                                float* g_art_r, float* g_art_d, float* g_gauss, void* stream);
+
 /* skin = -(|xyz_bone_b|^2 + relu(delta_raw_b)*0.1); p = softmax(skin); blend the per-bone transforms se3
  * (M,B,4)x2 with the arg-max bone's hemisphere; out = apply(blend, xyz).
  * Outputs: out (S,3), entropy (S) = logsumexp(skin) - max(skin), dskin (S) = mean_b delta_b^2. */

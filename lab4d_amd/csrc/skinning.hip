@@ -122,6 +122,55 @@ __global__ void __launch_bounds__(256) k_bone_bwd_p(const float* __restrict__ xy
   }
 }
 
+// Parameter gradients of the bone-coordinate map from its per-frame Gram matrix.  out[s,b,:] = (R_b x_s + t_b) / gauss_b
+// is affine in the point, so with G[m,b,k,j] = sum_{s in frame m} g[s,b,k] * [x_s, 1]_j (lab4d_gram_per_frame) every
+// per-sample adjoint of k_bone_bwd_p -- each bilinear in (g, [x,1]) -- collapses to one evaluation per (frame, bone):
+// the rotation adjoint is qrot_gq applied to the three unit points with the Gram columns as gradients, the translation
+// adjoint uses the homogeneous column.  One thread per (m,b); g_gauss is summed over frames with atomics.
+__global__ void __launch_bounds__(64) k_bone_param_from_gram(const float* __restrict__ ar, const float* __restrict__ ad, const float* __restrict__ gauss,
+                                                              const float* __restrict__ G, int M, int B, float* __restrict__ g_ar,
+                                                              float* __restrict__ g_ad, float* __restrict__ g_gauss) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * B) return;
+  const int b = i % B;
+  const float* r = ar + (size_t)i * 4;
+  const float* d = ad + (size_t)i * 4;
+  const float w = r[0], dw = d[0];
+  const V3 v = ldv3(r + 1), dv = ldv3(d + 1), gs = ldv3(gauss + 3 * b);
+  const float* g = G + (size_t)i * 12;  // [k][j], k = output coordinate, j = 0..2 point coordinate, 3 = homogeneous
+  // gauss: out_k = y_k / gs_k, y = R x + t  ->  d/d gs_k = - sum_j A[k][j] G[k][j] / gs_k^2, with A = [R | t] rows
+  const V3 e0 = {1.f, 0.f, 0.f}, e1 = {0.f, 1.f, 0.f}, e2 = {0.f, 0.f, 1.f};
+  const V3 t = (v * dw - dv * w + cross(v, dv)) * 2.f;
+  const V3 c0 = qrot(w, v * -1.f, e0), c1 = qrot(w, v * -1.f, e1), c2 = qrot(w, v * -1.f, e2);  // columns of R
+  const float yx = c0.x * g[0] + c1.x * g[1] + c2.x * g[2] + t.x * g[3];
+  const float yy = c0.y * g[4] + c1.y * g[5] + c2.y * g[6] + t.y * g[7];
+  const float yz = c0.z * g[8] + c1.z * g[9] + c2.z * g[10] + t.z * g[11];
+  if (g_gauss) {
+    atomicAdd(g_gauss + 3 * b + 0, -yx / (gs.x * gs.x));
+    atomicAdd(g_gauss + 3 * b + 1, -yy / (gs.y * gs.y));
+    atomicAdd(g_gauss + 3 * b + 2, -yz / (gs.z * gs.z));
+  }
+  if (g_ar || g_ad) {
+    // gradient columns scaled by 1/gauss: gy_j = (G[0][j]/gs.x, G[1][j]/gs.y, G[2][j]/gs.z)
+    const V3 gy0 = {g[0] / gs.x, g[4] / gs.y, g[8] / gs.z}, gy1 = {g[1] / gs.x, g[5] / gs.y, g[9] / gs.z};
+    const V3 gy2 = {g[2] / gs.x, g[6] / gs.y, g[10] / gs.z}, gyh = {g[3] / gs.x, g[7] / gs.y, g[11] / gs.z};
+    float qw0, qw1, qw2;
+    V3 qv0, qv1, qv2;
+    qrot_gq(w, v * -1.f, e0, gy0, qw0, qv0);
+    qrot_gq(w, v * -1.f, e1, gy1, qw1, qv1);
+    qrot_gq(w, v * -1.f, e2, gy2, qw2, qv2);
+    const float gqw = qw0 + qw1 + qw2;
+    const V3 gqv = qv0 + qv1 + qv2;
+    // translation t = 2 (dw v - w dv + v x dv): adjoint with sum_s gy_s = gyh
+    const float g_w = gqw - 2.f * dot(dv, gyh);
+    const V3 g_v = gqv * -1.f + gyh * (2.f * dw) + cross(dv, gyh) * 2.f;
+    const float g_dw = 2.f * dot(v, gyh);
+    const V3 g_dv = gyh * (-2.f * w) + cross(gyh, v) * 2.f;
+    if (g_ar) { float* o = g_ar + (size_t)i * 4; o[0] = g_w; o[1] = g_v.x; o[2] = g_v.y; o[3] = g_v.z; }
+    if (g_ad) { float* o = g_ad + (size_t)i * 4; o[0] = g_dw; o[1] = g_dv.x; o[2] = g_dv.y; o[3] = g_dv.z; }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // skin weights + dual-quaternion blend
 // ---------------------------------------------------------------------------------------------
@@ -333,6 +382,15 @@ extern "C" int lab4d_bone_coords_backward(const float* xyz, const float* ar, con
     SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_p<NB>), grid, dim3(256), 0, st, xyz, ar, ad, gauss, g_bone, (long)S, spf, chunk, g_ar, g_ad, g_gauss));
   }
   return check_launch("bone_coords_backward");
+}
+
+extern "C" int lab4d_bone_params_from_gram(const float* art_r, const float* art_d, const float* gauss, const float* G, int M, int B,
+                                           float* g_art_r, float* g_art_d, float* g_gauss, void* stream) {
+  LAB4D_REQUIRE(art_r && art_d && gauss && G, "bone_params_from_gram: null pointer");
+  if (M * B == 0) return LAB4D_OK;
+  hipLaunchKernelGGL(k_bone_param_from_gram, dim3(div_up(M * B, 64)), dim3(64), 0, (hipStream_t)stream, art_r, art_d, gauss, G, M, B, g_art_r,
+                     g_art_d, g_gauss);
+  return check_launch("bone_params_from_gram");
 }
 
 extern "C" int lab4d_skin_blend_forward(const float* xyz, const float* bone, const float* raw, const float* sr, const float* sd, int S, int spf,

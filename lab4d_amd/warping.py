@@ -14,6 +14,7 @@ _lib.register("lab4d_bone_coords_backward", [vp] * 5 + [ci] * 4 + [vp] * 4 + [vp
 _lib.register("lab4d_skin_blend_forward", [vp] * 5 + [ci] * 4 + [vp] * 3 + [vp])
 _lib.register("lab4d_skin_blend_backward", [vp] * 8 + [ci] * 4 + [vp] * 5 + [vp])
 _lib.register("lab4d_gram_per_frame", [vp, ci, vp, ci, ci, ci, ci, vp, vp])
+_lib.register("lab4d_bone_params_from_gram", [vp] * 4 + [ci] * 2 + [vp] * 3 + [vp])
 
 
 class BoneCoords(Function):
@@ -40,22 +41,21 @@ class BoneCoords(Function):
         gx = torch.empty_like(xyz)
         _lib.check(_lib.lib().lab4d_bone_coords_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(g), S, ctx.spf,
                                                          M, B, _lib.ptr(gx), None, None, None, _lib.stream()), "bone_coords_backward")
-        # parameter gradients: out[s,b,:] = (R_b x_s + t_b) / gauss_b is affine in x_s, so
-        #   L = sum_s <g, out> = sum_{m,b,k,j} A[m,b,k,j] / gauss[b,k] * G[m,b,k,j],  G = sum_{s in m} g[s,b,k] [x_s,1]_j
-        # G is one per-frame tall-skinny product on the device; the (M,B)-sized chain rule runs under torch autograd.
+        # parameter gradients: out[s,b,:] = (R_b x_s + t_b) / gauss_b is affine in x_s, so every one of them is a function
+        # of the per-frame Gram matrix G[m,b,k,j] = sum_{s in m} g[s,b,k] [x_s,1]_j: one tall-skinny product on the device
+        if not any(ctx.needs_input_grad[1:4]):
+            return gx, None, None, None, None
         xh = torch.cat([xyz, torch.ones_like(xyz[:, :1])], -1)
         G = torch.zeros(M, 3 * B, 4, device=xyz.device)
         _lib.check(_lib.lib().lab4d_gram_per_frame(_lib.ptr(g), 3 * B, _lib.ptr(xh), 4, S, ctx.spf, M, _lib.ptr(G), _lib.stream()), "gram_per_frame")
-        G = G.view(M, B, 3, 4)
-        with torch.enable_grad():
-            r, d, gs = art_r.detach().requires_grad_(True), art_d.detach().requires_grad_(True), gauss.detach().requires_grad_(True)
-            qi = Q.quaternion_conjugate(r)                                     # inverse bone rotation
-            t = 2 * Q.quaternion_mul(Q.quaternion_conjugate(d), r)[..., 1:]    # inverse bone translation (M,B,3)
-            eye = torch.eye(3, device=xyz.device).view(1, 1, 3, 3)
-            Rt = Q.quaternion_apply(qi[:, :, None, :], eye)                    # (M,B,j,k) = R[k][j]
-            Amat = torch.cat([Rt.transpose(-1, -2), t[..., None]], -1)         # (M,B,k,4)
-            L = (Amat / gs.view(1, B, 3, 1) * G).sum()
-            gar, gad, gg = torch.autograd.grad(L, [r, d, gs])
+        # (M,B)-sized chain rule: one thread per (frame, bone) (csrc/skinning.hip k_bone_param_from_gram)
+        need_r, need_d, need_g = ctx.needs_input_grad[1:4]
+        gar = torch.empty_like(art_r) if need_r else None
+        gad = torch.empty_like(art_d) if need_d else None
+        gg = torch.zeros_like(gauss) if need_g else None
+        if need_r or need_d or need_g:
+            _lib.check(_lib.lib().lab4d_bone_params_from_gram(_lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(G), M, B, _lib.ptr(gar),
+                                                              _lib.ptr(gad), _lib.ptr(gg), _lib.stream()), "bone_params_from_gram")
         return gx, gar, gad, gg, None
 
 
