@@ -82,7 +82,8 @@ int lab4d_mlp_pack(int net, int layer, int precision, int transposed, const floa
 typedef struct {
   int net, precision;
   int S;       /* samples                                                                                  */
-  int S_pad;   /* samples rounded up to a multiple of 64 (tail tiles are processed, never written to `out`) */
+  int S_pad;   /* samples rounded up to a multiple of 256 = one workgroup of 4 waves x 64 samples: the waves of a workgroup
+                  run in lock-step (tail tiles are processed, never written to `out`)                             */
   int ld;      /* leading dimension (elements) of every [feature][sample] buffer: >= S_pad, multiple of 8.
                   Pad it so that ld*sizeof(store) is NOT a large power of two (e.g. S_pad*2 B + 4352 B):
                   a power-of-two row stride maps every feature row to the same HBM channel.             */

@@ -561,8 +561,8 @@ extern "C" int lab4d_mlp_pack(int net, int layer, int precision, int transposed,
 
 extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
   LAB4D_REQUIRE(a, "mlp_forward: null args");
-  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0 && a->ld >= a->S_pad && a->ld % 8 == 0,
-                "mlp_forward: bad sizes S=%d S_pad=%d ld=%d spf=%d", a->S, a->S_pad, a->ld, a->spf);
+  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 256 == 0 && a->spf > 0 && a->ld >= a->S_pad && a->ld % 8 == 0,
+                "mlp_forward: bad sizes (S_pad must be a multiple of 256) S=%d S_pad=%d ld=%d spf=%d", a->S, a->S_pad, a->ld, a->spf);
   LAB4D_REQUIRE(a->x && a->out, "mlp_forward: null x/out");
   if (a->S == 0) return LAB4D_OK;
   return with_net(a->net, [&](auto n) {
@@ -587,7 +587,7 @@ extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
 
 extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
   LAB4D_REQUIRE(a, "mlp_backward: null args");
-  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0 && a->ld >= a->S_pad && a->ld % 8 == 0, "mlp_backward: bad sizes");
+  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 256 == 0 && a->spf > 0 && a->ld >= a->S_pad && a->ld % 8 == 0, "mlp_backward: bad sizes (S_pad must be a multiple of 256)");
   LAB4D_REQUIRE(a->d_out, "mlp_backward: null d_out");
   if (a->S == 0) return LAB4D_OK;
   return with_net(a->net, [&](auto n) {
@@ -674,7 +674,7 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
 extern "C" int lab4d_mlp_forward_tangent(const lab4d_mlp_fwd_args* a, void* stream) {
   LAB4D_REQUIRE(a, "mlp_forward_tangent: null args");
   LAB4D_REQUIRE(a->net == LAB4D_NET_FG_BASE, "mlp_forward_tangent: only the basefield/sdf network has an eikonal term (got net %d)", a->net);
-  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 64 == 0 && a->spf > 0, "mlp_forward_tangent: bad sizes");
+  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 256 == 0 && a->spf > 0, "mlp_forward_tangent: bad sizes (S_pad must be a multiple of 256)");
   LAB4D_REQUIRE(a->x && a->emb, "mlp_forward_tangent: null x / emb");
   if (a->S == 0) return LAB4D_OK;
   using Net = NetFgBase;

@@ -292,6 +292,21 @@ __device__ __forceinline__ void emb_pair(int pair, const float* x, const float* 
   }
 }
 
+// ---- workgroup-shared weight stream ---------------------------------------------------------------------------
+// The four waves of a workgroup walk the layers and M-tiles in lock-step (same code, same trip counts), so the 16 KiB of
+// packed weights one M-tile step needs is the SAME for all of them.  Fetched per wave it was 4 x 16 KiB through the
+// CU's vector-memory path per step (measured: removing those loads made the training-mode forward 1.57x faster).
+// Instead every wave fetches a quarter of the NEXT step's A groups into registers, drops them into an LDS buffer at
+// the end of the step, and after ONE barrier per step all waves read the groups they need back (lane-linear
+// ds_read_b128, conflict-free).  Up to ACACHE_G groups go through LDS (2 buffers x 16 KiB: with the four 32 KiB slabs
+// that is the CU's whole 160 KiB); the few groups beyond (skip-layer embedding columns) keep the direct path.
+constexpr int ACACHE_G = 16;
+__device__ __forceinline__ void wg_step_barrier() {
+  // LDS writes of this wave visible + everybody arrived.  Raw s_barrier: __syncthreads() would also drain the
+  // outstanding activation stores (vmcnt(0)), a full HBM round trip per step.
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- layer kinds ----------------------------------------------------------------------------------
 // Layers of identical shape share ONE copy of the layer code, executed from a runtime loop over the layers: the fully
 // unrolled chain (10 layer bodies, 70-120 KB of code) does not fit the 64 KB instruction cache two CUs share, and with
@@ -367,6 +382,7 @@ template <class Net, class P, bool TAN = false, bool ST = false>
 __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
   constexpr int NT = P::NT, TILE = P::TILE, KE = Net::KE, UE = KE / P::FPG, UW = Slab<Net, P>::UW;
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
+  __shared__ uint4 abuf[2 * ACACHE_G * 64];  // workgroup-shared A groups of the current / next M-tile step
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
   // the wave index is the same in all lanes, but the compiler only knows that after a readfirstlane: with it the tile
   // index and every tile base address are scalar (SGPR) values instead of 64-bit per-lane VGPR pairs
@@ -374,6 +390,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
   uint4* slab = slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE + lane;  // + (t*UW + u)*64
   const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
 
+  // ntiles is a multiple of 4 (host contract: S_pad % 256 == 0), so all four waves of a workgroup make the same number of
+  // trips -- they meet at one barrier per M-tile step
   for (int tile = wave; tile < a.ntiles; tile += nwaves) {
     const int s0 = tile * TILE;
     int sidx[NT], frame[NT];
@@ -511,6 +529,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       constexpr bool LAST = (R == Net::NL - 1);
       constexpr int MT = pad32(ls.mout) / 32;
       constexpr int GE = ls.ke / P::FPG, GA = ls.kin / P::FPG, G = GE + GA;
+      constexpr int GL = G < ACACHE_G ? G : ACACHE_G, NQ = (GL + 3) / 4;  // A groups shared through LDS / fetched per wave
       const GLOBAL_AS void* Wl = KARG_PTR(FwdK, const void*, W, l);
       const GLOBAL_AS float* bl = KARG_PTR(FwdK, const float*, bias, l);
       const GLOBAL_AS float* pfl = KARG_PTR(FwdK, const float*, pf_bias, l);
@@ -525,10 +544,6 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       // Software-pipelined M-tile loop: the A groups of tile mt+1 are requested right after the MFMAs of tile mt
       // have issued and BEFORE its activation stores.  vmcnt retires in order and counts stores too, so with the
       // loads ahead of the stores in the queue the next tile never waits for a store acknowledgement.
-      auto load_tile_a = [&](int mt, uint4 (&A)[G]) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) A[g] = load_a(Wl, G, mt, g, lane);
-      };
       // bias (+ per-frame bias) of one M-tile in accumulator layout: feature 32mt + 8i + 4h + (0..3).  Like the A groups it
       // is requested one tile ahead (right after the MFMAs issue, BEFORE the epilogue's stores): a bias load at the top
       // of the tile would sit behind those stores in the in-order vmcnt queue and cost a full store round trip per tile.
@@ -559,11 +574,31 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         for (int g = 0; g < G; ++g) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], g < GE ? emb[t][g < GE ? g : 0] : bin[t][g >= GE ? g - GE : 0]);
-#ifndef LAB4D_ABL_NOA
-          if constexpr (PRE) A[g] = load_a(Wl, G, pre, g, lane);
-#endif
+          if constexpr (PRE) {
+            if (g >= GL) A[g] = load_a(Wl, G, pre, g, lane);  // groups beyond the LDS-shared ones (g is unrolled)
+          }
         }
         if constexpr (PRE) load_bias(pre, bv);
+      };
+      // workgroup-shared A groups (see wg_step_barrier): wave w moves groups w, w+4, ... (clamped: a duplicate fetch of the
+      // last group keeps the code branch-free when GL is not a multiple of 4)
+      auto a_fetch = [&](int mt, uint4 (&stg)[NQ]) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
+          stg[i] = load_a(Wl, G, mt, g, lane);
+        }
+      };
+      auto a_stash = [&](int buf, const uint4 (&stg)[NQ]) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
+          abuf[(buf * ACACHE_G + g) * 64 + lane] = stg[i];
+        }
+      };
+      auto a_grab = [&](int buf, uint4 (&A)[G]) {
+#pragma unroll
+        for (int g = 0; g < GL; ++g) A[g] = abuf[(buf * ACACHE_G + g) * 64 + lane];
       };
       // ---- HBM inputs of an epilogue (tangent mode: the primal's sign bits; colour net: the basefield feature tile) are
       // requested one pipeline step ahead, like the A groups
@@ -635,26 +670,50 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       // MFMAs of tile k+1 into the second accumulator set and, in the same basic block, runs the epilogue of tile k, so
       // the VALU / LDS / store work of one tile overlaps the matrix pipe of the next.  Accumulator sets alternate, hence
       // the pair loop; MT is a compile-time constant so the tail is resolved statically.
-      uint4 A[G];
+      uint4 A[G], stg[NQ];
       f32x16_t bv[NB];
       f32x16_t acc0[NT], acc1[NT];
-      load_tile_a(0, A);
+      // prologue: tiles 0 and 1 into the two LDS buffers (the barrier in front keeps a fast wave from overwriting groups
+      // a slow one still has to read for the previous layer)
+      wg_step_barrier();
+      a_fetch(0, stg);
+      a_stash(0, stg);
+      if constexpr (MT > 1) {
+        a_fetch(1, stg);
+        a_stash(1, stg);
+      }
+#pragma unroll
+      for (int g = GL; g < G; ++g) A[g] = load_a(Wl, G, 0, g, lane);
       load_bias(0, bv);
       prefetch(0);
+      wg_step_barrier();
+      a_grab(0, A);
       mfma_tile(std::bool_constant<(MT > 1)>{}, 1, A, bv, acc0);
       constexpr int NSTEP = MT - 1, NPAIR = NSTEP / 2;
       if constexpr (NPAIR > 0) {
 #pragma nounroll
         for (int k = 0; k < 2 * NPAIR; k += 2) {
-          mfma_tile(std::true_type{}, k + 2 < MT ? k + 2 : MT - 1, A, bv, acc1);  // tile k+1 (its A arrived during the previous step)
+          // step k: A(k+1) is in buffer (k+1)&1 = 1; fetch A(k+2) for buffer 0 (read last in step k-1)
+          wg_step_barrier();
+          a_grab(1, A);
+          a_fetch(k + 2 < MT ? k + 2 : MT - 1, stg);
+          mfma_tile(std::true_type{}, k + 2 < MT ? k + 2 : MT - 1, A, bv, acc1);  // tile k+1
           epilogue(k, acc0);
           prefetch(k + 1);
+          a_stash(0, stg);
+          // step k+1
+          wg_step_barrier();
+          a_grab(0, A);
+          a_fetch(k + 3 < MT ? k + 3 : MT - 1, stg);
           mfma_tile(std::true_type{}, k + 3 < MT ? k + 3 : MT - 1, A, bv, acc0);  // tile k+2
           epilogue(k + 1, acc1);
           prefetch(k + 2 < MT ? k + 2 : MT - 1);
+          a_stash(1, stg);
         }
       }
       if constexpr (NSTEP % 2 == 1) {
+        wg_step_barrier();
+        a_grab(1, A);
         mfma_tile(std::false_type{}, 0, A, bv, acc1);  // tile MT-1
         epilogue(MT - 2, acc0);
         prefetch(MT - 1);
@@ -681,6 +740,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
   static_assert(Net::EMB == 0 || emb_layer_count<Net>() == 1, "raw-input nets may use the input in one layer only");
   constexpr int NT = P::NT, TILE = P::TILE, NL = Net::NL, UW = Slab<Net, P>::UW;
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
+  __shared__ uint4 abuf[2 * ACACHE_G * 64];  // workgroup-shared A groups (see wg_step_barrier)
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint4* slab = slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE + lane;
@@ -725,6 +785,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
       constexpr LS ls = Net::L[R];
       constexpr LS lp = Net::L[R > 0 ? R - 1 : 0];
       constexpr int GK = pad32(ls.mout) / P::FPG;        // K units = out features of layer l
+      constexpr int GL = GK < ACACHE_G ? GK : ACACHE_G, NQ = (GL + 3) / 4;  // A groups shared through LDS / fetched per wave
       constexpr int MTE = ls.ke / 32, MTA = ls.kin / 32;  // row tiles: embedding slots, then previous activation
       constexpr bool DO_ACT = (R > 0 && MTA > 0);
       const int lm1 = l > 0 ? l - 1 : 0;
@@ -748,8 +809,28 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
         for (int g = 0; g < GK; ++g) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], bin[t][g]);
-          if constexpr (PRE) A[g] = load_a(Wt, GK, pre, g, lane);
+          if constexpr (PRE) {
+            if (g >= GL) A[g] = load_a(Wt, GK, pre, g, lane);  // groups beyond the LDS-shared ones (g is unrolled)
+          }
         }
+      };
+      auto a_fetch = [&](int mt, uint4 (&stg)[NQ]) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
+          stg[i] = load_a(Wt, GK, mt, g, lane);
+        }
+      };
+      auto a_stash = [&](int buf, const uint4 (&stg)[NQ]) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
+          abuf[(buf * ACACHE_G + g) * 64 + lane] = stg[i];
+        }
+      };
+      auto a_grab = [&](int buf, uint4 (&A)[GK]) {
+#pragma unroll
+        for (int g = 0; g < GL; ++g) A[g] = abuf[(buf * ACACHE_G + g) * 64 + lane];
       };
       // Software pipeline over N row tiles starting at tile0 (same scheme as the forward chain): step k issues the MFMAs
       // of tile k+1 into the other accumulator set in the same basic block as the epilogue of tile k.
@@ -757,25 +838,44 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
       auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi) {
         constexpr int N = decltype(n_c)::value;
         if constexpr (N > 0) {
-          uint4 A[GK];
+          uint4 A[GK], stg[NQ];
           f32x16_t acc0[NT], acc1[NT];
+          wg_step_barrier();  // nobody still reads the buffers for the previous pipeline
+          a_fetch(tile0, stg);
+          a_stash(0, stg);
+          if constexpr (N > 1) {
+            a_fetch(tile0 + 1, stg);
+            a_stash(1, stg);
+          }
 #pragma unroll
-          for (int g = 0; g < GK; ++g) A[g] = load_a(Wt, GK, tile0, g, lane);
+          for (int g = GL; g < GK; ++g) A[g] = load_a(Wt, GK, tile0, g, lane);
           pre(0);
+          wg_step_barrier();
+          a_grab(0, A);
           mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, A, acc0);
           constexpr int NSTEP = N - 1, NPAIR = NSTEP / 2;
           if constexpr (NPAIR > 0) {
 #pragma nounroll
             for (int k = 0; k < 2 * NPAIR; k += 2) {
+              wg_step_barrier();
+              a_grab(1, A);
+              a_fetch(tile0 + (k + 2 < N ? k + 2 : N - 1), stg);
               mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), A, acc1);
               epi(k, acc0);
               pre(k + 1);
+              a_stash(0, stg);
+              wg_step_barrier();
+              a_grab(0, A);
+              a_fetch(tile0 + (k + 3 < N ? k + 3 : N - 1), stg);
               mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), A, acc0);
               epi(k + 1, acc1);
               pre(k + 2 < N ? k + 2 : N - 1);
+              a_stash(1, stg);
             }
           }
           if constexpr (NSTEP % 2 == 1) {
+            wg_step_barrier();
+            a_grab(1, A);
             mfma_tile(std::false_type{}, 0, A, acc1);
             epi(N - 2, acc0);
             pre(N - 1);

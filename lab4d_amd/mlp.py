@@ -239,7 +239,8 @@ def pf_bias_of(net, layer, W, cond):
 
 
 def s_pad_of(S):
-    return (S + 63) // 64 * 64
+    """Samples padded to whole workgroups of the chain kernels: 4 waves x 64 samples (lab4d_mlp.h)."""
+    return (S + 255) // 256 * 256
 
 
 def buf_numel(F, S_pad):
