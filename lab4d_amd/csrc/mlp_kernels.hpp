@@ -618,7 +618,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[t][r] = ((bits >> (16 * t + r)) & 1u) ? acc[t][r] : 0.f;
+              for (int r = 0; r < 16; ++r)
+                acc[t][r] = __uint_as_float(__float_as_uint(acc[t][r]) & (unsigned int)__builtin_amdgcn_sbfe((int)bits, 16 * t + r, 1));
           } else {
             if constexpr (ST && !LAST) {
               unsigned int bits = 0;
@@ -945,18 +946,19 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
         if constexpr (lp.add_ext != 0) {
           store_tile<P>((GLOBAL_AS void*)a.ext_gout, pad32(lp.mout), s0, j, lane, acc);  // y = relu(z) + ext  ->  dL/dext = dL/dy
         }
-        if constexpr (lp.relu != 0) {
+        // ReLU mask and the zero of the padded tail samples in one AND per value: bit -> all-ones / zero word (v_bfe_i32),
+        // then v_and with the fp32 bits (was: bit test + compare + select + a scalar AND per value)
+        {
+          unsigned int keep = lp.relu != 0 ? bits : 0xffffffffu;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (sidx[t] >= a.S) keep &= ~(0xffffu << (16 * t));
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = ((bits >> (16 * t + r)) & 1u) ? acc[t][r] : 0.f;
+            for (int r = 0; r < 16; ++r)
+              acc[t][r] = __uint_as_float(__float_as_uint(acc[t][r]) & (unsigned int)__builtin_amdgcn_sbfe((int)keep, 16 * t + r, 1));
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-          if (sidx[t] >= a.S) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-          }
         store_tile<P>(dzp, pad32(lp.mout), s0, j, lane, acc);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
