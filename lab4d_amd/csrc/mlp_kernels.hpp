@@ -300,7 +300,7 @@ __device__ __forceinline__ void emb_pair(int pair, const float* x, const float* 
 // the end of the step, and after ONE barrier per step all waves read the groups they need back (lane-linear
 // ds_read_b128, conflict-free).  Up to ACACHE_G groups go through LDS (2 buffers x 16 KiB: with the four 32 KiB slabs
 // that is the CU's whole 160 KiB); the few groups beyond (skip-layer embedding columns) keep the direct path.
-constexpr int ACACHE_G = 16;
+constexpr int ACACHE_G = 14;  // 2 x 14 KiB: leaves 4 KiB of the 160 KiB unallocated (a kernel that needs ALL of the LDS cannot be co-scheduled with anything, e.g. a profiler's helper)
 __device__ __forceinline__ void wg_step_barrier() {
   // LDS writes of this wave visible + everybody arrived.  Raw s_barrier: __syncthreads() would also drain the
   // outstanding activation stores (vmcnt(0)), a full HBM round trip per step.

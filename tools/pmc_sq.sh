@@ -6,7 +6,7 @@ CMD=${1:-"python $R/tools/bench_mlp_fwd.py 2097152"}
 i=0
 for grp in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY" "SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/sq_$i -- $CMD > /tmp/sq_$i.log 2>&1 || tail -5 /tmp/sq_$i.log
+  timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/sq_$i -- $CMD > /tmp/sq_$i.log 2>&1 || tail -5 /tmp/sq_$i.log
 done
 python - <<'PY'
 import csv, glob, re
