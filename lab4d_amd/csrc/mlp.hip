@@ -291,17 +291,28 @@ __device__ __forceinline__ u32x4_t lds_read16(unsigned addr) {
   return v;
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// MT = row tiles of dz (MO = 32*MT output features: 256 / 128 / 64); NBW = 64-row blocks of X one workgroup contracts
+// against (B operand = 64*NBW rows).  Waves 2x2: wave (wr, wc) owns MT/2 x NBW tiles.
+template <int MT, int NBW>
 __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __restrict__ dz, const unsigned short* __restrict__ emb,
                                                         const unsigned short* __restrict__ actp, int ke, int kin, int S_pad, int chunk,
                                                         int spf, int cpf, float* __restrict__ dW, float* __restrict__ db) {
   using P = PBF16;
-  constexpr int TM = 4, TN = 4, MO = 256;
-  constexpr int STAGE = 32768, NSTAGE = 4;  // bytes: A 16 KiB + B 16 KiB (32 samples x 256 rows x 2 B each)
+  constexpr int TM = MT / 2, TN = NBW, MO = 32 * MT, KB = 64 * NBW;
+  constexpr int A_BYTES = MT * 2048, STAGE = A_BYTES + NBW * 4096;  // 32 samples x (MO + KB) rows x 2 B
+  constexpr int NS0 = 65536 / STAGE, NSTAGE = NS0 < 4 ? 4 : (NS0 > 8 ? 8 : NS0);  // ring depth: >= 64 KiB in flight per CU
+  constexpr int PA = MT / 2, PW = PA + NBW;  // transfers per wave per stage (exact: the counted waits rely on it)
+  static_assert(PW * (NSTAGE - 2) <= 63, "vmcnt range");
   __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), row = lane & 31, h = lane >> 5;
   const int wr = wid >> 1, wc = wid & 1;
   const int K = ke + kin;
-  const int kb_n = (K + 255) / 256;
+  const int kb_n = (K + KB - 1) / KB;
   const int job = blockIdx.x;
   const int c = job / kb_n, kb = job - c * kb_n;
   int s_begin, s_end;
@@ -314,13 +325,13 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
     s_begin = c * chunk;
     s_end = min(S_pad, s_begin + chunk);
   }
-  // B rows [k0, k0+nb) of X = [emb (ke rows) ; act (kin rows)]: n1 rows from emb (from row k0), then n2 rows from act
-  const int k0 = kb * 256, nb = min(256, K - k0);
+  // B rows [k0, k0+nb) of X = [emb (ke rows) ; act (kin rows)]: n1 rows from emb (from row k0), then the rest from act
+  const int k0 = kb * KB, nb = min(KB, K - k0);
   const int n1 = k0 < ke ? min(nb, ke - k0) : 0;
   const int r2 = (k0 > ke ? k0 : ke) - ke;
   bool bv_[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) bv_[j] = (wc * 4 + j) * 32 < nb;
+  for (int j = 0; j < TN; ++j) bv_[j] = (wc * TN + j) * 32 < nb;
   const bool do_db = (kb == 0 && wc == 0 && db != nullptr);
 
   f32x16_t acc[TM][TN];
@@ -334,28 +345,27 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
 #pragma unroll
   for (int i = 0; i < TM; ++i) rs[i] = 0.f;
 
-  // LDS image of a stage operand: [256 rows][64 B]; row r keeps its 16-byte chunk c (4 per row) at slot c ^ ((r >> 2) & 3).
+  // LDS image of a stage operand: [rows][64 B]; row r keeps its 16-byte chunk c (4 per row) at slot c ^ ((r >> 2) & 3).
   // The DMA writes lane-linear (a 1-KiB piece = 16 rows, position = lane), so the swizzle is applied to the SOURCE chunk
   // a lane fetches; the 32-row x one-chunk ds_read_b128 pattern below then touches 16 distinct 4-bank slots per 16-lane
   // group (un-swizzled: 86 % of the LDS-active cycles were bank-conflict cycles).
   const int lane_src = (lane >> 2) * 128 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);  // within a 16-row piece of a block
-  // every wave issues exactly 8 transfers per stage (the counted waits below rely on it): B pieces past the end of a
-  // short B operand (nb < 256) re-fetch its last piece
+  // B pieces past the end of a short B operand (nb < KB) re-fetch its last piece: every wave issues exactly PW transfers
   const int nbp = nb / 16;
   auto issue = [&](int st_idx, int buf) {
     const int blk = (s_begin >> 6) + (st_idx >> 1), half = st_idx & 1;
     unsigned char* st = lds + buf * STAGE;
     const unsigned char* ga = reinterpret_cast<const unsigned char*>(dz + (size_t)blk * block_stride(MO)) + half * 64 + lane_src;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < PA; ++p) {
       const int piece = wid + 4 * p;
       dma_1k(ga + piece * 2048, st + piece * 1024);
     }
-    unsigned char* sb = st + 16384;
+    unsigned char* sb = st + A_BYTES;
     const unsigned char* g1 = reinterpret_cast<const unsigned char*>(emb + (size_t)blk * block_stride(ke) + (size_t)k0 * 64) + half * 64 + lane_src;
     const unsigned char* g2 = reinterpret_cast<const unsigned char*>(actp + (size_t)blk * block_stride(kin) + (size_t)r2 * 64) + half * 64 + lane_src;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NBW; ++p) {
       int q = wid + 4 * p;
       q = q < nbp ? q : nbp - 1;
       const int r0 = 16 * q;  // first row of the piece inside the B operand
@@ -365,8 +375,8 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
   };
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   const unsigned f = (row >> 2) & 3;
-  const unsigned la0 = lds_base + (unsigned)((wr * 128 + row) * 64) + ((unsigned)(h ^ f) * 16u);          // sub-step 0: chunk h
-  const unsigned lb0 = lds_base + 16384u + (unsigned)((wc * 128 + row) * 64) + ((unsigned)(h ^ f) * 16u);
+  const unsigned la0 = lds_base + (unsigned)((wr * TM * 32 + row) * 64) + ((unsigned)(h ^ f) * 16u);  // sub-step 0: chunk h
+  const unsigned lb0 = lds_base + (unsigned)A_BYTES + (unsigned)((wc * TN * 32 + row) * 64) + ((unsigned)(h ^ f) * 16u);
   auto compute = [&](int buf) {
     const unsigned oa = la0 + (unsigned)buf * STAGE, ob = lb0 + (unsigned)buf * STAGE;
 #pragma unroll
@@ -374,10 +384,16 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
       // chunk 2*sub + h -> slot (2*sub + h) ^ f = slot(sub 0) ^ (2*sub): byte address ^ 32
       const unsigned xa = oa ^ (unsigned)(32 * sub), xb = ob ^ (unsigned)(32 * sub);
       u32x4_t a4[TM], b4[TN];
-      a4[0] = lds_read16<0>(xa); a4[1] = lds_read16<2048>(xa); a4[2] = lds_read16<4096>(xa); a4[3] = lds_read16<6144>(xa);
-      b4[0] = lds_read16<0>(xb); b4[1] = lds_read16<2048>(xb); b4[2] = lds_read16<4096>(xb); b4[3] = lds_read16<6144>(xb);
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]), "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
+      sfor<0, TM>([&](auto ic) { a4[decltype(ic)::value] = lds_read16<decltype(ic)::value * 2048>(xa); });
+      sfor<0, TN>([&](auto jc) { b4[decltype(jc)::value] = lds_read16<decltype(jc)::value * 2048>(xb); });
+      // the reads are asm the compiler cannot see through: tie every destination to the wait
+      if constexpr (TM == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]));
+      else if constexpr (TM == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4[0]), "+v"(a4[1]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4[0]));
+      if constexpr (TN == 4) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
+      else if constexpr (TN == 3) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]));
+      else if constexpr (TN == 2) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]));
+      else asm volatile("" : "+v"(b4[0]));
 #pragma unroll
       for (int j = 0; j < TN; ++j)  // column tiles past the end of a short B operand multiply zeros (branch-free)
         if (!bv_[j]) b4[j] = u32x4_t{0u, 0u, 0u, 0u};
@@ -402,18 +418,26 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
   };
   const int N = ((s_end >> 6) - (s_begin >> 6)) * 2;  // 32-sample stages
   if (N > 0) {
-    issue(0, 0);
-    if (N > 1) issue(1, 1);
-    if (N > 2) issue(2, 2);
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i)
+      if (i < N) issue(i, i);
+    int buf = 0;
     for (int s = 0; s < N; ++s) {
-      // this wave's 8 transfers of stage s have landed once at most the later stages' transfers are outstanding
-      if (s + 2 < N) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (s + 1 < N) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // this wave's PW transfers of stage s have landed once at most the later stages' transfers are outstanding
+      const int later = min(NSTAGE - 2, N - 1 - s);
+      if (later == NSTAGE - 2) wait_vmcnt<PW * (NSTAGE - 2)>();
+      else {
+        bool done = false;
+        sfor<0, NSTAGE - 2>([&](auto rc) {
+          constexpr int R = decltype(rc)::value;
+          if (!done && later == R) { wait_vmcnt<PW * R>(); done = true; }
+        });
+      }
       __builtin_amdgcn_s_barrier();  // everybody's part of stage s has landed AND everybody is done reading stage s-1 ...
       asm volatile("" ::: "memory");
-      if (s + 3 < N) issue(s + 3, (s + 3) & 3);  // ... whose buffer stage s+3 overwrites
-      compute(s & 3);
+      if (s + NSTAGE - 1 < N) issue(s + NSTAGE - 1, buf == 0 ? NSTAGE - 1 : buf - 1);  // ... whose buffer this stage overwrites
+      compute(buf);
+      buf = buf + 1 == NSTAGE ? 0 : buf + 1;
     }
   }
 #pragma unroll
@@ -423,14 +447,14 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
       if (!bv_[j]) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = 32 * (wr * 4 + i) + drow(r, h);
-        const int k = k0 + 32 * (wc * 4 + j) + row;
+        const int o = 32 * (wr * TM + i) + drow(r, h);
+        const int k = k0 + 32 * (wc * TN + j) + row;
         atomicAdd(dW + (size_t)o * K + k, acc[i][j][r]);
       }
     }
     if (do_db) {
       const float v = rs[i] + __shfl_xor(rs[i], 32, 64);
-      if (h == 0) atomicAdd(db + 32 * (wr * 4 + i) + row, v);
+      if (h == 0) atomicAdd(db + 32 * (wr * TM + i) + row, v);
     }
   }
 }
@@ -622,9 +646,13 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   if (S == 0) return LAB4D_OK;
   const int mo_tiles = L.mout_pad / 32, nk_tiles = (L.ke + L.kin) / 32;
   const bool big = mo_tiles >= 8;  // 256-wide layers: 8x8-tile workgroup blocks (k_mlp_wgrad_big / k_mlp_wgrad_dma)
-  const bool dma = precision == LAB4D_PREC_BF16 && mo_tiles == 8;
+  // bf16 layers of 64 / 128 / 256 output features run the LDS-DMA ring; NBW = 64-row blocks of X per workgroup
+  const bool dma = precision == LAB4D_PREC_BF16 && (mo_tiles == 8 || mo_tiles == 4 || mo_tiles == 2);
+  const int Kt = L.ke + L.kin;
+  const int nbw = Kt <= 64 ? 1 : (Kt <= 128 ? 2 : (Kt <= 192 ? 3 : (Kt <= 256 ? 4 : 3)));  // K = 320 -> 192 + 128
   const int TM = mo_tiles >= 4 ? 4 : (mo_tiles >= 2 ? 2 : 1);
-  const int ob_n = big ? div_up(mo_tiles, 8) : div_up(mo_tiles, TM), kb_n = big ? div_up(nk_tiles, 8) : div_up(nk_tiles, 4);
+  const int ob_n = dma ? 1 : (big ? div_up(mo_tiles, 8) : div_up(mo_tiles, TM));
+  const int kb_n = dma ? div_up(Kt, 64 * nbw) : (big ? div_up(nk_tiles, 8) : div_up(nk_tiles, 4));
   // ~1024 workgroups in total (4 per CU); chunks are multiples of 256 samples (one 64-sample step per wave)
   int nchunks = 1024 / (ob_n * kb_n); if (nchunks < 1) nchunks = 1;
   int chunk = div_up(div_up(S_pad, nchunks), 256) * 256; if (chunk < 1024) chunk = 1024;
@@ -647,9 +675,14 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
                                       (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
 #define WGB(P) hipLaunchKernelGGL((k_mlp_wgrad_big<P>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
                                   (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
-  if (dma)
-    hipLaunchKernelGGL(k_mlp_wgrad_dma, grid, block, 0, st, (const unsigned short*)dz, (const unsigned short*)emb, (const unsigned short*)act_prev,
-                       L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg);
+#define WGD(MTV, NBV) hipLaunchKernelGGL((k_mlp_wgrad_dma<MTV, NBV>), grid, block, 0, st, (const unsigned short*)dz, (const unsigned short*)emb, \
+                                         (const unsigned short*)act_prev, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
+#define WGD_NB(MTV) do { if (nbw == 1) WGD(MTV, 1); else if (nbw == 2) WGD(MTV, 2); else if (nbw == 3) WGD(MTV, 3); else WGD(MTV, 4); } while (0)
+  if (dma) {
+    if (mo_tiles == 8) WGD_NB(8); else if (mo_tiles == 4) WGD_NB(4); else WGD_NB(2);
+  }
+#undef WGD_NB
+#undef WGD
   else if (precision == LAB4D_PREC_BF16) { if (big) WGB(PBF16); else if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
   else if (precision == LAB4D_PREC_F32) { if (big) WGB(PF32); else if (TM == 4) WG(PF32, 4); else if (TM == 2) WG(PF32, 2); else WG(PF32, 1); }
   else { set_error("mlp_wgrad: bad precision %d", precision); return LAB4D_EINVAL; }
