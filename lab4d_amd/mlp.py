@@ -324,7 +324,9 @@ class MlpChain(Function):
             a.ext = ext.data_ptr()
         out = torch.empty(S, d.c_out, device=dev)
         a.out = out.data_ptr()
-        with _lib.timed("k_mlp_fwd<%s>" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], 0.0)):
+        # algorithmic HBM bytes of this launch: every stored tensor written once, inputs read once
+        nbytes = sum(t.numel() * t.element_size() for t in acts + masks + [emb, ext, out, x] if t is not None)
+        with _lib.timed("k_mlp_fwd<%s>" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], float(nbytes))):
             _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
         ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
@@ -377,7 +379,12 @@ class MlpChain(Function):
         if ctx.needs_input_grad[3]:
             d_x = torch.empty(ctx.x_shape, device=dev)
             a.d_x = d_x.data_ptr()
-        with _lib.timed("k_mlp_bwd<%s>" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], 0.0)):
+        # algorithmic HBM bytes: every dZ written once; masks, head gradient, stored embedding / external tensors read once
+        nbytes = sum(t.numel() * t.element_size() for t in list(dz) + list(ctx.masks) + [d_out, d_x, ext_g, ctx.emb if d_x is not None else None]
+                     if t is not None)
+        if d_export is not None:
+            nbytes += d_export.numel() * d_export.element_size()
+        with _lib.timed("k_mlp_bwd<%s>" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], float(nbytes))):
             _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(a), _lib.stream()), "mlp_backward")
         # weight / bias gradients
         M = (S + spf - 1) // spf

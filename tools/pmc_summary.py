@@ -10,14 +10,19 @@ from collections import defaultdict
 
 
 def short(name):
+    """rocprof kernel symbol -> the name bench.py reports (k_mlp_fwd<FgBase>, k_mlp_wgrad_dma<8,4>, ...)."""
     m = re.match(r"(?:void )?(?:lab4d::)?(k_\w+)(<.*>)?", name)
     if not m:
         return name.split("(")[0][:60]
     base, targs = m.group(1), m.group(2) or ""
     net = re.search(r"Net(\w+?)[,>]", targs)
     if base in ("k_mlp_fwd", "k_mlp_bwd") and net:
-        tan = ", true" in targs or ",true" in targs
+        flags = re.findall(r"\b(true|false)\b", targs)  # k_mlp_fwd<Net, P, TAN, ST>
+        tan = base == "k_mlp_fwd" and len(flags) >= 1 and flags[0] == "true"
         return "%s<%s>%s" % (base, net.group(1), "@tangent" if tan else "")
+    if base == "k_mlp_wgrad_dma":
+        nums = re.findall(r"\d+", targs)
+        return "k_mlp_wgrad_dma<%s>" % ",".join(nums[:2])
     if base == "k_mlp_wgrad":
         tm = re.search(r"(\d+)\s*>$", targs)
         return "k_mlp_wgrad<%s>" % (tm.group(1) if tm else "?")
