@@ -127,6 +127,20 @@ int lab4d_composite_backward(const float* density, const float* deltas, const la
                              float* g_gauss_density, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 3b. Field composition -- nnutils/multifields.py:339-398 (MultiFields.compose_fields, "comp" configs).
+ *    The samples of two fields (fg: Da per ray, bg: Db per ray) are concatenated along the depth axis, z-sorted
+ *    (argsort of the concatenated depth) and every per-sample key is gathered with that permutation.
+ *    compose_order: depth_a (R,Da), depth_b (R,Db) -> order (R,Da+Db) int32 = argsort (stable: ties keep the
+ *    concatenation order) and pos (R,Da+Db) = its inverse (where each input sample went; the adjoint's gather index).
+ *    compose_gather: out (R,Dn,C) = [a (R,Da,C) | b (R,Db,C)][idx (R,Dn), row stride idx_ld]; a NULL part reads as
+ *    zeros (a key only one field produces, multifields.py:383-389).  Forward: idx = order, Dn = Da+Db.  Adjoint of part a:
+ *    a = g_out with Da := Da+Db, b = NULL, idx = pos, Dn = Da (part b: idx = pos + Da, Dn = Db).
+ * ------------------------------------------------------------------------------------------ */
+int lab4d_compose_order(const float* depth_a, int Da, const float* depth_b, int Db, int R, int32_t* order, int32_t* pos, void* stream);
+int lab4d_compose_gather(const float* a, int Da, const float* b, int Db, const int32_t* idx, int idx_ld, int R, int Dn, int C,
+                         float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 4. Fused positional-encoding + MLP stack -- nnutils/embedding.py:69-125 (PosEmbedding),
  *    nnutils/base.py:65-78,123-150 (BaseMLP/CondMLP), as used by nnutils/nerf.py:167-215,
  *    visibility.py:53-63, feature.py:136-150, skinning.py:108-119, warping.py:143-170.

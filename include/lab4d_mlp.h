@@ -7,7 +7,8 @@
  *   nnutils/base.py:65-78         BaseMLP.forward  (Linear+ReLU stack, skip = cat([x, out]))
  *   nnutils/base.py:123-150       CondMLP.forward  (per-frame code appended to the input)
  * as used by NeRF.forward (nerf.py:167-215), VisField.forward (visibility.py:53-63),
- * FeatureNeRF.compute_feat (feature.py:136-150) and SkinningField.forward (skinning.py:108-119).
+ * FeatureNeRF.compute_feat (feature.py:136-150), SkinningField.forward (skinning.py:108-119) and
+ * DenseWarp.forward (warping.py:143-170).
  *
  * Execution model (csrc/mlp.hip): one wavefront owns a tile of 64 (bf16) / 32 (fp32) samples and
  * carries their activations through ALL layers in registers: the 32x32 MFMA accumulator layout of
@@ -35,7 +36,8 @@
 #define LAB4D_NET_VIS 2       /* posenc10 -> 64 -> 64 -> 1                                           */
 #define LAB4D_NET_FEAT 3      /* posenc6  -> feature_field (5 layers W=128, skip at 4) -> 16         */
 #define LAB4D_NET_SKIN 4      /* raw 75 bone coords -> 64 -> 64 -> 25 (delta skinning weights)       */
-#define LAB4D_NET_COUNT 5
+#define LAB4D_NET_DENSE 5     /* posenc6 -> 256 -> 256 -> 3 (DenseWarp post-warp of ComposedWarp: dense translation field) */
+#define LAB4D_NET_COUNT 6
 
 #define LAB4D_PREC_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32, parity path                       */
 #define LAB4D_PREC_BF16 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate: throughput path            */

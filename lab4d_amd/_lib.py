@@ -143,6 +143,11 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def ptr_at(t):
+    """Device pointer of the first element of a (possibly non-contiguous) view; the caller passes the row stride."""
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -545,6 +545,7 @@ int with_net(int net, F&& f) {
     case LAB4D_NET_VIS: return f(NetVis{});
     case LAB4D_NET_FEAT: return f(NetFeat{});
     case LAB4D_NET_SKIN: return f(NetSkin{});
+    case LAB4D_NET_DENSE: return f(NetDense{});
     default: set_error("unknown net id %d", net); return LAB4D_EINVAL;
   }
 }

@@ -43,6 +43,13 @@ struct NetSkin {
   static constexpr LS L[NL] = {{96, 0, 64, 1, 1, 0, 0}, {0, 64, 64, 1, 0, 0, 0}, {0, 64, 25, 0, 0, 0, 0}};
 };
 
+// warping.py:105-170,445-483 : DenseWarp(D=2,W=256) post-warp of ComposedWarp: PosEmbedding(3,6)=39 (+128 time embedding
+// +32 instance code as per-frame bias) -> 256 -> 256 -> 3 ; one table serves forward_map and backward_map
+struct NetDense {
+  static constexpr int ID = LAB4D_NET_DENSE, NL = 3, EMB = 0, NFREQ = 6, CIN = 3, SLOTS = 39, KE = 64, COUT = 3;
+  static constexpr LS L[NL] = {{64, 0, 256, 1, 1, 0, 0}, {0, 256, 256, 1, 0, 0, 0}, {0, 256, 3, 0, 0, 0, 0}};
+};
+
 template <class Net>
 constexpr int net_wmax() {
   int w = 32;

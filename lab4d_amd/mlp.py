@@ -21,7 +21,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 MAXL = 12
-NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN = 0, 1, 2, 3, 4
+NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE = 0, 1, 2, 3, 4, 5
 PREC_F32, PREC_BF16 = 0, 1
 vp, ci = ctypes.c_void_p, ctypes.c_int
 
@@ -53,13 +53,13 @@ _lib.register("lab4d_mlp_forward_tangent", [ctypes.POINTER(FwdArgs), vp])
 _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
 
-NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin"}
+NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense"}
 # algorithmic MACs per sample (real layer shapes incl. conditioning columns)
-NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736}
+NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736, 5: 39 * 256 + 256 * 256 + 256 * 3}
 
 
 
-KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin"}  # template argument names in csrc/mlp_nets.hpp
+KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense"}  # template argument names in csrc/mlp_nets.hpp
 
 
 def wgrad_kernel_name(L, prec):
@@ -155,6 +155,11 @@ def bindings(net, prefix=""):
     if net == NET_SKIN:  # skinning.py:70-86: [3B bone coords | 128 time embedding | 32 instance code]
         q = p + "warp.skinning_model.delta_field."
         return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(75, 160)),
+                LayerBinding(q + "linear_2.0.weight", q + "linear_2.0.bias", prev0=0),
+                LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0)]
+    if net == NET_DENSE:  # warping.py:123-141: [39 posenc | 128 time embedding | 32 instance code]; prefix selects the map,
+        q = p  # "warp.post_warp.forward_map." / "warp.post_warp.backward_map." (the CondMLP itself, base.py:80-121)
+        return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(39, 160)),
                 LayerBinding(q + "linear_2.0.weight", q + "linear_2.0.bias", prev0=0),
                 LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0)]
     raise ValueError(net)

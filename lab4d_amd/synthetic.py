@@ -41,6 +41,26 @@ FG_EMBEDDINGS = [
 ]
 
 
+# ComposedWarp's dense post-warp (warping.py:445-447: DenseWarp(D=2, W=256)): two CondMLPs, 199 = 39 + 128 + 32 inputs
+DENSE_LINEARS = [(f"warp.post_warp.{m}.linear_1.0", 256, 199) for m in ("forward_map", "backward_map")] + \
+                [(f"warp.post_warp.{m}.linear_2.0", 256, 256) for m in ("forward_map", "backward_map")] + \
+                [(f"warp.post_warp.{m}.linear_final", 3, 256) for m in ("forward_map", "backward_map")]
+DENSE_EMBEDDINGS = [(f"warp.post_warp.{m}.inst_embedding.mapping.weight", 32) for m in ("forward_map", "backward_map")]
+
+
+def add_dense_weights(P, seed=0, num_inst=1):
+    """Adds the post-warp parameters of fg_motion "comp_skel-quad_dense" to a make_weights() dict (own generator, so the
+    skel-quad weights and their golden checksums are unchanged)."""
+    g = torch.Generator().manual_seed(seed + 7919)
+    for name, o, i in DENSE_LINEARS:
+        bound = 1.0 / math.sqrt(i)
+        P[name + ".weight"] = (torch.rand(o, i, generator=g) * 2 - 1) * bound
+        P[name + ".bias"] = (torch.rand(o, generator=g) * 2 - 1) * bound
+    for name, c in DENSE_EMBEDDINGS:
+        P[name] = torch.randn(num_inst, c, generator=g)
+    return P
+
+
 def make_weights(seed=0, num_inst=1, sdf_bias=None):
     """Flat dict of fp32 CPU tensors keyed by the reference's state_dict names."""
     g = torch.Generator().manual_seed(seed)
@@ -106,6 +126,7 @@ def make_frames(seed, M, res, num_inst=1):
     fr["t_articulation"] = tuple(x.contiguous() for x in _qt_to_dq(dq_q, t_t))
     fr["t_embed"] = 0.5 * torch.randn(M, 128, generator=g)
     fr["t_embed_mean"] = 0.5 * torch.randn(1, 128, generator=g)
+    fr["t_embed_dense"] = 0.5 * torch.randn(M, 128, generator=torch.Generator().manual_seed(seed + 104729))  # post-warp TimeEmbedding
     fr["appr_code"] = 0.5 * torch.randn(M, 32, generator=g)
     fr["frame_id"] = torch.arange(M, dtype=torch.long)
     fr["inst_id"] = torch.zeros(M, dtype=torch.long)
@@ -122,6 +143,9 @@ def add_codes(fr, P):
     fr["code_color"] = look("colorfield.inst_embedding.mapping.weight")
     fr["code_vis"] = look("vis_mlp.basefield.inst_embedding.mapping.weight")
     fr["code_skin"] = look("warp.skinning_model.delta_field.inst_embedding.mapping.weight")
+    if "warp.post_warp.forward_map.inst_embedding.mapping.weight" in P:
+        fr["dense"] = {"t_embed": fr["t_embed_dense"], "code_fw": look("warp.post_warp.forward_map.inst_embedding.mapping.weight"),
+                       "code_bw": look("warp.post_warp.backward_map.inst_embedding.mapping.weight")}
     return fr
 
 

@@ -124,3 +124,28 @@ def skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, back
     raw = mlp.run_chain(mlp.NET_SKIN, prec, P, bone, spf, conds={0: cond})
     out, ent, dsk = SkinBlend.apply(x, bone, raw, se3[0], se3[1], spf)
     return out.view(shape), {"skin_entropy": ent.view(shape[:-1] + (1,)), "delta_skin": dsk.view(shape[:-1] + (1,))}
+
+
+def dense_warp(P, xyz, t_embed, code, backward, prec=mlp.PREC_F32, prefix="warp.post_warp."):
+    """DenseWarp.forward (warping.py:143-170): xyz + 0.1 * CondMLP([posenc6(xyz) | time embedding | instance code]) with the
+    backward_map / forward_map weights.  t_embed: (M,128) output of the warp's own TimeEmbedding, code: (M,32)."""
+    shape = xyz.shape
+    spf = 1
+    for d in shape[1:-1]:
+        spf *= d
+    which = "backward_map." if backward else "forward_map."
+    cond = torch.cat([t_embed, code], -1)
+    motion = mlp.run_chain(mlp.NET_DENSE, prec, P, xyz.reshape(-1, 3), spf, conds={0: cond}, prefix=prefix + which)
+    return xyz + 0.1 * motion.view(shape)
+
+
+def composed_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, prec=mlp.PREC_F32, dense=None):
+    """ComposedWarp.forward (warping.py:445-483): skeleton skinning composed with a dense post-warp.  `dense` =
+    {"t_embed": (M,128), "code_fw": (M,32), "code_bw": (M,32)} for a known frame_id, or None (frame_id is None: the post
+    warp is skipped, warping.py:460,474)."""
+    if not backward and dense is not None:
+        xyz = dense_warp(P, xyz, dense["t_embed"], dense["code_fw"], False, prec)
+    out, aux = skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, prec)
+    if backward and dense is not None:
+        out = dense_warp(P, out, dense["t_embed"], dense["code_bw"], True, prec)
+    return out, aux

@@ -483,6 +483,24 @@ def vis_field(P, xyz, code):
     return cond_mlp(P, "vis_mlp.basefield", pos_embedding(xyz, 10), code, D=2, final_act=False)
 
 
+def dense_warp(P, xyz, t_embed, code, backward, prefix="warp.post_warp"):
+    """DenseWarp.forward (warping.py:143-170): xyz + 0.1 * CondMLP(D=2)([posenc6 | time embedding | instance code])."""
+    m = f"{prefix}.backward_map" if backward else f"{prefix}.forward_map"
+    te = t_embed.view(t_embed.shape[:1] + (1,) * (xyz.ndim - 2) + (-1,)).expand(xyz.shape[:-1] + (-1,))
+    feat = torch.cat([pos_embedding(xyz, 6), te], -1)
+    return xyz + 0.1 * cond_mlp(P, m, feat, code, D=2, final_act=False)
+
+
+def composed_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, dense=None):
+    """ComposedWarp.forward (warping.py:445-483)."""
+    if not backward and dense is not None:
+        xyz = dense_warp(P, xyz, dense["t_embed"], dense["code_fw"], False)
+    out, aux = skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward)
+    if backward and dense is not None:
+        out = dense_warp(P, out, dense["t_embed"], dense["code_bw"], True)
+    return out, aux
+
+
 def compute_feat(P, xyz):
     """FeatureNeRF.compute_feat (feature.py:136-150)."""
     f = base_mlp(P, "feature_field", pos_embedding(xyz, 6), D=5, final_act=False)
@@ -718,7 +736,9 @@ def compose_fields(multifields_dict, deltas_dict):
                 parts.append(torch.zeros_like(ref))  # multifields.py:383-389
         cat[k] = torch.cat(parts, 2)
     deltas = torch.cat([deltas_dict[c] for c in multifields_dict], 2)
-    order = cat["depth"].argsort(dim=2)  # z-sort (multifields.py:387)
+    # z-sort (multifields.py:387).  stable=True fixes the order of exactly equal depths (concatenation order), which the
+    # reference leaves to torch.argsort's implementation; for distinct depths it is the same permutation
+    order = cat["depth"].argsort(dim=2, stable=True)
     out = {k: torch.gather(v, 2, order.expand(-1, -1, -1, v.shape[-1])) for k, v in cat.items()}
     deltas = torch.gather(deltas, 2, order)
     return out, deltas

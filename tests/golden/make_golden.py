@@ -259,6 +259,48 @@ def gen_ops(ns):
     torch.save(out, path)
     print("ops ->", path, os.path.getsize(path) // 1024, "KiB")
 
+def gen_comp_warp(ns):
+    """ComposedWarp (skeleton skinning + dense post-warp, fg_motion "comp_skel-quad_dense", warping.py:143-170,445-483):
+    backward warp, forward warp, and the frame_id=None forward warp that skips the post-warp."""
+    P = synthetic.add_dense_weights(synthetic.make_weights(0))
+    torch.manual_seed(0)
+    di = ref_shim.synthetic_data_info(64)
+    f = ns.deformable.Deformable("comp_skel-quad_dense", di, num_freq_dir=-1, appr_channels=32, num_inst=1, init_scale=0.2)
+    f.category = "fg"
+    sd = {k: v for k, v in P.items() if k in f.state_dict()}
+    missing = [k for k in P if k not in f.state_dict() and k != "warp.skinning_model.symm_idx"]
+    assert not missing, missing
+    f.load_state_dict(sd, strict=False)
+    M, N, D = 2, 4, 6
+    fr = synthetic.make_frames(41, M, 64)
+    fr["frame_id"] = torch.tensor([3, 4])
+    fr = frames_from_reference(f, fr)
+    with torch.no_grad():
+        fr["t_embed_dense"] = f.warp.post_warp.time_embedding(fr["frame_id"]).clone()
+    fr = synthetic.add_codes(fr, P)
+    g = torch.Generator().manual_seed(43)
+    xyz = (torch.randn(M, N, D, 3, generator=g) * 0.06).requires_grad_(True)
+    w = torch.randn(M, N, D, 3, generator=g)
+    sdict = {"t_articulation": fr["t_articulation"], "rest_articulation": fr["rest_articulation"]}
+    out_bw, aux_bw = f.warp(xyz, fr["frame_id"], fr["inst_id"], backward=True, samples_dict=sdict, return_aux=True)
+    out_fw, aux_fw = f.warp(xyz, fr["frame_id"], fr["inst_id"], backward=False, samples_dict=sdict, return_aux=True)
+    out_fw_none = f.warp(xyz, None, fr["inst_id"], backward=False, samples_dict=sdict)
+    dense_fw = f.warp.post_warp(xyz, fr["frame_id"], fr["inst_id"], backward=False)
+    dense_bw = f.warp.post_warp(xyz, fr["frame_id"], fr["inst_id"], backward=True)
+    loss = (out_bw * w).sum() + (out_fw * w.flip(0)).sum()
+    names = ["warp.post_warp.forward_map.linear_1.0.weight", "warp.post_warp.backward_map.linear_2.0.weight",
+             "warp.post_warp.backward_map.linear_final.bias", "warp.skinning_model.delta_field.linear_1.0.weight"]
+    params = dict(f.named_parameters())
+    grads = torch.autograd.grad(loss, [xyz] + [params[n] for n in names])
+    out = {"weight_checksum": weight_checksum(P), "frames": {k: v for k, v in fr.items()}, "xyz": xyz.detach(), "w": w,
+           "out_bw": out_bw.detach(), "out_fw": out_fw.detach(), "out_fw_none": out_fw_none.detach(),
+           "dense_fw": dense_fw.detach(), "dense_bw": dense_bw.detach(),
+           "aux_bw": {k: v.detach() for k, v in aux_bw.items()}, "loss": loss.detach(),
+           "grad_xyz": grads[0], "grads": {n: compress_grad(gv) for n, gv in zip(names, grads[1:])}}
+    path = os.path.join(HERE, "comp_warp.pt")
+    torch.save(out, path)
+    print("comp_warp ->", path, os.path.getsize(path) // 1024, "KiB")
+
 
 if __name__ == "__main__":
     ns = ref_shim.load()
@@ -269,3 +311,4 @@ if __name__ == "__main__":
     gen_train(ns, "small", M=2, N=6, D=8, res=64, seed=11)
     gen_train(ns, "alpha", M=4, N=5, D=6, res=64, seed=21, alpha=0.45)
     gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)
+    gen_comp_warp(ns)

@@ -38,6 +38,7 @@ def test_library_exports_every_declared_symbol(so):
 def test_python_signatures_cover_the_header():
     import lab4d_amd.deformable  # noqa: F401  (registers the mlp / skinning / gauss-density signatures)
     import lab4d_amd.mlp  # noqa: F401
+    import lab4d_amd.multifields  # noqa: F401
     import lab4d_amd.warping  # noqa: F401
     sig = set(_lib.SIGNATURES)
     hdr = set(declared_symbols()) - {"lab4d_last_error", "lab4d_version", "lab4d_arch"}

@@ -266,3 +266,44 @@ def test_sort_depth_matches_torch_sort():
     b[:, 5] = b[:, 6] + 1e-7  # a local inversion, as rounding in sample_pdf can produce
     out = RU.sort_depth(a.to(DEV), b.to(DEV)).cpu()
     assert torch.equal(out, torch.sort(torch.cat([a, b], -1), -1)[0])
+
+
+def test_compose_fields_matches_oracle_and_reference_golden(golden_dir):
+    """MultiFields.compose_fields on the device vs the oracle (itself pinned to the reference's output in ops.pt)."""
+    import os
+    from lab4d_amd import multifields
+    from oracle import lab4d_oracle as O
+    ops = torch.load(os.path.join(golden_dir, "ops.pt"), weights_only=False)
+    fdA, fdB, dA, dB, comp, dcomp = ops["compose_fields"]
+    dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    out, deltas = multifields.compose_fields({"fg": dev(fdA), "bg": dev(fdB)}, {"fg": dA.to(DEV), "bg": dB.to(DEV)})
+    for k, v in comp.items():
+        assert torch.equal(out[k].cpu(), v), k  # pure data movement: bit-exact
+    assert torch.equal(deltas.cpu(), dcomp)
+    # larger random case incl. ties and gradients
+    g = torch.Generator().manual_seed(3)
+    M, N, Da, Db = 2, 37, 64, 64
+    mk = lambda D, c: torch.rand(M, N, D, c, generator=g)
+    fa = {"depth": torch.sort(mk(Da, 1), 2)[0], "rgb": mk(Da, 3), "density": mk(Da, 1), "cyc_dist": mk(Da, 1)}
+    fb = {"depth": torch.sort(mk(Db, 1), 2)[0], "rgb": mk(Db, 3), "density": mk(Db, 1)}
+    fb["depth"][:, :, :5] = fa["depth"][:, :, 10:15]  # exact ties between the fields
+    fb["depth"] = torch.sort(fb["depth"], 2)[0]
+    da, db = mk(Da, 1), mk(Db, 1)
+
+    def run(mod, to):
+        A = {k: to(v).clone().requires_grad_(k != "depth") for k, v in fa.items()}
+        B = {k: to(v).clone().requires_grad_(k != "depth") for k, v in fb.items()}
+        o, d = mod.compose_fields({"fg": A, "bg": B}, {"fg": to(da), "bg": to(db)})
+        w = {k: torch.rand(v.shape, generator=torch.Generator().manual_seed(len(k))) for k, v in o.items()}
+        loss = sum((o[k] * to(w[k])).sum() for k in o if k != "depth")
+        names = [("A", k) for k in A if k != "depth"] + [("B", k) for k in B if k != "depth"]
+        gs = torch.autograd.grad(loss, [A[k] for n, k in names if n == "A"] + [B[k] for n, k in names if n == "B"])
+        return o, d, dict(zip(names, gs))
+
+    ro, rd, rg = run(O, lambda t: t)
+    do, dd, dg = run(multifields, lambda t: t.to(DEV))
+    for k in ro:
+        assert torch.equal(do[k].cpu(), ro[k]), k
+    assert torch.equal(dd.cpu(), rd)
+    for k in rg:
+        assert torch.equal(dg[k].cpu(), rg[k]), k

@@ -58,3 +58,47 @@ def test_skinning_warp_forward_backward(backward, shape):
         assert rel(a, b) < 1e-4, f"{n}: {rel(a, b):.3e}"
     for k in rg:
         assert rel(dg[k], rg[k]) < 1e-3, f"grad {k}: {rel(dg[k], rg[k]):.3e}"
+
+
+@pytest.mark.parametrize("backward", [True, False])
+def test_composed_warp_dense_post_warp(backward):
+    """ComposedWarp (skinning + DenseWarp post-warp, LAB4D_NET_DENSE) forward + all gradients vs the oracle, fp32."""
+    from lab4d_amd import warping
+    M, N, D = 2, 9, 11
+    P = synthetic.add_dense_weights(synthetic.make_weights(4), seed=4)
+    fr = synthetic.add_codes(synthetic.make_frames(5, M, 64), P)
+    g = torch.Generator().manual_seed(8)
+    xyz = torch.randn(M, N, D, 3, generator=g) * 0.08
+    w_out = torch.randn(M, N, D, 3, generator=g)
+    m = "backward_map" if backward else "forward_map"
+    pkeys = [f"warp.post_warp.{m}.linear_1.0.weight", f"warp.post_warp.{m}.linear_2.0.weight", f"warp.post_warp.{m}.linear_final.weight",
+             f"warp.post_warp.{m}.linear_1.0.bias", f"warp.post_warp.{m}.linear_final.bias", "warp.skinning_model.delta_field.linear_1.0.weight"]
+
+    def run(dev, mod):
+        Pl = {k: (v.to(dev).clone().requires_grad_(True) if v.dtype.is_floating_point else v.to(dev)) for k, v in P.items()}
+        frl = synthetic.to_device(fr, dev)
+        dense = {k: v.clone().requires_grad_(True) for k, v in frl["dense"].items()}
+        x = xyz.to(dev).clone().requires_grad_(True)
+        te = frl["t_embed"] if backward else frl["t_embed_mean"]
+        out, aux = mod.composed_warp(Pl, x, frl["t_articulation"], frl["rest_articulation"], te, frl["code_skin"], backward, dense=dense)
+        loss = (out * w_out.to(dev)).sum()
+        dk = ["t_embed", "code_bw" if backward else "code_fw"]
+        gs = torch.autograd.grad(loss, [x] + [Pl[k] for k in pkeys] + [dense[k] for k in dk])
+        return out, dict(zip(["x"] + pkeys + dk, gs))
+
+    ro, rg = run("cpu", O)
+    do, dg = run(DEV, warping)
+    assert rel(do, ro) < 1e-4, f"xyz: {rel(do, ro):.3e}"
+    for k in rg:
+        assert rel(dg[k], rg[k]) < 1e-3, f"grad {k}: {rel(dg[k], rg[k]):.3e}"
+
+
+def test_dense_warp_bf16_close_to_fp32():
+    from lab4d_amd import mlp, warping
+    M, N, D = 2, 64, 16
+    P = synthetic.to_device(synthetic.add_dense_weights(synthetic.make_weights(4), seed=4), DEV)
+    fr = synthetic.to_device(synthetic.add_codes(synthetic.make_frames(5, M, 64), synthetic.add_dense_weights(synthetic.make_weights(4), seed=4)), DEV)
+    xyz = torch.randn(M, N, D, 3, device=DEV) * 0.08
+    a = warping.dense_warp(P, xyz, fr["dense"]["t_embed"], fr["dense"]["code_bw"], True, mlp.PREC_F32)
+    b = warping.dense_warp(P, xyz, fr["dense"]["t_embed"], fr["dense"]["code_bw"], True, mlp.PREC_BF16)
+    assert float((a - b).abs().max()) < 2e-3  # motion is 0.1 * O(0.3): bf16 operand rounding

@@ -152,3 +152,37 @@ def test_eval_graph_against_reference(golden_dir):
         close(fd[k], v, "feat_dict." + k, rtol=2e-4)
     for k, v in g["rendered"].items():
         close(out["rendered"][k], v, "rendered." + k, rtol=2e-4)
+
+
+def test_composed_warp_against_reference(golden_dir):
+    """ComposedWarp = skeleton skinning + DenseWarp post-warp (fg_motion "comp_skel-quad_dense", warping.py:143-170,445-483)."""
+    g = torch.load(os.path.join(golden_dir, "comp_warp.pt"), weights_only=False)
+    P = synthetic.add_dense_weights(synthetic.make_weights(0))
+    chk = float(sum(v.double().abs().sum() for k, v in sorted(P.items()) if v.dtype.is_floating_point))
+    assert abs(chk - g["weight_checksum"]) < 1e-6 * g["weight_checksum"]
+    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v) for k, v in P.items()}
+    fr = synthetic.add_codes(dict(g["frames"]), P)
+    xyz = g["xyz"].clone().requires_grad_(True)
+    close(O.dense_warp(P, xyz, fr["dense"]["t_embed"], fr["dense"]["code_fw"], False), g["dense_fw"], "dense_fw")
+    close(O.dense_warp(P, xyz, fr["dense"]["t_embed"], fr["dense"]["code_bw"], True), g["dense_bw"], "dense_bw")
+    out_bw, aux = O.composed_warp(P, xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, fr["dense"])
+    # the skinning field of a forward warp always sees the MEAN time embedding (frame_id = None, warping.py:314)
+    out_fw, _ = O.composed_warp(P, xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], fr["code_skin"], False, fr["dense"])
+    out_none, _ = O.composed_warp(P, xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], fr["code_skin"], False, None)
+    close(out_bw, g["out_bw"], "out_bw")
+    close(out_fw, g["out_fw"], "out_fw")
+    close(out_none, g["out_fw_none"], "out_fw_none")
+    for k, v in g["aux_bw"].items():
+        close(aux[k], v, "aux_bw." + k)
+    loss = (out_bw * g["w"]).sum() + (out_fw * g["w"].flip(0)).sum()
+    close(loss, g["loss"], "loss")
+    names = list(g["grads"].keys())
+    grads = torch.autograd.grad(loss, [xyz] + [P[n] for n in names])
+    close(grads[0], g["grad_xyz"], "grad_xyz", rtol=2e-3, atol=2e-6 * float(g["grad_xyz"].abs().max()) + 1e-9)
+    for n, gv in zip(names, grads[1:]):
+        ref = g["grads"][n]
+        if "full" in ref:
+            close(gv, ref["full"], "grad." + n, rtol=2e-3, atol=2e-6 * max(1.0, float(ref["full"].abs().max())) + 1e-9)
+        else:
+            close(gv.flatten()[:: ref["stride"]], ref["sub"], "grad." + n, rtol=2e-3, atol=1e-4 * float(ref["sub"].abs().max()) + 1e-10)
+            assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 1e-3 * float(ref["norm"]) + 1e-12, n
