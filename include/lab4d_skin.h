@@ -33,18 +33,25 @@ int lab4d_bone_coords_backward(const float* xyz, const float* art_r, const float
 int lab4d_bone_params_from_gram(const float* art_r, const float* art_d, const float* gauss, const float* G, int M, int B,
                                 float* g_art_r, float* g_art_d, float* g_gauss, void* stream);
 
-/* skin = -(|xyz_bone_b|^2 + relu(delta_raw_b)*0.1); p = softmax(skin); blend the per-bone transforms se3
- * (M,B,4)x2 with the arg-max bone's hemisphere; out = apply(blend, xyz).
- * Outputs: out (S,3), entropy (S) = logsumexp(skin) - max(skin), dskin (S) = mean_b delta_b^2. */
-int lab4d_skin_blend_forward(const float* xyz, const float* xyz_bone, const float* delta_raw, const float* se3_r,
-                             const float* se3_d, int S, int spf, int M, int B, float* out, float* entropy,
-                             float* dskin, void* stream);
-/* Adjoint.  g_ent / g_dskin may be NULL.  Writes g_xyz (S,3), g_bone (S,3B), g_raw (S,B); accumulates
- * g_se3 (M,B,8) = [d/d se3_r (4) | d/d se3_d (4)] (zero-fill first).  `work` is scratch of S*(B+8) floats. */
-int lab4d_skin_blend_backward(const float* xyz, const float* xyz_bone, const float* delta_raw, const float* se3_r,
-                              const float* se3_d, const float* g_out, const float* g_ent, const float* g_dskin,
-                              int S, int spf, int M, int B, float* g_xyz, float* g_bone, float* g_raw,
-                              float* g_se3, float* work, void* stream);
+/* skin = -(|c_b|^2 + relu(delta_raw_b)*0.1) with c_b the gaussian-scaled bone coordinate of the point (recomputed from
+ * art_r, art_d (M,B,4), gauss (B,3): the same arithmetic as lab4d_bone_coords_forward, so the (S,3B) tensor is only ever
+ * read by the delta-skin MLP); p = softmax(skin); blend the per-bone transforms se3 (M,B,4)x2 with the arg-max bone's
+ * hemisphere; out = apply(blend, xyz).
+ * Outputs: out (S,3), entropy (S) = logsumexp(skin) - max(skin), dskin (S) = mean_b delta_b^2.  `work`: scratch of
+ * M*B*12 floats (the per-frame affine form of the bone coordinates). */
+int lab4d_skin_blend_forward(const float* xyz, const float* art_r, const float* art_d, const float* gauss,
+                             const float* delta_raw, const float* se3_r, const float* se3_d, int S, int spf, int M, int B,
+                             float* out, float* entropy, float* dskin, float* work, void* stream);
+/* Adjoint.  g_ent / g_dskin may be NULL.  Writes g_xyz (S,3) (including the path through the bone coordinates) and
+ * g_raw (S,B); accumulates g_se3 (M,B,8) = [d/d se3_r (4) | d/d se3_d (4)] (zero-fill first); writes g_art_r, g_art_d
+ * (M,B,4) and accumulates g_gauss (B,3) (zero-fill first) -- the three may be NULL together.  The bone-coordinate
+ * gradient dL/dc_b = -2 dL/dskin_b * c_b is never materialised: it reaches the point analytically and the parameters
+ * through per-frame second moments.  `work`: scratch of S*(2B+18) + M*B*34 floats. */
+int lab4d_skin_blend_backward(const float* xyz, const float* art_r, const float* art_d, const float* gauss,
+                              const float* delta_raw, const float* se3_r, const float* se3_d, const float* g_out,
+                              const float* g_ent, const float* g_dskin, int S, int spf, int M, int B, float* g_xyz,
+                              float* g_raw, float* g_se3, float* g_art_r, float* g_art_d, float* g_gauss, float* work,
+                              void* stream);
 
 /* Gaussian-bone density  max_b exp(-0.5 |x - c_b|^2 / 0.01^2) * ibeta  (nnutils/deformable.py:329-356,
  * warping.py:355-387, utils/transforms.py:28-40).  centres: (B,3); ibeta: device scalar (no host sync).
@@ -55,7 +62,7 @@ int lab4d_gauss_density_forward(const float* xyz, const float* centres, int B, c
 int lab4d_gauss_density_backward(const float* xyz, const float* centres, int B, const float* ibeta, const int* best,
                                  const float* g, int S, float* g_xyz, float* g_centres, float* g_ibeta, void* stream);
 
-/* Per-frame tall-skinny product out[m][i][j] += sum_{s in frame m} A[s][i] * Bm[s][j]  (A: (S,CA<=80), Bm: (S,CB<=8),
+/* Per-frame tall-skinny product out[m][i][j] += sum_{s in frame m} A[s][i] * Bm[s][j]  (A: (S,CA<=80), Bm: (S,CB<=16), CA*CB<=640,
  * out: (M,CA,CB), accumulated).  All per-frame parameter gradients of the skinning warp reduce to this form
  * (bone transforms are affine in the point, the blended dual quaternion is linear in the skin weights). */
 int lab4d_gram_per_frame(const float* A, int CA, const float* Bm, int CB, int S, int spf, int M, float* out, void* stream);

