@@ -286,14 +286,16 @@ def main():
             # SURVEY 8d also asks for the forward-only rate: eval-mode render (importance sampling -> 128 samples, field,
             # normals through one first-order backward, compositing) of the same rays; 2 timed chunks after 1 warm-up
             try:
-                h0 = inputs[0][0]
+                half = inputs[0][0].shape[1] // 2  # half a training chunk per call: the 150 GiB graph pool stays resident
+                h0 = inputs[0][0][:, :half].contiguous()
                 torch.cuda.empty_cache()  # the eager training chunks of the roofline pass left ~130 GiB cached beside the graph pool
-                for _ in range(2):        # warm-up: re-grow the allocator pools for the eval graph (slow the first time)
-                    DF.render_eval(P, fr, h0, n_depth=spp, prec=prec)
+                n_ev = min(4, len(inputs))
+                ev_in = [h[:, :half].contiguous() for h, _ in inputs[:n_ev]]
+                for h in [h0] + ev_in:    # warm-up over the same inputs: re-grows the allocator pools (slow the first time)
+                    DF.render_eval(P, fr, h, n_depth=spp, prec=prec)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                n_ev = min(4, len(inputs))
-                for h, _ in inputs[:n_ev]:
+                for h in ev_in:
                     DF.render_eval(P, fr, h, n_depth=spp, prec=prec)
                 torch.cuda.synchronize()
                 out["eval_forward_only"] = {"value": round(n_ev * h0.shape[0] * h0.shape[1] / (time.perf_counter() - t0), 1), "unit": "rays/s",

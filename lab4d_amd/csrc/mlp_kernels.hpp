@@ -365,8 +365,58 @@ template <class Net, class P>
 struct Slab {
   static constexpr int W = net_wmax<Net>();
   static constexpr int UW = W / P::FPG;                 // units per n-tile
-  static constexpr int UNITS_PER_WAVE = P::NT * UW * 64;  // uint4 slots
+  // raw-input nets (and the tangent forward) stage a tile of their (S, C) fp32 input / input gradient through the slab:
+  // TILE x C floats, copied to / from global memory as one contiguous, coalesced region
+  static constexpr int STAGE_C = Net::EMB != 0 ? Net::CIN : Net::KE;
+  static constexpr bool STAGES = Net::EMB != 0 || Net::ID == LAB4D_NET_FG_BASE;  // raw input, or the tangent-mode forward
+  static constexpr int UNITS_STAGE = STAGES ? (P::TILE * STAGE_C * 4 + 15) / 16 : 0;
+  static constexpr int UNITS_LAYER = P::NT * UW * 64;
+  static constexpr int UNITS_PER_WAVE = UNITS_LAYER > UNITS_STAGE ? UNITS_LAYER : UNITS_STAGE;  // uint4 slots
 };
+
+// coalesced copy of a tile's TILE x C fp32 rows between global memory (rows s0.., clamped to the last valid element) and
+// the wave-private staging area.  The (S, C) input of a raw-input net has a row stride of C*4 bytes (300 B for the 75
+// bone coordinates): read per lane it costs one cache line per lane and load (measured: the 20 k-MAC skin net ran as
+// long as a 160 k-MAC colour net).
+template <int COUNT>
+__device__ __forceinline__ void stage_in(float* __restrict__ stage, const float* __restrict__ x, long e0, long e_last, int lane) {
+  const GLOBAL_AS float* gx = (const GLOBAL_AS float*)x;
+  if (e0 + COUNT - 1 <= e_last && (((size_t)(x + e0)) & 15) == 0 && (COUNT & 3) == 0) {
+    // all loads are issued before the first LDS write (a load -> wait -> write loop pays one memory latency per trip)
+    constexpr int N4 = COUNT / 4, TRIPS = (N4 + 63) / 64;
+    f32x4_t v[TRIPS];
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+      const int e = lane + 64 * i;
+      if (e < N4) v[i] = *(const GLOBAL_AS f32x4_t*)(gx + e0 + 4 * e);
+    }
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+      const int e = lane + 64 * i;
+      if (e < N4) reinterpret_cast<float4*>(stage)[e] = make_float4(v[i].x, v[i].y, v[i].z, v[i].w);
+    }
+  } else {
+    for (int e = lane; e < COUNT; e += 64) {
+      const long ge = e0 + e;
+      stage[e] = gx[ge <= e_last ? ge : e_last];
+    }
+  }
+}
+__device__ __forceinline__ void stage_out(const float* __restrict__ stage, float* __restrict__ y, long e0, int count, long e_last, int lane) {
+  GLOBAL_AS float* gy = (GLOBAL_AS float*)y;
+  if (e0 + count - 1 <= e_last && (((size_t)(y + e0)) & 15) == 0 && (count & 3) == 0) {
+    for (int e = lane; e < count / 4; e += 64) {
+      const float4 v = reinterpret_cast<const float4*>(stage)[e];
+      f32x4_t o = {v.x, v.y, v.z, v.w};
+      *(GLOBAL_AS f32x4_t*)(gy + e0 + 4 * e) = o;
+    }
+  } else {
+    for (int e = lane; e < count; e += 64) {
+      const long ge = e0 + e;
+      if (ge <= e_last) gy[ge] = stage[e];
+    }
+  }
+}
 
 // =================================================================================================
 // forward chain
@@ -403,6 +453,10 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
     }
     // ---- embedding as B units (identity slot order) ----
     uint4 emb[NT][UE];
+    constexpr bool RAW = (Net::EMB != 0) || TAN;
+    constexpr int CINR = TAN ? KE : Net::CIN;
+    float* stagef = reinterpret_cast<float*>(slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE);
+    if constexpr (RAW) stage_in<TILE * CINR>(stagef, a.x, (long)s0 * CINR, (long)a.S * CINR - 1, lane);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int s = sidx[t] < a.S ? sidx[t] : a.S - 1;
@@ -461,9 +515,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
             emb[t][g] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
           }
         }
-      } else {  // raw channels (tangent mode: KE slots)
-        constexpr int CINR = TAN ? KE : Net::CIN;
-        const float* xr = a.x + (size_t)s * CINR;
+      } else {  // raw channels (tangent mode: KE slots), from the staged tile: row of this lane's sample
+        const float* xr = stagef + (NT * n + t) * CINR;
 #pragma unroll
         for (int g = 0; g < UE; ++g) {
           if constexpr (P::BF16) {
@@ -745,6 +798,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint4* slab = slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE + lane;
+  float* stagef = reinterpret_cast<float*>(slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE);  // wave-private staging (raw-input nets)
   const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
 
   for (int tile = wave; tile < a.ntiles; tile += nwaves) {
@@ -928,7 +982,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int c = 32 * mt + drow(r, h);
-              if (c < Net::CIN && sidx[t] < a.S) a.d_x[(size_t)sidx[t] * Net::CIN + c] = acc[t][r];
+              if (c < Net::CIN) stagef[(NT * n + t) * Net::CIN + c] = acc[t][r];  // staged: copied out coalesced below
             }
         }
       };
@@ -970,7 +1024,12 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
       };
       // embedding row tiles come first in W^T; they are skipped when no input gradient is wanted
       if constexpr (MTE > 0) {
-        if (a.d_x != nullptr) pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb);
+        if (a.d_x != nullptr) {
+          pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb);
+          // raw-input nets: the (TILE, CIN) input-gradient tile sits in the wave's staging area (the slab is idle while the
+          // last layer's embedding tiles are processed); one contiguous coalesced copy, rows >= S dropped
+          if constexpr (Net::EMB != 0) stage_out(stagef, a.d_x, (long)s0 * Net::CIN, TILE * Net::CIN, (long)a.S * Net::CIN - 1, lane);
+        }
       }
       if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act);
     });
