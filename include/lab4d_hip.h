@@ -141,6 +141,13 @@ int lab4d_compose_gather(const float* a, int Da, const float* b, int Db, const i
                          float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 3c. Per-sample epilogues -- nnutils/feature.py:149-150 (FeatureNeRF.compute_feat): y = x / ||x||_2 over the last axis
+ *     (C = 16 feature channels, or 3), no epsilon, exactly the reference expression; backward g_x = (g - y (y.g)) / ||x||.
+ * ------------------------------------------------------------------------------------------ */
+int lab4d_l2_normalize_forward(const float* x, int S, int C, float* y, void* stream);
+int lab4d_l2_normalize_backward(const float* x, const float* g, int S, int C, float* g_x, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 4. Fused positional-encoding + MLP stack -- nnutils/embedding.py:69-125 (PosEmbedding),
  *    nnutils/base.py:65-78,123-150 (BaseMLP/CondMLP), as used by nnutils/nerf.py:167-215,
  *    visibility.py:53-63, feature.py:136-150, skinning.py:108-119, warping.py:143-170.

@@ -23,6 +23,8 @@ from .warping import skinning_warp
 vp, ci, cf = _lib.vp, _lib.ci, _lib.cf
 _lib.register("lab4d_gauss_density_forward", [vp, vp, ci, vp, ci, vp, vp, vp])
 _lib.register("lab4d_gauss_density_backward", [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp])
+_lib.register("lab4d_l2_normalize_forward", [vp, ci, ci, vp, vp])
+_lib.register("lab4d_l2_normalize_backward", [vp, vp, ci, ci, vp, vp])
 
 
 def flip_pair(x):
@@ -134,10 +136,34 @@ def vis_field(P, xyz, fr, prec):
     return out.view(xyz.shape[:-1] + (1,))
 
 
+class L2Normalize(Function):
+    """x / ||x||_2 over the last axis (feature.py:149-150) in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _lib.require_device(x)
+        S, C = x.shape
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().lab4d_l2_normalize_forward(_lib.ptr(x), S, C, _lib.ptr(y), _lib.stream()), "l2_normalize_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().lab4d_l2_normalize_backward(_lib.ptr(x), _lib.ptr(g), x.shape[0], x.shape[1], _lib.ptr(gx), _lib.stream()),
+                   "l2_normalize_backward")
+        return gx
+
+
 def compute_feat(P, xyz, prec):
     """FeatureNeRF.compute_feat (feature.py:136-150)."""
-    f = mlp.run_chain(mlp.NET_FEAT, prec, P, xyz.reshape(-1, 3), _spf(xyz)).view(xyz.shape[:-1] + (16,))
-    return f / f.norm(dim=-1, keepdim=True)
+    f = mlp.run_chain(mlp.NET_FEAT, prec, P, xyz.reshape(-1, 3), _spf(xyz))
+    return L2Normalize.apply(f).view(xyz.shape[:-1] + (16,))
 
 
 def global_match(P, feat_px, feat_canonical, xyz_canonical, perm):
