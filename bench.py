@@ -148,6 +148,30 @@ def main():
     inputs = [chunk_inputs(res, y, n, dev, seed=100 + i) for i, (y, n) in enumerate(chunks)]
     rays_per_step = 2 * res * res
 
+    # SURVEY 8d also asks for the forward-only rate: eval-mode render (importance sampling -> 128 samples, field, normals
+    # through one first-order backward, compositing) of the same rays.  Measured before the training graph is captured
+    # (its 150 GiB private pool would leave the allocator thrashing), eager launches, half a training chunk per call.
+    eval_result = None
+    if world == 1 and rank == 0:
+        try:
+            half = inputs[0][0].shape[1] // 2
+            n_ev = min(4, len(inputs))
+            ev_in = [h[:, :half].contiguous() for h, _ in inputs[:n_ev]]
+            for h in ev_in[:2]:
+                DF.render_eval(P, fr, h, n_depth=spp, prec=prec)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for h in ev_in:
+                DF.render_eval(P, fr, h, n_depth=spp, prec=prec)
+            torch.cuda.synchronize()
+            eval_result = {"value": round(n_ev * ev_in[0].shape[0] * ev_in[0].shape[1] / (time.perf_counter() - t0), 1), "unit": "rays/s",
+                           "what": "render_eval: importance sampling (%d coarse + %d fine samples), normals, compositing; eager, %d calls of %d rays"
+                                   % (spp // 2, spp // 2, n_ev, ev_in[0].shape[0] * ev_in[0].shape[1])}
+            del ev_in
+            torch.cuda.empty_cache()
+        except Exception as e:  # an extra, never the headline: report the failure instead of losing the bench line
+            eval_result = {"value": None, "error": repr(e)[:200]}
+
     M, N0 = inputs[0][0].shape[:2]
     S0 = M * N0 * spp
     uniform = all(h.shape == inputs[0][0].shape for h, _ in inputs)
@@ -282,27 +306,8 @@ def main():
             "whole_graph_frac_of_peak": round(value * spp * FLOP_PER_SAMPLE / peak, 4),
             "roofline": roofline,
         }
-        if world == 1:
-            # SURVEY 8d also asks for the forward-only rate: eval-mode render (importance sampling -> 128 samples, field,
-            # normals through one first-order backward, compositing) of the same rays; 2 timed chunks after 1 warm-up
-            try:
-                half = inputs[0][0].shape[1] // 2  # half a training chunk per call: the 150 GiB graph pool stays resident
-                h0 = inputs[0][0][:, :half].contiguous()
-                torch.cuda.empty_cache()  # the eager training chunks of the roofline pass left ~130 GiB cached beside the graph pool
-                n_ev = min(4, len(inputs))
-                ev_in = [h[:, :half].contiguous() for h, _ in inputs[:n_ev]]
-                for h in [h0] + ev_in:    # warm-up over the same inputs: re-grows the allocator pools (slow the first time)
-                    DF.render_eval(P, fr, h, n_depth=spp, prec=prec)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for h in ev_in:
-                    DF.render_eval(P, fr, h, n_depth=spp, prec=prec)
-                torch.cuda.synchronize()
-                out["eval_forward_only"] = {"value": round(n_ev * h0.shape[0] * h0.shape[1] / (time.perf_counter() - t0), 1), "unit": "rays/s",
-                                            "what": "render_eval: importance sampling (%d coarse + %d fine samples), normals, compositing; eager, %d chunks"
-                                                    % (spp // 2, spp // 2, n_ev)}
-            except Exception as e:  # an extra, never the headline: report the failure instead of losing the bench line
-                out["eval_forward_only"] = {"value": None, "error": repr(e)[:200]}
+        if eval_result is not None:
+            out["eval_forward_only"] = eval_result
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res, spp, a.cpu_rays)
         print(json.dumps(out))

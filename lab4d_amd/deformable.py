@@ -354,6 +354,11 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
     (xyz_cam, dir_cam, deltas, depth, _, _), inds = importance_sampling(P, fr, hxy, n_depth, alpha, prec)
     # normals need d sdf / d xyz_cam through the rigid transform and the warp (nerf.py:455-493): one first-order
     # backward pass through the same kernels, so the forward below is run under autograd with xyz_cam as the leaf.
+    # Only d sdf / d xyz_cam is wanted: parameters and per-frame inputs are detached, otherwise the backward below would
+    # also run every weight-gradient kernel (needs_input_grad follows requires_grad, not what autograd.grad asked for)
+    det = lambda v: tuple(t.detach() for t in v) if isinstance(v, tuple) else (v.detach() if torch.is_tensor(v) else v)
+    P = {k: det(v) for k, v in P.items()}
+    fr = {k: det(v) for k, v in fr.items()}
     with torch.enable_grad():
         xc = xyz_cam.detach().requires_grad_(True)
         qi, ti = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
