@@ -37,7 +37,10 @@
 #define LAB4D_NET_FEAT 3      /* posenc6  -> feature_field (5 layers W=128, skip at 4) -> 16         */
 #define LAB4D_NET_SKIN 4      /* raw 75 bone coords -> 64 -> 64 -> 25 (delta skinning weights)       */
 #define LAB4D_NET_DENSE 5     /* posenc6 -> 256 -> 256 -> 3 (DenseWarp post-warp of ComposedWarp: dense translation field) */
-#define LAB4D_NET_COUNT 6
+#define LAB4D_NET_BG_BASE 6   /* background NeRF: posenc6 -> basefield (5+1 layers W=128, skip at 4) -> sdf head               */
+#define LAB4D_NET_BG_COLOR 7  /* background NeRF: posenc8 -> colorfield (2+1, W=128) (+ feature) -> rgb (2) with the raw view
+                                 direction as a second per-sample input (x2)                                              */
+#define LAB4D_NET_COUNT 8
 
 #define LAB4D_PREC_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32, parity path                       */
 #define LAB4D_PREC_BF16 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate: throughput path            */
@@ -102,6 +105,7 @@ typedef struct {
   void* emb;                        /* [ke][ld] stored embedding or NULL                                */
   const void* ext;                  /* [mout_pad][ld] tensor added at the add_ext layer                 */
   float* out;                       /* (S, c_out) raw head output, fp32                                    */
+  const float* x2;                  /* LAB4D_NET_BG_COLOR: (S,3) second per-sample input (view direction, nerf.py:196); else NULL */
 } lab4d_mlp_fwd_args;
 int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream);
 
@@ -126,6 +130,7 @@ typedef struct {
   void* ext_gout;                              /* [mout_pad][ld] gradient wrt `ext` (written) or NULL   */
   void* dz[LAB4D_MLP_MAX_LAYERS];              /* [mout_pad][ld] dL/d(pre-activation) (written)         */
   float* d_x;                                  /* (S,3) or (S,c_in) gradient wrt the input, or NULL        */
+  float* d_x2;                                 /* LAB4D_NET_BG_COLOR: (S,3) gradient wrt x2 (written with d_x), or NULL */
 } lab4d_mlp_bwd_args;
 int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream);
 

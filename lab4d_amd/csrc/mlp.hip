@@ -546,6 +546,8 @@ int with_net(int net, F&& f) {
     case LAB4D_NET_FEAT: return f(NetFeat{});
     case LAB4D_NET_SKIN: return f(NetSkin{});
     case LAB4D_NET_DENSE: return f(NetDense{});
+    case LAB4D_NET_BG_BASE: return f(NetBgBase{});
+    case LAB4D_NET_BG_COLOR: return f(NetBgColor{});
     default: set_error("unknown net id %d", net); return LAB4D_EINVAL;
   }
 }
@@ -594,7 +596,8 @@ extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
     using Net = decltype(n);
     FwdK k;
     memset(&k, 0, sizeof(k));
-    k.S = a->S; k.S_pad = a->S_pad; k.ld = a->ld; k.spf = a->spf; k.x = a->x; k.freq_w = a->freq_w; k.emb = a->emb; k.ext = a->ext; k.out = a->out;
+    k.S = a->S; k.S_pad = a->S_pad; k.ld = a->ld; k.spf = a->spf; k.x = a->x; k.freq_w = a->freq_w; k.emb = a->emb; k.ext = a->ext; k.out = a->out; k.x2 = a->x2;
+    LAB4D_REQUIRE(!Net::AUX3 || a->x2, "mlp_forward: this network needs the second input x2");
     for (int l = 0; l < Net::NL; ++l) {
       LAB4D_REQUIRE(a->W[l] && a->bias[l], "mlp_forward: layer %d weights/bias missing", l);
       LAB4D_REQUIRE(!Net::L[l].pf || a->pf_bias[l], "mlp_forward: layer %d needs a per-frame bias", l);
@@ -620,7 +623,7 @@ extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
     BwdK k;
     memset(&k, 0, sizeof(k));
     k.S = a->S; k.S_pad = a->S_pad; k.ld = a->ld; k.spf = a->spf; k.emb = a->emb; k.ext = a->ext; k.d_out = a->d_out; k.ext_gin = a->ext_gin;
-    k.ext_gout = a->ext_gout; k.d_x = a->d_x;
+    k.ext_gout = a->ext_gout; k.d_x = a->d_x; k.d_x2 = a->d_x2;
     LAB4D_REQUIRE(!(a->d_x && Net::EMB == 0) || a->emb, "mlp_backward: d_x needs the stored embedding");
     for (int l = 0; l < Net::NL; ++l) {
       LAB4D_REQUIRE(a->WT[l], "mlp_backward: layer %d transposed weights missing", l);

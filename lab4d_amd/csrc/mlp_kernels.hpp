@@ -256,6 +256,7 @@ struct FwdK {
   void* emb;
   const void* ext;
   float* out;
+  const float* x2;  // nets with AUX3: second per-sample 3-vector (view direction), raw embedding slots 6L+3..6L+5
 };
 struct BwdK {
   int S, S_pad, ld, spf, ntiles;
@@ -269,11 +270,12 @@ struct BwdK {
   void* ext_gout;
   void* dz[LAB4D_MLP_MAX_LAYERS];
   float* d_x;
+  float* d_x2;  // nets with AUX3: gradient wrt the second 3-vector, or NULL
 };
 
 // values of embedding slots (2*pair, 2*pair+1) for a point x -- posenc nets
 template <class Net>
-__device__ __forceinline__ void emb_pair(int pair, const float* x, const float* freq_w, float& v0, float& v1) {
+__device__ __forceinline__ void emb_pair(int pair, const float* x /* [6]: point, then the aux 3-vector (or zeros) */, const float* freq_w, float& v0, float& v1) {
   // pair p < 3L: (sin, cos)(2^f x_a) * w_f with f = p / 3, a = p % 3 ; then x_0,x_1,x_2 ; then zeros
   constexpr int L = Net::NFREQ;
   if (pair < 3 * L) {
@@ -286,9 +288,10 @@ __device__ __forceinline__ void emb_pair(int pair, const float* x, const float* 
     v0 = s * w;
     v1 = c * w;
   } else {
-    const int s0 = 2 * pair - 6 * L;  // slot index relative to the raw block
-    v0 = s0 == 0 ? x[0] : (s0 == 1 ? x[1] : (s0 == 2 ? x[2] : 0.f));
-    v1 = s0 + 1 == 1 ? x[1] : (s0 + 1 == 2 ? x[2] : 0.f);
+    const int s0 = 2 * pair - 6 * L;  // slot index relative to the raw block: [x (3) | aux (3, nets with AUX3) | zeros]
+    constexpr int NR = Net::AUX3 ? 6 : 3;
+    v0 = s0 < NR ? x[s0 < NR ? s0 : 0] : 0.f;
+    v1 = s0 + 1 < NR ? x[s0 + 1 < NR ? s0 + 1 : 0] : 0.f;
   }
 }
 
@@ -461,7 +464,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
     for (int t = 0; t < NT; ++t) {
       const int s = sidx[t] < a.S ? sidx[t] : a.S - 1;
       if constexpr (Net::EMB == 0 && !TAN) {
-        const float x[3] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2]};
+        float x[6] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2], 0.f, 0.f, 0.f};
+        if constexpr (Net::AUX3) { x[3] = a.x2[(size_t)s * 3]; x[4] = a.x2[(size_t)s * 3 + 1]; x[5] = a.x2[(size_t)s * 3 + 2]; }
         if constexpr (P::BF16) {
           // bf16 path: sin/cos(2^f x) by angle doubling from one accurate sincos per axis
           // (sin 2a = 2 s c, cos 2a = 1 - 2 s^2).  The recurrence error doubles per octave (<= 2^11 * 6e-8 = 1.2e-4),
@@ -494,8 +498,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
                   v0[hh] = sv[f < L ? f : 0][ax] * wf; v1[hh] = cv[f < L ? f : 0][ax] * wf;
                 } else {
                   const int sl = 2 * pair - 6 * L;
-                  v0[hh] = sl < 3 ? x[sl < 3 ? sl : 0] : 0.f;
-                  v1[hh] = sl + 1 < 3 ? x[sl + 1 < 3 ? sl + 1 : 0] : 0.f;
+                  constexpr int NR = Net::AUX3 ? 6 : 3;  // raw block: [x | aux]
+                  v0[hh] = sl < NR ? x[sl < NR ? sl : 0] : 0.f;
+                  v1[hh] = sl + 1 < NR ? x[sl + 1 < NR ? sl + 1 : 0] : 0.f;
                 }
               }
               w[i] = pack2bf(h ? v0[1] : v0[0], h ? v1[1] : v1[0]);
@@ -807,8 +812,9 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) sidx[t] = s0 + NT * n + t;
     float dx[NT][3];  // posenc nets: gradient wrt the 3-vector (partial over this lane's slots)
+    float dx2[NT][3];  // ... and wrt the aux 3-vector (nets with AUX3)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) dx[t][0] = dx[t][1] = dx[t][2] = 0.f;
+    for (int t = 0; t < NT; ++t) { dx[t][0] = dx[t][1] = dx[t][2] = 0.f; dx2[t][0] = dx2[t][1] = dx2[t][2] = 0.f; }
 
     // ---- head gradient: (S, COUT) fp32 -> accumulator layout -> stored + B units in the slab ----
     {
@@ -974,6 +980,11 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
                 dx[t][0] += ax == 0 ? gv : 0.f;
                 dx[t][1] += ax == 1 ? gv : 0.f;
                 dx[t][2] += ax == 2 ? gv : 0.f;
+              } else if (Net::AUX3 && slot < 6 * L + 6) {
+                const int ax = slot - 6 * L - 3;
+                dx2[t][0] += ax == 0 ? gv : 0.f;
+                dx2[t][1] += ax == 1 ? gv : 0.f;
+                dx2[t][2] += ax == 2 ? gv : 0.f;
               }
             }
         } else {
@@ -1044,6 +1055,15 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
             a.d_x[(size_t)sidx[t] * 3 + 0] = dx[t][0];
             a.d_x[(size_t)sidx[t] * 3 + 1] = dx[t][1];
             a.d_x[(size_t)sidx[t] * 3 + 2] = dx[t][2];
+          }
+          if constexpr (Net::AUX3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dx2[t][k] += __shfl_xor(dx2[t][k], 32, 64);
+            if (h == 0 && sidx[t] < a.S && a.d_x2) {
+              a.d_x2[(size_t)sidx[t] * 3 + 0] = dx2[t][0];
+              a.d_x2[(size_t)sidx[t] * 3 + 1] = dx2[t][1];
+              a.d_x2[(size_t)sidx[t] * 3 + 2] = dx2[t][2];
+            }
           }
         }
       }

@@ -13,7 +13,7 @@ constexpr int pad32(int x) { return (x + 31) / 32 * 32; }
 
 // nerf.py:99-109,134 : PosEmbedding(3,10) -> CondMLP(D=8,W=256,skips=[4],final_act) -> sdf Linear(256,1)
 struct NetFgBase {
-  static constexpr int ID = LAB4D_NET_FG_BASE, NL = 10, EMB = 0, NFREQ = 10, CIN = 3, SLOTS = 63, KE = 64, COUT = 1;
+  static constexpr int ID = LAB4D_NET_FG_BASE, NL = 10, EMB = 0, NFREQ = 10, CIN = 3, SLOTS = 63, KE = 64, COUT = 1, AUX3 = 0;
   static constexpr LS L[NL] = {{64, 0, 256, 1, 1, 0, 0},  {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 0, 0},
                                {0, 256, 256, 1, 0, 0, 0}, {64, 256, 256, 1, 1, 0, 0}, {0, 256, 256, 1, 0, 0, 0},
                                {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 0, 1},
@@ -22,32 +22,49 @@ struct NetFgBase {
 // nerf.py:112-123,135-139,208-213 : PosEmbedding(3,12) -> CondMLP(D=2,W=256,final_act) ; + basefield feature ;
 // rgb = Linear(256+32 appr, 128) ReLU Linear(128,3)   (appearance code folded into the per-frame bias)
 struct NetFgColor {
-  static constexpr int ID = LAB4D_NET_FG_COLOR, NL = 5, EMB = 0, NFREQ = 12, CIN = 3, SLOTS = 75, KE = 96, COUT = 3;
+  static constexpr int ID = LAB4D_NET_FG_COLOR, NL = 5, EMB = 0, NFREQ = 12, CIN = 3, SLOTS = 75, KE = 96, COUT = 3, AUX3 = 0;
   static constexpr LS L[NL] = {{96, 0, 256, 1, 1, 0, 0}, {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 1, 0},
                                {0, 256, 128, 1, 1, 0, 0}, {0, 128, 3, 0, 0, 0, 0}};
 };
 // visibility.py:39-51 : PosEmbedding(3,10) -> CondMLP(D=2,W=64) -> 1
 struct NetVis {
-  static constexpr int ID = LAB4D_NET_VIS, NL = 3, EMB = 0, NFREQ = 10, CIN = 3, SLOTS = 63, KE = 64, COUT = 1;
+  static constexpr int ID = LAB4D_NET_VIS, NL = 3, EMB = 0, NFREQ = 10, CIN = 3, SLOTS = 63, KE = 64, COUT = 1, AUX3 = 0;
   static constexpr LS L[NL] = {{64, 0, 64, 1, 1, 0, 0}, {0, 64, 64, 1, 0, 0, 0}, {0, 64, 1, 0, 0, 0, 0}};
 };
 // feature.py:77-84 : PosEmbedding(3,6) -> BaseMLP(D=5,W=128,skips=[4]) -> 16
 struct NetFeat {
-  static constexpr int ID = LAB4D_NET_FEAT, NL = 6, EMB = 0, NFREQ = 6, CIN = 3, SLOTS = 39, KE = 64, COUT = 16;
+  static constexpr int ID = LAB4D_NET_FEAT, NL = 6, EMB = 0, NFREQ = 6, CIN = 3, SLOTS = 39, KE = 64, COUT = 16, AUX3 = 0;
   static constexpr LS L[NL] = {{64, 0, 128, 1, 0, 0, 0}, {0, 128, 128, 1, 0, 0, 0}, {0, 128, 128, 1, 0, 0, 0},
                                {0, 128, 128, 1, 0, 0, 0}, {64, 128, 128, 1, 0, 0, 0}, {0, 128, 16, 0, 0, 0, 0}};
 };
 // skinning.py:70-86 : 3B=75 bone coordinates (+128 time embedding +32 code as per-frame bias) -> 64 -> 64 -> B=25
 struct NetSkin {
-  static constexpr int ID = LAB4D_NET_SKIN, NL = 3, EMB = 1, NFREQ = 0, CIN = 75, SLOTS = 75, KE = 96, COUT = 25;
+  static constexpr int ID = LAB4D_NET_SKIN, NL = 3, EMB = 1, NFREQ = 0, CIN = 75, SLOTS = 75, KE = 96, COUT = 25, AUX3 = 0;
   static constexpr LS L[NL] = {{96, 0, 64, 1, 1, 0, 0}, {0, 64, 64, 1, 0, 0, 0}, {0, 64, 25, 0, 0, 0, 0}};
 };
 
 // warping.py:105-170,445-483 : DenseWarp(D=2,W=256) post-warp of ComposedWarp: PosEmbedding(3,6)=39 (+128 time embedding
 // +32 instance code as per-frame bias) -> 256 -> 256 -> 3 ; one table serves forward_map and backward_map
 struct NetDense {
-  static constexpr int ID = LAB4D_NET_DENSE, NL = 3, EMB = 0, NFREQ = 6, CIN = 3, SLOTS = 39, KE = 64, COUT = 3;
+  static constexpr int ID = LAB4D_NET_DENSE, NL = 3, EMB = 0, NFREQ = 6, CIN = 3, SLOTS = 39, KE = 64, COUT = 3, AUX3 = 0;
   static constexpr LS L[NL] = {{64, 0, 256, 1, 1, 0, 0}, {0, 256, 256, 1, 0, 0, 0}, {0, 256, 3, 0, 0, 0, 0}};
+};
+
+// multifields.py:86-93 + nerf.py:60-140 : the background field NeRF(num_freq_xyz=6, num_freq_dir=0, appr_channels=0, D=5, W=128):
+// PosEmbedding(3,6) -> CondMLP(D=5,W=128,skips=[4],final_act) -> sdf Linear(128,1)
+struct NetBgBase {
+  static constexpr int ID = LAB4D_NET_BG_BASE, NL = 7, EMB = 0, NFREQ = 6, CIN = 3, SLOTS = 39, KE = 64, COUT = 1, AUX3 = 0;
+  static constexpr LS L[NL] = {{64, 0, 128, 1, 1, 0, 0}, {0, 128, 128, 1, 0, 0, 0}, {0, 128, 128, 1, 0, 0, 0}, {0, 128, 128, 1, 0, 0, 0},
+                               {64, 128, 128, 1, 1, 0, 0}, {0, 128, 128, 1, 0, 0, 1}, {0, 128, 1, 0, 0, 0, 0}};
+};
+// PosEmbedding(3,8) -> CondMLP(D=2,W=128,final_act) ; + basefield feature ; rgb = Linear(128 + 3 view direction, 64) ReLU
+// Linear(64,3).  The raw view direction (PosEmbedding(3,0), nerf.py:196) is a second per-sample input: it rides in the
+// spare slots 6L+3..6L+5 of the 64-slot embedding block (AUX3) and the rgb layer consumes the block with weights that
+// are non-zero on exactly those three slots -- no second embedding path in the kernels.
+struct NetBgColor {
+  static constexpr int ID = LAB4D_NET_BG_COLOR, NL = 5, EMB = 0, NFREQ = 8, CIN = 3, SLOTS = 54, KE = 64, COUT = 3, AUX3 = 1;
+  static constexpr LS L[NL] = {{64, 0, 128, 1, 1, 0, 0}, {0, 128, 128, 1, 0, 0, 0}, {0, 128, 128, 1, 0, 1, 0}, {64, 128, 64, 1, 0, 0, 0},
+                               {0, 64, 3, 0, 0, 0, 0}};
 };
 
 template <class Net>

@@ -130,6 +130,29 @@ def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None
     return torch.sigmoid(rgb).view(shape[:-1] + (3,)), out
 
 
+def nerf_forward_bg(P, xyz, dir, codes, prec, get_density=True, alpha=None, prefix=""):
+    """NeRF.forward (nerf.py:167-215) for the background field NeRF(num_freq_xyz=6, num_freq_dir=0, appr_channels=0, D=5,
+    W=128) (multifields.py:86-93): the rgb head sees [feature | raw view direction].  codes = {"basefield": (M,32),
+    "colorfield": (M,32)}; dir (M,N,D,3) or None (sdf / density only)."""
+    shape = xyz.shape
+    spf = _spf(xyz)
+    x = xyz.reshape(-1, 3)
+    dev = x.device
+    sdf, feat = mlp.run_chain(mlp.NET_BG_BASE, prec, P, x, spf, conds={0: codes["basefield"], 4: codes["basefield"]}, export_layer=5,
+                              freq_w=posenc_window(alpha, 6, dev), prefix=prefix)
+    sdf = sdf.view(shape[:-1] + (1,))
+    if get_density:
+        ibeta = P[prefix + "logibeta"].exp()
+        out = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta
+    else:
+        out = sdf
+    if dir is None:
+        return out
+    rgb = mlp.run_chain(mlp.NET_BG_COLOR, prec, P, x, spf, conds={0: codes["colorfield"]}, ext=feat, freq_w=posenc_window(alpha, 8, dev),
+                        prefix=prefix, x2=dir.reshape(-1, 3))
+    return torch.sigmoid(rgb).view(shape[:-1] + (3,)), out
+
+
 def vis_field(P, xyz, fr, prec):
     """VisField.forward (visibility.py:53-63)."""
     out = mlp.run_chain(mlp.NET_VIS, prec, P, xyz.reshape(-1, 3), _spf(xyz), conds={0: fr["code_vis"]})

@@ -21,7 +21,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 MAXL = 12
-NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE = 0, 1, 2, 3, 4, 5
+NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE, NET_BG_BASE, NET_BG_COLOR = 0, 1, 2, 3, 4, 5, 6, 7
 PREC_F32, PREC_BF16 = 0, 1
 vp, ci = ctypes.c_void_p, ctypes.c_int
 
@@ -37,12 +37,13 @@ class NetDesc(ctypes.Structure):
 class FwdArgs(ctypes.Structure):
     _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("S_pad", ci), ("ld", ci), ("spf", ci), ("x", vp), ("freq_w", vp),
                 ("W", vp * MAXL), ("bias", vp * MAXL), ("pf_bias", vp * MAXL), ("act", vp * MAXL), ("mask", vp * MAXL), ("emb", vp),
-                ("ext", vp), ("out", vp)]
+                ("ext", vp), ("out", vp), ("x2", vp)]
 
 
 class BwdArgs(ctypes.Structure):
     _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("S_pad", ci), ("ld", ci), ("spf", ci), ("WT", vp * MAXL), ("act", vp * MAXL),
-                ("mask", vp * MAXL), ("emb", vp), ("ext", vp), ("d_out", vp), ("ext_gin", vp), ("ext_gout", vp), ("dz", vp * MAXL), ("d_x", vp)]
+                ("mask", vp * MAXL), ("emb", vp), ("ext", vp), ("d_out", vp), ("ext_gin", vp), ("ext_gout", vp), ("dz", vp * MAXL), ("d_x", vp),
+                ("d_x2", vp)]
 
 
 _lib.register("lab4d_mlp_describe", [ci, ctypes.POINTER(NetDesc)])
@@ -53,13 +54,14 @@ _lib.register("lab4d_mlp_forward_tangent", [ctypes.POINTER(FwdArgs), vp])
 _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
 
-NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense"}
+NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color"}
 # algorithmic MACs per sample (real layer shapes incl. conditioning columns)
-NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736, 5: 39 * 256 + 256 * 256 + 256 * 3}
+NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736, 5: 39 * 256 + 256 * 256 + 256 * 3,
+            6: 100096 + 128, 7: 43392 + 8576}
 
 
 
-KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense"}  # template argument names in csrc/mlp_nets.hpp
+KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor"}  # template argument names in csrc/mlp_nets.hpp
 
 
 def wgrad_kernel_name(L, prec):
@@ -114,8 +116,9 @@ def posenc_slot_to_ref_channel(n_freq, ke):
 class LayerBinding:
     """Which columns of the reference weight feed which kernel input block."""
 
-    def __init__(self, wname, bname, emb0=None, cond=None, prev0=None):
+    def __init__(self, wname, bname, emb0=None, cond=None, prev0=None, aux0=None):
         self.wname, self.bname = wname, bname
+        self.aux0 = aux0    # first reference column of the 3 aux (view direction) channels riding in the embedding block (or None)
         self.emb0 = emb0    # first reference column of the embedding block (or None)
         self.cond = cond    # (first column, count) of the per-frame conditioning block (or None)
         self.prev0 = prev0  # first reference column of the previous-activation block (or None)
@@ -162,6 +165,20 @@ def bindings(net, prefix=""):
         return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(39, 160)),
                 LayerBinding(q + "linear_2.0.weight", q + "linear_2.0.bias", prev0=0),
                 LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0)]
+    if net == NET_BG_BASE:  # multifields.py:86-93, nerf.py:95-109: [39 posenc | 32 instance code], D=5, skip at 4
+        b = [LayerBinding(p + "basefield.linear_1.0.weight", p + "basefield.linear_1.0.bias", emb0=0, cond=(39, 32))]
+        for i in (2, 3, 4):
+            b.append(LayerBinding(p + f"basefield.linear_{i}.0.weight", p + f"basefield.linear_{i}.0.bias", prev0=0))
+        b.append(LayerBinding(p + "basefield.linear_5.0.weight", p + "basefield.linear_5.0.bias", emb0=0, cond=(39, 32), prev0=71))
+        b.append(LayerBinding(p + "basefield.linear_final.0.weight", p + "basefield.linear_final.0.bias", prev0=0))
+        b.append(LayerBinding(p + "sdf.weight", p + "sdf.bias", prev0=0))
+        return b
+    if net == NET_BG_COLOR:  # nerf.py:112-139: [51 posenc | 32 code] ; rgb.0 input = [128 feature | 3 raw view direction]
+        return [LayerBinding(p + "colorfield.linear_1.0.weight", p + "colorfield.linear_1.0.bias", emb0=0, cond=(51, 32)),
+                LayerBinding(p + "colorfield.linear_2.0.weight", p + "colorfield.linear_2.0.bias", prev0=0),
+                LayerBinding(p + "colorfield.linear_final.0.weight", p + "colorfield.linear_final.0.bias", prev0=0),
+                LayerBinding(p + "rgb.0.weight", p + "rgb.0.bias", prev0=0, aux0=128),
+                LayerBinding(p + "rgb.2.weight", p + "rgb.2.bias", prev0=0)]
     raise ValueError(net)
 
 
@@ -178,7 +195,18 @@ def col_map(net, layer, device):
         cm = []
         if L.ke:
             if d.emb_kind == 0:
-                cm += [(-1 if c < 0 else bd.emb0 + c) for c in posenc_slot_to_ref_channel(d.n_freq, L.ke)]
+                # posenc slots -> reference channels of this layer's embedding block (if it has one); slots 6L+3..6L+5 carry
+                # the aux 3-vector of nets that have one (LAB4D_NET_BG_COLOR) and map to the layer's aux columns
+                ref = posenc_slot_to_ref_channel(d.n_freq, L.ke)
+                for slot in range(L.ke):
+                    c = ref[slot]
+                    a0 = 6 * d.n_freq + 3
+                    if bd.emb0 is not None and c >= 0:
+                        cm.append(bd.emb0 + c)
+                    elif bd.aux0 is not None and a0 <= slot < a0 + 3:
+                        cm.append(bd.aux0 + slot - a0)
+                    else:
+                        cm.append(-1)
             else:
                 cm += [(bd.emb0 + c if c < d.c_in else -1) for c in range(L.ke)]
         if L.kin:
@@ -265,7 +293,7 @@ class MlpChain(Function):
     """out (S, c_out) [, export] = net(x; weights), differentiable wrt x, ext, per-frame biases, weights."""
 
     @staticmethod
-    def forward(ctx, net, prec, spf, x, ext, freq_w, export_layer, n_pf, *rest):
+    def forward(ctx, net, prec, spf, x, ext, freq_w, export_layer, n_pf, x2, *rest):
         d = describe(net)
         NL = d.n_layers
         pfs = list(rest[:n_pf])
@@ -285,10 +313,14 @@ class MlpChain(Function):
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, ld, int(spf)
         a.x = x.data_ptr()
+        if x2 is not None:
+            x2 = x2.contiguous().float()
+            _lib.require_device(x2)
+            a.x2 = x2.data_ptr()
         if freq_w is not None:
             freq_w = freq_w.contiguous().float()
             a.freq_w = freq_w.data_ptr()
-        keep = []
+        keep = [x2]
         acts = [None] * NL
         masks = [None] * NL
         pf_i = 0
@@ -337,6 +369,7 @@ class MlpChain(Function):
         ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
         ctx.params = params
         ctx.x_shape = x.shape
+        ctx.has_x2 = x2 is not None
         if export_layer is not None and export_layer >= 0:
             return out, acts[export_layer]
         return out
@@ -381,9 +414,13 @@ class MlpChain(Function):
         d_out = d_out.contiguous().float()
         a.d_out = d_out.data_ptr()
         d_x = None
-        if ctx.needs_input_grad[3]:
+        d_x2 = None
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[8]:
             d_x = torch.empty(ctx.x_shape, device=dev)
             a.d_x = d_x.data_ptr()
+            if ctx.has_x2:  # written together with d_x by the kernel
+                d_x2 = torch.empty(ctx.x_shape, device=dev)
+                a.d_x2 = d_x2.data_ptr()
         # algorithmic HBM bytes: every dZ written once; masks, head gradient, stored embedding / external tensors read once
         nbytes = sum(t.numel() * t.element_size() for t in list(dz) + list(ctx.masks) + [d_out, d_x, ext_g, ctx.emb if d_x is not None else None]
                      if t is not None)
@@ -404,8 +441,8 @@ class MlpChain(Function):
         for l in range(NL):
             L = d.layers[l]
             K = L.ke + L.kin
-            need_w = ctx.needs_input_grad[8 + n_pf + 2 * l]
-            need_b = ctx.needs_input_grad[8 + n_pf + 2 * l + 1]
+            need_w = ctx.needs_input_grad[9 + n_pf + 2 * l]
+            need_b = ctx.needs_input_grad[9 + n_pf + 2 * l + 1]
             need_pf = bool(L.pf_bias)
             gW = gb = None
             if need_w or need_b or need_pf:
@@ -427,10 +464,10 @@ class MlpChain(Function):
                     grads_pf.append(pfd)
             aoff += sum(sizes[l])
             grads_params += [gW, gb]
-        return (None, None, None, d_x, ext_g, None, None, None, *grads_pf, *grads_params)
+        return (None, None, None, d_x, ext_g, None, None, None, d_x2, *grads_pf, *grads_params)
 
 
-def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_layer=None, prefix=""):
+def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_layer=None, prefix="", x2=None):
     """Convenience wrapper: P maps reference state_dict names -> device tensors; conds maps layer index ->
     (M, C) per-frame conditioning input of that layer.  Returns out or (out, exported activation)."""
     d = describe(net)
@@ -442,7 +479,7 @@ def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_la
     params = []
     for l in range(d.n_layers):
         params += [P[bd[l].wname], P[bd[l].bname]]
-    return MlpChain.apply(net, prec, spf, x, ext, freq_w, -1 if export_layer is None else export_layer, len(pfs), *pfs, *params)
+    return MlpChain.apply(net, prec, spf, x, ext, freq_w, -1 if export_layer is None else export_layer, len(pfs), x2, *pfs, *params)
 
 
 

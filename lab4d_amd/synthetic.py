@@ -61,6 +61,31 @@ def add_dense_weights(P, seed=0, num_inst=1):
     return P
 
 
+# the background field NeRF(num_freq_xyz=6, num_freq_dir=0, appr_channels=0, D=5, W=128) (multifields.py:86-93); SURVEY 8a notes
+BG_LINEARS = [
+    ("basefield.linear_1.0", 128, 71), ("basefield.linear_2.0", 128, 128), ("basefield.linear_3.0", 128, 128),
+    ("basefield.linear_4.0", 128, 128), ("basefield.linear_5.0", 128, 199), ("basefield.linear_final.0", 128, 128),
+    ("colorfield.linear_1.0", 128, 83), ("colorfield.linear_2.0", 128, 128), ("colorfield.linear_final.0", 128, 128),
+    ("sdf", 1, 128), ("rgb.0", 64, 131), ("rgb.2", 3, 64),
+]
+BG_EMBEDDINGS = [("basefield.inst_embedding.mapping.weight", 32), ("colorfield.inst_embedding.mapping.weight", 32)]
+
+
+def make_bg_weights(seed=0, num_inst=1):
+    """Per-sample parameters of the bg NeRF, keyed by its own state_dict names (no prefix)."""
+    g = torch.Generator().manual_seed(seed + 15485863)
+    P = {}
+    for name, o, i in BG_LINEARS:
+        bound = 1.0 / math.sqrt(i)
+        P[name + ".weight"] = (torch.rand(o, i, generator=g) * 2 - 1) * bound
+        P[name + ".bias"] = (torch.rand(o, generator=g) * 2 - 1) * bound
+    for name, c in BG_EMBEDDINGS:
+        P[name] = torch.randn(num_inst, c, generator=g)
+    P["logibeta"] = torch.tensor([-math.log(0.1)])
+    P["logscale"] = torch.tensor([math.log(0.1)])
+    return P
+
+
 def make_weights(seed=0, num_inst=1, sdf_bias=None):
     """Flat dict of fp32 CPU tensors keyed by the reference's state_dict names."""
     g = torch.Generator().manual_seed(seed)

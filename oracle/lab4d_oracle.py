@@ -447,7 +447,7 @@ def gauss_density(P, xyz, rest_articulation):
 # ----------------------------------------------------------------------------
 
 
-def nerf_forward(P, xyz, codes, with_color=True, appr_code=None, get_density=True, alpha=None, cfg=None):
+def nerf_forward(P, xyz, codes, with_color=True, appr_code=None, get_density=True, alpha=None, cfg=None, dir=None):
     """NeRF.forward (nerf.py:167-215), fg configuration: num_freq_dir=-1 (no view dependence),
     appearance code appended to the rgb head input.
 
@@ -466,6 +466,8 @@ def nerf_forward(P, xyz, codes, with_color=True, appr_code=None, get_density=Tru
     cfeat = cond_mlp(P, "colorfield", pos_embedding(xyz, cfg["num_freq_xyz"] + 2, alpha), codes["colorfield"],
                      D=2, final_act=True)
     feat = feat + cfeat
+    if dir is not None:  # view direction embedding (nerf.py:196,211); bg field: num_freq_dir = 0 -> the raw 3-vector
+        feat = torch.cat([feat, pos_embedding(dir, cfg.get("num_freq_dir", 0))], -1)
     if appr_code is not None:
         a = appr_code.view(appr_code.shape[:1] + (1,) * (xyz.ndim - 2) + (-1,)).expand(xyz.shape[:-1] + (-1,))
         feat = torch.cat([feat, a], -1)
@@ -475,7 +477,7 @@ def nerf_forward(P, xyz, codes, with_color=True, appr_code=None, get_density=Tru
 
 
 FG_CFG = {"D": 8, "W": 256, "num_freq_xyz": 10}
-BG_CFG = {"D": 5, "W": 128, "num_freq_xyz": 6}
+BG_CFG = {"D": 5, "W": 128, "num_freq_xyz": 6, "num_freq_dir": 0}
 
 
 def vis_field(P, xyz, code):

@@ -95,6 +95,8 @@ def load():
         tm.bounds = _Stub("trimesh.bounds")
         tm.bounds.corners = _corners
         tm.Trimesh = lambda *a, **k: _Sphere(0.0, (2, 2))
+        # NeRF.init_proxy (nerf.py:247) loads the bg proxy mesh from disk: a unit sphere stands in (only aabb / near-far use it)
+        tm.load = lambda *a, **k: _Sphere(1.0, (4, 4))
     sk = sys.modules["skimage"]
     if isinstance(sk, _Stub):
         sys.modules["skimage.measure"] = sk.measure

@@ -302,6 +302,41 @@ def gen_comp_warp(ns):
     print("comp_warp ->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_bg_field(ns):
+    """NeRF.forward of the background field NeRF(num_freq_xyz=6, num_freq_dir=0, appr_channels=0) (multifields.py:86-93):
+    rgb / density / sdf for random points and view directions, gradients wrt inputs and a few weights."""
+    P = synthetic.make_bg_weights(0)
+    torch.manual_seed(0)
+    di = ref_shim.synthetic_data_info(64)
+    f = ns.nerf.NeRF(di, num_freq_xyz=6, num_freq_dir=0, appr_channels=0, init_scale=0.1)
+    f.category = "bg"
+    sd = {k: v for k, v in P.items() if k in f.state_dict()}
+    missing = [k for k in P if k not in f.state_dict()]
+    assert not missing, missing
+    f.load_state_dict(sd, strict=False)
+    M, N, D = 2, 5, 7
+    g = torch.Generator().manual_seed(47)
+    xyz = (torch.randn(M, N, D, 3, generator=g) * 0.3).requires_grad_(True)
+    dirs = torch.randn(M, N, D, 3, generator=g)
+    dirs = (dirs / dirs.norm(dim=-1, keepdim=True)).requires_grad_(True)
+    frame_id, inst_id = torch.tensor([3, 4]), torch.zeros(2, dtype=torch.long)
+    rgb, density = f(xyz, dir=dirs, frame_id=frame_id, inst_id=inst_id)
+    sdf = f(xyz, inst_id=inst_id, get_density=False)
+    w = torch.randn(M, N, D, 3, generator=g)
+    w1 = torch.randn(M, N, D, 1, generator=g)
+    loss = (rgb * w).sum() + (density * w1).sum() * 0.01
+    names = ["basefield.linear_1.0.weight", "basefield.linear_5.0.weight", "colorfield.linear_1.0.weight", "rgb.0.weight", "rgb.2.bias",
+             "sdf.weight", "colorfield.inst_embedding.mapping.weight"]
+    params = dict(f.named_parameters())
+    grads = torch.autograd.grad(loss, [xyz, dirs] + [params[n] for n in names])
+    out = {"weight_checksum": weight_checksum(P), "xyz": xyz.detach(), "dir": dirs.detach(), "w": w, "w1": w1, "rgb": rgb.detach(),
+           "density": density.detach(), "sdf": sdf.detach(), "loss": loss.detach(), "grad_xyz": grads[0], "grad_dir": grads[1],
+           "grads": {n: compress_grad(gv) for n, gv in zip(names, grads[2:])}}
+    path = os.path.join(HERE, "bg_field.pt")
+    torch.save(out, path)
+    print("bg_field ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     ns = ref_shim.load()
     # give render_utils a private torch namespace so searchsorted can be observed
@@ -312,3 +347,4 @@ if __name__ == "__main__":
     gen_train(ns, "alpha", M=4, N=5, D=6, res=64, seed=21, alpha=0.45)
     gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)
     gen_comp_warp(ns)
+    gen_bg_field(ns)

@@ -186,3 +186,33 @@ def test_composed_warp_against_reference(golden_dir):
         else:
             close(gv.flatten()[:: ref["stride"]], ref["sub"], "grad." + n, rtol=2e-3, atol=1e-4 * float(ref["sub"].abs().max()) + 1e-10)
             assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 1e-3 * float(ref["norm"]) + 1e-12, n
+
+
+def test_bg_field_against_reference(golden_dir):
+    """NeRF.forward of the background field (num_freq_xyz=6, num_freq_dir=0, appr_channels=0, D=5, W=128; multifields.py:86-93)."""
+    g = torch.load(os.path.join(golden_dir, "bg_field.pt"), weights_only=False)
+    P = synthetic.make_bg_weights(0)
+    chk = float(sum(v.double().abs().sum() for k, v in sorted(P.items()) if v.dtype.is_floating_point))
+    assert abs(chk - g["weight_checksum"]) < 1e-6 * g["weight_checksum"]
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xyz, dirs = g["xyz"].clone().requires_grad_(True), g["dir"].clone().requires_grad_(True)
+    inst = torch.zeros(2, dtype=torch.long)
+    codes = {"basefield": O.inst_code(P, "basefield", inst), "colorfield": O.inst_code(P, "colorfield", inst)}
+    rgb, density = O.nerf_forward(P, xyz, codes, cfg=O.BG_CFG, dir=dirs)
+    sdf = O.nerf_forward(P, xyz, codes, with_color=False, get_density=False, cfg=O.BG_CFG)
+    close(rgb, g["rgb"], "rgb")
+    close(density, g["density"], "density")
+    close(sdf, g["sdf"], "sdf")
+    loss = (rgb * g["w"]).sum() + (density * g["w1"]).sum() * 0.01
+    close(loss, g["loss"], "loss")
+    names = list(g["grads"].keys())
+    grads = torch.autograd.grad(loss, [xyz, dirs] + [P[n] for n in names])
+    close(grads[0], g["grad_xyz"], "grad_xyz", rtol=2e-3, atol=2e-6 * float(g["grad_xyz"].abs().max()) + 1e-9)
+    close(grads[1], g["grad_dir"], "grad_dir", rtol=2e-3, atol=2e-6 * float(g["grad_dir"].abs().max()) + 1e-9)
+    for n, gv in zip(names, grads[2:]):
+        ref = g["grads"][n]
+        if "full" in ref:
+            close(gv, ref["full"], "grad." + n, rtol=2e-3, atol=2e-6 * max(1.0, float(ref["full"].abs().max())) + 1e-9)
+        else:
+            close(gv.flatten()[:: ref["stride"]], ref["sub"], "grad." + n, rtol=2e-3, atol=1e-4 * float(ref["sub"].abs().max()) + 1e-10)
+            assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 1e-3 * float(ref["norm"]) + 1e-12, n
