@@ -415,3 +415,62 @@ def render_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
     fd, deltas, dbg = query_field_eval(P, fr, hxy, n_depth, alpha, prec)
     out = RU.render_pixel(fd, deltas)
     return {"rendered": out, "aux_dict": {"fg": dict(out)}, "debug": dbg}
+
+
+# ---------------------------------------------------------------------------------------------------
+# background field + fg/bg composition in eval mode  (nerf.py:580-684 for category "bg"; engine/model.py:328-361, "comp")
+# ---------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def importance_sampling_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32, prefix=""):
+    """NeRF.importance_sampling (nerf.py:686-738) with the rigid backward warp of the background field."""
+    nc = n_depth // 2
+    codes = {"basefield": fr["code_base"], "colorfield": fr["code_color"]}
+    cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
+    _, _, deltas, depth, xyz, _ = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=nc)
+    density = nerf_forward_bg(P, xyz, None, codes, prec, alpha=alpha, prefix=prefix)
+    weights, _ = RU.compute_weights(density, deltas)
+    depth_mid = (0.5 * (depth[:, :, :-1] + depth[:, :, 1:])).reshape(-1, nc - 1)
+    new, inds = RU.sample_pdf(depth_mid, weights.reshape(-1, nc)[:, 1:-1].contiguous(), nc, det=True, return_inds=True)
+    depth_all = RU.sort_depth(depth.reshape(-1, nc), new).view(depth.shape[0], depth.shape[1], n_depth, 1)
+    return RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, depth=depth_all), inds
+
+
+def query_field_eval_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32, prefix=""):
+    """Eval-mode NeRF.query_field of the background field: rigid warp, no valid-index compaction (get_valid_idx returns
+    None for category "bg", nerf.py:524-526), zero cycle terms (nerf.py:905-925), normals through the rigid transform."""
+    (xyz_cam, dir_cam, deltas, depth, _, dir_f), inds = importance_sampling_bg(P, fr, hxy, n_depth, alpha, prec, prefix)
+    det = lambda v: tuple(t.detach() for t in v) if isinstance(v, tuple) else (v.detach() if torch.is_tensor(v) else v)
+    P = {k: det(v) for k, v in P.items()}
+    fr = {k: det(v) for k, v in fr.items()}
+    codes = {"basefield": fr["code_base"], "colorfield": fr["code_color"]}
+    with torch.enable_grad():
+        xc = xyz_cam.detach().requires_grad_(True)
+        qi, ti = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
+        xyz = rigid_apply(qi, ti, xc)
+        rgb, sdf = nerf_forward_bg(P, xyz, dir_f.detach(), codes, prec, get_density=False, alpha=alpha, prefix=prefix)
+        (g,) = torch.autograd.grad(sdf, xc, torch.ones_like(sdf))
+    with torch.no_grad():
+        xyz, rgb, sdf = xyz.detach(), rgb.detach(), sdf.detach()
+        ibeta = P[prefix + "logibeta"].exp()
+        density = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta
+        fd = {"rgb": rgb, "density": density, "density_bg": density, "vis": vis_field(P, xyz, fr, prec)}
+        for k in ("cyc_dist", "delta_skin", "skin_entropy"):
+            fd[k] = torch.zeros_like(density)
+        fd["eikonal"] = (g.norm(2, dim=-1, keepdim=True) - 1) ** 2
+        fd["normal"] = F.normalize(g, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=g.device)
+        fd["xyz"] = xyz
+        fd["xyz_cam"] = xyz_cam
+        fd["depth"] = depth / P[prefix + "logscale"].exp()
+    return fd, deltas, {"inds": inds}
+
+
+@torch.no_grad()
+def render_eval_comp(P_fg, fr_fg, P_bg, fr_bg, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
+    """dvr_model.render_samples for field_type == "comp" in eval mode (engine/model.py:328-361): both fields are queried on
+    the same rays, z-merged by MultiFields.compose_fields, and the composite and each field are rendered."""
+    from . import multifields
+    fd_fg, d_fg, _ = query_field_eval(P_fg, fr_fg, hxy, n_depth, alpha, prec)
+    fd_bg, d_bg, _ = query_field_eval_bg(P_bg, fr_bg, hxy, n_depth, alpha, prec)
+    fd, deltas = multifields.compose_fields({"fg": fd_fg, "bg": fd_bg}, {"fg": d_fg, "bg": d_bg})
+    return {"rendered": RU.render_pixel(fd, deltas), "aux_dict": {"fg": RU.render_pixel(fd_fg, d_fg), "bg": RU.render_pixel(fd_bg, d_bg)},
+            "composed": fd, "deltas": deltas}

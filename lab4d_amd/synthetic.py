@@ -67,8 +67,10 @@ BG_LINEARS = [
     ("basefield.linear_4.0", 128, 128), ("basefield.linear_5.0", 128, 199), ("basefield.linear_final.0", 128, 128),
     ("colorfield.linear_1.0", 128, 83), ("colorfield.linear_2.0", 128, 128), ("colorfield.linear_final.0", 128, 128),
     ("sdf", 1, 128), ("rgb.0", 64, 131), ("rgb.2", 3, 64),
+    ("vis_mlp.basefield.linear_1.0", 64, 95), ("vis_mlp.basefield.linear_2.0", 64, 64), ("vis_mlp.basefield.linear_final", 1, 64),
 ]
-BG_EMBEDDINGS = [("basefield.inst_embedding.mapping.weight", 32), ("colorfield.inst_embedding.mapping.weight", 32)]
+BG_EMBEDDINGS = [("basefield.inst_embedding.mapping.weight", 32), ("colorfield.inst_embedding.mapping.weight", 32),
+                 ("vis_mlp.basefield.inst_embedding.mapping.weight", 32)]
 
 
 def make_bg_weights(seed=0, num_inst=1):
@@ -84,6 +86,29 @@ def make_bg_weights(seed=0, num_inst=1):
     P["logibeta"] = torch.tensor([-math.log(0.1)])
     P["logscale"] = torch.tensor([math.log(0.1)])
     return P
+
+
+def make_bg_frames(seed, M, res):
+    """Per-frame inputs of the background field: its own camera pose (scene-to-camera) and near/far."""
+    g = torch.Generator().manual_seed(seed + 32452843)
+    fr = {}
+    K = torch.tensor([[res, 0, res / 2], [0, res, res / 2], [0, 0, 1]], dtype=torch.float32)
+    fr["Kinv"] = torch.linalg.inv(K)[None].repeat(M, 1, 1).contiguous()
+    q = _rand_unit_quat(g, M, 0.3)
+    t = torch.tensor([0.0, 0.0, 0.9]).repeat(M, 1) + 0.02 * torch.randn(M, 3, generator=g)
+    fr["field2cam"] = (q.contiguous(), t.contiguous())
+    fr["near_far"] = torch.stack([t[:, 2] - 0.6, t[:, 2] + 0.6], -1).contiguous()
+    fr["frame_id"] = torch.arange(M, dtype=torch.long)
+    fr["inst_id"] = torch.zeros(M, dtype=torch.long)
+    return fr
+
+
+def add_bg_codes(fr, P):
+    look = lambda name: P[name][torch.zeros_like(fr["inst_id"]) if P[name].shape[0] == 1 else fr["inst_id"]]
+    fr["code_base"] = look("basefield.inst_embedding.mapping.weight")
+    fr["code_color"] = look("colorfield.inst_embedding.mapping.weight")
+    fr["code_vis"] = look("vis_mlp.basefield.inst_embedding.mapping.weight")
+    return fr
 
 
 def make_weights(seed=0, num_inst=1, sdf_bias=None):

@@ -705,6 +705,54 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None):
     return fd, deltas, {"valid": valid, "inds": inds}
 
 
+def query_field_eval_bg(P, fr, hxy, n_depth=64, alpha=None):
+    """Eval-mode NeRF.query_field of the background field (nerf.py:580-684; rigid backward warp, get_valid_idx returns None
+    for category "bg" (nerf.py:524-526), train-only fields return {}): importance sampling, rgb / density, visibility,
+    normals through the rigid transform."""
+    codes = {"basefield": fr["code_base"], "colorfield": fr["code_color"]}
+    nc = n_depth // 2
+    xyz_cam, _, deltas, depth = sample_cam_rays(hxy, fr["Kinv"], fr["near_far"], n_depth=nc)
+    xyz, _ = cam_to_field(xyz_cam, None, fr["field2cam"])
+    density = nerf_forward(P, xyz, codes, with_color=False, alpha=alpha, cfg=BG_CFG)
+    weights, _ = compute_weights(density, deltas)
+    depth_mid = (0.5 * (depth[:, :, :-1] + depth[:, :, 1:])).view(-1, nc - 1)
+    new, inds = sample_pdf(depth_mid, weights.view(-1, nc)[:, 1:-1], nc, return_inds=True)
+    depth_all, _ = torch.sort(torch.cat([depth, new.reshape(depth.shape)], -2), -2)
+    xyz_cam, dir_cam, deltas, depth = sample_cam_rays(hxy, fr["Kinv"], fr["near_far"], depth=depth_all)
+    xyz, dirs = cam_to_field(xyz_cam, dir_cam, fr["field2cam"])
+    vis = vis_field(P, xyz, fr["code_vis"])
+    rgb, density = nerf_forward(P, xyz, codes, alpha=alpha, cfg=BG_CFG, dir=dirs)
+    fd = {"rgb": rgb, "density": density, "density_bg": density, "vis": vis}
+    # NeRF.cycle_loss (nerf.py:905-925) is not train-only: a rigid field reports zeros
+    for k in ("cyc_dist", "delta_skin", "skin_entropy"):
+        fd[k] = torch.zeros_like(density)
+
+    def fn_sdf(xc):
+        xx, _ = cam_to_field(xc, None, fr["field2cam"])
+        return nerf_forward(P, xx, codes, with_color=False, get_density=False, alpha=alpha, cfg=BG_CFG)
+
+    with torch.enable_grad():
+        xc = xyz_cam.detach().requires_grad_(True)
+        sv = fn_sdf(xc)
+        (g,) = torch.autograd.grad(sv, xc, torch.ones_like(sv))
+    fd["eikonal"] = (g.norm(2, dim=-1, keepdim=True) - 1) ** 2
+    fd["normal"] = F.normalize(g, dim=-1) * torch.tensor([1.0, -1.0, -1.0])
+    fd["xyz"] = xyz
+    fd["xyz_cam"] = xyz_cam
+    fd["depth"] = depth / P["logscale"].exp()
+    return fd, deltas, {"inds": inds}
+
+
+def render_eval_comp(P_fg, fr_fg, P_bg, fr_bg, hxy, n_depth=64):
+    """dvr_model.render_samples for field_type == "comp" in eval mode (engine/model.py:328-361): query both fields,
+    compose_fields, render_pixel of the composite and of each field."""
+    fd_fg, d_fg, _ = query_field_eval(P_fg, fr_fg, hxy, n_depth)
+    fd_bg, d_bg, _ = query_field_eval_bg(P_bg, fr_bg, hxy, n_depth)
+    fd, deltas = compose_fields({"fg": fd_fg, "bg": fd_bg}, {"fg": d_fg, "bg": d_bg})
+    return {"rendered": render_pixel(fd, deltas), "aux_dict": {"fg": render_pixel(fd_fg, d_fg), "bg": render_pixel(fd_bg, d_bg)},
+            "composed": fd, "deltas": deltas}
+
+
 def render_eval(P, fr, hxy, n_depth=64, alpha=None):
     fd, deltas, aux = query_field_eval(P, fr, hxy, n_depth, alpha)
     out = render_pixel(fd, deltas)

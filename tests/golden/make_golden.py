@@ -337,6 +337,54 @@ def gen_bg_field(ns):
     print("bg_field ->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_comp_eval(ns):
+    """field_type "comp" in eval mode, the way dvr_model.render_samples drives it (engine/model.py:328-361): fg
+    Deformable("skel-quad").query_field + bg NeRF.query_field on the same rays -> MultiFields.compose_fields -> render_pixel of
+    the composite and of each field."""
+    M, N, D, res, seed = 2, 6, 16, 64, 61
+    Pf = synthetic.make_weights(seed, sdf_bias=-0.02)
+    f = build_reference_field(ns, Pf)
+    f.eval()
+    frf = frames_from_reference(f, synthetic.make_frames(seed + 1, M, res))
+    Pb = synthetic.make_bg_weights(seed)
+    Pb["sdf.bias"] = torch.tensor([-0.1])  # some occupancy in the bg so the composite has contributions from both fields
+    torch.manual_seed(0)
+    di = ref_shim.synthetic_data_info(64)
+    b = ns.nerf.NeRF(di, num_freq_xyz=6, num_freq_dir=0, appr_channels=0, init_scale=0.1)
+    b.category = "bg"
+    missing = [k for k in Pb if k not in b.state_dict()]
+    assert not missing, missing
+    b.load_state_dict({k: v for k, v in Pb.items()}, strict=False)
+    b.eval()
+    frb = synthetic.make_bg_frames(seed + 3, M, res)
+    g = torch.Generator().manual_seed(seed + 2)
+    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
+    for fld in (f, b):
+        orig = fld.importance_sampling
+        fld.importance_sampling = (lambda o: (lambda *a, **k: o(*a, n_depth=D, **k)))(orig)
+    sdf_ = samples_dict_of(frf, hxy, None)
+    del sdf_["feature"]
+    sdb = {"Kinv": frb["Kinv"], "field2cam": frb["field2cam"], "frame_id": frb["frame_id"], "inst_id": frb["inst_id"],
+           "near_far": frb["near_far"], "hxy": hxy}
+    fd_f, d_f, _ = f.query_field(sdf_)
+    fd_b, d_b, _ = b.query_field(sdb)
+    comp, dcomp = ns.multifields.MultiFields.compose_fields({"fg": dict(fd_f), "bg": dict(fd_b)}, {"fg": d_f, "bg": d_b})
+    rendered = ns.render_utils.render_pixel(comp, dcomp)
+    r_f = ns.render_utils.render_pixel(fd_f, d_f)
+    r_b = ns.render_utils.render_pixel(fd_b, d_b)
+    det = lambda d: {k: v.detach() for k, v in d.items()}
+    out = {"meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "bg_sdf_bias": -0.1, "fg_sdf_bias": -0.02,
+                    "weight_checksum_fg": weight_checksum(Pf), "weight_checksum_bg": weight_checksum(Pb)},
+           "frames_fg": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in frf.items()},
+           "frames_bg": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in frb.items()},
+           "hxy": hxy, "bg_feat_dict": det(fd_b), "bg_deltas": d_b.detach(), "rendered": det(rendered), "rendered_fg": det(r_f),
+           "rendered_bg": det(r_b), "composed_depth": comp["depth"].detach(), "composed_keys": sorted(comp.keys())}
+    path = os.path.join(HERE, "comp_eval.pt")
+    torch.save(out, path)
+    print("comp_eval ->", path, os.path.getsize(path) // 1024, "KiB", "keys", sorted(comp.keys()), "bg mask", float(r_b["mask"].mean()),
+          "fg mask", float(r_f["mask"].mean()))
+
+
 if __name__ == "__main__":
     ns = ref_shim.load()
     # give render_utils a private torch namespace so searchsorted can be observed
@@ -348,3 +396,4 @@ if __name__ == "__main__":
     gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)
     gen_comp_warp(ns)
     gen_bg_field(ns)
+    gen_comp_eval(ns)

@@ -216,3 +216,31 @@ def test_bg_field_against_reference(golden_dir):
         else:
             close(gv.flatten()[:: ref["stride"]], ref["sub"], "grad." + n, rtol=2e-3, atol=1e-4 * float(ref["sub"].abs().max()) + 1e-10)
             assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 1e-3 * float(ref["norm"]) + 1e-12, n
+
+
+def _load_comp_eval(golden_dir):
+    g = torch.load(os.path.join(golden_dir, "comp_eval.pt"), weights_only=False)
+    meta = g["meta"]
+    Pf = synthetic.make_weights(meta["seed"], sdf_bias=meta["fg_sdf_bias"])
+    Pb = synthetic.make_bg_weights(meta["seed"])
+    Pb["sdf.bias"] = torch.tensor([meta["bg_sdf_bias"]])
+    return g, meta, Pf, Pb
+
+
+def test_comp_eval_against_reference(golden_dir):
+    """field_type "comp", eval mode: bg NeRF.query_field, compose_fields with the fg field, render_pixel of all three."""
+    g, meta, Pf, Pb = _load_comp_eval(golden_dir)
+    frf = synthetic.add_codes(dict(g["frames_fg"]), Pf)
+    frb = synthetic.add_bg_codes(dict(g["frames_bg"]), Pb)
+    fd_b, d_b, _ = O.query_field_eval_bg(Pb, frb, g["hxy"], n_depth=meta["D"])
+    assert sorted(fd_b.keys()) == sorted(g["bg_feat_dict"].keys())
+    for k, v in g["bg_feat_dict"].items():
+        close(fd_b[k], v, "bg." + k, rtol=2e-4)
+    close(d_b, g["bg_deltas"], "bg_deltas")
+    res = O.render_eval_comp(Pf, frf, Pb, frb, g["hxy"], n_depth=meta["D"])
+    assert sorted(res["composed"].keys()) == g["composed_keys"]
+    assert torch.equal(res["composed"]["depth"], g["composed_depth"])
+    for name, ref in (("rendered", g["rendered"]), ("fg", g["rendered_fg"]), ("bg", g["rendered_bg"])):
+        got = res["rendered"] if name == "rendered" else res["aux_dict"][name]
+        for k, v in ref.items():
+            close(got[k], v, f"{name}.{k}", rtol=2e-4)
