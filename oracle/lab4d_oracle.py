@@ -743,6 +743,67 @@ def query_field_eval_bg(P, fr, hxy, n_depth=64, alpha=None):
     return fd, deltas, {"inds": inds}
 
 
+def compute_eikonal_bg(P, xyz, code, rand_inds, alpha=None):
+    """NeRF.compute_eikonal (nerf.py:416-453) for the bg field on the host-drawn ray subset."""
+    M, N, D, _ = xyz.shape
+    pts = xyz.reshape(M * N, D, 3)
+    c = code[:, None, :].expand(M, N, code.shape[-1]).reshape(M * N, -1)
+    out = torch.zeros(M * N, D)
+    if rand_inds is None:
+        rand_inds = torch.arange(M * N)
+
+    def fn(x):
+        return nerf_forward(P, x, {"basefield": c[rand_inds]}, with_color=False, get_density=False, alpha=alpha, cfg=BG_CFG)
+
+    with torch.enable_grad():
+        x = pts[rand_inds].detach().requires_grad_(True)
+        sv = fn(x)
+        (g,) = torch.autograd.grad(sv, x, torch.ones_like(sv), create_graph=True)
+    out[rand_inds] = (g.norm(2, dim=-1) - 1) ** 2
+    return out.reshape(M, N, D, 1)
+
+
+def query_field_train_bg(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None):
+    """Training-mode NeRF.query_field of the background field (nerf.py:580-684): rigid warps, flow into the pair partner's
+    camera (nerf.py:948-997), zero cycle terms, eikonal on the host-drawn ray subset.  ORACLE ONLY this round: the HIP path
+    has the eval-mode bg query (deformable.query_field_eval_bg); this pins the training-mode target for the next one."""
+    codes = {"basefield": fr["code_base"], "colorfield": fr["code_color"]}
+    xyz_cam, dir_cam, deltas, depth = sample_cam_rays(hxy, fr["Kinv"], fr["near_far"], n_depth=n_depth)
+    xyz, dirs = cam_to_field(xyz_cam, dir_cam, fr["field2cam"])
+    fd = {}
+    vis = vis_field(P, xyz, fr["code_vis"])
+    rgb, density = nerf_forward(P, xyz, codes, alpha=alpha, cfg=BG_CFG, dir=dirs)
+    fd["rgb"], fd["density"], fd["density_bg"], fd["vis"] = rgb, density, density, vis
+    nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam"]})
+    xyz_cam_next = field_to_cam(xyz, nxt["field2cam"])
+    hxy_next = pinhole_projection(kmatinv(nxt["Kinv"]), xyz_cam_next)
+    flow = (hxy_next - hxy.unsqueeze(-2))[..., :2]
+    valid = xyz_cam_next[..., -1:] > 1e-6
+    if flow_thresh is not None:
+        valid = valid & (flow.norm(dim=-1, keepdim=True) < float(flow_thresh))
+    fd["flow"] = torch.cat([flow, valid.to(flow.dtype)], -1)
+    for k in ("cyc_dist", "delta_skin", "skin_entropy"):
+        fd[k] = torch.zeros_like(density)
+    fd["eikonal"] = compute_eikonal_bg(P, xyz, fr["code_base"], rng.get("eik_inds_bg"), alpha)
+    fd["xyz"] = xyz
+    fd["xyz_cam"] = xyz_cam
+    fd["depth"] = depth / P["logscale"].exp()
+    return fd, deltas, {}
+
+
+def render_train_comp(P_fg, fr_fg, P_bg, fr_bg, hxy, rng, flow_thresh=None, n_depth=64):
+    """dvr_model.render_samples for field_type == "comp" in training mode (engine/model.py:328-361)."""
+    fd_fg, d_fg, aux = query_field_train(P_fg, fr_fg, hxy, rng, flow_thresh, n_depth)
+    fd_bg, d_bg, _ = query_field_train_bg(P_bg, fr_bg, hxy, rng, flow_thresh, n_depth)
+    fd, deltas = compose_fields({"fg": fd_fg, "bg": fd_bg}, {"fg": d_fg, "bg": d_bg})
+    rendered = render_pixel(fd, deltas)
+    aux_fg = dict(aux)
+    aux_fg.update(render_pixel(fd_fg, d_fg))
+    rendered["xyz_matches"] = aux["xyz_matches"]
+    rendered["xyz_reproj"] = aux["xyz_reproj"]
+    return {"rendered": rendered, "aux_dict": {"fg": aux_fg, "bg": render_pixel(fd_bg, d_bg)}}
+
+
 def render_eval_comp(P_fg, fr_fg, P_bg, fr_bg, hxy, n_depth=64):
     """dvr_model.render_samples for field_type == "comp" in eval mode (engine/model.py:328-361): query both fields,
     compose_fields, render_pixel of the composite and of each field."""
@@ -835,6 +896,49 @@ def recon_losses_fg(results, batch, train_res, weights=None):
             L[k] = L[k] * mfg
         else:
             L[k] = L[k] * (mfg * vis2d)
+        if k in ("mask", "feature", "feat_reproj"):
+            L[k] = L[k] * det
+    L["reg_eikonal"] = r["eikonal"]
+    L["reg_deform_cyc"] = a["cyc_dist"]
+    L["reg_delta_skin"] = a["delta_skin"]
+    L["reg_skin_entropy"] = a["skin_entropy"]
+    out = {}
+    for k, v in L.items():
+        v = v[v > 0].mean()
+        if k in ("flow", "feat_reproj"):
+            v = v / train_res
+        if weights is not None and k + "_wt" in weights:
+            v = v * weights[k + "_wt"]
+        out[k] = v
+    return out
+
+
+def recon_losses_comp(results, batch, train_res, weights=None):
+    """compute_recon_loss + mask_losses + apply_loss_weights for field_type == "comp" (model.py:426-501, 528-611): the fg mask
+    is the rendered mask_fg, the composite must be opaque ((mask - 1)^2), visibility is supervised per field (bg at 1 %),
+    dense terms are masked by vis2d only."""
+    r, a, b = results["rendered"], results["aux_dict"]["fg"], results["aux_dict"]["bg"]
+    L = {}
+    L["mask"] = (r["mask_fg"] - batch["mask"].float()).pow(2) * mask_balance_wt(batch["mask"], batch["vis2d"], batch["is_detected"]) \
+        + (r["mask"] - 1).pow(2)
+    L["feature"] = (a["feature"] - batch["feature"]).norm(2, -1, keepdim=True)
+    L["feat_reproj"] = (a["xy_reproj"] - batch["hxy"][..., :2]).norm(2, -1, keepdim=True)
+    L["rgb"] = (r["rgb"] - batch["rgb"]).pow(2)
+    L["depth"] = (r["depth"] - batch["depth"]).norm(2, -1, keepdim=True)
+    L["flow"] = (r["flow"] - batch["flow"]).norm(2, -1, keepdim=True) * (batch["flow_uct"] > 0).float()
+    L["vis"] = a["vis"] + 0.01 * b["vis"]
+    L["reg_gauss_mask"] = (a["gauss_mask"] - r["mask_fg"].detach()).pow(2)
+    vis2d, mfg = batch["vis2d"].float(), batch["mask"].float()
+    det = batch["is_detected"].float()[:, None, None]
+    for k in list(L.keys()):
+        if k == "reg_gauss_mask":
+            continue
+        if k == "mask":
+            L[k] = L[k] * vis2d
+        elif k in ("feature", "feat_reproj"):
+            L[k] = L[k] * mfg
+        else:
+            L[k] = L[k] * vis2d
         if k in ("mask", "feature", "feat_reproj"):
             L[k] = L[k] * det
     L["reg_eikonal"] = r["eikonal"]

@@ -385,6 +385,84 @@ def gen_comp_eval(ns):
           "fg mask", float(r_f["mask"].mean()))
 
 
+def gen_comp_train(ns):
+    """field_type "comp", training mode: fg Deformable.query_field + bg NeRF.query_field -> compose_fields -> render_pixel ->
+    dvr_model.compute_recon_loss / mask_losses / apply_loss_weights with config field_type = "comp", plus gradients of the
+    total loss wrt a few fg and bg weights.  Pins the oracle (render_train_comp / recon_losses_comp); the HIP path for the
+    bg training query is next-round work."""
+    M, N, D, res, seed = 2, 6, 8, 64, 71
+    Pf = synthetic.make_weights(seed)
+    f = build_reference_field(ns, Pf)
+    f.train()
+    frf = frames_from_reference(f, synthetic.make_frames(seed + 1, M, res))
+    Pb = synthetic.make_bg_weights(seed)
+    Pb["sdf.bias"] = torch.tensor([-0.1])
+    torch.manual_seed(0)
+    di = ref_shim.synthetic_data_info(64)
+    b = ns.nerf.NeRF(di, num_freq_xyz=6, num_freq_dir=0, appr_channels=0, init_scale=0.1)
+    b.category = "bg"
+    b.load_state_dict({k: v for k, v in Pb.items()}, strict=False)
+    b.train()
+    frb = synthetic.make_bg_frames(seed + 3, M, res)
+    g = torch.Generator().manual_seed(seed + 2)
+    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
+    batch = synthetic.make_targets(seed + 3, M, N, res, hxy)
+    eik_inds = torch.randperm(M * N, generator=g)[: max(M * N // 16, 1)]
+    match_perm = torch.randperm(M * N * D, generator=g)[: min(1024, M * N * D)]
+    ns.nerf.torch.multinomial = lambda probs, n, replacement=False: eik_inds.clone()
+    ns.feature.torch = ns.nerf.torch.__class__(**vars(ns.nerf.torch))
+    ns.feature.torch.randperm = lambda n: torch.cat([match_perm, torch.arange(n)])
+    ns.nerf.sample_cam_rays = partial(ns.render_utils.sample_cam_rays, n_depth=D)
+    sdf_ = samples_dict_of(frf, hxy, batch["feature"])
+    sdb = {"Kinv": frb["Kinv"], "field2cam": frb["field2cam"], "frame_id": frb["frame_id"], "inst_id": frb["inst_id"],
+           "near_far": frb["near_far"], "hxy": hxy}
+    fd_f, d_f, aux = f.query_field(sdf_, flow_thresh=float(res))
+    fd_b, d_b, _ = b.query_field(sdb, flow_thresh=float(res))
+    comp, dcomp = ns.multifields.MultiFields.compose_fields({"fg": dict(fd_f), "bg": dict(fd_b)}, {"fg": d_f, "bg": d_b})
+    rendered = ns.render_utils.render_pixel(comp, dcomp)
+    aux_fg = dict(aux)
+    aux_fg.update(ns.render_utils.render_pixel(fd_f, d_f))
+    aux_bg = ns.render_utils.render_pixel(fd_b, d_b)
+    results = {"rendered": dict(rendered), "aux_dict": {"fg": aux_fg, "bg": dict(aux_bg)}}
+    results["rendered"]["xyz_matches"] = aux["xyz_matches"]
+    results["rendered"]["xyz_reproj"] = aux["xyz_reproj"]
+    ref_out = {"rendered": {k: v.detach().clone() for k, v in results["rendered"].items()},
+               "aux_fg": {k: v.detach().clone() for k, v in aux_fg.items()}, "aux_bg": {k: v.detach().clone() for k, v in aux_bg.items()}}
+    import importlib
+    model = importlib.import_module("lab4d.engine.model").dvr_model
+    config = {"field_type": "comp", "train_res": res}
+    loss_dict = {}
+    model.compute_recon_loss(loss_dict, results, batch, config)  # (scales aux_dict["bg"]["vis"] by 0.01 in place)
+    model.mask_losses(loss_dict, batch, config)
+    loss_dict["reg_eikonal"] = rendered["eikonal"]
+    loss_dict["reg_deform_cyc"] = aux_fg["cyc_dist"]
+    loss_dict["reg_delta_skin"] = aux_fg["delta_skin"]
+    loss_dict["reg_skin_entropy"] = aux_fg["skin_entropy"]
+    from oracle.lab4d_oracle import DEFAULT_LOSS_WT
+    config.update(DEFAULT_LOSS_WT)
+    model.apply_loss_weights(loss_dict, config)
+    total = sum(loss_dict.values())
+    pf, pb = dict(f.named_parameters()), dict(b.named_parameters())
+    fnames = ["basefield.linear_1.0.weight", "rgb.0.weight", "warp.skinning_model.delta_field.linear_1.0.weight", "sdf.weight"]
+    bnames = ["basefield.linear_1.0.weight", "basefield.linear_5.0.weight", "colorfield.linear_2.0.weight", "rgb.0.weight", "sdf.weight",
+              "vis_mlp.basefield.linear_1.0.weight"]
+    grads = torch.autograd.grad(total, [pf[k] for k in fnames] + [pb[k] for k in bnames], allow_unused=True)
+    gd = {}
+    for k, gv in zip(["fg:" + k for k in fnames] + ["bg:" + k for k in bnames], grads):
+        if gv is not None:
+            gd[k] = compress_grad(gv.detach())
+    out = {"meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "bg_sdf_bias": -0.1, "flow_thresh": float(res),
+                    "weight_checksum_fg": weight_checksum(Pf), "weight_checksum_bg": weight_checksum(Pb)},
+           "frames_fg": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in frf.items()},
+           "frames_bg": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in frb.items()},
+           "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds, "eik_inds_bg": eik_inds, "match_perm": match_perm},
+           "bg_feat_dict": {k: v.detach() for k, v in fd_b.items()}, **ref_out,
+           "loss": {k: v.detach() for k, v in loss_dict.items()}, "grads": gd}
+    path = os.path.join(HERE, "comp_train.pt")
+    torch.save(out, path)
+    print("comp_train ->", path, os.path.getsize(path) // 1024, "KiB", {k: round(float(v), 6) for k, v in loss_dict.items()})
+
+
 if __name__ == "__main__":
     ns = ref_shim.load()
     # give render_utils a private torch namespace so searchsorted can be observed
@@ -397,3 +475,4 @@ if __name__ == "__main__":
     gen_comp_warp(ns)
     gen_bg_field(ns)
     gen_comp_eval(ns)
+    gen_comp_train(ns)

@@ -244,3 +244,44 @@ def test_comp_eval_against_reference(golden_dir):
         got = res["rendered"] if name == "rendered" else res["aux_dict"][name]
         for k, v in ref.items():
             close(got[k], v, f"{name}.{k}", rtol=2e-4)
+
+
+def test_comp_train_against_reference(golden_dir):
+    """field_type "comp", training mode (oracle only this round): bg NeRF.query_field with flow / eikonal, compose_fields, the
+    three renders, dvr_model's comp losses and gradients wrt fg and bg weights."""
+    g = torch.load(os.path.join(golden_dir, "comp_train.pt"), weights_only=False)
+    meta = g["meta"]
+    Pf = synthetic.make_weights(meta["seed"])
+    Pb = synthetic.make_bg_weights(meta["seed"])
+    Pb["sdf.bias"] = torch.tensor([meta["bg_sdf_bias"]])
+    Pf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v) for k, v in Pf.items()}
+    Pb = {k: v.clone().requires_grad_(True) for k, v in Pb.items()}
+    frf = synthetic.add_codes(dict(g["frames_fg"]), Pf)
+    frf["feature"] = g["batch"]["feature"]
+    frb = synthetic.add_bg_codes(dict(g["frames_bg"]), Pb)
+    fd_b, _, _ = O.query_field_train_bg(Pb, frb, g["hxy"], g["rng"], flow_thresh=meta["flow_thresh"], n_depth=meta["D"])
+    assert sorted(fd_b.keys()) == sorted(g["bg_feat_dict"].keys())
+    for k, v in g["bg_feat_dict"].items():
+        close(fd_b[k], v, "bg." + k, rtol=2e-4)
+    res = O.render_train_comp(Pf, frf, Pb, frb, g["hxy"], g["rng"], flow_thresh=meta["flow_thresh"], n_depth=meta["D"])
+    for k, v in g["rendered"].items():
+        close(res["rendered"][k], v, "rendered." + k, rtol=2e-4)
+    for k, v in g["aux_fg"].items():
+        close(res["aux_dict"]["fg"][k], v, "aux_fg." + k, rtol=2e-4)
+    for k, v in g["aux_bg"].items():
+        close(res["aux_dict"]["bg"][k], v, "aux_bg." + k, rtol=2e-4)
+    losses = O.recon_losses_comp(res, g["batch"], meta["res"], O.DEFAULT_LOSS_WT)
+    for k, v in g["loss"].items():
+        close(losses[k], v, "loss." + k, rtol=5e-4)
+    total = sum(losses.values())
+    names = list(g["grads"].keys())
+    tensors = [(Pf if n.startswith("fg:") else Pb)[n[3:]] for n in names]
+    grads = torch.autograd.grad(total, tensors, allow_unused=True)
+    for n, gv in zip(names, grads):
+        ref = g["grads"][n]
+        assert gv is not None, n
+        if "full" in ref:
+            close(gv, ref["full"], "grad." + n, rtol=3e-3, atol=3e-6 * max(1.0, float(ref["full"].abs().max())) + 1e-9)
+        else:
+            close(gv.flatten()[:: ref["stride"]], ref["sub"], "grad." + n, rtol=3e-3, atol=2e-4 * float(ref["sub"].abs().max()) + 1e-10)
+            assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 2e-3 * float(ref["norm"]) + 1e-12, n
