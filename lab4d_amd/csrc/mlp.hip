@@ -708,13 +708,9 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
 
 // Tangent-mode forward (eikonal term): x = (S, ke) tangent vector in embedding-slot order, mask[l] = sign bits stored by the
 // primal forward, no biases.  Stores the tangent activations (act) and the tangent embedding (emb) for lab4d_mlp_wgrad.
-extern "C" int lab4d_mlp_forward_tangent(const lab4d_mlp_fwd_args* a, void* stream) {
-  LAB4D_REQUIRE(a, "mlp_forward_tangent: null args");
-  LAB4D_REQUIRE(a->net == LAB4D_NET_FG_BASE, "mlp_forward_tangent: only the basefield/sdf network has an eikonal term (got net %d)", a->net);
-  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 256 == 0 && a->spf > 0, "mlp_forward_tangent: bad sizes (S_pad must be a multiple of 256)");
-  LAB4D_REQUIRE(a->x && a->emb, "mlp_forward_tangent: null x / emb");
-  if (a->S == 0) return LAB4D_OK;
-  using Net = NetFgBase;
+namespace {
+template <class Net>
+int forward_tangent_impl(const lab4d_mlp_fwd_args* a, void* stream) {
   FwdK k;
   memset(&k, 0, sizeof(k));
   k.S = a->S; k.S_pad = a->S_pad; k.ld = a->ld; k.spf = a->spf; k.x = a->x; k.emb = a->emb; k.out = a->out;
@@ -725,4 +721,16 @@ extern "C" int lab4d_mlp_forward_tangent(const lab4d_mlp_fwd_args* a, void* stre
     k.W[l] = a->W[l]; k.bias[l] = a->bias[l] ? a->bias[l] : (const float*)a->W[l]; k.act[l] = a->act[l]; k.mask[l] = (unsigned int*)a->mask[l];
   }
   return launch_mlp_fwd_tangent<Net>(a->precision, k, a->S, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int lab4d_mlp_forward_tangent(const lab4d_mlp_fwd_args* a, void* stream) {
+  LAB4D_REQUIRE(a, "mlp_forward_tangent: null args");
+  LAB4D_REQUIRE(a->net == LAB4D_NET_FG_BASE || a->net == LAB4D_NET_BG_BASE,
+                "mlp_forward_tangent: only the basefield/sdf networks (fg, bg) have an eikonal term (got net %d)", a->net);
+  LAB4D_REQUIRE(a->S >= 0 && a->S_pad >= a->S && a->S_pad % 256 == 0 && a->spf > 0, "mlp_forward_tangent: bad sizes (S_pad must be a multiple of 256)");
+  LAB4D_REQUIRE(a->x && a->emb, "mlp_forward_tangent: null x / emb");
+  if (a->S == 0) return LAB4D_OK;
+  if (a->net == LAB4D_NET_FG_BASE) return forward_tangent_impl<NetFgBase>(a, stream);
+  return forward_tangent_impl<NetBgBase>(a, stream);
 }

@@ -371,7 +371,7 @@ struct Slab {
   // raw-input nets (and the tangent forward) stage a tile of their (S, C) fp32 input / input gradient through the slab:
   // TILE x C floats, copied to / from global memory as one contiguous, coalesced region
   static constexpr int STAGE_C = Net::EMB != 0 ? Net::CIN : Net::KE;
-  static constexpr bool STAGES = Net::EMB != 0 || Net::ID == LAB4D_NET_FG_BASE;  // raw input, or the tangent-mode forward
+  static constexpr bool STAGES = Net::EMB != 0 || Net::ID == LAB4D_NET_FG_BASE || Net::ID == LAB4D_NET_BG_BASE;  // raw input, or the tangent-mode forward
   static constexpr int UNITS_STAGE = STAGES ? (P::TILE * STAGE_C * 4 + 15) / 16 : 0;
   static constexpr int UNITS_LAYER = P::NT * UW * 64;
   static constexpr int UNITS_PER_WAVE = UNITS_LAYER > UNITS_STAGE ? UNITS_LAYER : UNITS_STAGE;  // uint4 slots

@@ -198,7 +198,7 @@ def global_match(P, feat_px, feat_canonical, xyz_canonical, perm):
     return (prob @ xc).view(shape[:-1] + (3,))
 
 
-def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32):
+def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32, net=mlp.NET_FG_BASE, prefix=""):
     """NeRF.compute_eikonal (nerf.py:416-453) on the host-drawn 1/16 ray subset: (|d sdf/dx| - 1)^2 with gradients to the
     basefield / sdf weights, via the primal + tangent-mode chain kernels (mlp.EikonalSdf) -- no second-order autograd."""
     M, N, D, _ = xyz.shape
@@ -208,7 +208,7 @@ def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32):
         rand_inds = torch.arange(M * N, device=xyz.device)
     ray_code = code[torch.div(rand_inds, N, rounding_mode="floor")]
     x = pts[rand_inds].detach().reshape(-1, 3)
-    e = mlp.eikonal_sdf(P, x, ray_code, D, prec, freq_w=posenc_window(alpha, 10, xyz.device))
+    e = mlp.eikonal_sdf(P, x, ray_code, D, prec, freq_w=posenc_window(alpha, mlp.describe(net).n_freq, xyz.device), prefix=prefix, net=net)
     out = out.index_put((rand_inds,), e.view(-1, D))
     return out.reshape(M, N, D, 1)
 
@@ -462,6 +462,92 @@ def query_field_eval_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32, p
         fd["xyz_cam"] = xyz_cam
         fd["depth"] = depth / P[prefix + "logscale"].exp()
     return fd, deltas, {"inds": inds}
+
+
+def query_field_train_bg(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None, prec=mlp.PREC_F32, prefix=""):
+    """Training-mode NeRF.query_field of the background field (nerf.py:580-684): rigid warps, flow into the pair partner's
+    camera (nerf.py:948-997), zero cycle terms (nerf.py:905-925), eikonal on the host-drawn ray subset (same contract as
+    oracle.lab4d_oracle.query_field_train_bg)."""
+    codes = {"basefield": fr["code_base"], "colorfield": fr["code_color"]}
+    cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
+    xyz_cam, _, deltas, depth, xyz, dirs = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=n_depth)
+    fd = {}
+    vis = vis_field(P, xyz, fr, prec)
+    rgb, density = nerf_forward_bg(P, xyz, dirs, codes, prec, alpha=alpha, prefix=prefix)
+    fd["rgb"], fd["density"], fd["density_bg"], fd["vis"] = rgb, density, density, vis
+    nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam"]})
+    xyz_cam_next = rigid_apply(nxt["field2cam"][0], nxt["field2cam"][1], xyz)
+    hxy_next = pinhole_projection(Q.kmatinv(nxt["Kinv"]), xyz_cam_next)
+    flow = (hxy_next - hxy.unsqueeze(-2))[..., :2]
+    valid = xyz_cam_next[..., -1:] > 1e-6
+    if flow_thresh is not None:
+        valid = valid & (flow.norm(dim=-1, keepdim=True) < float(flow_thresh))
+    fd["flow"] = torch.cat([flow, valid.to(flow.dtype)], -1)
+    for k in ("cyc_dist", "delta_skin", "skin_entropy"):
+        fd[k] = torch.zeros_like(density)
+    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds_bg"), alpha, prec, net=mlp.NET_BG_BASE, prefix=prefix)
+    fd["xyz"] = xyz
+    fd["xyz_cam"] = xyz_cam
+    fd["depth"] = depth / P[prefix + "logscale"].exp()
+    return fd, deltas, {}
+
+
+def render_train_comp(P_fg, fr_fg, P_bg, fr_bg, hxy, rng, flow_thresh=None, n_depth=64, alpha=None, prec=mlp.PREC_F32):
+    """dvr_model.render_samples for field_type == "comp" in training mode (engine/model.py:328-361)."""
+    from . import multifields
+    fd_fg, d_fg, aux = query_field_train(P_fg, fr_fg, hxy, rng, flow_thresh, n_depth, alpha, prec)
+    fd_bg, d_bg, _ = query_field_train_bg(P_bg, fr_bg, hxy, rng, flow_thresh, n_depth, alpha, prec)
+    fd, deltas = multifields.compose_fields({"fg": fd_fg, "bg": fd_bg}, {"fg": d_fg, "bg": d_bg})
+    rendered = dict(RU.render_pixel(fd, deltas))
+    aux_fg = dict(aux)
+    aux_fg.update(RU.render_pixel(fd_fg, d_fg))
+    rendered["xyz_matches"] = aux["xyz_matches"]
+    rendered["xyz_reproj"] = aux["xyz_reproj"]
+    return {"rendered": rendered, "aux_dict": {"fg": aux_fg, "bg": dict(RU.render_pixel(fd_bg, d_bg))}}
+
+
+def losses_comp(results, batch, train_res, weights):
+    """compute_recon_loss + mask_losses + rendered regularisers + apply_loss_weights for field_type "comp" (model.py:426-611):
+    fg mask = rendered mask_fg, the composite must be opaque, visibility supervised per field (bg at 1 %), dense terms
+    masked by vis2d only."""
+    r, a, b = results["rendered"], results["aux_dict"]["fg"], results["aux_dict"]["bg"]
+    L = {}
+    L["mask"] = (r["mask_fg"] - batch["mask"].float()).pow(2) * mask_balance_wt(batch["mask"], batch["vis2d"], batch["is_detected"]) \
+        + (r["mask"] - 1).pow(2)
+    L["feature"] = (a["feature"] - batch["feature"]).norm(2, -1, keepdim=True)
+    L["feat_reproj"] = (a["xy_reproj"] - batch["hxy"][..., :2]).norm(2, -1, keepdim=True)
+    L["rgb"] = (r["rgb"] - batch["rgb"]).pow(2)
+    L["depth"] = (r["depth"] - batch["depth"]).norm(2, -1, keepdim=True)
+    L["flow"] = (r["flow"] - batch["flow"]).norm(2, -1, keepdim=True) * (batch["flow_uct"] > 0).float()
+    L["vis"] = a["vis"] + 0.01 * b["vis"]
+    L["reg_gauss_mask"] = (a["gauss_mask"] - r["mask_fg"].detach()).pow(2)
+    vis2d, mfg = batch["vis2d"].float(), batch["mask"].float()
+    det = batch["is_detected"].float()[:, None, None]
+    for k in list(L.keys()):
+        if k == "reg_gauss_mask":
+            continue
+        if k == "mask":
+            L[k] = L[k] * vis2d
+        elif k in ("feature", "feat_reproj"):
+            L[k] = L[k] * mfg
+        else:
+            L[k] = L[k] * vis2d
+        if k in ("mask", "feature", "feat_reproj"):
+            L[k] = L[k] * det
+    L["reg_eikonal"] = r["eikonal"]
+    L["reg_deform_cyc"] = a["cyc_dist"]
+    L["reg_delta_skin"] = a["delta_skin"]
+    L["reg_skin_entropy"] = a["skin_entropy"]
+    out = {}
+    for k, v in L.items():
+        pos = (v > 0).to(v.dtype)
+        v = (v * pos).sum() / pos.sum()
+        if k in ("flow", "feat_reproj"):
+            v = v / train_res
+        if weights is not None and k + "_wt" in weights:
+            v = v * weights[k + "_wt"]
+        out[k] = v
+    return out
 
 
 @torch.no_grad()

@@ -491,8 +491,9 @@ class EikonalSdf(Function):
     lab4d_mlp_forward_tangent in include/lab4d_mlp.h for the derivation."""
 
     @staticmethod
-    def forward(ctx, prec, spf, x, freq_w, pf0, pf4, *params):
-        net = NET_FG_BASE
+    def forward(ctx, net, prec, spf, x, freq_w, pf0, pf4, *params):
+        if net not in (NET_FG_BASE, NET_BG_BASE):
+            raise RuntimeError("EikonalSdf: the eikonal term exists for the basefield / sdf networks only (net %d)" % net)
         d = describe(net)
         NL = d.n_layers
         Ws, bs = params[0::2], params[1::2]
@@ -563,7 +564,7 @@ class EikonalSdf(Function):
         bk.d_x = g.data_ptr()
         _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(bk), _lib.stream()), "mlp_backward(eikonal primal)")
         gn = g.norm(2, dim=-1, keepdim=True)
-        ctx.meta = (prec, int(spf), S, S_pad)
+        ctx.meta = (net, prec, int(spf), S, S_pad)
         ctx.saved = (x, fw, g, gn, dz, masks, packed, tact)
         ctx.params = params
         return (gn - 1) ** 2
@@ -571,9 +572,8 @@ class EikonalSdf(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, ge):
-        prec, spf, S, S_pad = ctx.meta
+        net, prec, spf, S, S_pad = ctx.meta
         x, fw, g, gn, dz, masks, packed, tact = ctx.saved
-        net = NET_FG_BASE
         d = describe(net)
         NL, L0 = d.n_layers, d.n_freq
         Ws = ctx.params[0::2]
@@ -605,7 +605,7 @@ class EikonalSdf(Function):
         for l in range(NL):
             L = d.layers[l]
             gW = None
-            if ctx.needs_input_grad[6 + 2 * l]:
+            if ctx.needs_input_grad[7 + 2 * l]:
                 dWk = arena[off:off + sizes[l]].view(L.mout_pad, L.ke + L.kin)
                 prev = tact[l - 1] if L.kin else None
                 with _lib.timed(wgrad_kernel_name(L, prec) + "@eik", wgrad_work(L, S_pad, prec)):
@@ -616,16 +616,16 @@ class EikonalSdf(Function):
                 gW[:, rcols] = dWk[:L.mout][:, kcols]
             off += sizes[l]
             grads += [gW, None]
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
-def eikonal_sdf(P, x, ray_code, spf, prec, freq_w=None, prefix=""):
+def eikonal_sdf(P, x, ray_code, spf, prec, freq_w=None, prefix="", net=NET_FG_BASE):
     """(|d sdf/dx| - 1)^2 at detached points x (S,3); ray_code (S/spf, 32) = instance code of the ray each group of `spf`
-    consecutive samples belongs to."""
-    bd = bindings(NET_FG_BASE, prefix)
-    pf0 = pf_bias_of(NET_FG_BASE, 0, P[bd[0].wname], ray_code)
-    pf4 = pf_bias_of(NET_FG_BASE, 4, P[bd[4].wname], ray_code)
+    consecutive samples belongs to.  net = NET_FG_BASE or NET_BG_BASE (both condition layers 0 and 4 on the code)."""
+    bd = bindings(net, prefix)
+    pf0 = pf_bias_of(net, 0, P[bd[0].wname], ray_code)
+    pf4 = pf_bias_of(net, 4, P[bd[4].wname], ray_code)
     params = []
-    for l in range(describe(NET_FG_BASE).n_layers):
+    for l in range(describe(net).n_layers):
         params += [P[bd[l].wname], P[bd[l].bname]]
-    return EikonalSdf.apply(prec, spf, x, freq_w, pf0, pf4, *params)
+    return EikonalSdf.apply(net, prec, spf, x, freq_w, pf0, pf4, *params)

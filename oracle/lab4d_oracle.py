@@ -765,8 +765,7 @@ def compute_eikonal_bg(P, xyz, code, rand_inds, alpha=None):
 
 def query_field_train_bg(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None):
     """Training-mode NeRF.query_field of the background field (nerf.py:580-684): rigid warps, flow into the pair partner's
-    camera (nerf.py:948-997), zero cycle terms, eikonal on the host-drawn ray subset.  ORACLE ONLY this round: the HIP path
-    has the eval-mode bg query (deformable.query_field_eval_bg); this pins the training-mode target for the next one."""
+    camera (nerf.py:948-997), zero cycle terms, eikonal on the host-drawn ray subset."""
     codes = {"basefield": fr["code_base"], "colorfield": fr["code_color"]}
     xyz_cam, dir_cam, deltas, depth = sample_cam_rays(hxy, fr["Kinv"], fr["near_far"], n_depth=n_depth)
     xyz, dirs = cam_to_field(xyz_cam, dir_cam, fr["field2cam"])

@@ -388,8 +388,8 @@ def gen_comp_eval(ns):
 def gen_comp_train(ns):
     """field_type "comp", training mode: fg Deformable.query_field + bg NeRF.query_field -> compose_fields -> render_pixel ->
     dvr_model.compute_recon_loss / mask_losses / apply_loss_weights with config field_type = "comp", plus gradients of the
-    total loss wrt a few fg and bg weights.  Pins the oracle (render_train_comp / recon_losses_comp); the HIP path for the
-    bg training query is next-round work."""
+    total loss wrt a few fg and bg weights.  Pins the oracle (render_train_comp / recon_losses_comp) and, through it and
+    directly, the device path (tests/test_gpu_field.py)."""
     M, N, D, res, seed = 2, 6, 8, 64, 71
     Pf = synthetic.make_weights(seed)
     f = build_reference_field(ns, Pf)

@@ -164,3 +164,44 @@ def test_comp_eval_matches_reference_goldens(golden_dir):
         got = res["rendered"] if name == "rendered" else res["aux_dict"][name]
         for k, v in ref.items():
             assert rel(got[k], v) < (5e-3 if k in loose else 5e-4), f"{name}.{k}: {rel(got[k], v):.3e}"
+
+
+def test_comp_train_matches_reference_goldens(golden_dir):
+    """field_type "comp", training mode on the device: bg NeRF.query_field (flow, eikonal through the tangent kernel of the bg
+    basefield), compose_fields, the three renders, the comp losses and gradients wrt fg and bg weights vs the
+    reference-generated fixture (fp32)."""
+    from lab4d_amd import deformable as DF
+    g = torch.load(os.path.join(golden_dir, "comp_train.pt"), weights_only=False)
+    meta = g["meta"]
+    Pf = synthetic.make_weights(meta["seed"])
+    Pb = synthetic.make_bg_weights(meta["seed"])
+    Pb["sdf.bias"] = torch.tensor([meta["bg_sdf_bias"]])
+    Pf = {k: (v.to(DEV).clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v.to(DEV)) for k, v in Pf.items()}
+    Pb = {k: v.to(DEV).clone().requires_grad_(True) for k, v in Pb.items()}
+    frf = synthetic.add_codes(synthetic.to_device(dict(g["frames_fg"]), DEV), Pf)
+    batch = synthetic.to_device(g["batch"], DEV)
+    frf["feature"] = batch["feature"]
+    frb = synthetic.add_bg_codes(synthetic.to_device(dict(g["frames_bg"]), DEV), Pb)
+    rng = synthetic.to_device(g["rng"], DEV)
+    hxy = g["hxy"].to(DEV)
+    loose = ("vis", "eikonal")
+    fd_b, _, _ = DF.query_field_train_bg(Pb, frb, hxy, rng, flow_thresh=meta["flow_thresh"], n_depth=meta["D"])
+    assert sorted(fd_b.keys()) == sorted(g["bg_feat_dict"].keys())
+    for k, v in g["bg_feat_dict"].items():
+        assert rel(fd_b[k], v) < (5e-3 if k in loose else 5e-4), f"bg.{k}: {rel(fd_b[k], v):.3e}"
+    res = DF.render_train_comp(Pf, frf, Pb, frb, hxy, rng, flow_thresh=meta["flow_thresh"], n_depth=meta["D"])
+    for name, ref in (("rendered", g["rendered"]), ("fg", g["aux_fg"]), ("bg", g["aux_bg"])):
+        got = res["rendered"] if name == "rendered" else res["aux_dict"][name]
+        for k, v in ref.items():
+            assert rel(got[k], v) < (5e-3 if k in loose else 5e-4), f"{name}.{k}: {rel(got[k], v):.3e}"
+    losses = DF.losses_comp(res, batch, meta["res"], DF.DEFAULT_LOSS_WT)
+    for k, v in g["loss"].items():
+        assert rel(losses[k], v) < 2e-3, f"loss.{k}: {rel(losses[k], v):.3e}"
+    total = sum(losses.values())
+    names = list(g["grads"].keys())
+    grads = torch.autograd.grad(total, [(Pf if n.startswith("fg:") else Pb)[n[3:]] for n in names], allow_unused=True)
+    for n, gv in zip(names, grads):
+        ref = g["grads"][n]
+        assert gv is not None, n
+        e = rel(gv, ref["full"]) if "full" in ref else rel(gv.flatten()[:: ref["stride"]], ref["sub"])
+        assert e < 1e-2, f"grad {n}: {e:.3e}"
