@@ -205,3 +205,25 @@ def test_comp_train_matches_reference_goldens(golden_dir):
         assert gv is not None, n
         e = rel(gv, ref["full"]) if "full" in ref else rel(gv.flatten()[:: ref["stride"]], ref["sub"])
         assert e < 1e-2, f"grad {n}: {e:.3e}"
+
+
+def test_render_samples_dispatches_comp(golden_dir):
+    """model.render_samples with per-category samples_dict / parameters = dvr_model.render_samples for field_type "comp"."""
+    from lab4d_amd import deformable as DF, model
+    g = torch.load(os.path.join(golden_dir, "comp_eval.pt"), weights_only=False)
+    meta = g["meta"]
+    Pf = synthetic.to_device(synthetic.make_weights(meta["seed"], sdf_bias=meta["fg_sdf_bias"]), DEV)
+    Pb = synthetic.make_bg_weights(meta["seed"])
+    Pb["sdf.bias"] = torch.tensor([meta["bg_sdf_bias"]])
+    Pb = synthetic.to_device(Pb, DEV)
+    sf = synthetic.to_device(dict(g["frames_fg"]), DEV)
+    sb = synthetic.to_device(dict(g["frames_bg"]), DEV)
+    sf["hxy"] = sb["hxy"] = g["hxy"].to(DEV)
+    res = model.render_samples({"fg": Pf, "bg": Pb}, {"fg": sf, "bg": sb}, training=False, n_depth=meta["D"])
+    for k, v in g["rendered"].items():
+        assert rel(res["rendered"][k], v) < (5e-3 if k in ("vis", "eikonal", "normal") else 5e-4), k
+    assert set(res["aux_dict"].keys()) == {"fg", "bg"}
+    chunked = model.render_samples_chunk({"fg": Pf, "bg": Pb}, {"fg": sf, "bg": sb}, chunk_size=6, training=False, n_depth=meta["D"])
+    for k, v in res["rendered"].items():
+        if k != "vis":  # vis is normalised by the mean transmittance of the (chunk of) rays
+            assert rel(chunked["rendered"][k].cpu(), v.cpu()) < 1e-5, k
