@@ -285,3 +285,64 @@ def test_comp_train_against_reference(golden_dir):
         else:
             close(gv.flatten()[:: ref["stride"]], ref["sub"], "grad." + n, rtol=3e-3, atol=2e-4 * float(ref["sub"].abs().max()) + 1e-10)
             assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 2e-3 * float(ref["norm"]) + 1e-12, n
+
+
+# ---- per-frame pose / articulation path: oracle/pose_oracle.py vs tests/golden/pose.pt ------------------
+
+
+@pytest.fixture(scope="module")
+def pose(golden_dir):
+    return torch.load(os.path.join(golden_dir, "pose.pt"), weights_only=False)
+
+
+def _leaf(P):
+    return {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in P.items()}
+
+
+def test_pose_fk_ops(pose):
+    from oracle import pose_oracle as PO
+    fk, edges = pose["fk"], pose["skel"]["edges"]
+    so3, local, shift = fk["so3"].clone().requires_grad_(True), fk["local"].clone().requires_grad_(True), fk["shift"].clone().requires_grad_(True)
+    jr, jd = PO.fk_se3(local, so3, edges)
+    close(jr, fk["joints_dq"][0], "joint qr"); close(jd, fk["joints_dq"][1], "joint qd")
+    br, bd = PO.shift_joints_to_bones_dq((jr, jd), edges, shift=shift)
+    close(br, fk["bones_dq"][0], "bone qr"); close(bd, fk["bones_dq"][1], "bone qd")
+    c = fk["cot"]
+    gj = torch.autograd.grad((jr * c[0]).sum() + (jd * c[1]).sum(), [so3, local], retain_graph=True)
+    gb = torch.autograd.grad((br * c[2]).sum() + (bd * c[3]).sum(), [so3, local, shift])
+    for a, b, n in zip(gj + gb, fk["g_joints"] + fk["g_bones"], ["gj_so3", "gj_local", "gb_so3", "gb_local", "gb_shift"]):
+        close(a, b, n, rtol=2e-4, atol=2e-5 * float(b.abs().max()))
+
+
+def test_pose_articulation_skel(pose):
+    from oracle import pose_oracle as PO
+    P = _leaf({"art." + k: v for k, v in pose["art_state"].items()})
+    skel, info, fid, ref = pose["skel"], dict(pose["time_info"]), pose["frame_id"], pose["art"]
+    close(PO.time_embedding(P, "art.time_embedding", fid, info), ref["t_embed"], "t_embed")
+    close(PO.time_embedding_mean(P, "art.time_embedding", info), ref["t_embed_mean"], "t_embed_mean")
+    close(PO.articulation_so3(P, "art", ref["t_embed"]), ref["so3"], "so3")
+    close(PO.rel_rest_joints(P, "art", skel, info["raw_fid_to_vid"][fid]), ref["rel_rest_joints_inst"], "rel inst")
+    close(PO.rel_rest_joints(P, "art", skel), ref["rel_rest_joints_mean"], "rel mean")
+    (tr, td), (mr, md) = PO.articulation_skel_vals_and_mean(P, "art", skel, fid, info)
+    close(tr, ref["t"][0], "t qr"); close(td, ref["t"][1], "t qd"); close(mr, ref["mean"][0], "mean qr"); close(md, ref["mean"][1], "mean qd")
+    cot = pose["cot"]
+    ((tr * cot[0]).sum() + (td * cot[1]).sum() + (mr * cot[2]).sum() + (md * cot[3]).sum()).backward()
+    for k, g in ref["grads"].items():
+        close(P["art." + k].grad, g, "grad " + k, rtol=2e-4, atol=2e-5 * max(float(g.abs().max()), 1e-6))
+    # all frames (frame_id=None)
+    te = PO.time_embedding(P, "art.time_embedding", None, info)
+    qr, qd = PO.articulation_skel_forward(P, "art", skel, te, info["frame_to_vid"])
+    close(qr, ref["all_frames"][0], "all qr"); close(qd, ref["all_frames"][1], "all qd")
+
+
+def test_pose_camera(pose):
+    from oracle import pose_oracle as PO
+    P = _leaf({"cam." + k: v for k, v in pose["cam_state"].items()})
+    info, fid, ref = dict(pose["time_info"]), pose["frame_id"], pose["cam"]
+    q, t = PO.camera_vals(P, "cam", fid, info)
+    close(q, ref["quat"], "quat"); close(t, ref["trans"], "trans")
+    ((q * ref["cot"][0]).sum() + (t * ref["cot"][1]).sum()).backward()
+    for k, g in ref["grads"].items():
+        close(P["cam." + k].grad, g, "grad " + k, rtol=2e-4, atol=2e-5 * max(float(g.abs().max()), 1e-6))
+    qa, ta = PO.camera_vals(P, "cam", None, info)
+    close(qa, ref["all_frames"][0], "all quat"); close(ta, ref["all_frames"][1], "all trans")
