@@ -162,6 +162,13 @@ int lab4d_l2_normalize_backward(const float* x, const float* g, int S, int C, fl
  * ------------------------------------------------------------------------------------------ */
 #include "lab4d_skin.h"
 
+/* ------------------------------------------------------------------------------------------
+ * 6. Skeleton forward kinematics of the per-frame articulation path --
+ *    utils/skel_utils.py:50-145, utils/geom_utils.py:110-140, utils/quat_transform.py:468-532,
+ *    nnutils/pose.py:417-502.  See lab4d_pose.h.
+ * ------------------------------------------------------------------------------------------ */
+#include "lab4d_pose.h"
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,243 @@
+"""Host-side mirror of the per-frame pose / articulation path: lab4d/nnutils/pose.py
+(`CameraMLP.get_vals`, `ArticulationSkelMLP.forward / get_vals_and_mean`), lab4d/nnutils/embedding.py (`TimeEmbedding`),
+lab4d/nnutils/time.py (`TimeMLP`) and the forward kinematics of lab4d/utils/skel_utils.py.
+
+What is native: the kinematic tree -- bone lengths, `so3_to_exp_map`, `fk_se3`, `matrix_to_quaternion`,
+`shift_joints_to_bones_dq` and their adjoint -- is ONE gfx950 kernel each way (csrc/fk.hip, include/lab4d_pose.h) where
+the reference runs a 25-step Python loop.  The (M-row x 256) time MLPs in front of it are dense layers on M <= a few
+hundred rows and stay torch device GEMMs; the camera's quaternion product uses the library's quaternion_mul kernel.
+
+Weights: flat dict keyed by the reference's state_dict names under a prefix (e.g. "warp.articulation" / "camera_mlp").
+`info` holds TimeEmbedding's frame tables (embedding.py:153-175): frame_to_vid, frame_mapping, raw_fid_to_vid,
+raw_fid_to_vidlen, raw_fid_to_vstart, max_ts, num_freq_t.  `skel` = {"rest_joints" (B,3), "edges" {child: parent, 1-based,
+0 = root}, "symm_idx" [B]} = the buffers / attributes of ArticulationSkelMLP (pose.py:345-368).
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from .quaternion import quaternion_mul
+
+vp, ci = _lib.vp, _lib.ci
+_lib.register("lab4d_fk_forward", [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp])
+_lib.register("lab4d_fk_backward", [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp])
+_lib.register("lab4d_skel_bones_forward", [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp])
+_lib.register("lab4d_skel_bones_backward", [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp])
+
+_SKEL_CACHE = {}
+
+
+def skeleton_arrays(edges, B, device, symm_idx=None):
+    """`edges` ({child: parent}, 1-based, 0 = root, iteration order = the reference's visiting order, skel_utils.py:82) ->
+    int32 device arrays (order (B), parent (B), symm (B) or None)."""
+    key = (tuple(edges.items()), B, str(device), None if symm_idx is None else tuple(int(s) for s in symm_idx))
+    hit = _SKEL_CACHE.get(key)
+    if hit is None:
+        if len(edges) != B or sorted(edges.keys()) != list(range(1, B + 1)):
+            raise RuntimeError("skeleton: edges must name every joint 1..%d exactly once" % B)
+        order = torch.tensor([k - 1 for k in edges.keys()], dtype=torch.int32, device=device)
+        parent = torch.tensor([edges[k] - 1 for k in range(1, B + 1)], dtype=torch.int32, device=device)
+        symm = None if symm_idx is None else torch.tensor([int(s) for s in symm_idx], dtype=torch.int32, device=device)
+        hit = _SKEL_CACHE[key] = (order, parent, symm)
+    return hit
+
+
+class _Fk(Function):
+    """(so3 (R,B,3), local (R,B,3), shift (3)|None) -> dual quaternions ((R,B,4), (R,B,4)); bones: 0 = joints (fk_se3),
+    1 = bone centres (fk_se3 + shift_joints_to_bones_dq)."""
+
+    @staticmethod
+    def forward(ctx, so3, local, shift, order, parent, bones):
+        so3, local = so3.contiguous().float(), local.contiguous().float()
+        shift_c = None if shift is None else shift.contiguous().float()
+        _lib.require_device(so3, local, shift_c)
+        R, B = so3.shape[:2]
+        qr, qd = torch.empty(R, B, 4, device=so3.device), torch.empty(R, B, 4, device=so3.device)
+        _lib.check(_lib.lib().lab4d_fk_forward(_lib.ptr(so3), _lib.ptr(local), _lib.ptr(shift_c), _lib.ptr(order), _lib.ptr(parent), R, B,
+                                               int(bones), _lib.ptr(qr), _lib.ptr(qd), _lib.stream()), "fk_forward")
+        ctx.save_for_backward(so3, local, shift_c if shift_c is not None else so3.new_empty(0), order, parent)
+        ctx.meta = (int(bones), shift is not None)
+        return qr, qd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_qr, g_qd):
+        so3, local, shift, order, parent = ctx.saved_tensors
+        bones, has_shift = ctx.meta
+        R, B = so3.shape[:2]
+        g_qr, g_qd = g_qr.contiguous().float(), g_qd.contiguous().float()
+        g_so3, g_local = torch.empty_like(so3), torch.empty_like(local)
+        g_shift = torch.empty(R, 3, device=so3.device) if has_shift else None
+        _lib.check(_lib.lib().lab4d_fk_backward(_lib.ptr(so3), _lib.ptr(local), _lib.ptr(shift) if has_shift else None, _lib.ptr(order),
+                                                _lib.ptr(parent), _lib.ptr(g_qr), _lib.ptr(g_qd), R, B, bones, _lib.ptr(g_so3), _lib.ptr(g_local),
+                                                _lib.ptr(g_shift), _lib.stream()), "fk_backward")
+        return g_so3, g_local, (g_shift.sum(0) if has_shift else None), None, None, None
+
+
+def _rows(x, B, C):
+    return x.reshape(-1, B, C)
+
+
+def fk_se3(local_rest_joints, so3, edges):
+    """skel_utils.fk_se3(local_rest_joints, so3, edges, to_dq=True) (skel_utils.py:50-103): (..., B, 3) x2 ->
+    ((..., B, 4), (..., B, 4)) joint-to-object dual quaternions."""
+    B = so3.shape[-2]
+    order, parent, _ = skeleton_arrays(edges, B, so3.device)
+    qr, qd = _Fk.apply(_rows(so3, B, 3), _rows(local_rest_joints.expand_as(so3), B, 3), None, order, parent, 0)
+    return qr.reshape(so3.shape[:-1] + (4,)), qd.reshape(so3.shape[:-1] + (4,))
+
+
+def fk_bones(local_rest_joints, so3, edges, shift=None):
+    """shift_joints_to_bones_dq(fk_se3(local_rest_joints, so3, edges), edges, shift) (skel_utils.py:50-145) in one launch."""
+    B = so3.shape[-2]
+    order, parent, _ = skeleton_arrays(edges, B, so3.device)
+    qr, qd = _Fk.apply(_rows(so3, B, 3), _rows(local_rest_joints.expand_as(so3), B, 3), shift, order, parent, 1)
+    return qr.reshape(so3.shape[:-1] + (4,)), qd.reshape(so3.shape[:-1] + (4,))
+
+
+class _SkelBones(Function):
+    """(so3 (R,B,3), loglen (R,B), logscale (1), rest_local (B,3), shift (3)) -> bone dual quaternions."""
+
+    @staticmethod
+    def forward(ctx, so3, loglen, logscale, rest_local, shift, order, parent, symm):
+        so3, loglen = so3.contiguous().float(), loglen.contiguous().float()
+        logscale, rest_local, shift = logscale.contiguous().float(), rest_local.contiguous().float(), shift.contiguous().float()
+        _lib.require_device(so3, loglen, logscale, rest_local, shift)
+        R, B = so3.shape[:2]
+        qr, qd = torch.empty(R, B, 4, device=so3.device), torch.empty(R, B, 4, device=so3.device)
+        _lib.check(_lib.lib().lab4d_skel_bones_forward(_lib.ptr(so3), _lib.ptr(loglen), _lib.ptr(logscale), _lib.ptr(rest_local), _lib.ptr(shift),
+                                                       _lib.ptr(order), _lib.ptr(parent), _lib.ptr(symm), R, B, _lib.ptr(qr), _lib.ptr(qd),
+                                                       _lib.stream()), "skel_bones_forward")
+        ctx.save_for_backward(so3, loglen, logscale, rest_local, shift, order, parent, symm)
+        return qr, qd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_qr, g_qd):
+        so3, loglen, logscale, rest_local, shift, order, parent, symm = ctx.saved_tensors
+        R, B = so3.shape[:2]
+        g_qr, g_qd = g_qr.contiguous().float(), g_qd.contiguous().float()
+        g_so3, g_ll = torch.empty_like(so3), torch.empty_like(loglen)
+        g_ls, g_sh = torch.empty(R, device=so3.device), torch.empty(R, 3, device=so3.device)
+        _lib.check(_lib.lib().lab4d_skel_bones_backward(_lib.ptr(so3), _lib.ptr(loglen), _lib.ptr(logscale), _lib.ptr(rest_local), _lib.ptr(shift),
+                                                        _lib.ptr(order), _lib.ptr(parent), _lib.ptr(symm), _lib.ptr(g_qr), _lib.ptr(g_qd), R, B,
+                                                        _lib.ptr(g_so3), _lib.ptr(g_ll), _lib.ptr(g_ls), _lib.ptr(g_sh), _lib.stream()),
+                   "skel_bones_backward")
+        return g_so3, g_ll, g_ls.sum().reshape(logscale.shape), None, g_sh.sum(0), None, None, None
+
+
+def rest_joints_to_local(rest_joints, edges):
+    """skel_utils.rest_joints_to_local (skel_utils.py:35-47): child - parent for the edges whose parent is a joint."""
+    pairs = [(c - 1, p - 1) for c, p in edges.items() if p > 0]
+    idx = torch.tensor([c for c, _ in pairs], device=rest_joints.device)
+    par = torch.tensor([p for _, p in pairs], device=rest_joints.device)
+    local = rest_joints.clone()
+    local[idx] = rest_joints[idx] - rest_joints[par]
+    return local
+
+
+def skel_bones(so3, log_bone_len_inc, logscale, skel, shift):
+    """ArticulationSkelMLP.forward after the so3 head (pose.py:449-470): compute_rel_rest_joints (bone lengths
+    exp(inc + logscale), symmetrised) + fk_se3 + shift_joints_to_bones_dq.  so3 (R,B,3); log_bone_len_inc (R,B) or (1,B)."""
+    R, B = so3.shape[:2]
+    order, parent, symm = skeleton_arrays(skel["edges"], B, so3.device, skel["symm_idx"])
+    rest_local = rest_joints_to_local(skel["rest_joints"], skel["edges"])
+    return _SkelBones.apply(so3, log_bone_len_inc.expand(R, B), logscale, rest_local, shift, order, parent, symm)
+
+
+# ---- the per-frame modules around it ------------------------------------------------------------------------------------------
+
+
+def _linear(P, name, x):
+    return F.linear(x, P[name + ".weight"], P[name + ".bias"])
+
+
+def _fourier(t, n_freq):
+    """PosEmbedding(1, n_freq) (embedding.py:69-125) of a (M,1) time coordinate: [t, sin(2^k t), cos(2^k t)]_k."""
+    if n_freq <= 0:
+        return t
+    ang = t * (2.0 ** torch.arange(n_freq, device=t.device, dtype=t.dtype))
+    return torch.cat([t, torch.stack([torch.sin(ang), torch.cos(ang)], -1).reshape(t.shape[0], -1)], -1)
+
+
+def frame_tid(frame_id, info):
+    """embedding.py:177-184."""
+    fid = frame_id.long()
+    sub = frame_id - info["raw_fid_to_vstart"][fid]
+    return (sub - info["raw_fid_to_vidlen"][fid] / 2) / info["max_ts"] * 2 * info.get("time_scale", 1.0)
+
+
+def _vid_code(P, prefix, inst_id):
+    w = P[prefix + ".inst_embedding.mapping.weight"]
+    return w[torch.zeros_like(inst_id) if w.shape[0] == 1 else inst_id]
+
+
+def time_embedding(P, prefix, frame_id, info):
+    """TimeEmbedding.forward (embedding.py:194-217)."""
+    if frame_id is None:
+        inst_id, t = info["frame_to_vid"], frame_tid(info["frame_mapping"], info)
+    else:
+        inst_id, t = info["raw_fid_to_vid"][frame_id], frame_tid(frame_id, info)
+    coeff = _linear(P, prefix + ".mapping1", _fourier(t[:, None].float(), info["num_freq_t"]))
+    return _linear(P, prefix + ".mapping2", torch.cat([coeff, _vid_code(P, prefix, inst_id)], -1))
+
+
+def time_embedding_mean(P, prefix, info):
+    """TimeEmbedding.get_mean_embedding (embedding.py:219-227)."""
+    return time_embedding(P, prefix, info["frame_mapping"], info).mean(0, keepdim=True)
+
+
+def time_mlp(P, prefix, t_embed, D=5):
+    """TimeMLP.forward (time.py:65-73): D x (Linear + ReLU) + final Linear + ReLU."""
+    x = t_embed
+    for i in range(D):
+        x = F.relu(_linear(P, f"{prefix}.linear_{i+1}.0", x))
+    return F.relu(_linear(P, f"{prefix}.linear_final.0", x))
+
+
+def _head(P, prefix, x):
+    return _linear(P, prefix + ".2", F.relu(_linear(P, prefix + ".0", x)))
+
+
+def camera_vals(P, prefix, frame_id, info):
+    """CameraMLP.get_vals (pose.py:116-147) -> (quat (M,4), trans (M,3))."""
+    feat = time_mlp(P, prefix, time_embedding(P, prefix + ".time_embedding", frame_id, info))
+    quat = F.normalize(_head(P, prefix + ".quat", feat), dim=-1)
+    inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]
+    base = F.normalize(P[prefix + ".base_quat"][inst_id], dim=-1)
+    return quaternion_mul(quat, base), _head(P, prefix + ".trans", feat)
+
+
+def log_bone_len(P, prefix, inst_id, rows):
+    """CondMLP(num_inst, in_channels=0, D=2, W=64) (pose.py:381-388): the instance code alone; inst_id None -> mean code."""
+    w = P[prefix + ".inst_embedding.mapping.weight"]
+    x = w.mean(0).expand(rows, -1) if inst_id is None else w[torch.zeros_like(inst_id) if w.shape[0] == 1 else inst_id]
+    for i in range(2):
+        x = F.relu(_linear(P, f"{prefix}.linear_{i+1}.0", x))
+    return _linear(P, prefix + ".linear_final", x)
+
+
+def articulation_so3(P, prefix, t_embed):
+    """pose.py:442-447: joint angles (M,B,3)."""
+    return _head(P, prefix + ".so3", time_mlp(P, prefix, t_embed)).reshape(t_embed.shape[0], -1, 3)
+
+
+def articulation_skel_forward(P, prefix, skel, t_embed, inst_id):
+    """ArticulationSkelMLP.forward (pose.py:417-470) -> ((M,B,4), (M,B,4))."""
+    so3 = articulation_so3(P, prefix, t_embed)
+    ll = log_bone_len(P, prefix + ".log_bone_len", inst_id, so3.shape[0] if inst_id is not None else 1)
+    return skel_bones(so3, ll, P[prefix + ".logscale"], skel, P[prefix + ".shift"])
+
+
+def articulation_skel_vals_and_mean(P, prefix, skel, frame_id, info):
+    """ArticulationSkelMLP.get_vals_and_mean (pose.py:526-573): frames and rest pose in one batched FK launch."""
+    inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]
+    bs = inst_id.shape[0]
+    te = time_embedding(P, prefix + ".time_embedding", frame_id, info)
+    te_mean = time_embedding_mean(P, prefix + ".time_embedding", info).expand(bs, -1)
+    so3 = articulation_so3(P, prefix, torch.cat([te, te_mean], 0))
+    ll = torch.cat([log_bone_len(P, prefix + ".log_bone_len", inst_id, bs), log_bone_len(P, prefix + ".log_bone_len", None, 1).expand(bs, -1)], 0)
+    qr, qd = skel_bones(so3, ll, P[prefix + ".logscale"], skel, P[prefix + ".shift"])
+    return (qr[:bs], qd[:bs]), (qr[bs:], qd[bs:])

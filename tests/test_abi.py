@@ -39,6 +39,7 @@ def test_python_signatures_cover_the_header():
     import lab4d_amd.deformable  # noqa: F401  (registers the mlp / skinning / gauss-density signatures)
     import lab4d_amd.mlp  # noqa: F401
     import lab4d_amd.multifields  # noqa: F401
+    import lab4d_amd.pose  # noqa: F401
     import lab4d_amd.warping  # noqa: F401
     sig = set(_lib.SIGNATURES)
     hdr = set(declared_symbols()) - {"lab4d_last_error", "lab4d_version", "lab4d_arch"}
@@ -68,3 +69,20 @@ def test_ops_refuse_cpu_tensors():
     from lab4d_amd import quaternion
     with pytest.raises(RuntimeError, match="no CPU path"):
         quaternion.quaternion_mul(torch.randn(3, 4), torch.randn(3, 4))
+
+
+def test_fk_arguments_are_validated(so):
+    so.lab4d_last_error.restype = ctypes.c_char_p
+    buf = ctypes.create_string_buffer(64)
+    rc = so.lab4d_fk_forward(buf, buf, None, buf, buf, 1, 33, 0, buf, buf, None)
+    assert rc == -1 and b"B <= 32" in so.lab4d_last_error()
+    rc = so.lab4d_skel_bones_forward(buf, None, buf, buf, buf, buf, buf, buf, 1, 25, buf, buf, None)
+    assert rc == -1 and b"null" in so.lab4d_last_error()
+    assert so.lab4d_fk_forward(buf, buf, None, buf, buf, 0, 25, 0, buf, buf, None) == 0  # empty input: nothing to launch
+
+
+def test_pose_refuses_cpu_tensors():
+    import torch
+    from lab4d_amd import pose
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pose.fk_se3(torch.zeros(2, 3, 3), torch.zeros(2, 3, 3), {1: 0, 2: 1, 3: 2})

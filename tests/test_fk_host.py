@@ -1,0 +1,109 @@
+"""The row arithmetic of the skeleton-FK kernels (lab4d_amd/csrc/fk_math.hpp), compiled for the CPU with g++
+(tests/host_harness/fk_host.cpp) and held to the reference-generated fixture tests/golden/pose.pt and to the oracle.
+CPU only: this checks the math the gfx950 kernels execute without needing a GPU; tests/test_gpu_zpose.py runs the kernels."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F32 = ctypes.POINTER(ctypes.c_float)
+I32 = ctypes.POINTER(ctypes.c_int)
+
+
+@pytest.fixture(scope="module")
+def host():
+    out = os.path.join(ROOT, "tests", "host_harness", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "fk_host.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I", os.path.join(ROOT, "lab4d_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_harness", "fk_host.cpp"), "-o", so])
+    return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="module")
+def pose(golden_dir):
+    return torch.load(os.path.join(golden_dir, "pose.pt"), weights_only=False)
+
+
+def fp(a):
+    return a.ctypes.data_as(F32)
+
+
+def ip(a):
+    return a.ctypes.data_as(I32)
+
+
+def arr(t):
+    return np.ascontiguousarray(t.detach().numpy(), dtype=np.float32)
+
+
+def skel_arrays(edges, B):
+    order = np.asarray([k - 1 for k in edges.keys()], dtype=np.int32)
+    parent = np.full(B, -1, dtype=np.int32)
+    for k, p in edges.items():
+        parent[k - 1] = p - 1
+    return order, parent
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def test_fk_rows_match_the_reference(host, pose):
+    fk, edges = pose["fk"], pose["skel"]["edges"]
+    so3, local, shift = arr(fk["so3"]), arr(fk["local"]), arr(fk["shift"])
+    R, B = so3.shape[:2]
+    order, parent = skel_arrays(edges, B)
+    qr, qd = np.empty((R, B, 4), np.float32), np.empty((R, B, 4), np.float32)
+    host.fk_host_forward(fp(so3), fp(local), None, ip(order), ip(parent), R, B, 0, fp(qr), fp(qd))
+    assert relerr(qr, fk["joints_dq"][0]) < 1e-5 and relerr(qd, fk["joints_dq"][1]) < 1e-5
+    c = [arr(x) for x in fk["cot"]]
+    g_so3, g_loc, g_sh = np.empty_like(so3), np.empty_like(local), np.empty((R, 3), np.float32)
+    host.fk_host_backward(fp(so3), fp(local), None, ip(order), ip(parent), fp(c[0]), fp(c[1]), R, B, 0, fp(g_so3), fp(g_loc), fp(g_sh))
+    assert relerr(g_so3, fk["g_joints"][0]) < 1e-4 and relerr(g_loc, fk["g_joints"][1]) < 1e-4
+    # + shift_joints_to_bones_dq
+    host.fk_host_forward(fp(so3), fp(local), fp(shift), ip(order), ip(parent), R, B, 1, fp(qr), fp(qd))
+    assert relerr(qr, fk["bones_dq"][0]) < 1e-5 and relerr(qd, fk["bones_dq"][1]) < 1e-5
+    host.fk_host_backward(fp(so3), fp(local), fp(shift), ip(order), ip(parent), fp(c[2]), fp(c[3]), R, B, 1, fp(g_so3), fp(g_loc), fp(g_sh))
+    assert relerr(g_so3, fk["g_bones"][0]) < 1e-4 and relerr(g_loc, fk["g_bones"][1]) < 1e-4
+    assert relerr(g_sh.sum(0), fk["g_bones"][2]) < 1e-4
+
+
+def test_skel_rows_match_the_oracle(host, pose):
+    """Fused bone lengths + FK + bones against oracle.rel_rest_joints / fk_se3 / shift_joints_to_bones_dq, with gradients wrt
+    so3, the log bone lengths, logscale and shift; also an `edges` order in which a child is visited before its parent."""
+    from oracle import pose_oracle as PO
+    skel = pose["skel"]
+    B = skel["rest_joints"].shape[0]
+    g = torch.Generator().manual_seed(2)
+    R = 7
+    rest_local = PO.rest_joints_to_local(skel["rest_joints"], skel["edges"])
+    keys = list(skel["edges"].keys())
+    shuffled = dict((k, skel["edges"][k]) for k in [keys[i] for i in torch.randperm(len(keys), generator=g).tolist()])
+    for edges in (skel["edges"], shuffled):
+        so3 = (torch.randn(R, B, 3, generator=g) * 1.2).requires_grad_(True)
+        ll = (torch.randn(R, B, generator=g) * 0.3).requires_grad_(True)
+        ls = torch.tensor(-0.2, requires_grad=True)
+        shift = torch.tensor([0.03, -0.01, 0.02], requires_grad=True)
+        length = (ll + ls).exp()
+        length = (length + length[:, skel["symm_idx"]]) / 2
+        dq = PO.fk_se3(rest_local[None] * length[..., None], so3, edges)
+        br, bd = PO.shift_joints_to_bones_dq(dq, edges, shift=shift)
+        c0, c1 = torch.randn(R, B, 4, generator=g), torch.randn(R, B, 4, generator=g)
+        ref = torch.autograd.grad((br * c0).sum() + (bd * c1).sum(), [so3, ll, ls, shift])
+        order, parent = skel_arrays(edges, B)
+        symm = np.asarray(skel["symm_idx"], dtype=np.int32)
+        a_so3, a_ll, a_rest, a_sh = arr(so3), arr(ll), arr(rest_local), arr(shift)
+        qr, qd = np.empty((R, B, 4), np.float32), np.empty((R, B, 4), np.float32)
+        host.skel_host_forward(fp(a_so3), fp(a_ll), ctypes.c_float(float(ls.detach())), fp(a_rest), fp(a_sh), ip(order), ip(parent), ip(symm), R, B, fp(qr), fp(qd))
+        assert relerr(qr, br.detach()) < 1e-5 and relerr(qd, bd.detach()) < 1e-5
+        g_so3, g_ll, g_ls, g_sh = np.empty_like(a_so3), np.empty_like(a_ll), np.empty(R, np.float32), np.empty((R, 3), np.float32)
+        host.skel_host_backward(fp(a_so3), fp(a_ll), ctypes.c_float(float(ls.detach())), fp(a_rest), fp(a_sh), ip(order), ip(parent), ip(symm), fp(arr(c0)),
+                                fp(arr(c1)), R, B, fp(g_so3), fp(g_ll), fp(g_ls), fp(g_sh))
+        assert relerr(g_so3, ref[0]) < 1e-4 and relerr(g_ll, ref[1]) < 1e-4
+        assert relerr(g_ls.sum(), ref[2]) < 1e-4 and relerr(g_sh.sum(0), ref[3]) < 1e-4
