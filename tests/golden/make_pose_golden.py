@@ -103,6 +103,16 @@ def main():
     out["cam"] = {"quat": q.detach().clone(), "trans": t.detach().clone(), "cot": (cq, ct),
                   "all_frames": tuple(x.detach().clone() for x in cam.get_vals()),
                   "grads": {k: p.grad.clone() for k, p in cam.named_parameters() if p.grad is not None}}
+    # ---- the two priors of compute_reg_loss that live on these modules (engine/model.py:525-526) ----
+    art.zero_grad()
+    loss = art.skel_prior_loss()
+    loss.backward()
+    out["skel_prior"] = {"loss": loss.detach().clone(), "grads": {k: p.grad.clone() for k, p in art.named_parameters() if p.grad is not None}}
+    cam.zero_grad()
+    loss = cam.compute_distance_to_prior()
+    loss.backward()
+    out["cam_prior"] = {"loss": loss.detach().clone(), "init_vals": cam.init_vals.clone(),
+                        "grads": {k: p.grad.clone() for k, p in cam.named_parameters() if p.grad is not None}}
     path = os.path.join(HERE, "pose.pt")
     torch.save(out, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; matrix_to_quaternion branches:", out["fk"]["branch_hist"].tolist())

@@ -346,3 +346,65 @@ def test_pose_camera(pose):
         close(P["cam." + k].grad, g, "grad " + k, rtol=2e-4, atol=2e-5 * max(float(g.abs().max()), 1e-6))
     qa, ta = PO.camera_vals(P, "cam", None, info)
     close(qa, ref["all_frames"][0], "all quat"); close(ta, ref["all_frames"][1], "all trans")
+
+
+# ---- regularisation terms of compute_reg_loss: oracle/reg_oracle.py vs tests/golden/reg.pt ---------------
+
+
+def _expand_grad(g, ref, name):
+    if "full" in ref:
+        close(g, ref["full"], name, rtol=2e-4, atol=2e-5 * max(float(ref["full"].abs().max()), 1e-9))
+    else:
+        sub = g.flatten()[::ref["stride"]]
+        close(sub, ref["sub"], name, rtol=2e-4, atol=2e-5 * max(float(ref["sub"].abs().max()), 1e-9))
+        assert abs(float(g.double().norm()) - float(ref["norm"])) <= 2e-4 * float(ref["norm"]), name
+
+
+def test_reg_losses(golden_dir):
+    from oracle import reg_oracle as RO
+    fx = torch.load(os.path.join(golden_dir, "reg.pt"), weights_only=False)
+    P = synthetic.add_dense_weights(synthetic.make_weights(0, sdf_bias=fx["sdf_bias"]))
+    assert abs(sum(float(v.double().abs().sum()) for k, v in sorted(P.items()) if v.dtype.is_floating_point) - fx["weight_checksum"]) < 1e-6 * fx["weight_checksum"]
+    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v) for k, v in P.items()}
+    aabb = fx["aabb"]
+    # visibility decay
+    v = fx["vis"]
+    pts = RO.sample_points_aabb(aabb, v["u"], v["extend_factor"])
+    loss = RO.visibility_decay_loss(P, pts, P["vis_mlp.basefield.inst_embedding.mapping.weight"][v["inst_id"]])
+    close(loss, v["loss"], "vis loss")
+    for (k, ref), g in zip(v["grads"].items(), torch.autograd.grad(loss, [P[k] for k in v["grads"]])):
+        _expand_grad(g, ref, k)
+    # gauss / skin consistency
+    v = fx["gauss_skin"]
+    art = tuple(x.clone().requires_grad_(True) for x in v["rest_articulation_mean"])
+    pts = RO.sample_points_aabb(aabb, v["u"], v["extend_factor"])
+    loss = RO.gauss_skin_consistency_loss(P, pts, art, P["basefield.inst_embedding.mapping.weight"].mean(0, keepdim=True))
+    close(loss, v["loss"], "gauss_skin loss")
+    for a, b, n in zip(torch.autograd.grad(loss, list(art)), v["g_art"], ["g_qr", "g_qd"]):
+        close(a, b, n, rtol=2e-4, atol=2e-5 * float(b.abs().max()))
+    # soft deformation
+    v = fx["soft_deform"]
+    pts = RO.sample_points_aabb(aabb, v["u"], v["extend_factor"])
+    loss = RO.soft_deform_loss(P, pts, v["t_embed_dense"], P["warp.post_warp.forward_map.inst_embedding.mapping.weight"][v["inst_id"]],
+                               P["warp.post_warp.backward_map.inst_embedding.mapping.weight"][v["inst_id"]])
+    close(loss, v["loss"], "soft_deform loss", atol=1e-9)
+    for (k, ref), g in zip(v["grads"].items(), torch.autograd.grad(loss, [P[k] for k in v["grads"]])):
+        _expand_grad(g, ref, k)
+
+
+def test_reg_priors(pose):
+    from oracle import reg_oracle as RO
+    info = dict(pose["time_info"])
+    P = _leaf({"art." + k: v for k, v in pose["art_state"].items()})
+    loss = RO.skel_prior_loss(P, "art", info)
+    close(loss, pose["skel_prior"]["loss"], "skel_prior")
+    loss.backward()
+    for k, g in pose["skel_prior"]["grads"].items():
+        got = P["art." + k].grad
+        close(got if got is not None else torch.zeros_like(g), g, "grad " + k, rtol=2e-4, atol=2e-5 * max(float(g.abs().max()), 1e-6))
+    P = _leaf({"cam." + k: v for k, v in pose["cam_state"].items()})
+    loss = RO.cam_prior_loss(P, "cam", info, pose["cam_prior"]["init_vals"])
+    close(loss, pose["cam_prior"]["loss"], "cam_prior")
+    loss.backward()
+    for k, g in pose["cam_prior"]["grads"].items():
+        close(P["cam." + k].grad, g, "grad " + k, rtol=2e-4, atol=2e-5 * max(float(g.abs().max()), 1e-6))
