@@ -18,7 +18,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from .quaternion import quaternion_mul
+from .quat_utils import quaternion_mul
 
 vp, ci = _lib.vp, _lib.ci
 _lib.register("lab4d_fk_forward", [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp])
@@ -241,3 +241,29 @@ def articulation_skel_vals_and_mean(P, prefix, skel, frame_id, info):
     ll = torch.cat([log_bone_len(P, prefix + ".log_bone_len", inst_id, bs), log_bone_len(P, prefix + ".log_bone_len", None, 1).expand(bs, -1)], 0)
     qr, qd = skel_bones(so3, ll, P[prefix + ".logscale"], skel, P[prefix + ".shift"])
     return (qr[:bs], qd[:bs]), (qr[bs:], qd[bs:])
+
+
+def axis_angle_to_quaternion(aa):
+    """quat_transform.py:149-174."""
+    ang = aa.norm(dim=-1, keepdim=True)
+    k = torch.where(ang.abs() < 1e-6, 0.5 - ang * ang / 48, torch.sin(ang * 0.5) / ang)
+    return torch.cat([torch.cos(ang * 0.5), aa * k], -1)
+
+
+def articulation_flat_forward(P, prefix, t_embed):
+    """ArticulationFlatMLP.forward (pose.py:287-303), bag-of-bones motion ("bob"): ((M,B,4), (M,B,4)).  The dual part is
+    0.5 * (0,t) x q on the library's quaternion_mul kernel (3-vector operand = pure quaternion, quaternion.cu:46-57)."""
+    feat = time_mlp(P, prefix, t_embed)
+    trans = (_head(P, prefix + ".trans", feat) * 0.1).reshape(t_embed.shape[0], -1, 3)
+    qr = axis_angle_to_quaternion(_head(P, prefix + ".so3", feat).reshape(t_embed.shape[0], -1, 3))
+    return qr, 0.5 * quaternion_mul(trans, qr)
+
+
+def intrinsics_vals(P, prefix, frame_id, info):
+    """IntrinsicsMLP.get_vals (intrinsics.py:86-107) -> (M,4) [fx, fy, px, py].  `info`: the module's own TimeEmbedding tables
+    (num_freq_t = 0 and time_scale = 0.1 by default)."""
+    focal = _head(P, prefix + ".focal", time_mlp(P, prefix, time_embedding(P, prefix + ".time_embedding", frame_id, info))).exp()
+    inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]
+    focal = focal * P[prefix + ".base_logfocal"][inst_id].exp()
+    focal = (focal + focal.flip(-1)) / 2
+    return torch.cat([focal, P[prefix + ".base_ppoint"][inst_id].expand_as(focal)], -1)

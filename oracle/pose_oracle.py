@@ -223,3 +223,23 @@ def articulation_skel_vals_and_mean(P, prefix, skel, frame_id, info):
     rel = torch.cat([rel_rest_joints(P, prefix, skel, inst_id), rel_rest_joints(P, prefix, skel).expand(bs, -1, -1)], 0)
     qr, qd = articulation_skel_forward(P, prefix, skel, torch.cat([te, te_mean], 0), None, local_rest_joints=rel)
     return (qr[:bs], qd[:bs]), (qr[bs:], qd[bs:])
+
+
+def articulation_flat_forward(P, prefix, t_embed):
+    """ArticulationFlatMLP.forward (pose.py:287-303), bag-of-bones motion: per-bone translation (x 0.1, ScaleLayer) and axis-angle
+    heads on the time feature -> dual quaternions."""
+    feat = time_mlp(P, prefix, t_embed)
+    trans = (_head(P, f"{prefix}.trans", feat) * 0.1).reshape(t_embed.shape[:-1] + (-1, 3))
+    so3 = _head(P, f"{prefix}.so3", feat).reshape(t_embed.shape[:-1] + (-1, 3))
+    return quaternion_translation_to_dual_quaternion(axis_angle_to_quaternion(so3), trans)
+
+
+def intrinsics_vals(P, prefix, frame_id, info):
+    """IntrinsicsMLP.get_vals (intrinsics.py:86-107): (M,4) = [fx, fy, px, py]; focal = exp(head) * exp(base_logfocal[vid]),
+    averaged over x/y (square pixels); principal point = base_ppoint[vid].  info: the module's own TimeEmbedding tables
+    (num_freq_t = 0, time_scale = 0.1 by default)."""
+    focal = _head(P, f"{prefix}.focal", time_mlp(P, prefix, time_embedding(P, f"{prefix}.time_embedding", frame_id, info))).exp()
+    inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]
+    focal = focal * P[f"{prefix}.base_logfocal"][inst_id].exp()
+    focal = (focal + focal.flip(-1)) / 2
+    return torch.cat([focal, P[f"{prefix}.base_ppoint"][inst_id].expand_as(focal)], -1)

@@ -113,6 +113,33 @@ def main():
     loss.backward()
     out["cam_prior"] = {"loss": loss.detach().clone(), "init_vals": cam.init_vals.clone(),
                         "grads": {k: p.grad.clone() for k, p in cam.named_parameters() if p.grad is not None}}
+    # ---- bag-of-bones articulation (fg_motion "bob") and intrinsics ----
+    intrinsics_mod = importlib.import_module("lab4d.nnutils.intrinsics")
+    torch.manual_seed(7)
+    flat = pose.ArticulationFlatMLP(frame_info, 25, W=64)
+    with torch.no_grad():
+        flat.so3[2].weight.mul_(6.0)
+    out["flat_state"] = {k: v.clone() for k, v in flat.state_dict().items()}
+    flat.zero_grad()
+    fr_, fd_ = flat.get_vals(fid)
+    mr_, md_ = flat.get_mean_vals()
+    ((fr_ * cot[0]).sum() + (fd_ * cot[1]).sum() + (mr_ * cot[2][:1]).sum() + (md_ * cot[3][:1]).sum()).backward()
+    out["flat"] = {"t": (fr_.detach().clone(), fd_.detach().clone()), "mean": (mr_.detach().clone(), md_.detach().clone()),
+                   "grads": {k: p.grad.clone() for k, p in flat.named_parameters() if p.grad is not None}}
+    torch.manual_seed(9)
+    intr = intrinsics_mod.IntrinsicsMLP(np.tile(np.asarray([[64.0, 64.0, 32.0, 32.0]], dtype=np.float32), (T, 1)), frame_info=frame_info, W=64)
+    with torch.no_grad():
+        intr.base_logfocal.copy_(torch.tensor([[4.1, 4.2], [4.0, 3.9]]))
+        intr.base_ppoint.copy_(torch.tensor([[32.0, 31.0], [30.0, 33.0]]))
+    ti = intr.time_embedding
+    out["intr_state"] = {k: v.clone() for k, v in intr.state_dict().items()}
+    out["intr_time"] = {"num_freq_t": (ti.fourier_embedding.out_channels - 1) // 2, "time_scale": 0.1}
+    intr.zero_grad()
+    kv = intr.get_vals(fid)
+    ck = torch.randn(len(fid), 4, generator=g)
+    (kv * ck).sum().backward()
+    out["intr"] = {"vals": kv.detach().clone(), "cot": ck, "all_frames": intr.get_vals().detach().clone(),
+                   "grads": {k: p.grad.clone() for k, p in intr.named_parameters() if p.grad is not None}}
     path = os.path.join(HERE, "pose.pt")
     torch.save(out, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; matrix_to_quaternion branches:", out["fk"]["branch_hist"].tolist())

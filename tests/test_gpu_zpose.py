@@ -100,3 +100,25 @@ def test_fk_properties_at_scale(pose_fx):
     assert float((ident - torch.tensor([1.0, 0, 0, 0])).abs().max()) < 1e-6
     ref_r, ref_d = PO.shift_joints_to_bones_dq(PO.fk_se3(local.expand(R, B, 3)[:64], so3[:64], edges), edges, shift=shift)
     assert rel(qr[:64], ref_r) < 1e-5 and rel(qd[:64], ref_d) < 1e-5
+
+
+def test_flat_articulation_and_intrinsics_match_the_reference(pose_fx):
+    from lab4d_amd import pose
+    info, fid = dev_info(pose_fx["time_info"]), pose_fx["frame_id"].to(DEV)
+    cot = [x.to(DEV) for x in pose_fx["cot"]]
+    P = {"flat." + k: (v.to(DEV).requires_grad_(True) if v.dtype.is_floating_point else v.to(DEV)) for k, v in pose_fx["flat_state"].items()}
+    qr, qd = pose.articulation_flat_forward(P, "flat", pose.time_embedding(P, "flat.time_embedding", fid, info))
+    mr, md = pose.articulation_flat_forward(P, "flat", pose.time_embedding_mean(P, "flat.time_embedding", info))
+    for a, b in zip((qr, qd, mr, md), pose_fx["flat"]["t"] + pose_fx["flat"]["mean"]):
+        assert rel(a, b) < 1e-4
+    ((qr * cot[0]).sum() + (qd * cot[1]).sum() + (mr * cot[2][:1]).sum() + (md * cot[3][:1]).sum()).backward()
+    for k, g in pose_fx["flat"]["grads"].items():
+        assert rel(P["flat." + k].grad, g) < 3e-4, k
+    P = {"intr." + k: (v.to(DEV).requires_grad_(True) if v.dtype.is_floating_point else v.to(DEV)) for k, v in pose_fx["intr_state"].items()}
+    info_k = dict(info, **pose_fx["intr_time"])
+    kv = pose.intrinsics_vals(P, "intr", fid, info_k)
+    assert rel(kv, pose_fx["intr"]["vals"]) < 1e-4
+    (kv * pose_fx["intr"]["cot"].to(DEV)).sum().backward()
+    for k, g in pose_fx["intr"]["grads"].items():
+        assert rel(P["intr." + k].grad, g) < 3e-4, k
+    assert rel(pose.intrinsics_vals(P, "intr", None, info_k), pose_fx["intr"]["all_frames"]) < 1e-4

@@ -408,3 +408,24 @@ def test_reg_priors(pose):
     loss.backward()
     for k, g in pose["cam_prior"]["grads"].items():
         close(P["cam." + k].grad, g, "grad " + k, rtol=2e-4, atol=2e-5 * max(float(g.abs().max()), 1e-6))
+
+
+def test_pose_flat_articulation_and_intrinsics(pose):
+    from oracle import pose_oracle as PO
+    info, fid, cot = dict(pose["time_info"]), pose["frame_id"], pose["cot"]
+    P = _leaf({"flat." + k: v for k, v in pose["flat_state"].items()})
+    qr, qd = PO.articulation_flat_forward(P, "flat", PO.time_embedding(P, "flat.time_embedding", fid, info))
+    mr, md = PO.articulation_flat_forward(P, "flat", PO.time_embedding_mean(P, "flat.time_embedding", info))
+    for a, b, n in zip((qr, qd, mr, md), pose["flat"]["t"] + pose["flat"]["mean"], ["qr", "qd", "mr", "md"]):
+        close(a, b, "flat " + n)
+    ((qr * cot[0]).sum() + (qd * cot[1]).sum() + (mr * cot[2][:1]).sum() + (md * cot[3][:1]).sum()).backward()
+    for k, g in pose["flat"]["grads"].items():
+        close(P["flat." + k].grad, g, "grad " + k, rtol=2e-4, atol=2e-5 * max(float(g.abs().max()), 1e-6))
+    P = _leaf({"intr." + k: v for k, v in pose["intr_state"].items()})
+    info_k = dict(info, **pose["intr_time"])
+    kv = PO.intrinsics_vals(P, "intr", fid, info_k)
+    close(kv, pose["intr"]["vals"], "intrinsics")
+    (kv * pose["intr"]["cot"]).sum().backward()
+    for k, g in pose["intr"]["grads"].items():
+        close(P["intr." + k].grad, g, "grad " + k, rtol=2e-4, atol=2e-5 * max(float(g.abs().max()), 1e-6))
+    close(PO.intrinsics_vals(P, "intr", None, info_k), pose["intr"]["all_frames"], "intrinsics all")
