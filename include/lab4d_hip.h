@@ -169,6 +169,11 @@ int lab4d_l2_normalize_backward(const float* x, const float* g, int S, int C, fl
  * ------------------------------------------------------------------------------------------ */
 #include "lab4d_pose.h"
 
+/* ------------------------------------------------------------------------------------------
+ * 7. Optimizer step -- engine/trainer.py:164-190,350,581-604.  See lab4d_optim.h.
+ * ------------------------------------------------------------------------------------------ */
+#include "lab4d_optim.h"
+
 #ifdef __cplusplus
 }
 #endif

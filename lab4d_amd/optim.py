@@ -1,0 +1,83 @@
+"""Optimizer step on the gfx950 kernels of csrc/optim.hip (include/lab4d_optim.h): the reference's
+`torch.nn.utils.clip_grad_norm_` + `torch.optim.AdamW` over one group per parameter (lab4d/engine/trainer.py:164-190,350,
+581-604) as three launches over ONE flat fp32 buffer.
+
+`FlatAdamW(params, lr)` moves the parameters into a flat buffer (each padded to a multiple of 4 elements) and re-points
+`p.data` / `p.grad` at views of it, so autograd keeps accumulating into the flat gradient buffer and `flat_grad` is directly
+what a data-parallel job all-reduces (one RCCL call, no gather / scatter copies).
+"""
+import torch
+
+from . import _lib
+
+vp, ci, cf, i64 = _lib.vp, _lib.ci, _lib.cf, __import__("ctypes").c_int64
+_lib.register("lab4d_grad_norm_clip", [vp, i64, cf, vp, vp, vp, vp])
+_lib.register("lab4d_adamw_step", [vp, vp, vp, vp, i64, vp, vp, ci, cf, cf, cf, cf, ci, vp, vp])
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics (decoupled weight decay, bias-corrected moments) with one learning rate per parameter.
+
+    params: list of leaf tensors on one device; lr: float or one float per parameter (the reference's per-parameter
+    OneCycleLR rates; update with set_lr).  betas / eps / weight_decay default to the reference's (trainer.py:185-190)."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4):
+        self.params = list(params)
+        if not self.params:
+            raise RuntimeError("FlatAdamW: no parameters")
+        _lib.require_device(*[p.detach().contiguous() for p in self.params])
+        dev = self.params[0].device
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        ends, off = [], 0
+        self.offsets = []
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise RuntimeError("FlatAdamW: fp32 parameters only")
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+            ends.append(off)
+        self.n = off
+        self.flat = torch.zeros(off, device=dev)
+        self.flat_grad = torch.zeros(off, device=dev)
+        self.m = torch.zeros(off, device=dev)
+        self.v = torch.zeros(off, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat[o:o + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+        self.seg_end = torch.tensor(ends, dtype=torch.int64, device=dev)
+        self.seg_lr = torch.empty(len(ends), device=dev)
+        self.set_lr(lr)
+        self.work = torch.empty(512, device=dev)
+        self.norm = torch.zeros(1, device=dev)
+        self.coef = torch.ones(1, device=dev)
+        self.steps = 0
+
+    def set_lr(self, lr):
+        lrs = [float(lr)] * len(self.params) if not hasattr(lr, "__len__") else [float(x) for x in lr]
+        if len(lrs) != len(self.params):
+            raise RuntimeError("FlatAdamW: %d learning rates for %d parameters" % (len(lrs), len(self.params)))
+        self.seg_lr.copy_(torch.tensor(lrs), non_blocking=True)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def grad_norm_clip(self, max_norm):
+        """Global gradient norm and clip_grad_norm_'s coefficient, both left on the device (no host sync); returns the norm."""
+        _lib.check(_lib.lib().lab4d_grad_norm_clip(_lib.ptr(self.flat_grad), self.n, float(max_norm), _lib.ptr(self.work), _lib.ptr(self.norm),
+                                                   _lib.ptr(self.coef), _lib.stream()), "grad_norm_clip")
+        return self.norm
+
+    def step(self, max_norm=None):
+        """One AdamW step; with max_norm the gradients are scaled by min(1, max_norm / (norm + 1e-6)) inside the update."""
+        if max_norm is not None:
+            self.grad_norm_clip(max_norm)
+        self.steps += 1
+        _lib.check(_lib.lib().lab4d_adamw_step(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.m), _lib.ptr(self.v), self.n,
+                                               _lib.ptr(self.seg_end), _lib.ptr(self.seg_lr), len(self.params), self.betas[0], self.betas[1], self.eps,
+                                               self.weight_decay, self.steps, _lib.ptr(self.coef) if max_norm is not None else None, _lib.stream()),
+                   "adamw_step")
+        # the kernel wrote through raw pointers: tell autograd (and the packed-weight caches keyed on it) that the data changed
+        torch.autograd.graph.increment_version(self.params)
