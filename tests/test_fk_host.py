@@ -107,3 +107,49 @@ def test_skel_rows_match_the_oracle(host, pose):
                                 fp(arr(c1)), R, B, fp(g_so3), fp(g_ll), fp(g_ls), fp(g_sh))
         assert relerr(g_so3, ref[0]) < 1e-4 and relerr(g_ll, ref[1]) < 1e-4
         assert relerr(g_ls.sum(), ref[2]) < 1e-4 and relerr(g_sh.sum(0), ref[3]) < 1e-4
+
+
+def test_fk_rows_on_random_trees(host):
+    """hypothesis: random skeletons (1..32 joints, random parents, random visiting order incl. child-before-parent), random
+    angles incl. exact zeros: the row arithmetic equals the oracle's fk_se3 + shift_joints_to_bones_dq, forward and adjoint."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    from oracle import pose_oracle as PO
+
+    @given(st.integers(0, 10_000), st.integers(1, 32), st.booleans(), st.booleans())
+    @settings(max_examples=30, deadline=None)
+    def run(seed, B, topo, bones):
+        g = torch.Generator().manual_seed(seed)
+        parents = [0] + [int(torch.randint(0, j + 1, (1,), generator=g)) for j in range(1, B)]  # joint j+1 hangs off 0..j (0 = root)
+        keys = list(range(1, B + 1))
+        if not topo:
+            keys = [keys[i] for i in torch.randperm(B, generator=g).tolist()]
+        edges = {k: parents[k - 1] for k in keys}
+        R = 3
+        so3 = torch.randn(R, B, 3, generator=g) * 1.3
+        so3[0, ::3] = 0
+        local = torch.randn(R, B, 3, generator=g) * 0.1
+        shift = torch.randn(3, generator=g) * 0.05 if bones else None
+        so3_t, local_t = so3.clone().requires_grad_(True), local.clone().requires_grad_(True)
+        shift_t = shift.clone().requires_grad_(True) if bones else None
+        dq = PO.fk_se3(local_t, so3_t, edges)
+        if bones:
+            dq = PO.shift_joints_to_bones_dq(dq, edges, shift=shift_t)
+        c0, c1 = torch.randn(R, B, 4, generator=g), torch.randn(R, B, 4, generator=g)
+        ref = torch.autograd.grad((dq[0] * c0).sum() + (dq[1] * c1).sum(), [so3_t, local_t] + ([shift_t] if bones else []))
+        order, parent = skel_arrays(edges, B)
+        a_so3, a_loc = arr(so3), arr(local)
+        a_sh = arr(shift) if bones else None
+        qr, qd = np.empty((R, B, 4), np.float32), np.empty((R, B, 4), np.float32)
+        host.fk_host_forward(fp(a_so3), fp(a_loc), fp(a_sh) if bones else None, ip(order), ip(parent), R, B, int(bones), fp(qr), fp(qd))
+        assert np.allclose(qr, dq[0].detach().numpy(), atol=2e-5) and np.allclose(qd, dq[1].detach().numpy(), atol=2e-5)
+        g_so3, g_loc, g_sh = np.empty_like(a_so3), np.empty_like(a_loc), np.empty((R, 3), np.float32)
+        host.fk_host_backward(fp(a_so3), fp(a_loc), fp(a_sh) if bones else None, ip(order), ip(parent), fp(arr(c0)), fp(arr(c1)), R, B, int(bones),
+                              fp(g_so3), fp(g_loc), fp(g_sh))
+        scale = max(1.0, float(ref[0].abs().max()))
+        assert np.allclose(g_so3, ref[0].numpy(), atol=3e-4 * scale), float(np.abs(g_so3 - ref[0].numpy()).max())
+        assert np.allclose(g_loc, ref[1].numpy(), atol=3e-4 * max(1.0, float(ref[1].abs().max())))
+        if bones:
+            assert np.allclose(g_sh.sum(0), ref[2].numpy(), atol=3e-4 * max(1.0, float(ref[2].abs().max())))
+
+    run()
