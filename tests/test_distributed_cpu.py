@@ -11,9 +11,12 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the sharding / all-reduce helpers of the real bench, not a copy)
+
+
 def bands(res, world):
-    rows = res // world
-    return [(r * rows, (r + 1) * rows if r < world - 1 else res) for r in range(world)]
+    return [bench.row_band(r, world, res) for r in range(world)]
 
 
 def test_row_bands_partition_the_frame():
@@ -34,11 +37,11 @@ def _worker(rank, world, port, q):
     x_all = torch.randn(64, 3, generator=g)
     r0, r1 = bands(64, world)[rank]
     loss = (O.pos_embedding(x_all[r0:r1], 10) @ W.t()).pow(2).mean()   # per-rank normaliser (DDP semantics)
+    b = torch.randn(5, requires_grad=True)              # a second parameter: the flat buffer must be split back correctly
+    loss = loss + (b * (rank + 1)).sum()
     loss.backward()
-    flat = W.grad.reshape(-1).clone()
-    dist.all_reduce(flat)
-    flat /= world
-    q.put((rank, flat))
+    bench.allreduce_grads([W, b], world)
+    q.put((rank, torch.cat([W.grad.reshape(-1), b.grad])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,4 +63,5 @@ def test_gradient_allreduce_matches_single_process():
     x_all = torch.randn(64, 3, generator=g)
     # equal band sizes -> mean of per-band means == global mean
     (O.pos_embedding(x_all, 10) @ W.t()).pow(2).mean().backward()
-    assert torch.allclose(res[0], W.grad.reshape(-1), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(res[0][:-5], W.grad.reshape(-1), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(res[0][-5:], torch.full((5,), 1.5))  # mean over ranks of d/db sum(b * (rank + 1)) = (1 + 2) / 2
