@@ -1,0 +1,22 @@
+/*
+ * lab4d_hashgrid.h -- multiresolution hash encoding (included by lab4d_hip.h).
+ *
+ * BASELINE.json config 5 ("hash-grid (instant-NGP) encoding variant") names it; the reference has NO implementation
+ * (lab4d/nnutils/nerf.py:98 is a TODO), so there is no reference interface to replace: the definition follows
+ * Mueller et al. 2022, section 3 (restated in lab4d_amd/csrc/hashgrid_math.hpp and oracle/hashgrid_oracle.py) and its parity
+ * against the reference is UNPINNED.  It would sit where PosEmbedding does (nnutils/embedding.py:69-125) in front of the basefield.
+ *
+ * x: (S,3) in [0,1]^3 (clamped); table: (L, 2^log2_T, F) fp32; res: (L) int32 grid resolutions (host-computed
+ * floor(N_min * b^l)); out: (S, L*F) level-major.  L <= 32, F <= 8, 4 <= log2_T <= 24.
+ */
+#ifndef LAB4D_HASHGRID_H
+#define LAB4D_HASHGRID_H
+
+int lab4d_hashgrid_forward(const float* x, const float* table, const int32_t* res, int S, int L, int log2_T, int F, float* out,
+                           void* stream);
+/* g_out (S, L*F) -> g_table (L, 2^log2_T, F) ACCUMULATED with fp32 atomics (zero-fill first; may be NULL) and g_x (S,3) written
+ * (may be NULL; the trilinear weights' derivative, piecewise constant in x). */
+int lab4d_hashgrid_backward(const float* x, const float* table, const int32_t* res, const float* g_out, int S, int L, int log2_T, int F,
+                            float* g_table, float* g_x, void* stream);
+
+#endif /* LAB4D_HASHGRID_H */

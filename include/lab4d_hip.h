@@ -174,6 +174,11 @@ int lab4d_l2_normalize_backward(const float* x, const float* g, int S, int C, fl
  * ------------------------------------------------------------------------------------------ */
 #include "lab4d_optim.h"
 
+/* ------------------------------------------------------------------------------------------
+ * 8. Multiresolution hash encoding (BASELINE config 5; not in the reference, parity unpinned).  See lab4d_hashgrid.h.
+ * ------------------------------------------------------------------------------------------ */
+#include "lab4d_hashgrid.h"
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,84 @@
+// Multiresolution hash encoding (Mueller et al., "Instant Neural Graphics Primitives", 2022, section 3), one sample at a time.
+// BASELINE config 5 names this encoding; the reference has none (lab4d/nnutils/nerf.py:98 is a TODO), so the
+// definition below is this repository's restatement of the paper and its parity is UNPINNED against the reference:
+//   level l has grid resolution res[l] (host-computed floor(N_min * b^l), b = exp((ln N_max - ln N_min) / (L - 1)));
+//   x in [0,1]^3 is scaled by res, the 8 surrounding vertices are looked up -- 1:1 when (res+1)^3 <= T, otherwise through the
+//   spatial hash  (ix * 1) ^ (iy * 2654435761) ^ (iz * 805459861)  mod T  (paper eq. 4) -- and blended tri-linearly;
+//   F features per level, output (L * F) level-major.  Table layout (L, T, F) fp32.
+// Plain C++ (LAB4D_HD convention of fk_math.hpp): the CPU suite builds this header with g++ and holds it to
+// oracle/hashgrid_oracle.py; the kernels of hashgrid.hip call the same functions.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LAB4D_HD __host__ __device__ inline
+#else
+#define LAB4D_HD inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LAB4D_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
+#else
+#define LAB4D_ATOMIC_ADD(ptr, v) (*(ptr) += (v))
+#endif
+
+namespace lab4d_hash {
+
+constexpr int MAXF = 8;
+
+LAB4D_HD uint32_t vertex_index(uint32_t ix, uint32_t iy, uint32_t iz, int res, int log2_T) {
+    const uint64_t n = (uint64_t)res + 1, T = (uint64_t)1 << log2_T;
+    if (n * n * n <= T) return (uint32_t)(ix + n * (iy + n * iz));
+    return (ix ^ (iy * 2654435761u) ^ (iz * 805459861u)) & (uint32_t)(T - 1);
+}
+
+// cell origin and fractional position of x (clamped to [0,1]) at resolution res; x == 1 lands in the last cell with w = 1
+LAB4D_HD void cell_of(const float* x, int res, uint32_t* i0, float* w) {
+    for (int a = 0; a < 3; ++a) {
+        const float xc = fminf(fmaxf(x[a], 0.f), 1.f);
+        const float p = xc * (float)res;
+        float f = floorf(p);
+        if (f > (float)(res - 1)) f = (float)(res - 1);
+        i0[a] = (uint32_t)f;
+        w[a] = p - f;
+    }
+}
+
+// out[f] = sum over the 8 vertices of weight * table[vertex][f]
+LAB4D_HD void encode_level(const float* x, const float* tab, int res, int log2_T, int F, float* out) {
+    uint32_t i0[3];
+    float w[3];
+    cell_of(x, res, i0, w);
+    for (int f = 0; f < F; ++f) out[f] = 0.f;
+    for (int c = 0; c < 8; ++c) {
+        const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+        const float wt = (dx ? w[0] : 1.f - w[0]) * (dy ? w[1] : 1.f - w[1]) * (dz ? w[2] : 1.f - w[2]);
+        const float* e = tab + (size_t)vertex_index(i0[0] + dx, i0[1] + dy, i0[2] + dz, res, log2_T) * F;
+        for (int f = 0; f < F; ++f) out[f] += wt * e[f];
+    }
+}
+
+// adjoint: g_tab[vertex][f] += weight * g[f] (atomic on the device); gx[a] += d out / d x_a . g  (gx may be null)
+LAB4D_HD void encode_level_bwd(const float* x, const float* tab, int res, int log2_T, int F, const float* g, float* g_tab, float* gx) {
+    uint32_t i0[3];
+    float w[3];
+    cell_of(x, res, i0, w);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < 8; ++c) {
+        const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+        const float wx = dx ? w[0] : 1.f - w[0], wy = dy ? w[1] : 1.f - w[1], wz = dz ? w[2] : 1.f - w[2];
+        const size_t v = (size_t)vertex_index(i0[0] + dx, i0[1] + dy, i0[2] + dz, res, log2_T) * F;
+        float dot = 0.f;
+        for (int f = 0; f < F; ++f) {
+            if (g_tab) LAB4D_ATOMIC_ADD(g_tab + v + f, wx * wy * wz * g[f]);
+            dot += tab[v + f] * g[f];
+        }
+        acc[0] += (dx ? 1.f : -1.f) * wy * wz * dot;
+        acc[1] += wx * (dy ? 1.f : -1.f) * wz * dot;
+        acc[2] += wx * wy * (dz ? 1.f : -1.f) * dot;
+    }
+    if (gx)
+        for (int a = 0; a < 3; ++a) gx[a] += acc[a] * (float)res;
+}
+
+}  // namespace lab4d_hash

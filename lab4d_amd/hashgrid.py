@@ -1,0 +1,58 @@
+"""Multiresolution hash encoding (Mueller et al. 2022) on the gfx950 kernels of csrc/hashgrid.hip -- BASELINE config 5's
+encoding variant.  The reference has no such module (lab4d/nnutils/nerf.py:98 is a TODO), so this mirrors no reference
+interface; it is shaped like `PosEmbedding.forward` (embedding.py:69-125: (..., 3) -> (..., C)) so that it can stand in front of
+a basefield.  Parity is unpinned against the reference; the arithmetic is checked against oracle/hashgrid_oracle.py.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+vp, ci = _lib.vp, _lib.ci
+_lib.register("lab4d_hashgrid_forward", [vp, vp, vp, ci, ci, ci, ci, vp, vp])
+_lib.register("lab4d_hashgrid_backward", [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp])
+
+
+def level_resolutions(L, n_min, n_max):
+    """N_l = floor(N_min * b^l), b = exp((ln N_max - ln N_min) / (L - 1))  (paper eq. 2-3)."""
+    b = math.exp((math.log(n_max) - math.log(n_min)) / (L - 1)) if L > 1 else 1.0
+    return [int(math.floor(n_min * b ** l + 1e-9)) for l in range(L)]
+
+
+class _HashEncode(Function):
+    @staticmethod
+    def forward(ctx, x, table, res, log2_T):
+        x, table = x.contiguous().float(), table.contiguous().float()
+        _lib.require_device(x, table, res)
+        S, (L, T, F) = x.shape[0], table.shape
+        if T != 1 << log2_T or res.numel() != L:
+            raise RuntimeError("hash_encode: table must be (L, 2^log2_T, F) with one resolution per level")
+        out = torch.empty(S, L * F, device=x.device)
+        _lib.check(_lib.lib().lab4d_hashgrid_forward(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), S, L, log2_T, F, _lib.ptr(out), _lib.stream()),
+                   "hashgrid_forward")
+        ctx.save_for_backward(x, table, res)
+        ctx.log2_T = log2_T
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, table, res = ctx.saved_tensors
+        S, (L, T, F) = x.shape[0], table.shape
+        g = g.contiguous().float()
+        g_table = torch.zeros_like(table) if ctx.needs_input_grad[1] else None
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if g_table is None and g_x is None:
+            return None, None, None, None
+        _lib.check(_lib.lib().lab4d_hashgrid_backward(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), _lib.ptr(g), S, L, ctx.log2_T, F, _lib.ptr(g_table),
+                                                      _lib.ptr(g_x), _lib.stream()), "hashgrid_backward")
+        return g_x, g_table, None, None
+
+
+def hash_encode(x, table, res, log2_T):
+    """x (..., 3) in [0,1]^3, table (L, 2^log2_T, F), res: int32 device tensor (L) from level_resolutions -> (..., L*F)."""
+    out = _HashEncode.apply(x.reshape(-1, 3), table, res, log2_T)
+    return out.view(x.shape[:-1] + (out.shape[-1],))
