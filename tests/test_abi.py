@@ -88,3 +88,30 @@ def test_pose_refuses_cpu_tensors():
     from lab4d_amd import pose
     with pytest.raises(RuntimeError, match="no CPU path"):
         pose.fk_se3(torch.zeros(2, 3, 3), torch.zeros(2, 3, 3), {1: 0, 2: 1, 3: 2})
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it."""
+    import ast
+    pkg = os.path.join(ROOT, "lab4d_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, f)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
+    # bench.py: the oracle is imported inside cpu_baseline() only
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+        assert uses == (fn.name == "cpu_baseline"), fn.name
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in tree.body)
