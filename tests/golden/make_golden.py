@@ -35,10 +35,15 @@ def compress_grad(g):
     return {"norm": g.double().norm().float(), "stride": stride, "sub": g.flatten()[::stride].clone()}
 
 
-def build_reference_field(ns, P):
+def build_reference_field(ns, P, num_inst=1):
     torch.manual_seed(0)
     di = ref_shim.synthetic_data_info(64)
-    f = ns.deformable.Deformable("skel-quad", di, num_freq_dir=-1, appr_channels=32, num_inst=1, init_scale=0.2)
+    if num_inst > 1:  # one video per instance: the skinning / time modules size their tables from frame_info (skinning.py:70-86)
+        import numpy as np
+        off = np.asarray([round(64 * i / num_inst) for i in range(num_inst + 1)])
+        di["frame_info"]["frame_offset"] = off
+        di["frame_info"]["frame_offset_raw"] = off.copy()
+    f = ns.deformable.Deformable("skel-quad", di, num_freq_dir=-1, appr_channels=32, num_inst=num_inst, init_scale=0.2)
     f.category = "fg"
     sd = {k: v for k, v in P.items() if k in f.state_dict()}
     missing = [k for k in P if k not in f.state_dict() and k != "warp.skinning_model.symm_idx"]
@@ -82,13 +87,19 @@ def leafify(fr, names):
     return out, leaves
 
 
-def gen_train(ns, tag, M, N, D, res, seed, alpha=None):
-    P = synthetic.make_weights(seed)
-    f = build_reference_field(ns, P)
+def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None, frame_id=None):
+    """num_inst > 1 / inst_id: the multi-instance configuration (BASELINE config 4): per-instance codes in every CondMLP
+    (base.py:123-150), frames of one pair share their video's instance id."""
+    P = synthetic.make_weights(seed, num_inst=num_inst)
+    f = build_reference_field(ns, P, num_inst)
     f.train()
     f.pos_embedding.set_alpha(alpha)
     f.pos_embedding_color.set_alpha(alpha)
     fr = synthetic.make_frames(seed + 1, M, res)
+    if inst_id is not None:
+        fr["inst_id"] = torch.tensor(inst_id, dtype=torch.long)
+    if frame_id is not None:
+        fr["frame_id"] = torch.tensor(frame_id, dtype=torch.long)
     fr = frames_from_reference(f, fr)
     g = torch.Generator().manual_seed(seed + 2)
     hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
@@ -135,7 +146,7 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None):
         if gv is not None:
             gd[k] = compress_grad(gv.detach())
     out = {
-        "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "alpha": alpha,
+        "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "alpha": alpha, "num_inst": num_inst,
                  "weight_checksum": weight_checksum(P), "flow_thresh": float(res)},
         "frames": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in fr.items()},
         "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds, "match_perm": match_perm},
@@ -471,6 +482,7 @@ if __name__ == "__main__":
     gen_ops(ns)
     gen_train(ns, "small", M=2, N=6, D=8, res=64, seed=11)
     gen_train(ns, "alpha", M=4, N=5, D=6, res=64, seed=21, alpha=0.45)
+    gen_train(ns, "multi", M=4, N=5, D=6, res=64, seed=31, num_inst=3, inst_id=[1, 1, 2, 2], frame_id=[22, 23, 44, 45])
     gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)
     gen_comp_warp(ns)
     gen_bg_field(ns)

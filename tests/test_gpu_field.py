@@ -19,7 +19,7 @@ def rel(a, b):
 
 def load_case(golden_dir, name):
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
-    P = synthetic.make_weights(g["meta"]["seed"], sdf_bias=g["meta"].get("sdf_bias"))
+    P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"))
     return g, P
 
 
@@ -75,6 +75,14 @@ def test_training_graph_matches_reference_goldens(golden_dir, case):
             e = rel(gv.flatten()[:: ref["stride"]], ref["sub"])
         worst = max(worst, e)
         assert e < 5e-3, f"grad {k}: {e:.3e}"
+
+
+@pytest.mark.skipif(not os.environ.get("LAB4D_RUN_UNVALIDATED"), reason="fixture added after round 1's GPU budget was spent (set LAB4D_RUN_UNVALIDATED=1)")
+def test_training_graph_multi_instance(golden_dir):
+    """BASELINE config 4's shape: 3 instances, two frame pairs from different videos, per-instance codes in every CondMLP.  The
+    oracle is pinned to this reference-generated fixture on the CPU (tests/test_oracle_golden.py); the device run is opt-in
+    until it has passed once on hardware."""
+    test_training_graph_matches_reference_goldens(golden_dir, "train_multi.pt")
 
 
 def test_bf16_training_graph_is_close_to_fp32(golden_dir):

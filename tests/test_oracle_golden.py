@@ -88,15 +88,16 @@ def test_compose_fields(ops):
 
 def _load_case(golden_dir, name):
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
-    P = synthetic.make_weights(g["meta"]["seed"], sdf_bias=g["meta"].get("sdf_bias"))
+    P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"))
     chk = float(sum(v.double().abs().sum() for k, v in sorted(P.items()) if v.dtype.is_floating_point))
     assert abs(chk - g["meta"]["weight_checksum"]) < 1e-6 * chk, "synthetic weights differ from the generator's"
     fr = synthetic.add_codes(dict(g["frames"]), P)
     return g, P, fr
 
 
-@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt"])
+@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_multi.pt"])
 def test_training_graph_against_reference(golden_dir, case):
+    """train_multi: BASELINE config 4's shape -- 3 instances, two frame pairs from different videos, per-instance codes."""
     g, P, fr = _load_case(golden_dir, case)
     meta = g["meta"]
     P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v) for k, v in P.items()}
