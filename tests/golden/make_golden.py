@@ -87,7 +87,7 @@ def leafify(fr, names):
     return out, leaves
 
 
-def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None, frame_id=None):
+def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None, frame_id=None, full_grid_stride=None):
     """num_inst > 1 / inst_id: the multi-instance configuration (BASELINE config 4): per-instance codes in every CondMLP
     (base.py:123-150), frames of one pair share their video's instance id."""
     P = synthetic.make_weights(seed, num_inst=num_inst)
@@ -102,7 +102,11 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
         fr["frame_id"] = torch.tensor(frame_id, dtype=torch.long)
     fr = frames_from_reference(f, fr)
     g = torch.Generator().manual_seed(seed + 2)
-    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
+    if full_grid_stride:  # BASELINE config 0: the whole res x res crop of every frame; only every stride-th ray is stored
+        hxy = synthetic.make_rays(res, M)
+        N = hxy.shape[1]
+    else:
+        hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
     batch = synthetic.make_targets(seed + 3, M, N, res, hxy)
     eik_n = max(M * N // 16, 1)
     eik_inds = torch.randperm(M * N, generator=g)[:eik_n]
@@ -149,12 +153,19 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
         "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "alpha": alpha, "num_inst": num_inst,
                  "weight_checksum": weight_checksum(P), "flow_thresh": float(res)},
         "frames": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in fr.items()},
-        "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds, "match_perm": match_perm},
+        "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds.clone(), "match_perm": match_perm.clone()},
         "feat_dict": {k: v.detach() for k, v in feat_dict.items()}, "deltas": deltas.detach(),
         "rendered": {k: v.detach() for k, v in results["rendered"].items()},
         "aux_fg": {k: v.detach() for k, v in aux_fg.items()},
         "loss": {k: v.detach() for k, v in loss_dict.items()}, "grads": gd,
     }
+    if full_grid_stride:  # compact fixture: inputs are regenerated from the seeds by the tests (make_rays / make_targets)
+        st = full_grid_stride
+        out["meta"]["full_grid_stride"] = st
+        for k in ("hxy", "batch", "feat_dict", "deltas"):
+            out.pop(k)
+        out["rendered"] = {k: v[:, ::st].clone() for k, v in out["rendered"].items()}
+        out["aux_fg"] = {k: (v[:, ::st].clone() if v.dim() >= 2 and v.shape[1] == N else v) for k, v in out["aux_fg"].items()}
     path = os.path.join(HERE, f"train_{tag}.pt")
     torch.save(out, path)
     print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", {k: float(v) for k, v in loss_dict.items()})
@@ -416,7 +427,11 @@ def gen_comp_train(ns):
     b.train()
     frb = synthetic.make_bg_frames(seed + 3, M, res)
     g = torch.Generator().manual_seed(seed + 2)
-    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
+    if full_grid_stride:  # BASELINE config 0: the whole res x res crop of every frame; only every stride-th ray is stored
+        hxy = synthetic.make_rays(res, M)
+        N = hxy.shape[1]
+    else:
+        hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
     batch = synthetic.make_targets(seed + 3, M, N, res, hxy)
     eik_inds = torch.randperm(M * N, generator=g)[: max(M * N // 16, 1)]
     match_perm = torch.randperm(M * N * D, generator=g)[: min(1024, M * N * D)]
@@ -483,6 +498,7 @@ if __name__ == "__main__":
     gen_train(ns, "small", M=2, N=6, D=8, res=64, seed=11)
     gen_train(ns, "alpha", M=4, N=5, D=6, res=64, seed=21, alpha=0.45)
     gen_train(ns, "multi", M=4, N=5, D=6, res=64, seed=31, num_inst=3, inst_id=[1, 1, 2, 2], frame_id=[22, 23, 44, 45])
+    gen_train(ns, "c1", M=2, N=None, D=64, res=64, seed=41, full_grid_stride=16)  # BASELINE config 0: 64x64 crop x 64 samples
     gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)
     gen_comp_warp(ns)
     gen_bg_field(ns)

@@ -430,3 +430,35 @@ def test_pose_flat_articulation_and_intrinsics(pose):
     for k, g in pose["intr"]["grads"].items():
         close(P["intr." + k].grad, g, "grad " + k, rtol=2e-4, atol=2e-5 * max(float(g.abs().max()), 1e-6))
     close(PO.intrinsics_vals(P, "intr", None, info_k), pose["intr"]["all_frames"], "intrinsics all")
+
+
+def test_training_graph_at_baseline_config0_size(golden_dir):
+    """BASELINE.json configs[0]: the full 64x64 crop of a frame pair x 64 samples/ray (8,192 rays, 524,288 samples) through the whole
+    training graph.  The fixture (reference-generated) stores every 16th ray of the render, the losses and compressed gradients;
+    rays and targets are regenerated from the seeds.  ~1 minute on 8 cores."""
+    g = torch.load(os.path.join(golden_dir, "train_c1.pt"), weights_only=False)
+    meta = g["meta"]
+    st, M, res, seed = meta["full_grid_stride"], meta["M"], meta["res"], meta["seed"]
+    P = synthetic.make_weights(seed)
+    assert abs(sum(float(v.double().abs().sum()) for k, v in sorted(P.items()) if v.dtype.is_floating_point) - meta["weight_checksum"]) < 1e-6 * meta["weight_checksum"]
+    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v) for k, v in P.items()}
+    hxy = synthetic.make_rays(res, M)
+    batch = synthetic.make_targets(seed + 3, M, hxy.shape[1], res, hxy)
+    fr = synthetic.add_codes(dict(g["frames"]), P)
+    fr["feature"] = batch["feature"]
+    out = O.render_train(P, fr, hxy, g["rng"], flow_thresh=meta["flow_thresh"], n_depth=meta["D"], alpha=meta["alpha"])
+    for k, v in g["rendered"].items():
+        close(out["rendered"][k][:, ::st], v, "rendered." + k, rtol=2e-4)
+    losses = O.recon_losses_fg(out, batch, res, O.DEFAULT_LOSS_WT)
+    for k, v in g["loss"].items():
+        close(losses[k], v, "loss." + k, rtol=2e-4)
+    names = [k for k in g["grads"] if not k.startswith("frame:")]
+    grads = torch.autograd.grad(sum(losses.values()), [P[k] for k in names], allow_unused=True)
+    for k, gv in zip(names, grads):
+        ref = g["grads"][k]
+        assert gv is not None, k
+        if "full" in ref:
+            close(gv, ref["full"], "grad." + k, rtol=5e-3, atol=1e-4 * max(float(ref["full"].abs().max()), 1e-12))
+        else:
+            close(gv.flatten()[:: ref["stride"]], ref["sub"], "grad." + k, rtol=5e-3, atol=2e-4 * float(ref["sub"].abs().max()) + 1e-10)
+            assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 2e-3 * float(ref["norm"]) + 1e-12, k
