@@ -153,3 +153,35 @@ def test_fk_rows_on_random_trees(host):
             assert np.allclose(g_sh.sum(0), ref[2].numpy(), atol=3e-4 * max(1.0, float(ref[2].abs().max())))
 
     run()
+
+
+def test_fk_rows_equal_quaternion_composition(host, pose):
+    """The reference's own known-answer test for this op (lab4d/tests/test_ops.py:181-267, test_fk): forward kinematics through
+    4x4 matrices equals forward kinematics through quaternion-translation composition.  Here: the row arithmetic of the
+    kernels (matrix chain + matrix_to_quaternion) against a quaternion-composition walk built from the oracle's quaternion ops,
+    compared as SE(3) so the quaternion's sign convention drops out."""
+    from oracle import lab4d_oracle as O
+    from oracle import pose_oracle as PO
+    from oracle import reg_oracle as RO
+    skel = pose["skel"]
+    edges, B = skel["edges"], skel["rest_joints"].shape[0]
+    g = torch.Generator().manual_seed(8)
+    R = 16
+    so3 = torch.randn(R, B, 3, generator=g) * 1.4
+    local = PO.rest_joints_to_local(skel["rest_joints"], edges)[None].expand(R, B, 3).contiguous()
+    q_loc = PO.axis_angle_to_quaternion(so3)
+    gq = [torch.tensor([1.0, 0, 0, 0]).expand(R, 4)] * B
+    gt = [torch.zeros(R, 3)] * B
+    for idx, par in edges.items():
+        pq, pt = (gq[par - 1], gt[par - 1]) if par > 0 else (torch.tensor([1.0, 0, 0, 0]).expand(R, 4), torch.zeros(R, 3))
+        gq[idx - 1] = O.quaternion_mul(pq, q_loc[:, idx - 1])
+        gt[idx - 1] = O.quaternion_apply(pq, local[:, idx - 1]) + pt
+    ref = RO.quaternion_translation_to_se3(torch.stack(gq, 1), torch.stack(gt, 1))
+    order, parent = skel_arrays(edges, B)
+    a_so3, a_loc = arr(so3), arr(local)
+    qr, qd = np.empty((R, B, 4), np.float32), np.empty((R, B, 4), np.float32)
+    host.fk_host_forward(fp(a_so3), fp(a_loc), None, ip(order), ip(parent), R, B, 0, fp(qr), fp(qd))
+    qr_t, qd_t = torch.from_numpy(qr), torch.from_numpy(qd)
+    t = 2 * O.quaternion_mul(qd_t, O.quaternion_conjugate(qr_t))[..., 1:]
+    got = RO.quaternion_translation_to_se3(qr_t, t)
+    assert torch.allclose(got, ref, atol=2e-5), float((got - ref).abs().max())
