@@ -18,8 +18,18 @@
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LAB4D_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
+// x * res must be ROUNDED before the cell origin is subtracted: contracted into fma(x, res, -floor) the fractional position
+// differs from the definition by up to ulp(x * res) = 1.2e-4 at res = 2048 (first MI355X run of the large case: 2e-5 off)
+// (__fmul_rn alone is still fused by the backend under HIP's default -ffp-contract=fast: the product is made opaque instead)
+LAB4D_HD float lab4d_mul_rn(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+#define LAB4D_MUL_RN(a, b) lab4d_mul_rn((a), (b))
 #else
 #define LAB4D_ATOMIC_ADD(ptr, v) (*(ptr) += (v))
+#define LAB4D_MUL_RN(a, b) ((a) * (b))
 #endif
 
 namespace lab4d_hash {
@@ -36,7 +46,7 @@ LAB4D_HD uint32_t vertex_index(uint32_t ix, uint32_t iy, uint32_t iz, int res, i
 LAB4D_HD void cell_of(const float* x, int res, uint32_t* i0, float* w) {
     for (int a = 0; a < 3; ++a) {
         const float xc = fminf(fmaxf(x[a], 0.f), 1.f);
-        const float p = xc * (float)res;
+        const float p = LAB4D_MUL_RN(xc, (float)res);
         float f = floorf(p);
         if (f > (float)(res - 1)) f = (float)(res - 1);
         i0[a] = (uint32_t)f;

@@ -16,6 +16,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
+OUT_DIR = os.environ.get("LAB4D_GOLDEN_OUT", HERE)  # tests/test_golden_generator.py regenerates into a temp dir
 
 from oracle import ref_shim  # noqa: E402
 from lab4d_amd import synthetic  # noqa: E402
@@ -166,7 +167,7 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
             out.pop(k)
         out["rendered"] = {k: v[:, ::st].clone() for k, v in out["rendered"].items()}
         out["aux_fg"] = {k: (v[:, ::st].clone() if v.dim() >= 2 and v.shape[1] == N else v) for k, v in out["aux_fg"].items()}
-    path = os.path.join(HERE, f"train_{tag}.pt")
+    path = os.path.join(OUT_DIR, f"train_{tag}.pt")
     torch.save(out, path)
     print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", {k: float(v) for k, v in loss_dict.items()})
 
@@ -214,7 +215,7 @@ def gen_eval(ns, tag, M, N, D, res, seed):
         "rendered": {k: v.detach() for k, v in rendered.items()},
         "inds": captured["inds"], "valid": captured["valid"],
     }
-    path = os.path.join(HERE, f"eval_{tag}.pt")
+    path = os.path.join(OUT_DIR, f"eval_{tag}.pt")
     torch.save(out, path)
     print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "valid frac", float(captured["valid"].float().mean()))
 
@@ -277,7 +278,7 @@ def gen_ops(ns):
     dA, dB = torch.rand(2, 3, 4, 1, generator=g), torch.rand(2, 3, 4, 1, generator=g)
     comp, dcomp = ns.multifields.MultiFields.compose_fields({"fg": dict(fdA), "bg": dict(fdB)}, {"fg": dA, "bg": dB})
     out["compose_fields"] = (fdA, fdB, dA, dB, {k: v.clone() for k, v in comp.items()}, dcomp)
-    path = os.path.join(HERE, "ops.pt")
+    path = os.path.join(OUT_DIR, "ops.pt")
     torch.save(out, path)
     print("ops ->", path, os.path.getsize(path) // 1024, "KiB")
 
@@ -319,7 +320,7 @@ def gen_comp_warp(ns):
            "dense_fw": dense_fw.detach(), "dense_bw": dense_bw.detach(),
            "aux_bw": {k: v.detach() for k, v in aux_bw.items()}, "loss": loss.detach(),
            "grad_xyz": grads[0], "grads": {n: compress_grad(gv) for n, gv in zip(names, grads[1:])}}
-    path = os.path.join(HERE, "comp_warp.pt")
+    path = os.path.join(OUT_DIR, "comp_warp.pt")
     torch.save(out, path)
     print("comp_warp ->", path, os.path.getsize(path) // 1024, "KiB")
 
@@ -354,7 +355,7 @@ def gen_bg_field(ns):
     out = {"weight_checksum": weight_checksum(P), "xyz": xyz.detach(), "dir": dirs.detach(), "w": w, "w1": w1, "rgb": rgb.detach(),
            "density": density.detach(), "sdf": sdf.detach(), "loss": loss.detach(), "grad_xyz": grads[0], "grad_dir": grads[1],
            "grads": {n: compress_grad(gv) for n, gv in zip(names, grads[2:])}}
-    path = os.path.join(HERE, "bg_field.pt")
+    path = os.path.join(OUT_DIR, "bg_field.pt")
     torch.save(out, path)
     print("bg_field ->", path, os.path.getsize(path) // 1024, "KiB")
 
@@ -401,7 +402,7 @@ def gen_comp_eval(ns):
            "frames_bg": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in frb.items()},
            "hxy": hxy, "bg_feat_dict": det(fd_b), "bg_deltas": d_b.detach(), "rendered": det(rendered), "rendered_fg": det(r_f),
            "rendered_bg": det(r_b), "composed_depth": comp["depth"].detach(), "composed_keys": sorted(comp.keys())}
-    path = os.path.join(HERE, "comp_eval.pt")
+    path = os.path.join(OUT_DIR, "comp_eval.pt")
     torch.save(out, path)
     print("comp_eval ->", path, os.path.getsize(path) // 1024, "KiB", "keys", sorted(comp.keys()), "bg mask", float(r_b["mask"].mean()),
           "fg mask", float(r_f["mask"].mean()))
@@ -427,11 +428,7 @@ def gen_comp_train(ns):
     b.train()
     frb = synthetic.make_bg_frames(seed + 3, M, res)
     g = torch.Generator().manual_seed(seed + 2)
-    if full_grid_stride:  # BASELINE config 0: the whole res x res crop of every frame; only every stride-th ray is stored
-        hxy = synthetic.make_rays(res, M)
-        N = hxy.shape[1]
-    else:
-        hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
+    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
     batch = synthetic.make_targets(seed + 3, M, N, res, hxy)
     eik_inds = torch.randperm(M * N, generator=g)[: max(M * N // 16, 1)]
     match_perm = torch.randperm(M * N * D, generator=g)[: min(1024, M * N * D)]
@@ -484,23 +481,34 @@ def gen_comp_train(ns):
            "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds, "eik_inds_bg": eik_inds, "match_perm": match_perm},
            "bg_feat_dict": {k: v.detach() for k, v in fd_b.items()}, **ref_out,
            "loss": {k: v.detach() for k, v in loss_dict.items()}, "grads": gd}
-    path = os.path.join(HERE, "comp_train.pt")
+    path = os.path.join(OUT_DIR, "comp_train.pt")
     torch.save(out, path)
     print("comp_train ->", path, os.path.getsize(path) // 1024, "KiB", {k: round(float(v), 6) for k, v in loss_dict.items()})
 
 
-if __name__ == "__main__":
+def main(only=None):
+    """Regenerate every fixture (or the named subset: tests/test_golden_generator.py keeps this recipe from rotting)."""
     ns = ref_shim.load()
     # give render_utils a private torch namespace so searchsorted can be observed
     import types
     ns.render_utils.torch = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
-    gen_ops(ns)
-    gen_train(ns, "small", M=2, N=6, D=8, res=64, seed=11)
-    gen_train(ns, "alpha", M=4, N=5, D=6, res=64, seed=21, alpha=0.45)
-    gen_train(ns, "multi", M=4, N=5, D=6, res=64, seed=31, num_inst=3, inst_id=[1, 1, 2, 2], frame_id=[22, 23, 44, 45])
-    gen_train(ns, "c1", M=2, N=None, D=64, res=64, seed=41, full_grid_stride=16)  # BASELINE config 0: 64x64 crop x 64 samples
-    gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)
-    gen_comp_warp(ns)
-    gen_bg_field(ns)
-    gen_comp_eval(ns)
-    gen_comp_train(ns)
+    jobs = [
+        ("ops", lambda: gen_ops(ns)),
+        ("train_small", lambda: gen_train(ns, "small", M=2, N=6, D=8, res=64, seed=11)),
+        ("train_alpha", lambda: gen_train(ns, "alpha", M=4, N=5, D=6, res=64, seed=21, alpha=0.45)),
+        ("train_multi", lambda: gen_train(ns, "multi", M=4, N=5, D=6, res=64, seed=31, num_inst=3, inst_id=[1, 1, 2, 2], frame_id=[22, 23, 44, 45])),
+        # BASELINE config 0: 64x64 crop x 64 samples
+        ("train_c1", lambda: gen_train(ns, "c1", M=2, N=None, D=64, res=64, seed=41, full_grid_stride=16)),
+        ("eval_small", lambda: gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)),
+        ("comp_warp", lambda: gen_comp_warp(ns)),
+        ("bg_field", lambda: gen_bg_field(ns)),
+        ("comp_eval", lambda: gen_comp_eval(ns)),
+        ("comp_train", lambda: gen_comp_train(ns)),
+    ]
+    for name, job in jobs:
+        if only is None or name in only:
+            job()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or None)

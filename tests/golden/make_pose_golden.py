@@ -16,6 +16,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
+OUT_DIR = os.environ.get("LAB4D_GOLDEN_OUT", HERE)  # tests/test_golden_generator.py regenerates into a temp dir
 
 from oracle import ref_shim  # noqa: E402
 
@@ -140,7 +141,7 @@ def main():
     (kv * ck).sum().backward()
     out["intr"] = {"vals": kv.detach().clone(), "cot": ck, "all_frames": intr.get_vals().detach().clone(),
                    "grads": {k: p.grad.clone() for k, p in intr.named_parameters() if p.grad is not None}}
-    path = os.path.join(HERE, "pose.pt")
+    path = os.path.join(OUT_DIR, "pose.pt")
     torch.save(out, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; matrix_to_quaternion branches:", out["fk"]["branch_hist"].tolist())
 

@@ -14,6 +14,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
+OUT_DIR = os.environ.get("LAB4D_GOLDEN_OUT", HERE)  # tests/test_golden_generator.py regenerates into a temp dir
 
 from oracle import ref_shim  # noqa: E402
 from lab4d_amd import synthetic  # noqa: E402
@@ -73,7 +74,7 @@ def main():
         te = f.warp.post_warp.time_embedding(frame_id).clone()
     out["soft_deform"] = {"u": u, "frame_id": frame_id, "inst_id": inst, "extend_factor": 1.0, "t_embed_dense": te, "loss": loss.detach(),
                           "grads": {k: compress_grad(v) for k, v in zip(names, g)}}
-    path = os.path.join(HERE, "reg.pt")
+    path = os.path.join(OUT_DIR, "reg.pt")
     torch.save(out, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: float(out[k]["loss"]) for k in ("vis", "gauss_skin", "soft_deform")})
 

@@ -17,6 +17,25 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+# Bound per rendered channel, as a fraction of the channel's largest reference value, fp32 path.  Everything is held to 3e-4
+# except the eikonal channel: (|d sdf/dx| - 1)^2 is a squared first derivative through 9 layers and a 2^f-weighted sum over
+# the positional-encoding slots, and the REFERENCE'S OWN fp32 arithmetic is 6.8e-4 of the channel maximum away from the same
+# graph evaluated in fp64 (tests/test_oracle_properties.py::test_eikonal_fp32_noise_floor measures it): no fp32
+# implementation with a different accumulation order can agree with it more closely than that.
+RENDER_TOL_F32 = {"eikonal": 2e-3}
+
+
+def report(tag, measured):
+    """Measured errors go to stdout (pytest -s / -rP) and to gpurun_out/parity_<tag>.json so that the bound and the measurement
+    can be read side by side."""
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_%s.json" % tag), "w") as f:
+        json.dump({k: float("%.3e" % v) for k, v in measured.items()}, f, indent=1, sort_keys=True)
+    print(tag, {k: "%.2e" % v for k, v in measured.items()})
+
+
 def load_case(golden_dir, name):
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
     P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"))
@@ -77,15 +96,12 @@ def test_training_graph_matches_reference_goldens(golden_dir, case):
         assert e < 5e-3, f"grad {k}: {e:.3e}"
 
 
-@pytest.mark.skipif(not os.environ.get("LAB4D_RUN_UNVALIDATED"), reason="fixture added after round 1's GPU budget was spent (set LAB4D_RUN_UNVALIDATED=1)")
 def test_training_graph_multi_instance(golden_dir):
     """BASELINE config 4's shape: 3 instances, two frame pairs from different videos, per-instance codes in every CondMLP.  The
-    oracle is pinned to this reference-generated fixture on the CPU (tests/test_oracle_golden.py); the device run is opt-in
-    until it has passed once on hardware."""
+    oracle is pinned to this reference-generated fixture on the CPU (tests/test_oracle_golden.py)."""
     test_training_graph_matches_reference_goldens(golden_dir, "train_multi.pt")
 
 
-@pytest.mark.skipif(not os.environ.get("LAB4D_RUN_UNVALIDATED"), reason="fixture added after round 1's GPU budget was spent (set LAB4D_RUN_UNVALIDATED=1)")
 def test_training_graph_at_baseline_config0_size(golden_dir):
     """BASELINE.json configs[0] at full size on the device: the 64x64 crop of a frame pair x 64 samples/ray (524,288 samples) against
     the reference-generated fixture (every 16th ray of the render, losses, compressed gradients); fp32 path."""
@@ -101,18 +117,22 @@ def test_training_graph_at_baseline_config0_size(golden_dir):
     fr["feature"] = batch["feature"]
     out = DF.render_train(Pd, fr, hxy.to(DEV), synthetic.to_device(g["rng"], DEV), flow_thresh=meta["flow_thresh"], n_depth=meta["D"],
                           alpha=meta["alpha"])
+    measured = {}
     for k, v in g["rendered"].items():
-        assert rel(out["rendered"][k][:, ::st], v) < 3e-4, f"rendered.{k}: {rel(out['rendered'][k][:, ::st], v):.3e}"
+        e = measured["rendered." + k] = rel(out["rendered"][k][:, ::st], v)
+        assert e < RENDER_TOL_F32.get(k, 3e-4), f"rendered.{k}: {e:.3e}"
     losses = DF.losses_fg(out, batch, res, DF.DEFAULT_LOSS_WT)
     for k, v in g["loss"].items():
-        assert rel(losses[k], v) < 5e-4, f"loss.{k}: {rel(losses[k], v):.3e}"
+        e = measured["loss." + k] = rel(losses[k], v)
+        assert e < (2e-3 if k == "reg_eikonal" else 5e-4), f"loss.{k}: {e:.3e}"
     names = [k for k in g["grads"] if not k.startswith("frame:")]
     grads = torch.autograd.grad(sum(losses.values()), [Pd[k] for k in names], allow_unused=True)
     for k, gv in zip(names, grads):
         ref = g["grads"][k]
         assert gv is not None, k
-        e = rel(gv, ref["full"]) if "full" in ref else rel(gv.flatten()[:: ref["stride"]], ref["sub"])
+        e = measured["grad." + k] = rel(gv, ref["full"]) if "full" in ref else rel(gv.flatten()[:: ref["stride"]], ref["sub"])
         assert e < 1e-2, f"grad {k}: {e:.3e}"
+    report("config0_fp32", measured)
 
 
 def test_bf16_training_graph_is_close_to_fp32(golden_dir):

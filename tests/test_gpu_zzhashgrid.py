@@ -1,17 +1,16 @@
-"""GPU check of the hash-grid encoding kernels (csrc/hashgrid.hip) against oracle/hashgrid_oracle.py.
+"""GPU check of the hash-grid encoding kernels (csrc/hashgrid.hip) through the Python wrapper lab4d_amd/hashgrid.py against
+oracle/hashgrid_oracle.py (parity vs the reference is unpinned by nature: the reference has no hash grid).
 
-The kernels were added at the very end of round 1's GPU budget: their arithmetic is held to the oracle on the CPU
-(tests/test_hashgrid_host.py builds the same header with g++) and the kernels themselves ran on an MI355X through the C ABI in
-the native self-check tests/host_harness/gpu_selfcheck.cpp (profiles/r01_hashgrid_selfcheck.txt: match), but THIS test -- the
-Python wrapper lab4d_amd/hashgrid.py on the device -- has not run yet.  Until it has, it is opt-in (LAB4D_RUN_UNVALIDATED=1) so
-that an unproven path cannot turn the parity suite red; remove the gate once it has passed on hardware."""
+First hardware run (round 2) found the kernels 2e-5 off at the finest level (res 2048): the compiler had fused
+`x * res - floor(x * res)` into fma(x, res, -floor), i.e. an UNROUNDED product, which moves the fractional cell position by up
+to ulp(x * res) = 1.2e-4.  The product is now opaque to the optimiser (hashgrid_math.hpp lab4d_mul_rn) and the forward bound
+is a few ulp."""
 import os
 
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.environ.get("LAB4D_RUN_UNVALIDATED"), reason="first MI355X run of the Python wrapper pending (set LAB4D_RUN_UNVALIDATED=1)")]
+pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
@@ -33,7 +32,8 @@ def test_hash_encode_matches_the_oracle(L, F, log2_T, n_min, n_max, S):
     xd, td = x.to(DEV).requires_grad_(True), table.to(DEV).requires_grad_(True)
     rd = torch.tensor(res, dtype=torch.int32, device=DEV)
     out = hashgrid.hash_encode(xd, td, rd, log2_T)
-    assert torch.allclose(out[:n_ref].cpu(), ref.detach(), atol=2e-5)
+    e_out = float((out[:n_ref].cpu() - ref.detach()).abs().max())
+    assert e_out < 2e-6, "forward: max abs error %.3e" % e_out  # tri-linear blend of 8 entries of magnitude 0.1: a few ulp
     gx, gt = torch.autograd.grad((out[:n_ref] * c[:n_ref].to(DEV)).sum(), [xd, td])
     assert torch.allclose(gt.cpu(), gt_ref, atol=1e-4)
     inside = ((x[:n_ref] > 0) & (x[:n_ref] < 1)).all(-1)
