@@ -32,7 +32,7 @@ def test_hash_encode_matches_the_oracle(L, F, log2_T, n_min, n_max, S):
     xd, td = x.to(DEV).requires_grad_(True), table.to(DEV).requires_grad_(True)
     rd = torch.tensor(res, dtype=torch.int32, device=DEV)
     out = hashgrid.hash_encode(xd, td, rd, log2_T)
-    e_out = float((out[:n_ref].cpu() - ref.detach()).abs().max())
+    e_out = float((out[:n_ref].detach().cpu() - ref.detach()).abs().max())
     assert e_out < 2e-6, "forward: max abs error %.3e" % e_out  # tri-linear blend of 8 entries of magnitude 0.1: a few ulp
     gx, gt = torch.autograd.grad((out[:n_ref] * c[:n_ref].to(DEV)).sum(), [xd, td])
     assert torch.allclose(gt.cpu(), gt_ref, atol=1e-4)
