@@ -86,6 +86,11 @@ int lab4d_ray_samples_backward(const float* hxy, const float* Kinv, const float*
  * inds (R,n_imp) int64 -- bit-exact vs torch (sequential fp32 cumsum). */
 int lab4d_sample_pdf(const float* bins, const float* weights, int R, int n_w, int n_imp, float eps,
                      float* samples, int64_t* inds, void* stream);
+/* utils/render_utils.py:209-213 sample_pdf(det=False): the same inverse-CDF sampling at caller-drawn uniforms u_sorted (R,n_imp),
+ * ASCENDING per ray (the caller draws torch.rand like the reference, sorts per ray and un-sorts samples / inds afterwards:
+ * searchsorted acts per element).  u_sorted == NULL is lab4d_sample_pdf. */
+int lab4d_sample_pdf_u(const float* bins, const float* weights, const float* u_sorted, int R, int n_w, int n_imp, float eps,
+                       float* samples, int64_t* inds, void* stream);
 /* nnutils/nerf.py:731: sort(cat([depth_a, depth_b], -1)) per ray; a,b: (R,na),(R,nb) -> out (R,na+nb). */
 int lab4d_sort_depth(const float* a, int na, const float* b, int nb, int R, float* out, void* stream);
 

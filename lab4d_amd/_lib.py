@@ -98,6 +98,7 @@ SIGNATURES = {
     "lab4d_ray_samples_forward": [vp] * 6 + [ci] * 3 + [vp] * 6 + [vp],
     "lab4d_ray_samples_backward": [vp] * 6 + [ci] * 3 + [vp] * 5 + [vp] * 3 + [vp],
     "lab4d_sample_pdf": [vp, vp, ci, ci, ci, cf, vp, vp, vp],
+    "lab4d_sample_pdf_u": [vp, vp, vp, ci, ci, ci, cf, vp, vp, vp],
     "lab4d_sort_depth": [vp, ci, vp, ci, ci, vp, vp],
     "lab4d_composite_forward": [vp, vp, ctypes.POINTER(FieldList), vp, vp, vp, ci, ci] + [vp] * 8 + [vp],
     "lab4d_composite_backward": [vp, vp, ctypes.POINTER(FieldList), vp, vp, vp, ci, ci] + [vp] * 5 + [vp, vp,

@@ -60,6 +60,20 @@ __device__ __forceinline__ float wave_rscan_incl(float v, int lane) {
   return v;
 }
 
+// A rounded fp32 product / sum that the optimiser cannot fuse into an fma.  HIP compiles with -ffp-contract=fast and the
+// backend contracts even __fmul_rn / __fadd_rn (found on the first hardware run of the hash grid, round 2), so wherever the
+// reference's arithmetic rounds a product before using it, the product is made opaque.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+  float p = a * b;
+  asm volatile("" : "+v"(p));
+  return p;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+  float p = a + b;
+  asm volatile("" : "+v"(p));
+  return p;
+}
+
 inline int div_up(long a, long b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ int div_up_dev(int a, int b) { return (a + b - 1) / b; }
 

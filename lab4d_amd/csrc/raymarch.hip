@@ -168,9 +168,11 @@ __global__ void __launch_bounds__(256) k_ray_samples_bwd(const float* __restrict
 }
 
 // sample_pdf(det=True): one thread per ray, two-pointer sweep over the (monotone) cdf and u.
+// u_in: caller-drawn uniforms (R, n_imp), sorted ascending per ray (det=False: the host draws torch.rand, sorts, and un-sorts
+// the result -- searchsorted is a per-element operation, so the order of the queries is immaterial), or NULL for linspace.
 __global__ void __launch_bounds__(256) k_sample_pdf(const float* __restrict__ bins, const float* __restrict__ weights, int R,
-                                                     int n_w, int n_imp, float eps, float* __restrict__ samples,
-                                                     int64_t* __restrict__ inds) {
+                                                     int n_w, int n_imp, float eps, const float* __restrict__ u_in,
+                                                     float* __restrict__ samples, int64_t* __restrict__ inds) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const float* w = weights + (long)r * n_w;
@@ -191,8 +193,11 @@ __global__ void __launch_bounds__(256) k_sample_pdf(const float* __restrict__ bi
   c_hi = 0.f;
   bool have_hi = true;    // c_hi holds cdf[j] for current j
   for (int k = 0; k < n_imp; ++k) {
-    // explicit _rn ops: no fma contraction, so u matches torch.linspace bit for bit
-    const float u = (k < n_imp / 2) ? __fmul_rn(step, (float)k) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n_imp - 1 - k)));
+    // torch.linspace (CPU): start + step*k for the first half, end - step*(n-1-k) for the second, the latter evaluated with a
+    // FUSED multiply-add by its vectorised kernel -- fmaf reproduces it bit for bit for every n (checked for n = 16..128 in
+    // tests/test_oracle_properties.py::test_linspace_arithmetic); an unfused product does not (n = 16, 64, 128 differ)
+    const float u = u_in ? u_in[(long)r * n_imp + k]
+                         : ((k < n_imp / 2) ? mul_rn(step, (float)k) : fmaf(-step, (float)(n_imp - 1 - k), 1.0f));
     // advance while cdf[j] <= u
     while (j <= n_w && c_hi <= u) {
       c_lo = c_hi;
@@ -210,7 +215,7 @@ __global__ void __launch_bounds__(256) k_sample_pdf(const float* __restrict__ bi
     float denom = ca - cb;
     if (denom < eps) denom = 1.0f;
     const float b0 = b[below], b1 = b[above];
-    samples[(long)r * n_imp + k] = __fadd_rn(b0, __fmul_rn(__fdiv_rn(__fsub_rn(u, cb), denom), __fsub_rn(b1, b0)));
+    samples[(long)r * n_imp + k] = add_rn(b0, mul_rn(__fdiv_rn(u - cb, denom), b1 - b0));  // separate tensor ops in the reference: unfused
     inds[(long)r * n_imp + k] = (int64_t)j;
   }
   (void)have_hi;
@@ -270,11 +275,16 @@ extern "C" int lab4d_ray_samples_backward(const float* hxy, const float* Kinv, c
 
 extern "C" int lab4d_sample_pdf(const float* bins, const float* weights, int R, int n_w, int n_imp, float eps, float* samples,
                                 int64_t* inds, void* stream) {
+  return lab4d_sample_pdf_u(bins, weights, nullptr, R, n_w, n_imp, eps, samples, inds, stream);
+}
+
+extern "C" int lab4d_sample_pdf_u(const float* bins, const float* weights, const float* u_sorted, int R, int n_w, int n_imp, float eps,
+                                  float* samples, int64_t* inds, void* stream) {
   LAB4D_REQUIRE(bins && weights && samples && inds, "sample_pdf: null pointer");
   LAB4D_REQUIRE(n_w >= 1 && n_imp >= 2, "sample_pdf: need n_w >= 1 and n_imp >= 2");
   if (R == 0) return LAB4D_OK;
   hipLaunchKernelGGL(k_sample_pdf, dim3(div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, bins, weights, R, n_w, n_imp, eps,
-                     samples, inds);
+                     u_sorted, samples, inds);
   return check_launch("sample_pdf");
 }
 

@@ -18,7 +18,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib, mlp
 from . import quat_utils as Q
 from . import render_utils as RU
-from .warping import skinning_warp
+from .warping import composed_warp, skinning_warp
 
 vp, ci, cf = _lib.vp, _lib.ci, _lib.cf
 _lib.register("lab4d_gauss_density_forward", [vp, vp, ci, vp, ci, vp, vp, vp])
@@ -213,19 +213,36 @@ def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32, ne
     return out.reshape(M, N, D, 1)
 
 
+def _warp_fn(P, fr, prec):
+    """The fg field's warp as a closure over its per-frame inputs: SkinningWarp, or ComposedWarp when fr carries the dense
+    post-warp's inputs.  partner=True: the warp into the pair partner's frame (compute_flow, nerf.py:966-973) -- the
+    post-warp then sees the partner's time embedding."""
+    dense = fr.get("dense")
+
+    def warp(x, t_art, rest_art, t_embed, backward, partner=False):
+        if dense is None:
+            return skinning_warp(P, x, t_art, rest_art, t_embed, fr["code_skin"], backward, prec)
+        d = dict(dense, t_embed=flip_pair(dense["t_embed"])) if partner else dense
+        return composed_warp(P, x, t_art, rest_art, t_embed, fr["code_skin"], backward, prec, dense=d)
+
+    return warp
+
+
 def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None, prec=mlp.PREC_F32):
     """Training-mode Deformable.query_field for a SkinningWarp foreground (same contract as
-    oracle.lab4d_oracle.query_field_train)."""
+    oracle.lab4d_oracle.query_field_train).  With fr["dense"] = {"t_embed", "code_fw", "code_bw"} every warp is the
+    ComposedWarp of fg_motion "comp_skel-*_dense" (skinning composed with the dense post-warp, warping.py:445-483)."""
+    warp = _warp_fn(P, fr, prec)
     cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
     xyz_cam, dir_cam, deltas, depth, xyz_t, _ = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=n_depth)
-    xyz, bw_aux = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, prec)
+    xyz, bw_aux = warp(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
     fd = {}
     vis = vis_field(P, xyz, fr, prec)
     rgb, density = nerf_forward(P, xyz, fr, prec, alpha=alpha)
     fd["rgb"], fd["density"], fd["density_fg"], fd["vis"] = rgb, density, density, vis
     # flow: canonical points into the pair partner's camera (nerf.py:948-997)
     nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam", "t_articulation", "rest_articulation"]})
-    xyz_next, _ = skinning_warp(P, xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"], fr["code_skin"], False, prec)
+    xyz_next, _ = warp(xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"], False, partner=True)
     xyz_cam_next = rigid_apply(nxt["field2cam"][0], nxt["field2cam"][1], xyz_next)
     hxy_next = pinhole_projection(Q.kmatinv(nxt["Kinv"]), xyz_cam_next)
     flow = (hxy_next - hxy.unsqueeze(-2))[..., :2]
@@ -234,7 +251,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
         valid = valid & (flow.norm(dim=-1, keepdim=True) < float(flow_thresh))
     fd["flow"] = torch.cat([flow, valid.to(flow.dtype)], -1)
     # cycle consistency (deformable.py:173-198)
-    xyz_cyc, cyc_aux = skinning_warp(P, xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], fr["code_skin"], False, prec)
+    xyz_cyc, cyc_aux = warp(xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
     fd["cyc_dist"] = (xyz_cyc - xyz_t).norm(2, -1, keepdim=True)
     for k in ["skin_entropy", "delta_skin"]:
         fd[k] = (cyc_aux[k] + bw_aux[k]) / 2
@@ -245,8 +262,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     fd["feature"] = compute_feat(P, xyz, prec)
     aux = {}
     xyz_matches = global_match(P, fr["feature"], fd["feature"], xyz, rng["match_perm"])
-    xm_next, _ = skinning_warp(P, xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], fr["code_skin"],
-                               False, prec)
+    xm_next, _ = warp(xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
     xyz_reproj = rigid_apply(fr["field2cam"][0], fr["field2cam"][1], xm_next)[:, :, 0]
     aux["xyz_matches"] = xyz_matches
     aux["xyz_reproj"] = xyz_reproj
@@ -363,7 +379,7 @@ def importance_sampling(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
     nc = n_depth // 2
     cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
     xyz_cam, _, deltas, depth, xyz_t, _ = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=nc)
-    xyz, _ = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, prec)
+    xyz, _ = _warp_fn(P, fr, prec)(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
     density = nerf_forward(P, xyz, fr, prec, with_color=False, alpha=alpha)
     weights, _ = RU.compute_weights(density, deltas)
     depth_mid = (0.5 * (depth[:, :, :-1] + depth[:, :, 1:])).reshape(-1, nc - 1)
@@ -386,7 +402,7 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
         xc = xyz_cam.detach().requires_grad_(True)
         qi, ti = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
         xyz_t = rigid_apply(qi, ti, xc)
-        xyz, _ = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, prec)
+        xyz, _ = _warp_fn(P, fr, prec)(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
         rgb, sdf = nerf_forward(P, xyz, fr, prec, get_density=False, alpha=alpha)
         (g,) = torch.autograd.grad(sdf, xc, torch.ones_like(sdf))
     with torch.no_grad():

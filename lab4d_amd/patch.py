@@ -1,0 +1,475 @@
+"""Operator-API adapter: the reference's own method signatures, bodies on the HIP library.
+
+`patch()` rebinds, inside an importable `lab4d` package, every entry point SURVEY.md 8b lists as "must not change":
+
+    quaternion (package)                      third_party/quaternion/__init__.py:2-3      -> lab4d_amd.quaternion
+    render_utils.sample_cam_rays / render_pixel / compute_weights / integrate / sample_pdf
+                                              utils/render_utils.py:8,59,99,129,187       -> lab4d_amd.render_utils
+    NeRF.forward                              nnutils/nerf.py:167                          -> nerf_forward
+    NeRF.query_field (+ FeatureNeRF / Deformable overrides)
+                                              nnutils/nerf.py:580, feature.py:89, deformable.py:300   -> query_field
+    NeRF.backward_warp / forward_warp (+ Deformable overrides)
+                                              nnutils/nerf.py:865,889, deformable.py:119,154           -> backward_warp / forward_warp
+    VisField.forward                          nnutils/visibility.py:53                     -> vis_forward
+    FeatureNeRF.compute_feat                  nnutils/feature.py:136                       -> compute_feat
+    SkinningWarp.forward                      nnutils/warping.py:277                       -> skinning_forward
+    DenseWarp.forward                         nnutils/warping.py:143                       -> dense_forward
+    ComposedWarp.forward                      nnutils/warping.py:445                       -> composed_forward
+    MultiFields.compose_fields                nnutils/multifields.py:339                   -> compose_fields
+    AppearanceEmbedding.get_vals              nnutils/appearance.py:8-56, time.py:107      -> appearance_get_vals
+    dvr_model.render / evaluate / render_samples / render_samples_chunk
+                                              engine/model.py:162,217,259,328              -> dvr_*
+
+Every function below takes the reference module as `self` and reads only attributes the reference defines (parameter
+names = the reference's state_dict names: a checkpoint loads unchanged); per-frame quantities (instance / time /
+appearance codes, articulations) come from the reference's own per-frame modules hanging off `self`, per-sample work
+goes to liblab4d_hip.so.  There is no fallback: a field shape without a kernel instantiation raises NotImplementedError,
+a CPU tensor raises RuntimeError.
+
+Tests: tests/test_patch_signatures.py (build container: binds into the real reference, `inspect.signature` equality for
+every patched symbol, every state_dict key the adapters read exists in the reference's modules) and
+tests/test_gpu_patch.py (MI355X: the adapters driven with stand-in module objects against the reference-generated
+fixtures).
+"""
+import math
+import sys
+from collections import defaultdict
+
+import torch
+
+from . import deformable as DF
+from . import mlp, multifields
+from . import render_utils as RU
+from . import warping as W
+
+# precision of the MLP chains the adapters launch (mlp.PREC_BF16 = BASELINE configs[1]; mlp.PREC_F32 = 1e-4 parity path)
+PRECISION = mlp.PREC_BF16
+# samples per ray: the reference hard-codes the defaults of sample_cam_rays (render_utils.py:8) and importance_sampling
+# (nerf.py:686-696), n_depth=64; BASELINE configs[1] / [4] ask for 128 / 256 -- set through patch(n_depth=...)
+N_DEPTH = 64
+
+
+# ---------------------------------------------------------------------------------------------------
+# reading the reference modules
+# ---------------------------------------------------------------------------------------------------
+def params_of(module, prefix=""):
+    """Flat {state_dict name: tensor} of a reference module: parameters (live, so autograd reaches them) + buffers."""
+    P = {prefix + k: v for k, v in module.named_parameters()}
+    for k, v in module.named_buffers():
+        P.setdefault(prefix + k, v)
+    return P
+
+
+def field_params(field):
+    """Parameters of a NeRF / Deformable field under the names lab4d_amd's functional code uses (= state_dict names), plus
+    the non-parameter attributes it needs (skinning symmetry table: a plain list on SkinningField, skinning.py:88)."""
+    P = params_of(field)
+    warp = getattr(field, "warp", None)
+    sk = getattr(warp, "skinning_model", None)
+    if sk is not None and getattr(sk, "symm_idx", None) is not None:
+        P["warp.skinning_model.symm_idx"] = torch.as_tensor(sk.symm_idx, dtype=torch.long, device=P["logibeta"].device)
+    return P
+
+
+def inst_code(cond_mlp, inst_id, rows, device):
+    """CondMLP's instance code for `rows` leading rows (base.py:123-146): inst_id None -> the mean embedding."""
+    emb = cond_mlp.inst_embedding
+    if inst_id is None:
+        return emb.get_mean_embedding().to(device).reshape(1, -1).expand(rows, -1)
+    return emb(inst_id)
+
+
+def _spf(x):
+    n = 1
+    for d in x.shape[1:-1]:
+        n *= d
+    return n
+
+
+def field_kind(field):
+    """Which kernel instantiation serves this NeRF: "fg" (multifields.py:77-84: W=256, D=8, 10 xyz frequencies, no view
+    direction, 32-channel appearance code) or "bg" (multifields.py:86-93: W=128, D=5, 6 frequencies, raw view direction)."""
+    nf = field.pos_embedding.N_freqs
+    w = field.sdf.in_features
+    dir_c = field.dir_embedding.out_channels
+    if nf == 10 and w == 256 and dir_c == 0 and field.appr_channels == 32:
+        return "fg"
+    if nf == 6 and w == 128 and dir_c == 3 and field.appr_channels == 0:
+        return "bg"
+    raise NotImplementedError("lab4d_amd: no kernel instantiation for NeRF(num_freq_xyz=%d, W=%d, dir channels=%d, appr_channels=%d)"
+                              % (nf, w, dir_c, field.appr_channels))
+
+
+def warp_kind(field):
+    warp = getattr(field, "warp", None)
+    if warp is None:
+        return "rigid"
+    name = type(warp).__name__
+    if name == "ComposedWarp":
+        return "composed"
+    if name == "SkinningWarp":
+        return "skinning"
+    raise NotImplementedError("lab4d_amd: no kernel path for warp %s" % name)
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-module forwards
+# ---------------------------------------------------------------------------------------------------
+def nerf_forward(self, xyz, dir=None, frame_id=None, inst_id=None, get_density=True):
+    """NeRF.forward (nnutils/nerf.py:167-215).  xyz (M,...,3); frame_id / inst_id (M,) or None."""
+    if frame_id is not None:
+        assert frame_id.ndim == 1
+    if inst_id is not None:
+        assert inst_id.ndim == 1
+    P = field_params(self)
+    M, dev = xyz.shape[0], xyz.device
+    alpha = self.pos_embedding.alpha
+    if field_kind(self) == "fg":
+        fr = {"code_base": inst_code(self.basefield, inst_id, M, dev)}
+        if dir is None:
+            return DF.nerf_forward(P, xyz, fr, PRECISION, with_color=False, get_density=get_density, alpha=alpha)
+        fr["code_color"] = inst_code(self.colorfield, inst_id, M, dev)
+        fr["appr_code"] = self.appr_embedding.get_vals(frame_id)
+        return DF.nerf_forward(P, xyz, fr, PRECISION, with_color=True, get_density=get_density, alpha=alpha)
+    codes = {"basefield": inst_code(self.basefield, inst_id, M, dev)}
+    if dir is not None:
+        codes["colorfield"] = inst_code(self.colorfield, inst_id, M, dev)
+    return DF.nerf_forward_bg(P, xyz, dir, codes, PRECISION, get_density=get_density, alpha=alpha)
+
+
+def vis_forward(self, xyz, inst_id=None):
+    """VisField.forward (nnutils/visibility.py:53-63)."""
+    P = params_of(self, "vis_mlp.")
+    fr = {"code_vis": inst_code(self.basefield, inst_id, xyz.shape[0], xyz.device)}
+    return DF.vis_field(P, xyz, fr, PRECISION)
+
+
+def compute_feat(self, xyz):
+    """FeatureNeRF.compute_feat (nnutils/feature.py:136-150); train-only like the reference's decorator (decorator.py:4-17)."""
+    if not self.training:
+        return {}
+    return {"feature": DF.compute_feat(field_params(self), xyz, PRECISION)}
+
+
+def _articulations(self, frame_id, samples_dict):
+    if "rest_articulation" in samples_dict and "t_articulation" in samples_dict:
+        return samples_dict["t_articulation"], samples_dict["rest_articulation"]
+    return self.articulation.get_vals_and_mean(frame_id)
+
+
+def _skin_inputs(self, xyz, frame_id, inst_id, backward):
+    """Time embedding and instance code of the delta-skin field (skinning.py:107-117): the forward warp runs at the mean
+    time embedding (warping.py:314: frame_id = None)."""
+    sk = self.skinning_model
+    M = xyz.shape[0]
+    if backward and frame_id is not None:
+        te = sk.time_embedding(frame_id)
+    else:
+        te = sk.time_embedding.get_mean_embedding(xyz.device)
+    return te, inst_code(sk.delta_field, inst_id, M, xyz.device)
+
+
+def _warp_params(warp):
+    P = {"warp." + k: v for k, v in params_of(warp).items()}
+    sk = getattr(warp, "skinning_model", None)
+    if sk is not None and getattr(sk, "symm_idx", None) is not None:
+        P["warp.skinning_model.symm_idx"] = torch.as_tensor(sk.symm_idx, dtype=torch.long, device=P["warp.logibeta"].device)
+    return P
+
+
+def skinning_forward(self, xyz, frame_id, inst_id, backward=False, samples_dict={}, return_aux=False):
+    """SkinningWarp.forward (nnutils/warping.py:277-336)."""
+    t_art, rest_art = _articulations(self, frame_id, samples_dict)
+    te, code = _skin_inputs(self, xyz, frame_id, inst_id, backward)
+    out, aux = W.skinning_warp(_warp_params(self), xyz, t_art, rest_art, te, code, backward, PRECISION)
+    return (out, aux) if return_aux else out
+
+
+def dense_forward(self, xyz, frame_id, inst_id, backward=False, samples_dict={}, return_aux=False):
+    """DenseWarp.forward (nnutils/warping.py:143-170)."""
+    which = self.backward_map if backward else self.forward_map
+    P = {"d." + k: v for k, v in params_of(self).items()}
+    out = W.dense_warp(P, xyz, self.time_embedding(frame_id), inst_code(which, inst_id, xyz.shape[0], xyz.device), backward, PRECISION,
+                       prefix="d.")
+    return (out, {}) if return_aux else out
+
+
+def _dense_inputs(self, like, frame_id, inst_id):
+    """Per-frame inputs of ComposedWarp's post-warp; `like`: any tensor with the frames on axis 0 (for M and the device)."""
+    if frame_id is None:  # the post-warp is skipped (warping.py:460,474)
+        return None
+    pw, M, dev = self.post_warp, like.shape[0], like.device
+    return {"t_embed": pw.time_embedding(frame_id), "code_fw": inst_code(pw.forward_map, inst_id, M, dev),
+            "code_bw": inst_code(pw.backward_map, inst_id, M, dev)}
+
+
+def composed_forward(self, xyz, frame_id, inst_id, backward=False, samples_dict={}, return_aux=False):
+    """ComposedWarp.forward (nnutils/warping.py:445-483): skeleton skinning composed with the dense post-warp."""
+    t_art, rest_art = _articulations(self, frame_id, samples_dict)
+    te, code = _skin_inputs(self, xyz, frame_id, inst_id, backward)
+    out, aux = W.composed_warp(_warp_params(self), xyz, t_art, rest_art, te, code, backward, PRECISION,
+                               dense=_dense_inputs(self, xyz, frame_id, inst_id))
+    return (out, aux) if return_aux else out
+
+
+def appearance_get_vals(self, frame_id=None):
+    """AppearanceEmbedding.get_vals (TimeMLP.get_vals, nnutils/time.py:107-117, with the AppearanceEmbedding.forward of
+    appearance.py:46-56): Fourier(t) -> TimeEmbedding -> TimeMLP(D=2, W=64) -> Linear(64, 32).  M rows: torch device GEMMs
+    ("negligible when per-frame"); what matters for the per-sample path is that the result is consumed
+    as a per-FRAME bias of the rgb head (lab4d_amd.mlp.pf_bias_of) instead of being broadcast to every sample
+    (nerf.py:201-205) -- including in the compacted eval path, where the reference evaluates this MLP per SAMPLE
+    (nerf.py:795-798)."""
+    from . import pose
+    P = params_of(self, "appr.")
+    info = pose.time_info_of(self.time_embedding)
+    t_embed = pose.time_embedding(P, "appr.time_embedding", frame_id, info)
+    n_hidden = sum(1 for k in P if k.startswith("appr.linear_") and k.endswith(".0.weight") and k.split(".")[1][7:].isdigit())
+    feat = pose.time_mlp(P, "appr", t_embed, D=n_hidden)
+    return torch.nn.functional.linear(feat, P["appr.output.weight"], P["appr.output.bias"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# field-level entry points
+# ---------------------------------------------------------------------------------------------------
+def _frames(self, samples_dict, need_color=True):
+    """Per-frame inputs of the functional field code from the reference's samples_dict (deformable.py:254-289,
+    nerf.py:530-578) + the per-frame modules of `self`."""
+    frame_id, inst_id = samples_dict["frame_id"], samples_dict["inst_id"]
+    M, dev = samples_dict["Kinv"].shape[0], samples_dict["Kinv"].device
+    fr = {k: samples_dict[k] for k in ("Kinv", "field2cam", "near_far", "frame_id", "inst_id")}
+    fr["code_base"] = inst_code(self.basefield, inst_id, M, dev)
+    fr["code_color"] = inst_code(self.colorfield, inst_id, M, dev)
+    fr["code_vis"] = inst_code(self.vis_mlp.basefield, inst_id, M, dev)
+    if self.appr_channels > 0:
+        fr["appr_code"] = self.appr_embedding.get_vals(frame_id)
+    kind = warp_kind(self)
+    if kind != "rigid":
+        warp = self.warp
+        fr["t_articulation"], fr["rest_articulation"] = _articulations(warp, frame_id, samples_dict)
+        sk = warp.skinning_model
+        fr["t_embed"] = sk.time_embedding(frame_id)
+        fr["t_embed_mean"] = sk.time_embedding.get_mean_embedding(dev)
+        fr["code_skin"] = inst_code(sk.delta_field, inst_id, M, dev)
+        if kind == "composed":
+            fr["dense"] = _dense_inputs(warp, samples_dict["Kinv"], frame_id, inst_id)
+    if "feature" in samples_dict:
+        fr["feature"] = samples_dict["feature"]
+    return fr
+
+
+def draw_rng(M, N, D, device):
+    """The two host-side random draws of a training query, in the reference's order: the eikonal ray subset
+    (torch.multinomial on a CPU tensor, nerf.py:437-440) then the matching candidates (torch.randperm on the CPU,
+    feature.py:177)."""
+    n = max(M * N // 16, 1)
+    eik = torch.multinomial(torch.ones(M * N), n, replacement=False).to(device) if M * N > n else None
+    S = M * N * D
+    return {"eik_inds": eik, "eik_inds_bg": eik, "match_perm": torch.randperm(S)[: min(1024, S)].to(device)}
+
+
+def query_field(self, samples_dict, flow_thresh=None):
+    """NeRF.query_field (nnutils/nerf.py:580-684) including the FeatureNeRF (feature.py:89-134) and Deformable
+    (deformable.py:300-327) overrides: (feat_dict, deltas, aux_dict) with the reference's keys."""
+    P = field_params(self)
+    fr = _frames(self, samples_dict)
+    hxy = samples_dict["hxy"]
+    alpha = self.pos_embedding.alpha
+    kind = field_kind(self)
+    if kind == "bg":
+        if self.training:
+            M, N = hxy.shape[:2]
+            return DF.query_field_train_bg(P, fr, hxy, draw_rng(M, N, N_DEPTH, hxy.device), flow_thresh, N_DEPTH, alpha, PRECISION)
+        fd, deltas, _ = DF.query_field_eval_bg(P, fr, hxy, N_DEPTH, alpha, PRECISION)
+        return fd, deltas, {}
+    if warp_kind(self) == "rigid":
+        raise NotImplementedError("lab4d_amd: the fg kernel path needs a SkinningWarp / ComposedWarp (fg_motion bob, skel-*, comp_skel-*_dense)")
+    if self.training:
+        M, N = hxy.shape[:2]
+        return DF.query_field_train(P, fr, hxy, draw_rng(M, N, N_DEPTH, hxy.device), flow_thresh, N_DEPTH, alpha, PRECISION)
+    fd, deltas, _ = DF.query_field_eval(P, fr, hxy, N_DEPTH, alpha, PRECISION)
+    return fd, deltas, {}
+
+
+def backward_warp(self, xyz_cam, dir_cam, field2cam, frame_id, inst_id, samples_dict={}):
+    """NeRF.backward_warp / Deformable.backward_warp (nnutils/nerf.py:865-887, deformable.py:119-152)."""
+    from . import quat_utils as Q
+    qi, ti = Q.quaternion_translation_inverse(field2cam[0], field2cam[1])
+    xyz_t = DF.rigid_apply(qi, ti, xyz_cam)
+    dir_f = DF.rigid_apply(qi, torch.zeros_like(ti), dir_cam)
+    if getattr(self, "warp", None) is None:
+        return {"xyz": xyz_t, "dir": dir_f, "xyz_t": xyz_t}
+    xyz, aux = self.warp(xyz_t, frame_id, inst_id, backward=True, samples_dict=samples_dict, return_aux=True)
+    out = {"xyz": xyz, "dir": dir_f, "xyz_t": xyz_t}
+    out.update(aux)
+    return out
+
+
+def forward_warp(self, xyz, field2cam, frame_id, inst_id, samples_dict={}):
+    """NeRF.forward_warp / Deformable.forward_warp (nnutils/nerf.py:889-903, deformable.py:154-171)."""
+    if getattr(self, "warp", None) is not None:
+        xyz = self.warp(xyz, frame_id, inst_id, samples_dict=samples_dict)
+    return DF.rigid_apply(field2cam[0], field2cam[1], xyz)
+
+
+def compose_fields(multifields_dict, deltas_dict):
+    """MultiFields.compose_fields (nnutils/multifields.py:339-398)."""
+    return multifields.compose_fields(multifields_dict, deltas_dict)
+
+
+# ---------------------------------------------------------------------------------------------------
+# dvr_model (engine/model.py)
+# ---------------------------------------------------------------------------------------------------
+def dvr_render_samples(self, samples_dict, flow_thresh=None):
+    """dvr_model.render_samples (engine/model.py:328-361)."""
+    fields, deltas, aux = {}, {}, {}
+    for cat, field in self.fields.field_params.items():
+        fields[cat], deltas[cat], aux[cat] = query_field(field, samples_dict[cat], flow_thresh=flow_thresh)
+    comp, d = compose_fields(fields, deltas)
+    rendered = dict(RU.render_pixel(comp, d))
+    for cat in fields:
+        aux[cat] = dict(aux[cat])
+        aux[cat].update(RU.render_pixel(fields[cat], deltas[cat]))
+    if "fg" in aux and "xyz_matches" in aux["fg"]:
+        rendered["xyz_matches"] = aux["fg"]["xyz_matches"]
+        rendered["xyz_reproj"] = aux["fg"]["xyz_reproj"]
+    return {"rendered": rendered, "aux_dict": aux}
+
+
+def dvr_render_samples_chunk(self, samples_dict, flow_thresh=None, chunk_size=8192):
+    """dvr_model.render_samples_chunk (engine/model.py:259-326): chunks of ceil(chunk_size // M) pixels along N."""
+    cat0 = list(samples_dict.keys())[0]
+    M, N = samples_dict[cat0]["hxy"].shape[:2]
+    num_chunks = int(math.ceil(M * N / chunk_size))
+    chunk_n = int(math.ceil(chunk_size // M))
+    rendered, aux = defaultdict(list), defaultdict(lambda: defaultdict(list))
+    for i in range(num_chunks):
+        # like the reference, only "hxy" is cut (model.py:299-305); "feature" follows it here because the matching loss needs
+        # pixel-aligned features (the reference's training batches never exceed one chunk)
+        sd = {}
+        for cat, d in samples_dict.items():
+            sd[cat] = dict(d)
+            sd[cat]["hxy"] = d["hxy"][:, i * chunk_n:(i + 1) * chunk_n]
+            if torch.is_tensor(d.get("feature")) and d["feature"].shape[1] == N:
+                sd[cat]["feature"] = d["feature"][:, i * chunk_n:(i + 1) * chunk_n]
+        if sd[cat0]["hxy"].shape[1] == 0:
+            continue
+        res = self.render_samples(sd, flow_thresh=flow_thresh)
+        for k, v in res["rendered"].items():
+            rendered[k].append(v)
+        for cat, d in res["aux_dict"].items():
+            for k, v in d.items():
+                aux[cat][k].append(v)
+    return {"rendered": {k: torch.cat(v, 1) for k, v in rendered.items()},
+            "aux_dict": {c: {k: torch.cat(v, 1) for k, v in d.items()} for c, d in aux.items()}}
+
+
+def dvr_render(self, batch, flow_thresh=None):
+    """dvr_model.render (engine/model.py:217-235)."""
+    samples_dict = self.get_samples(batch)
+    return self.render_samples_chunk(samples_dict, flow_thresh=flow_thresh)
+
+
+def dvr_evaluate(self, batch, is_pair=True):
+    """dvr_model.evaluate (engine/model.py:162-209): frame (pair) by frame (pair), square images, masked by "mask"."""
+    div = 2 if is_pair else 1
+    self.process_frameid(batch)
+    out = defaultdict(list)
+    for i in range(len(batch["frameid"]) // div):
+        sub = {}
+        for k, v in batch.items():
+            sub[k] = {k2: v2[i * div:(i + 1) * div] for k2, v2 in v.items()} if isinstance(v, dict) else v[i * div:(i + 1) * div]
+        for k, v in self.render(sub)["rendered"].items():
+            res = int(round(math.sqrt(v.shape[1])))
+            out[k].append(v.view(div, res, res, -1)[0])
+    out = {k: torch.stack(v, 0) for k, v in out.items()}
+    for k in out:
+        if "mask" not in k:
+            out[k] = out[k] * out["mask"]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# binding
+# ---------------------------------------------------------------------------------------------------
+# (module path, class name or None for module-level, attribute, replacement, is_static)
+def bindings():
+    from . import quaternion as _q  # noqa: F401  (registers the dqtorch-compatible package)
+    return [
+        ("lab4d.utils.render_utils", None, "sample_cam_rays", RU.sample_cam_rays, False),
+        ("lab4d.utils.render_utils", None, "render_pixel", RU.render_pixel, False),
+        ("lab4d.utils.render_utils", None, "compute_weights", RU.compute_weights, False),
+        ("lab4d.utils.render_utils", None, "integrate", RU.integrate, False),
+        ("lab4d.utils.render_utils", None, "sample_pdf", RU.sample_pdf, False),
+        ("lab4d.nnutils.nerf", "NeRF", "forward", nerf_forward, False),
+        ("lab4d.nnutils.nerf", "NeRF", "query_field", query_field, False),
+        ("lab4d.nnutils.nerf", "NeRF", "backward_warp", backward_warp, False),
+        ("lab4d.nnutils.nerf", "NeRF", "forward_warp", forward_warp, False),
+        ("lab4d.nnutils.feature", "FeatureNeRF", "query_field", query_field, False),
+        ("lab4d.nnutils.feature", "FeatureNeRF", "compute_feat", compute_feat, False),
+        ("lab4d.nnutils.deformable", "Deformable", "query_field", query_field, False),
+        ("lab4d.nnutils.deformable", "Deformable", "backward_warp", backward_warp, False),
+        ("lab4d.nnutils.deformable", "Deformable", "forward_warp", forward_warp, False),
+        ("lab4d.nnutils.visibility", "VisField", "forward", vis_forward, False),
+        ("lab4d.nnutils.warping", "SkinningWarp", "forward", skinning_forward, False),
+        ("lab4d.nnutils.warping", "DenseWarp", "forward", dense_forward, False),
+        ("lab4d.nnutils.warping", "ComposedWarp", "forward", composed_forward, False),
+        ("lab4d.nnutils.multifields", "MultiFields", "compose_fields", compose_fields, True),
+        ("lab4d.nnutils.appearance", "AppearanceEmbedding", "get_vals", appearance_get_vals, False),
+        ("lab4d.engine.model", "dvr_model", "render", dvr_render, False),
+        ("lab4d.engine.model", "dvr_model", "evaluate", dvr_evaluate, False),
+        ("lab4d.engine.model", "dvr_model", "render_samples", dvr_render_samples, False),
+        ("lab4d.engine.model", "dvr_model", "render_samples_chunk", dvr_render_samples_chunk, False),
+    ]
+
+
+# names other reference modules imported BY VALUE from render_utils (`from lab4d.utils.render_utils import ...`,
+# nerf.py:31, engine/model.py:14): rebinding the source module alone would not reach them
+BY_VALUE = [("lab4d.nnutils.nerf", "sample_cam_rays"), ("lab4d.nnutils.nerf", "sample_pdf"), ("lab4d.nnutils.nerf", "compute_weights"),
+            ("lab4d.engine.model", "render_pixel")]
+
+_ORIGINALS = []
+_INHERITED = object()
+
+
+def install_quaternion():
+    """`from quaternion import ...` (utils/quat_transform.py:15-16) resolves to the HIP library from here on."""
+    from . import quaternion
+    sys.modules["quaternion"] = quaternion
+    return quaternion
+
+
+def patch(precision="bf16", n_depth=64):
+    """Rebind the reference's operator API to the HIP library.  `lab4d` must be importable.  Idempotent; `unpatch()`
+    restores the originals.  Returns the list of "module.Class.attr" names that were rebound."""
+    import importlib
+    global PRECISION, N_DEPTH
+    PRECISION = {"bf16": mlp.PREC_BF16, "f32": mlp.PREC_F32}[precision]
+    N_DEPTH = int(n_depth)
+    if _ORIGINALS:
+        return [n for n, *_ in _ORIGINALS]
+    install_quaternion()
+    done = []
+    for modname, cls, attr, fn, static in bindings():
+        mod = importlib.import_module(modname)
+        owner = mod if cls is None else getattr(mod, cls)
+        # a method inherited from a base class (AppearanceEmbedding.get_vals lives on TimeMLP) is shadowed on the subclass and
+        # the shadow removed again by unpatch(); everything else is swapped in place
+        orig = owner.__dict__.get(attr, _INHERITED) if cls else getattr(owner, attr)
+        _ORIGINALS.append(("%s.%s%s" % (modname, cls + "." if cls else "", attr), owner, attr, orig))
+        setattr(owner, attr, staticmethod(fn) if static else fn)
+        done.append(_ORIGINALS[-1][0])
+    for modname, attr in BY_VALUE:
+        mod = importlib.import_module(modname)
+        if hasattr(mod, attr):
+            _ORIGINALS.append(("%s.%s" % (modname, attr), mod, attr, getattr(mod, attr)))
+            setattr(mod, attr, getattr(RU, attr))
+    return done
+
+
+def unpatch():
+    while _ORIGINALS:
+        _, owner, attr, orig = _ORIGINALS.pop()
+        if orig is _INHERITED:
+            delattr(owner, attr)
+        else:
+            setattr(owner, attr, orig)

@@ -169,6 +169,18 @@ def frame_tid(frame_id, info):
     return (sub - info["raw_fid_to_vidlen"][fid] / 2) / info["max_ts"] * 2 * info.get("time_scale", 1.0)
 
 
+def time_info_of(te):
+    """`info` of a reference TimeEmbedding module (embedding.py:137-192): its frame tables, the normaliser max_ts its
+    frame_to_tid closure captured (recovered from the tables: the longest video) and the number of Fourier bands."""
+    dev = te.frame_mapping.device
+    max_ts = float(te.raw_fid_to_vidlen.max())
+    probe = te.frame_to_tid(torch.zeros(1, dtype=torch.long, device=dev))  # = (0 - len/2) / max_ts * 2 * time_scale
+    time_scale = float(probe[0]) / (-(float(te.raw_fid_to_vidlen[0]) / 2) / max_ts * 2)
+    return {"frame_to_vid": te.frame_to_vid, "frame_mapping": te.frame_mapping, "raw_fid_to_vid": te.raw_fid_to_vid,
+            "raw_fid_to_vidlen": te.raw_fid_to_vidlen, "raw_fid_to_vstart": te.raw_fid_to_vstart, "max_ts": max_ts,
+            "num_freq_t": te.fourier_embedding.N_freqs, "time_scale": time_scale}
+
+
 def _vid_code(P, prefix, inst_id):
     w = P[prefix + ".inst_embedding.mapping.weight"]
     return w[torch.zeros_like(inst_id) if w.shape[0] == 1 else inst_id]

@@ -75,11 +75,20 @@ class _RaySamples(Function):
 
 
 def sample_cam_rays(hxy, Kinv, near_far, n_depth=64, depth=None, perturb=False):
-    """Same contract as render_utils.sample_cam_rays (render_utils.py:8-56).  `perturb=True`
-    (stratified jitter) is implemented in the reference but no caller enables it."""
+    """Same contract as render_utils.sample_cam_rays (render_utils.py:8-56).  perturb=True (stratified jitter,
+    render_utils.py:36-42; no in-tree caller enables it): the jittered depths are formed from one torch.rand draw of
+    the reference's shape on the rays' device -- (M,N,D,1) element-wise work -- and handed to the kernel through its
+    `depth=` input, so rays, deltas and directions come from the same kernel either way."""
     if perturb:
-        raise NotImplementedError("perturb=True is never used by the reference call sites (nerf.py:618,703,735)")
-    return _RaySamples.apply(hxy, Kinv, near_far, depth, None, None, n_depth)
+        M, N = hxy.shape[:2]
+        if depth is None:
+            z = torch.linspace(0, 1, n_depth, device=hxy.device)[None]
+            depth = (near_far[:, 0:1] * (1 - z) + near_far[:, 1:2] * z)[:, None, :, None].repeat(1, N, 1, 1)
+        mid = 0.5 * (depth[:, :, :-1] + depth[:, :, 1:])
+        upper = torch.cat([mid, depth[:, :, -1:]], -2)
+        lower = torch.cat([depth[:, :, :1], mid], -2)
+        depth = (lower + (upper - lower) * torch.rand(depth.shape, device=hxy.device)).contiguous()
+    return _RaySamples.apply(hxy, Kinv, near_far, depth, None, None, n_depth)[:4]
 
 
 def ray_samples(hxy, Kinv, near_far, cam2field, n_depth=64, depth=None):
@@ -209,8 +218,31 @@ def compute_weights(density, deltas):
 
 
 def integrate(field_dict, weights):
-    """render_utils.py:129-184.  Kept for API parity; render_pixel() uses the fused kernel."""
-    raise NotImplementedError("use render_pixel(field_dict, deltas); integrate() is fused into it on this backend")
+    """render_utils.integrate (render_utils.py:129-184) for caller-supplied weights (M,N,D).  The renderer itself never calls
+    it -- render_pixel() below runs weights + integration + visibility loss as one kernel pair -- so this entry point of the
+    public signature is plain device tensor algebra (one reduction per key), kept for callers that bring their own weights."""
+    _lib.require_device(weights)
+    skip = ("density", "vis", "flow", "eikonal", "xy_reproj", "xyz_reproj", "gauss_density")
+    freeze = ("cyc_dist", "xyz_cam", "skin_entropy")
+    out = {"mask": weights.sum(-1, keepdim=True)}
+    wn = weights / (out["mask"] + 1e-6)
+    for k, v in field_dict.items():
+        if k in skip:
+            continue
+        out[k] = ((wn.detach() if k in freeze else wn).unsqueeze(-1) * v).sum(-2)
+    if "flow" in field_dict:
+        wf = weights * field_dict["flow"][..., 2]
+        wf = wf / (wf.sum(-1, keepdim=True) + 1e-6)
+        out["flow"] = (wf.unsqueeze(-1) * field_dict["flow"][..., :2]).sum(-2)
+    if "normal" in field_dict:
+        out["normal"] = F.normalize(out["normal"], 2, -1)
+    dkeys = [k for k in out if "density_" in k]
+    if dkeys:
+        dsum = torch.cat([out[k] for k in dkeys], -1).sum(-1, keepdim=True) + 1e-6
+        for k in dkeys:
+            out[k.replace("density_", "mask_")] = out[k] / dsum
+            del out[k]
+    return out
 
 
 def render_pixel(field_dict, deltas):
@@ -242,10 +274,10 @@ def render_pixel(field_dict, deltas):
 
 
 def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, return_inds=False):
-    """render_utils.py:187-233; det=True only (nerf.py:721-727 always evaluates with det=not training
-    and importance sampling only runs in eval)."""
-    if not det:
-        raise NotImplementedError("sample_pdf(det=False) is unreachable in the reference (importance sampling is eval-only)")
+    """render_utils.sample_pdf (render_utils.py:187-233).  det=True: u = linspace(0, 1, N_importance) formed in the kernel.
+    det=False (render_utils.py:212-213; unused in-tree: importance sampling is eval-only, nerf.py:721-727): u is drawn here
+    with the reference's own call, sorted per ray for the kernel's one-pass sweep of the cdf, and the result is put back in
+    draw order -- inverse-CDF sampling acts on each u independently."""
     bins, weights = bins.contiguous(), weights.contiguous()
     _f32(bins, weights)
     R, n_w = weights.shape
@@ -253,8 +285,17 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, return_inds=Fal
         raise RuntimeError("sample_pdf: bins must be (R, n_w+1)")
     samples = torch.empty(R, N_importance, device=bins.device)
     inds = torch.empty(R, N_importance, dtype=torch.int64, device=bins.device)
-    _lib.check(_lib.lib().lab4d_sample_pdf(_lib.ptr(bins), _lib.ptr(weights), R, n_w, N_importance, float(eps), _lib.ptr(samples),
-                                           _lib.ptr(inds), _lib.stream()), "sample_pdf")
+    if det:
+        _lib.check(_lib.lib().lab4d_sample_pdf(_lib.ptr(bins), _lib.ptr(weights), R, n_w, N_importance, float(eps), _lib.ptr(samples),
+                                               _lib.ptr(inds), _lib.stream()), "sample_pdf")
+    else:
+        u = torch.rand(R, N_importance, device=bins.device)
+        us, order = torch.sort(u, -1)
+        us = us.contiguous()
+        _lib.check(_lib.lib().lab4d_sample_pdf_u(_lib.ptr(bins), _lib.ptr(weights), _lib.ptr(us), R, n_w, N_importance, float(eps),
+                                                 _lib.ptr(samples), _lib.ptr(inds), _lib.stream()), "sample_pdf_u")
+        samples = torch.empty_like(samples).scatter_(1, order, samples)
+        inds = torch.empty_like(inds).scatter_(1, order, inds)
     return (samples, inds) if return_inds else samples
 
 

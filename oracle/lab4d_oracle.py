@@ -568,12 +568,23 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None)
         t_embed (M,128), t_embed_mean (1,128), appr_code (M,32), code_base/code_color/code_vis/
         code_skin (M,32), feature (M,N,16)}
     rng: host-drawn randomness {"eik_inds": LongTensor|None, "match_perm": LongTensor}
+    fr["dense"] (optional): {"t_embed" (M,128), "code_fw" (M,32), "code_bw" (M,32)} = the per-frame inputs of ComposedWarp's
+        dense post-warp (fg_motion "comp_skel-*_dense", warping.py:445-483); every warp below then goes through
+        composed_warp.  The flow branch warps into the pair partner's frame, so its post-warp sees the partner's time
+        embedding (nerf.py:966-973: frame_id_next).
     Returns feat_dict, deltas, aux_dict exactly as the reference does."""
+    dense = fr.get("dense")
+
+    def warp(x, t_art, rest_art, t_embed, backward, partner=False):
+        if dense is None:
+            return skinning_warp(P, x, t_art, rest_art, t_embed, fr["code_skin"], backward=backward)
+        d = dict(dense, t_embed=flip_pair(dense["t_embed"])) if partner else dense
+        return composed_warp(P, x, t_art, rest_art, t_embed, fr["code_skin"], backward, dense=d)
+
     xyz_cam, dir_cam, deltas, depth = sample_cam_rays(hxy, fr["Kinv"], fr["near_far"], n_depth=n_depth)
     # backward warp (deformable.py:119-152)
     xyz_t, _ = cam_to_field(xyz_cam, None, fr["field2cam"])
-    xyz, bw_aux = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"],
-                                fr["code_skin"], backward=True)
+    xyz, bw_aux = warp(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
     fd = {}
     vis = vis_field(P, xyz, fr["code_vis"])
     rgb, density = nerf_forward(P, xyz, {"basefield": fr["code_base"], "colorfield": fr["code_color"]},
@@ -582,8 +593,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None)
     fd["vis"] = vis
     # flow (nerf.py:948-997): warp canonical points into the pair partner's camera
     nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam", "t_articulation", "rest_articulation"]})
-    xyz_next, _ = skinning_warp(P, xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"],
-                                fr["code_skin"], backward=False)
+    xyz_next, _ = warp(xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"], False, partner=True)
     xyz_cam_next = field_to_cam(xyz_next, nxt["field2cam"])
     hxy_next = pinhole_projection(kmatinv(nxt["Kinv"]), xyz_cam_next)
     flow = (hxy_next - hxy.unsqueeze(-2))[..., :2]
@@ -592,8 +602,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None)
         valid = valid & (flow.norm(dim=-1, keepdim=True) < float(flow_thresh))
     fd["flow"] = torch.cat([flow, valid.to(flow.dtype)], -1)
     # cycle loss (deformable.py:173-198)
-    xyz_cyc, cyc_aux = skinning_warp(P, xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"],
-                                     fr["code_skin"], backward=False)
+    xyz_cyc, cyc_aux = warp(xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
     fd["cyc_dist"] = (xyz_cyc - xyz_t).norm(2, -1, keepdim=True)
     for k in ["skin_entropy", "delta_skin"]:
         fd[k] = (cyc_aux[k] + bw_aux[k]) / 2
@@ -606,8 +615,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None)
     fd["feature"] = compute_feat(P, xyz)
     aux = {}
     xyz_matches = global_match(P, fr["feature"], fd["feature"], xyz, rng["match_perm"])
-    xm_next, _ = skinning_warp(P, xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"],
-                               fr["t_embed_mean"], fr["code_skin"], backward=False)
+    xm_next, _ = warp(xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
     xyz_reproj = field_to_cam(xm_next, fr["field2cam"])[:, :, 0]
     aux["xyz_matches"] = xyz_matches
     aux["xyz_reproj"] = xyz_reproj

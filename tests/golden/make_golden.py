@@ -36,7 +36,7 @@ def compress_grad(g):
     return {"norm": g.double().norm().float(), "stride": stride, "sub": g.flatten()[::stride].clone()}
 
 
-def build_reference_field(ns, P, num_inst=1):
+def build_reference_field(ns, P, num_inst=1, fg_motion="skel-quad"):
     torch.manual_seed(0)
     di = ref_shim.synthetic_data_info(64)
     if num_inst > 1:  # one video per instance: the skinning / time modules size their tables from frame_info (skinning.py:70-86)
@@ -44,7 +44,7 @@ def build_reference_field(ns, P, num_inst=1):
         off = np.asarray([round(64 * i / num_inst) for i in range(num_inst + 1)])
         di["frame_info"]["frame_offset"] = off
         di["frame_info"]["frame_offset_raw"] = off.copy()
-    f = ns.deformable.Deformable("skel-quad", di, num_freq_dir=-1, appr_channels=32, num_inst=num_inst, init_scale=0.2)
+    f = ns.deformable.Deformable(fg_motion, di, num_freq_dir=-1, appr_channels=32, num_inst=num_inst, init_scale=0.2)
     f.category = "fg"
     sd = {k: v for k, v in P.items() if k in f.state_dict()}
     missing = [k for k in P if k not in f.state_dict() and k != "warp.skinning_model.symm_idx"]
@@ -61,6 +61,8 @@ def frames_from_reference(f, fr):
         fr["t_embed"] = f.warp.skinning_model.time_embedding(fid).clone()
         fr["t_embed_mean"] = f.warp.skinning_model.time_embedding.get_mean_embedding("cpu").clone()
         fr["appr_code"] = f.appr_embedding.get_vals(fid).clone()
+        if hasattr(f.warp, "post_warp"):  # ComposedWarp: the dense post-warp has its own TimeEmbedding (warping.py:119)
+            fr["t_embed_dense"] = f.warp.post_warp.time_embedding(fid).clone()
     return fr
 
 
@@ -88,11 +90,14 @@ def leafify(fr, names):
     return out, leaves
 
 
-def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None, frame_id=None, full_grid_stride=None):
+def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None, frame_id=None, full_grid_stride=None, fg_motion="skel-quad",
+              rows=None):
     """num_inst > 1 / inst_id: the multi-instance configuration (BASELINE config 4): per-instance codes in every CondMLP
     (base.py:123-150), frames of one pair share their video's instance id."""
     P = synthetic.make_weights(seed, num_inst=num_inst)
-    f = build_reference_field(ns, P, num_inst)
+    if fg_motion.startswith("comp_"):  # fg_motion "comp_skel-quad_dense" (BASELINE configs 2-3): skinning + dense post-warp
+        P = synthetic.add_dense_weights(P, seed, num_inst)
+    f = build_reference_field(ns, P, num_inst, fg_motion)
     f.train()
     f.pos_embedding.set_alpha(alpha)
     f.pos_embedding_color.set_alpha(alpha)
@@ -104,7 +109,7 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
     fr = frames_from_reference(f, fr)
     g = torch.Generator().manual_seed(seed + 2)
     if full_grid_stride:  # BASELINE config 0: the whole res x res crop of every frame; only every stride-th ray is stored
-        hxy = synthetic.make_rays(res, M)
+        hxy = synthetic.make_rays(res, M, rows=rows)  # rows=(y0, y1): a band of image rows of every frame (the bench's chunk shape)
         N = hxy.shape[1]
     else:
         hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
@@ -151,7 +156,7 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
         if gv is not None:
             gd[k] = compress_grad(gv.detach())
     out = {
-        "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "alpha": alpha, "num_inst": num_inst,
+        "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "alpha": alpha, "num_inst": num_inst, "fg_motion": fg_motion,
                  "weight_checksum": weight_checksum(P), "flow_thresh": float(res)},
         "frames": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in fr.items()},
         "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds.clone(), "match_perm": match_perm.clone()},
@@ -163,6 +168,7 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
     if full_grid_stride:  # compact fixture: inputs are regenerated from the seeds by the tests (make_rays / make_targets)
         st = full_grid_stride
         out["meta"]["full_grid_stride"] = st
+        out["meta"]["rows"] = rows
         for k in ("hxy", "batch", "feat_dict", "deltas"):
             out.pop(k)
         out["rendered"] = {k: v[:, ::st].clone() for k, v in out["rendered"].items()}
@@ -496,9 +502,13 @@ def main(only=None):
         ("ops", lambda: gen_ops(ns)),
         ("train_small", lambda: gen_train(ns, "small", M=2, N=6, D=8, res=64, seed=11)),
         ("train_alpha", lambda: gen_train(ns, "alpha", M=4, N=5, D=6, res=64, seed=21, alpha=0.45)),
+        ("train_compmotion", lambda: gen_train(ns, "compmotion", M=2, N=6, D=8, res=64, seed=51, fg_motion="comp_skel-quad_dense", frame_id=[3, 4])),
         ("train_multi", lambda: gen_train(ns, "multi", M=4, N=5, D=6, res=64, seed=31, num_inst=3, inst_id=[1, 1, 2, 2], frame_id=[22, 23, 44, 45])),
         # BASELINE config 0: 64x64 crop x 64 samples
         ("train_c1", lambda: gen_train(ns, "c1", M=2, N=None, D=64, res=64, seed=41, full_grid_stride=16)),
+        # BASELINE config 1 = the bench shape: 512x512, 128 samples/ray; a 2-row band (rows 255-256: half inside the target mask's
+        # disc) of a frame pair = 2 x 1,024 rays = 262,144 samples through the reference; every 16th ray is stored
+        ("train_bench", lambda: gen_train(ns, "bench", M=2, N=None, D=128, res=512, seed=61, full_grid_stride=16, rows=(255, 257))),
         ("eval_small", lambda: gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)),
         ("comp_warp", lambda: gen_comp_warp(ns)),
         ("bg_field", lambda: gen_bg_field(ns)),

@@ -7,6 +7,7 @@ import torch
 
 from lab4d_amd import synthetic
 from oracle import lab4d_oracle as O
+from parity_report import report
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -23,26 +24,20 @@ def rel(a, b):
 # graph evaluated in fp64 (tests/test_oracle_properties.py::test_eikonal_fp32_noise_floor measures it): no fp32
 # implementation with a different accumulation order can agree with it more closely than that.
 RENDER_TOL_F32 = {"eikonal": 2e-3}
-
-
-def report(tag, measured):
-    """Measured errors go to stdout (pytest -s / -rP) and to gpurun_out/parity_<tag>.json so that the bound and the measurement
-    can be read side by side."""
-    import json
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_%s.json" % tag), "w") as f:
-        json.dump({k: float("%.3e" % v) for k, v in measured.items()}, f, indent=1, sort_keys=True)
-    print(tag, {k: "%.2e" % v for k, v in measured.items()})
+# importance-sampling indices that may differ from the reference's (by one bin, at a cdf entry equal to the query to rounding)
+# on eval_small.pt: 16 rays x 8 fine samples = 128 indices.  Measured on MI355X: see gpurun_out/parity_eval_indices.json.
+EVAL_INDEX_MISMATCH_MAX = 2  # measured: 1 of 128
 
 
 def load_case(golden_dir, name):
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
     P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"))
+    if g["meta"].get("fg_motion", "skel-quad").startswith("comp_"):
+        P = synthetic.add_dense_weights(P, g["meta"]["seed"], g["meta"].get("num_inst", 1))
     return g, P
 
 
-@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt"])
+@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_compmotion.pt"])
 def test_training_graph_matches_reference_goldens(golden_dir, case):
     from lab4d_amd import deformable as DF
     g, P = load_case(golden_dir, case)
@@ -102,37 +97,95 @@ def test_training_graph_multi_instance(golden_dir):
     test_training_graph_matches_reference_goldens(golden_dir, "train_multi.pt")
 
 
-def test_training_graph_at_baseline_config0_size(golden_dir):
-    """BASELINE.json configs[0] at full size on the device: the 64x64 crop of a frame pair x 64 samples/ray (524,288 samples) against
-    the reference-generated fixture (every 16th ray of the render, losses, compressed gradients); fp32 path."""
+def _run_full_size(golden_dir, name, prec):
+    """A reference-generated fixture at a BASELINE size (rays / targets regenerated from the seeds, every stride-th ray of the
+    reference's render stored): device render + losses + gradients, returned as measured errors relative to the reference.
+    rendered.* / loss.*: max abs error over the largest reference value; grad.*: relative L2 error of the (sub-sampled) tensor."""
     from lab4d_amd import deformable as DF
-    g = torch.load(os.path.join(golden_dir, "train_c1.pt"), weights_only=False)
+    g = torch.load(os.path.join(golden_dir, name), weights_only=False)
     meta = g["meta"]
     st, M, res, seed = meta["full_grid_stride"], meta["M"], meta["res"], meta["seed"]
     P = synthetic.make_weights(seed)
     Pd = {k: (v.to(DEV).clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v.to(DEV)) for k, v in P.items()}
-    hxy = synthetic.make_rays(res, M)
+    hxy = synthetic.make_rays(res, M, rows=meta.get("rows"))
     batch = synthetic.to_device(synthetic.make_targets(seed + 3, M, hxy.shape[1], res, hxy), DEV)
     fr = synthetic.add_codes(synthetic.to_device(dict(g["frames"]), DEV), Pd)
     fr["feature"] = batch["feature"]
     out = DF.render_train(Pd, fr, hxy.to(DEV), synthetic.to_device(g["rng"], DEV), flow_thresh=meta["flow_thresh"], n_depth=meta["D"],
-                          alpha=meta["alpha"])
+                          alpha=meta["alpha"], prec=prec)
     measured = {}
     for k, v in g["rendered"].items():
-        e = measured["rendered." + k] = rel(out["rendered"][k][:, ::st], v)
-        assert e < RENDER_TOL_F32.get(k, 3e-4), f"rendered.{k}: {e:.3e}"
+        measured["rendered." + k] = rel(out["rendered"][k][:, ::st], v)
+    mse = float(((out["rendered"]["rgb"][:, ::st].detach().cpu() - g["rendered"]["rgb"]) ** 2).mean())
+    measured["psnr_rgb_db"] = -10.0 * torch.log10(torch.tensor(max(mse, 1e-20))).item()
     losses = DF.losses_fg(out, batch, res, DF.DEFAULT_LOSS_WT)
     for k, v in g["loss"].items():
-        e = measured["loss." + k] = rel(losses[k], v)
-        assert e < (2e-3 if k == "reg_eikonal" else 5e-4), f"loss.{k}: {e:.3e}"
+        measured["loss." + k] = rel(losses[k], v)
     names = [k for k in g["grads"] if not k.startswith("frame:")]
     grads = torch.autograd.grad(sum(losses.values()), [Pd[k] for k in names], allow_unused=True)
     for k, gv in zip(names, grads):
         ref = g["grads"][k]
         assert gv is not None, k
-        e = measured["grad." + k] = rel(gv, ref["full"]) if "full" in ref else rel(gv.flatten()[:: ref["stride"]], ref["sub"])
-        assert e < 1e-2, f"grad {k}: {e:.3e}"
-    report("config0_fp32", measured)
+        a, b = (gv, ref["full"]) if "full" in ref else (gv.flatten()[:: ref["stride"]], ref["sub"])
+        a, b = a.detach().double().cpu().flatten(), b.double().flatten()
+        measured["grad." + k] = float((a - b).norm() / (b.norm() + 1e-30))
+    return measured
+
+
+def _assert_bounds(tag, measured, bounds, default):
+    report(tag, measured)
+    bad = {}
+    for k, e in measured.items():
+        if k == "psnr_rgb_db":
+            continue
+        family = k.split(".")[0]
+        b = bounds.get(k, bounds.get(family, default))
+        if not e < b:
+            bad[k] = (e, b)
+    assert not bad, bad
+
+
+# fp32 path: every rendered channel / loss within 3e-4 of the channel's largest reference value (eikonal: RENDER_TOL_F32),
+# every gradient tensor within 1e-3 relative L2.
+F32_BOUNDS = {"rendered.eikonal": 2e-3, "loss.reg_eikonal": 2e-3, "rendered": 3e-4, "loss": 5e-4, "grad": 1e-3}
+
+
+def test_training_graph_at_baseline_config0_size(golden_dir):
+    """BASELINE.json configs[0] at full size on the device: the 64x64 crop of a frame pair x 64 samples/ray (524,288 samples)
+    against the reference-generated fixture (every 16th ray of the render, losses, compressed gradients); fp32 path."""
+    from lab4d_amd import mlp
+    _assert_bounds("config0_fp32", _run_full_size(golden_dir, "train_c1.pt", mlp.PREC_F32), F32_BOUNDS, 3e-4)
+
+
+def test_training_graph_at_the_bench_shape_fp32(golden_dir):
+    """BASELINE.json configs[1]'s shape (the shape bench.py times): 512x512 frame pair, 128 samples/ray -- a 2-row band of both
+    frames (2,048 rays, 262,144 samples) through the whole training graph against the reference's own output; fp32 path."""
+    from lab4d_amd import mlp
+    _assert_bounds("bench_fp32", _run_full_size(golden_dir, "train_bench.pt", mlp.PREC_F32), F32_BOUNDS, 3e-4)
+
+
+# bf16 path (the dtype bench.py times; BASELINE configs[1] says bf16).  MFMA operands -- weights and every stored activation --
+# are rounded to 8 significant bits (unit roundoff u = 2^-9 = 2.0e-3), accumulation is fp32.  A rendered channel passes through
+# up to 10 (sdf) + 5 (colour) such layers; rounding errors are independent per layer, so the expected relative error of a
+# per-sample output is ~ sqrt(15) u = 8e-3; compositing 128 samples (weights sum to <= 1, errors independent per sample)
+# averages that down by ~ sqrt(128), to the 1e-4 level the geometry / colour channels show.  Bounds = the values measured on
+# MI355X for this fixture (profiles/r02_parity_bench_bf16.json; worst rendered channel 7.6e-5, worst gradient 1.1e-2) with a
+# 2-3x margin.  Channels with their own rows: eikonal ((|d sdf/dx| - 1)^2: a squared derivative, 8.3e-3 measured), the
+# 16-channel feature field and the soft-argmax match built on it (L2-normalised 128-wide MLP output, 3.3e-3 / 1.7e-3), and
+# delta_skin (mean square of a 64-wide MLP's output, 8.3e-4).  Gradients: relative L2 per parameter tensor (the dgrad chain
+# sees bf16 weights and bf16 stored dZ; wgrad contracts bf16 dZ with bf16 activations in fp32).
+BF16_BOUNDS = {
+    "rendered": 2e-4, "rendered.eikonal": 2e-2, "rendered.feature": 1e-2, "rendered.xyz_matches": 5e-3, "rendered.delta_skin": 3e-3,
+    "loss": 1.5e-4, "loss.reg_eikonal": 2e-3, "loss.reg_delta_skin": 1e-3, "grad": 2.5e-2,
+}
+
+
+def test_training_graph_at_the_bench_shape_bf16(golden_dir):
+    """The benched dtype at the benched shape against the reference (fp32) render of the same rays / weights."""
+    from lab4d_amd import mlp
+    m = _run_full_size(golden_dir, "train_bench.pt", mlp.PREC_BF16)
+    _assert_bounds("bench_bf16", m, BF16_BOUNDS, 2e-2)
+    assert m["psnr_rgb_db"] > 90.0, m["psnr_rgb_db"]  # measured 99.3 dB vs the reference render
 
 
 def test_bf16_training_graph_is_close_to_fp32(golden_dir):
@@ -163,15 +216,18 @@ def test_eval_graph_matches_reference_goldens(golden_dir):
     out = DF.render_eval(Pd, fr, g["hxy"].to(DEV), n_depth=meta["D"])
     inds = out["debug"]["inds"].cpu()
     mism = (inds != g["inds"]).float().mean().item()
-    # the density that feeds sample_pdf went through the warp and 10 fp32 MFMA layers: indices may differ from the
-    # reference only where u falls within rounding of a cdf entry, i.e. by one bin and rarely; the
-    # rendered channels below (2e-4) are the functional check
-    assert mism <= 0.03, mism
-    assert int((inds - g["inds"]).abs().max()) <= 1
+    # The density that feeds sample_pdf went through the warp and 10 fp32 MFMA layers, so a cdf entry can land on the other
+    # side of a query u where the two agree to rounding: such an index differs by exactly one bin and the interpolated sample
+    # is the same point (the rendered channels below are the functional check).  The measured rate on this fixture is
+    # printed / stored next to the bound; the bound is the fixture's measured count + 1 sample, not a blanket percentage.
+    n_diff = int((inds != g["inds"]).sum())
     valid = out["debug"]["valid"].cpu()
-    vm = (valid != g["valid"]).float().mean().item()
-    assert vm <= 0.002, vm
-    assert vm == 0.0, "valid mask must be identical on this fixture"
+    vm = int((valid != g["valid"]).sum())
+    report("eval_indices", {"importance_index_mismatch_rate": mism, "importance_index_mismatch_count": float(n_diff),
+                            "importance_index_total": float(inds.numel()), "valid_mask_mismatch_count": float(vm)})
+    assert n_diff <= EVAL_INDEX_MISMATCH_MAX, (n_diff, inds.numel())
+    assert int((inds - g["inds"]).abs().max()) <= 1
+    assert vm == 0, "valid mask must be identical (bit-exact bool) on this fixture"
     # index differences are confined to exact cdf ties (the u = 1 end point): the resulting samples coincide, so every
     # rendered channel must still match the reference render at 1e-4 (fp32 path)
     for k, v in g["rendered"].items():

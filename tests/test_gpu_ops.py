@@ -224,29 +224,43 @@ def test_sample_pdf_indices_and_samples(golden_dir):
     ops = torch.load(os.path.join(golden_dir, "ops.pt"), weights_only=False)
     bins, wts, s_ref, inds_ref = ops["sample_pdf"]  # produced by the reference itself
     s, inds = RU.sample_pdf(bins.to(DEV), wts.to(DEV), 16, det=True, return_inds=True)
-    _check_inds(inds.cpu(), s.cpu(), bins, wts, 16)
+    _check_inds(inds.cpu(), s.cpu(), bins, wts, 16, "reference_golden")
     close(s, s_ref, "samples", rtol=1e-4)
-    # larger random case against the oracle
+    # larger random cases against the oracle: rows with all-positive weights, and rows with a run of 30 zero-weight bins -- there
+    # the cdf climbs by eps / sum = 3e-7 per entry, i.e. 30 consecutive entries sit within a few ulp of each other and of any
+    # query u that lands among them, which is where (and only where) the last-ulp difference between torch's vectorised fp32
+    # row sum and the kernel's sequential sum can move an index by one bin.  The two populations are measured separately.
     g = gen(8)
     R, nw, ni = 5000, 62, 64
     bins = torch.sort(torch.rand(R, nw + 1, generator=g), -1)[0]
     wts = torch.rand(R, nw, generator=g) + 0.01  # keep pdf away from the eps=1e-5 switch (a discontinuity of the reference)
-    wts[::7, 10:40] = 0
+    flat = torch.zeros(R, dtype=torch.bool)
+    flat[::7] = True
+    wts[flat, 10:40] = 0
     s, inds = RU.sample_pdf(bins.to(DEV), wts.to(DEV), ni, det=True, return_inds=True)
-    _check_inds(inds.cpu(), s.cpu(), bins, wts, ni)
+    _check_inds(inds.cpu()[~flat], s.cpu()[~flat], bins[~flat], wts[~flat], ni, "random_positive_weights")
+    _check_inds(inds.cpu()[flat], s.cpu()[flat], bins[flat], wts[flat], ni, "random_zero_weight_runs")
     s_o, inds_o = O.sample_pdf(bins, wts, ni, return_inds=True)
     same = (inds.cpu() == inds_o)  # at an fp tie inside a zero-weight bin the sample legitimately jumps a bin
     close(torch.where(same, s.cpu(), s_o), s_o, "samples vs oracle", rtol=1e-4, atol=1e-5)
     assert bool((s.cpu()[:, 1:] >= s.cpu()[:, :-1] - 1e-6).all()), "det=True samples must be monotone"
 
 
-def _check_inds(inds, samples, bins, wts, n_imp):
-    """Indices must equal torch's searchsorted(right=True) except at exact ties created by the
-    fp32 normaliser (sum over the row), where torch's own CPU builds (AVX2/AVX512) and its CUDA
-    build already disagree with each other: there the u value sits within 2 ulp of a cdf entry."""
+# measured on MI355X (gpurun_out/parity_sample_pdf_*.json): mismatching searchsorted indices / total
+SAMPLE_PDF_MISMATCH_MAX = {"reference_golden": 0, "random_positive_weights": 64, "random_zero_weight_runs": 1000}
+
+
+def _check_inds(inds, samples, bins, wts, n_imp, tag):
+    """Indices must equal torch's searchsorted(right=True) (the reference's own output for `reference_golden`) except at
+    ties created by the fp32 row normaliser, where torch's own CPU builds (AVX2 / AVX-512 lane order) and its GPU reduction
+    already disagree with each other: there u sits within 3 ulp of a cdf entry and the index moves by exactly one bin.
+    The measured count is reported and held to a per-case bound (not a blanket percentage)."""
     s_ref, inds_ref = O.sample_pdf(bins, wts, n_imp, return_inds=True)
     mism = inds != inds_ref
-    if mism.any():
+    n_bad = int(mism.sum())
+    from parity_report import report
+    report("sample_pdf_" + tag, {"mismatch_count": float(n_bad), "total": float(inds.numel()), "rate": n_bad / inds.numel()})
+    if n_bad:
         w = wts + 1e-5
         cdf = torch.cat([torch.zeros(len(w), 1), torch.cumsum(w / w.sum(-1, keepdim=True), -1)], -1)
         u = torch.linspace(0, 1, n_imp).expand(len(w), n_imp)
@@ -255,7 +269,76 @@ def _check_inds(inds, samples, bins, wts, n_imp):
             j = min(int(inds[r, c]), int(inds_ref[r, c]))
             assert abs(int(inds[r, c]) - int(inds_ref[r, c])) == 1
             assert abs(float(cdf[r, j]) - float(u[r, c])) <= 3 * 1.2e-7 * max(1.0, float(u[r, c])), (r, c)
-        assert mism.float().mean() < 2e-2
+    assert n_bad <= SAMPLE_PDF_MISMATCH_MAX[tag], (tag, n_bad, inds.numel())
+
+
+def test_sample_pdf_random_draws_and_stratified_rays():
+    """The two branches of the public signatures no in-tree caller enables: sample_pdf(det=False) and
+    sample_cam_rays(perturb=True).  The device draws its own torch.rand, so the checks are on what the branch must
+    satisfy: det=False samples = the inverse-CDF map of SOME u in [0,1) per element -- recovered through the oracle with the
+    device's draw replayed; perturb=True depths stay inside their strata and rays / deltas follow from them."""
+    from lab4d_amd import render_utils as RU
+    g = gen(21)
+    R, nw, ni = 300, 30, 16
+    bins = torch.sort(torch.rand(R, nw + 1, generator=g), -1)[0]
+    wts = torch.rand(R, nw, generator=g) + 0.05
+    torch.manual_seed(5)
+    s, inds = RU.sample_pdf(bins.to(DEV), wts.to(DEV), ni, det=False, return_inds=True)
+    torch.manual_seed(5)
+    u = torch.rand(R, ni, device=DEV).cpu()  # the draw sample_pdf made
+    w = wts + 1e-5
+    cdf = torch.cat([torch.zeros(R, 1), torch.cumsum(w / w.sum(-1, keepdim=True), -1)], -1)
+    inds_ref = torch.searchsorted(cdf, u.contiguous(), right=True)
+    assert float((inds.cpu() != inds_ref).float().mean()) < 2e-3
+    below, above = (inds_ref - 1).clamp_min(0), inds_ref.clamp_max(nw)
+    c0, c1, b0, b1 = cdf.gather(1, below), cdf.gather(1, above), bins.gather(1, below), bins.gather(1, above)
+    den = c1 - c0
+    den[den < 1e-5] = 1
+    s_ref = b0 + (u - c0) / den * (b1 - b0)
+    ok = inds.cpu() == inds_ref
+    assert torch.allclose(s.cpu()[ok], s_ref[ok], rtol=1e-4, atol=1e-5)
+    assert not bool((s.cpu()[:, 1:] >= s.cpu()[:, :-1]).all()), "det=False samples come back in draw order, not sorted"
+    # stratified rays
+    M, N, D = 2, 50, 16
+    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * 64, torch.ones(M, N, 1)], -1).to(DEV)
+    Kinv = torch.linalg.inv(torch.tensor([[64.0, 0, 32], [0, 64, 32], [0, 0, 1]]))[None].repeat(M, 1, 1).to(DEV)
+    nf = torch.tensor([[0.4, 0.8], [0.5, 0.9]], device=DEV)
+    xyz0, dir0, del0, dep0 = RU.sample_cam_rays(hxy, Kinv, nf, n_depth=D)
+    xyz, dirs, deltas, depth = RU.sample_cam_rays(hxy, Kinv, nf, n_depth=D, perturb=True)
+    mid = 0.5 * (dep0[:, :, :-1] + dep0[:, :, 1:])
+    lower, upper = torch.cat([dep0[:, :, :1], mid], 2), torch.cat([mid, dep0[:, :, -1:]], 2)
+    assert bool(((depth >= lower - 1e-6) & (depth <= upper + 1e-6)).all()) and float((depth - dep0).abs().max()) > 1e-3
+    assert torch.allclose(dirs, dir0) and torch.allclose(xyz, xyz0 / dep0 * depth, rtol=1e-5, atol=1e-6)
+    dn = (hxy @ Kinv.transpose(1, 2)).norm(dim=-1)[:, :, None, None]
+    ref_d = torch.cat([depth[:, :, 1:] - depth[:, :, :-1], depth[:, :, -1:] - depth[:, :, -2:-1]], 2) * dn
+    assert torch.allclose(deltas, ref_d, rtol=1e-5, atol=1e-7)
+
+
+def test_integrate_with_caller_weights_equals_render_pixel():
+    """render_utils.integrate(field_dict, weights) (public signature; the renderer itself uses the fused render_pixel): with the
+    weights compute_weights returns it must reproduce render_pixel's integrated channels, and the oracle's integrate."""
+    from lab4d_amd import render_utils as RU
+    g = gen(22)
+    M, N, D = 2, 9, 12
+    fd = {"density": torch.rand(M, N, D, 1, generator=g) * 30, "rgb": torch.rand(M, N, D, 3, generator=g), "xyz": torch.randn(M, N, D, 3, generator=g),
+          "cyc_dist": torch.rand(M, N, D, 1, generator=g), "flow": torch.cat([torch.randn(M, N, D, 2, generator=g), (torch.rand(M, N, D, 1, generator=g) > 0.3).float()], -1),
+          "normal": torch.randn(M, N, D, 3, generator=g)}
+    fd["density_fg"] = fd["density"]
+    deltas = torch.rand(M, N, D, 1, generator=g) * 0.02
+    fdd, dd = synthetic_to(fd), deltas.to(DEV)
+    w, _ = RU.compute_weights(fdd["density"], dd)
+    out = RU.integrate(fdd, w)
+    ref = O.integrate(fd, O.compute_weights(fd["density"], deltas)[0])
+    assert set(out.keys()) == set(ref.keys())
+    for k, v in ref.items():
+        close(out[k], v, "integrate." + k, rtol=1e-4)
+    rp = RU.render_pixel(fdd, dd)
+    for k in ("mask", "rgb", "xyz", "cyc_dist", "flow", "normal", "mask_fg"):
+        close(out[k], rp[k].cpu(), "integrate vs render_pixel." + k, rtol=1e-4)
+
+
+def synthetic_to(d):
+    return {k: v.to(DEV) for k, v in d.items()}
 
 
 def test_sort_depth_matches_torch_sort():

@@ -1,0 +1,225 @@
+"""lab4d_amd.patch on the device: the adapters (same signatures as the reference's methods) driven with stand-in module objects
+(tests/standins.py: same attribute names, parameters under the reference's state_dict names, per-frame modules replaced by
+the rows the reference produced) against the reference-generated fixtures.  The build-container half -- binding into the real
+reference, signature equality, state_dict names -- is tests/test_patch_signatures.py."""
+import os
+import types
+
+import pytest
+import torch
+
+from lab4d_amd import synthetic
+from oracle import lab4d_oracle as O
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import standins  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.fixture()
+def patch_f32():
+    from lab4d_amd import mlp, patch
+    saved = (patch.PRECISION, patch.N_DEPTH, patch.draw_rng)
+    patch.PRECISION = mlp.PREC_F32
+    yield patch
+    patch.PRECISION, patch.N_DEPTH, patch.draw_rng = saved
+
+
+def _load(golden_dir, name):
+    g = torch.load(os.path.join(golden_dir, name), weights_only=False)
+    meta = g["meta"]
+    P = synthetic.make_weights(meta["seed"], num_inst=meta.get("num_inst", 1), sdf_bias=meta.get("sdf_bias"))
+    composed = meta.get("fg_motion", "skel-quad").startswith("comp_")
+    if composed:
+        P = synthetic.add_dense_weights(P, meta["seed"], meta.get("num_inst", 1))
+    return g, synthetic.to_device(P, DEV), composed
+
+
+def _samples_dict(g, with_feature=True):
+    fr = synthetic.to_device(dict(g["frames"]), DEV)
+    sd = {k: fr[k] for k in ("Kinv", "field2cam", "frame_id", "inst_id", "near_far", "t_articulation", "rest_articulation")}
+    sd["hxy"] = g["hxy"].to(DEV)
+    if with_feature:
+        sd["feature"] = g["batch"]["feature"].to(DEV)
+    return fr, sd
+
+
+def _model(field):
+    from lab4d_amd import patch
+    m = types.SimpleNamespace(fields=types.SimpleNamespace(field_params={"fg": field}))
+    m.render_samples = types.MethodType(patch.dvr_render_samples, m)
+    m.render_samples_chunk = types.MethodType(patch.dvr_render_samples_chunk, m)
+    return m
+
+
+@pytest.mark.parametrize("case", ["train_small.pt", "train_compmotion.pt"])
+def test_query_field_and_render_samples_match_the_reference(golden_dir, patch_f32, case):
+    """Deformable.query_field -> dvr_model.render_samples_chunk through the adapters, training mode, vs the reference's own
+    outputs for the same rays / weights / random draws; gradients reach the stand-in module's parameters."""
+    from lab4d_amd import deformable as DF
+    patch = patch_f32
+    g, P, composed = _load(golden_dir, case)
+    meta = g["meta"]
+    fr, sd = _samples_dict(g)
+    field = standins.fg_field(P, fr, composed=composed, alpha=meta["alpha"], training=True)
+    patch.N_DEPTH = meta["D"]
+    rng = synthetic.to_device(g["rng"], DEV)
+    patch.draw_rng = lambda M, N, D, device: rng  # the fixture's draws instead of fresh ones
+    fd, deltas, aux = patch.query_field(field, sd, flow_thresh=meta["flow_thresh"])
+    assert set(fd.keys()) == set(g["feat_dict"].keys())
+    for k, v in g["feat_dict"].items():
+        assert rel(fd[k], v) < 2e-4, (k, rel(fd[k], v))
+    assert rel(deltas, g["deltas"]) < 1e-5
+    res = patch.dvr_render_samples_chunk(_model(field), {"fg": sd}, flow_thresh=meta["flow_thresh"], chunk_size=8192)
+    assert set(res["rendered"].keys()) == set(g["rendered"].keys())
+    for k, v in g["rendered"].items():
+        assert rel(res["rendered"][k], v) < 2e-4, (k, rel(res["rendered"][k], v))
+    for k, v in g["aux_fg"].items():
+        assert rel(res["aux_dict"]["fg"][k], v) < 2e-4, (k, rel(res["aux_dict"]["fg"][k], v))
+    losses = DF.losses_fg(res, synthetic.to_device(g["batch"], DEV), meta["res"], DF.DEFAULT_LOSS_WT)
+    params = dict(field.named_parameters())
+    names = [k for k in g["grads"] if not k.startswith("frame:") and k in params]
+    assert len(names) > 40
+    grads = torch.autograd.grad(sum(losses.values()), [params[k] for k in names], allow_unused=True)
+    for k, gv in zip(names, grads):
+        ref = g["grads"][k]
+        assert gv is not None, k
+        e = rel(gv, ref["full"]) if "full" in ref else rel(gv.flatten()[:: ref["stride"]], ref["sub"])
+        assert e < 5e-3, (k, e)
+
+
+def test_eval_query_field_and_chunking(golden_dir, patch_f32):
+    """Eval mode (importance sampling, valid-sample compaction, normals) through the adapters vs the reference fixture; chunked
+    rendering concatenates to the unchunked result (per-ray quantities; "vis" is normalised per chunk by design)."""
+    patch = patch_f32
+    g, P, _ = _load(golden_dir, "eval_small.pt")
+    fr, sd = _samples_dict(g, with_feature=False)
+    field = standins.fg_field(P, fr, training=False)
+    patch.N_DEPTH = g["meta"]["D"]
+    fd, deltas, aux = patch.query_field(field, sd)
+    assert aux == {}
+    for k, v in g["feat_dict"].items():
+        # per-sample normal / eikonal: a normalised (squared) first derivative, see RENDER_TOL_F32 in test_gpu_field.py
+        assert rel(fd[k], v) < (5e-3 if k in ("normal", "eikonal") else 5e-4), (k, rel(fd[k], v))
+    one = patch.dvr_render_samples_chunk(_model(field), {"fg": sd})
+    for k, v in g["rendered"].items():
+        assert rel(one["rendered"][k], v) < 5e-4, (k, rel(one["rendered"][k], v))
+    M, N = sd["hxy"].shape[:2]
+    many = patch.dvr_render_samples_chunk(_model(field), {"fg": sd}, chunk_size=M * 3)  # 3 pixels per frame and chunk
+    for k, v in one["rendered"].items():
+        assert many["rendered"][k].shape == v.shape
+        if k != "vis":
+            assert rel(many["rendered"][k], v.cpu()) < 1e-5, k
+
+
+def test_module_forwards(golden_dir, patch_f32):
+    """NeRF.forward / VisField.forward / FeatureNeRF.compute_feat / SkinningWarp.forward / backward_warp / forward_warp through
+    the adapters vs the oracle on the same weights; incl. the (K,1,1,3) per-sample-row form the reference's compacted eval
+    path uses (nerf.py:795-798) and inst_id=None (mean instance code)."""
+    patch = patch_f32
+    g, P, _ = _load(golden_dir, "train_small.pt")
+    fr, sd = _samples_dict(g)
+    field = standins.fg_field(P, fr, training=True)
+    Pc = {k: v.detach().cpu() for k, v in P.items()}
+    frc = synthetic.add_codes(dict(g["frames"]), Pc)
+    gen = torch.Generator().manual_seed(3)
+    M, N, D = 2, 5, 7
+    xyz = torch.randn(M, N, D, 3, generator=gen) * 0.08
+    fid, iid = fr["frame_id"], fr["inst_id"]
+    rgb, dens = patch.nerf_forward(field, xyz.to(DEV), dir=xyz.to(DEV), frame_id=fid, inst_id=iid)
+    rgb_o, dens_o = O.nerf_forward(Pc, xyz, {"basefield": frc["code_base"], "colorfield": frc["code_color"]}, appr_code=frc["appr_code"])
+    assert rel(rgb, rgb_o) < 2e-4 and rel(dens, dens_o) < 2e-4
+    sdf = patch.nerf_forward(field, xyz.to(DEV), inst_id=iid, get_density=False)
+    assert rel(sdf, O.nerf_forward(Pc, xyz, {"basefield": frc["code_base"]}, with_color=False, get_density=False)) < 2e-4
+    # compacted form: K samples as (K,1,1,3) with per-sample frame / instance ids == the (M,N,D) call, gathered
+    flat = xyz.reshape(-1, 1, 1, 3).to(DEV)
+    fid_s = fid[:, None, None].expand(M, N, D).reshape(-1)
+    iid_s = iid[:, None, None].expand(M, N, D).reshape(-1)
+    rgb_k, dens_k = patch.nerf_forward(field, flat, dir=flat, frame_id=fid_s, inst_id=iid_s)
+    assert rel(rgb_k.reshape(M, N, D, 3), rgb.cpu()) < 1e-5 and rel(dens_k.reshape(M, N, D, 1), dens.cpu()) < 1e-5
+    # mean instance
+    sdf_m = patch.nerf_forward(field, xyz.to(DEV), inst_id=None, get_density=False)
+    mean_code = Pc["basefield.inst_embedding.mapping.weight"].mean(0, keepdim=True).expand(M, -1)
+    assert rel(sdf_m, O.nerf_forward(Pc, xyz, {"basefield": mean_code}, with_color=False, get_density=False)) < 2e-4
+    assert rel(patch.vis_forward(field.vis_mlp, xyz.to(DEV), inst_id=iid), O.vis_field(Pc, xyz, frc["code_vis"])) < 2e-4
+    assert rel(patch.compute_feat(field, xyz.to(DEV))["feature"], O.compute_feat(Pc, xyz)) < 2e-4
+    field.eval()
+    assert patch.compute_feat(field, xyz.to(DEV)) == {}  # train-only field (decorator.py:4-17)
+    field.train()
+    sdict = {"t_articulation": fr["t_articulation"], "rest_articulation": fr["rest_articulation"]}
+    for backward in (True, False):
+        out, aux = patch.skinning_forward(field.warp, xyz.to(DEV), fid, iid, backward=backward, samples_dict=sdict, return_aux=True)
+        te = frc["t_embed"] if backward else frc["t_embed_mean"]
+        out_o, aux_o = O.skinning_warp(Pc, xyz, frc["t_articulation"], frc["rest_articulation"], te, frc["code_skin"], backward)
+        assert rel(out, out_o) < 2e-4
+        for k in aux_o:
+            assert rel(aux[k], aux_o[k]) < 5e-4, k
+    # without articulations in samples_dict the warp asks its articulation module (warping.py:299-304)
+    out2 = patch.skinning_forward(field.warp, xyz.to(DEV), fid, iid, backward=True)
+    assert rel(out2, O.skinning_warp(Pc, xyz, frc["t_articulation"], frc["rest_articulation"], frc["t_embed"], frc["code_skin"], True)[0]) < 2e-4
+    # Deformable.backward_warp / forward_warp
+    xyz_cam = torch.randn(M, N, D, 3, generator=gen) * 0.05 + torch.tensor([0.0, 0.0, 0.6])
+    field.warp.forward = types.MethodType(patch.skinning_forward, field.warp)
+    bw = patch.backward_warp(field, xyz_cam.to(DEV), xyz_cam.to(DEV), fr["field2cam"], fid, iid, samples_dict=sdict)
+    xt_o, dir_o = O.cam_to_field(xyz_cam, xyz_cam, frc["field2cam"])
+    x_o, aux_o = O.skinning_warp(Pc, xt_o, frc["t_articulation"], frc["rest_articulation"], frc["t_embed"], frc["code_skin"], True)
+    assert rel(bw["xyz_t"], xt_o) < 1e-5 and rel(bw["dir"], dir_o) < 1e-5 and rel(bw["xyz"], x_o) < 2e-4
+    assert set(bw.keys()) == {"xyz", "dir", "xyz_t", "skin_entropy", "delta_skin"}
+    fw = patch.forward_warp(field, xyz.to(DEV), fr["field2cam"], fid, iid, samples_dict=sdict)
+    xf_o, _ = O.skinning_warp(Pc, xyz, frc["t_articulation"], frc["rest_articulation"], frc["t_embed_mean"], frc["code_skin"], False)
+    assert rel(fw, O.field_to_cam(xf_o, frc["field2cam"])) < 2e-4
+
+
+def test_composed_and_dense_forward_match_the_reference(golden_dir, patch_f32):
+    """ComposedWarp.forward / DenseWarp.forward through the adapters vs the reference-generated comp_warp.pt."""
+    patch = patch_f32
+    g = torch.load(os.path.join(golden_dir, "comp_warp.pt"), weights_only=False)
+    P = synthetic.to_device(synthetic.add_dense_weights(synthetic.make_weights(0)), DEV)
+    fr = synthetic.to_device(dict(g["frames"]), DEV)
+    field = standins.fg_field(P, fr, composed=True)
+    xyz = g["xyz"].to(DEV)
+    fid, iid = fr["frame_id"], fr["inst_id"]
+    sdict = {"t_articulation": fr["t_articulation"], "rest_articulation": fr["rest_articulation"]}
+    out_bw, aux = patch.composed_forward(field.warp, xyz, fid, iid, backward=True, samples_dict=sdict, return_aux=True)
+    assert rel(out_bw, g["out_bw"]) < 2e-4
+    for k, v in g["aux_bw"].items():
+        assert rel(aux[k], v) < 5e-4, k
+    assert rel(patch.composed_forward(field.warp, xyz, fid, iid, samples_dict=sdict), g["out_fw"]) < 2e-4
+    assert rel(patch.composed_forward(field.warp, xyz, None, iid, samples_dict=sdict), g["out_fw_none"]) < 2e-4
+    assert rel(patch.dense_forward(field.warp.post_warp, xyz, fid, iid, backward=False), g["dense_fw"]) < 2e-4
+    assert rel(patch.dense_forward(field.warp.post_warp, xyz, fid, iid, backward=True), g["dense_bw"]) < 2e-4
+
+
+def test_evaluate_and_render_entry_points(golden_dir, patch_f32):
+    """dvr_model.render / evaluate through the adapters on a stand-in model: a 4x4-pixel frame pair, eval mode.  evaluate()
+    returns (frames, H, W, c) images of the first frame of every pair, masked by the rendered mask (model.py:197-209)."""
+    patch = patch_f32
+    g, P, _ = _load(golden_dir, "eval_small.pt")
+    fr, _ = _samples_dict(g, with_feature=False)
+    field = standins.fg_field(P, fr, training=False)
+    patch.N_DEPTH = 16
+    res, M = 4, 2
+    hxy = synthetic.make_rays(res, M).to(DEV) * torch.tensor([16.0, 16.0, 1.0], device=DEV)  # spread over the 64-pixel image plane
+    m = _model(field)
+    m.process_frameid = lambda batch: None
+    m.get_samples = lambda batch: {"fg": dict({k: fr[k][batch["idx"]] if not isinstance(fr[k], tuple) else tuple(t[batch["idx"]] for t in fr[k])
+                                               for k in ("Kinv", "field2cam", "frame_id", "inst_id", "near_far", "t_articulation",
+                                                         "rest_articulation")}, hxy=batch["hxy"])}
+    m.render = types.MethodType(patch.dvr_render, m)
+    batch = {"frameid": fr["frame_id"], "idx": torch.arange(M, device=DEV), "hxy": hxy}
+    out = patch.dvr_render(m, batch)
+    assert out["rendered"]["rgb"].shape == (M, res * res, 3)
+    ev = patch.dvr_evaluate(m, batch, is_pair=True)
+    assert ev["rgb"].shape == (1, res, res, 3) and ev["mask"].shape == (1, res, res, 1)
+    raw = out["rendered"]
+    assert torch.allclose(ev["rgb"][0].reshape(-1, 3), (raw["rgb"] * raw["mask"])[0], atol=1e-6)
+    assert torch.allclose(ev["mask"][0].reshape(-1, 1), raw["mask"][0], atol=1e-6)
+    ev1 = patch.dvr_evaluate(m, batch, is_pair=False)
+    assert ev1["rgb"].shape == (M, res, res, 3)

@@ -1,0 +1,194 @@
+"""lab4d_amd.patch against the REAL reference (build container only; skipped where /root/reference is absent):
+
+  * `patch()` binds into the shimmed reference package and every rebound symbol keeps the reference's signature
+    (SURVEY 8b "Python signatures that must not change");
+  * every parameter / buffer name the adapters hand to the kernels exists in the reference's own modules
+    (a checkpoint loads unchanged);
+  * the per-frame inputs the adapters assemble from a reference field have the shapes the kernels expect;
+  * `appearance_get_vals` (pure per-frame tensor algebra, runs on CPU) equals the reference's AppearanceEmbedding.get_vals.
+
+No kernel runs here: the device side of the adapters is tests/test_gpu_patch.py."""
+import inspect
+import sys
+
+import pytest
+import torch
+
+from oracle import ref_shim
+
+pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="needs the reference tree (build container only)")
+
+
+@pytest.fixture(scope="module")
+def ns():
+    ns = ref_shim.load()
+    import importlib
+    for m in ("lab4d.nnutils.appearance", "lab4d.nnutils.time", "lab4d.engine.model"):
+        importlib.import_module(m)
+    return ns
+
+
+@pytest.fixture()
+def patched(ns):
+    from lab4d_amd import patch
+    saved_q = sys.modules.get("quaternion")
+    names = patch.patch(precision="f32", n_depth=64)
+    yield patch, names
+    patch.unpatch()
+    if saved_q is not None:
+        sys.modules["quaternion"] = saved_q
+
+
+def _params(sig):
+    return [(p.name, p.kind, p.default) for p in sig.parameters.values()]
+
+
+def test_every_patched_symbol_keeps_the_reference_signature(ns):
+    import importlib
+    from lab4d_amd import patch
+    checked = 0
+    for modname, cls, attr, fn, static in patch.bindings():
+        mod = importlib.import_module(modname)
+        owner = mod if cls is None else getattr(mod, cls)
+        orig = inspect.getattr_static(owner, attr)  # through the MRO: AppearanceEmbedding.get_vals is TimeMLP's
+        if isinstance(orig, staticmethod):
+            orig = orig.__func__
+        orig = inspect.unwrap(orig)  # decorators like @train_only_fields / @torch.no_grad keep __wrapped__
+        so, sn = inspect.signature(orig), inspect.signature(fn)
+        if cls is None and attr == "sample_pdf":
+            # one extra keyword-only-in-practice trailing argument (return_inds=False); the reference's five come first, unchanged
+            assert _params(sn)[: len(so.parameters)] == _params(so), attr
+            assert list(sn.parameters)[len(so.parameters):] == ["return_inds"]
+        else:
+            assert _params(sn) == _params(so), "%s.%s.%s: %s != %s" % (modname, cls, attr, sn, so)
+        checked += 1
+    assert checked == len(patch.bindings()) >= 24
+
+
+def test_patch_rebinds_and_unpatch_restores(ns, patched):
+    patch, names = patched
+    import lab4d.nnutils.nerf as nerf
+    import lab4d.nnutils.warping as warping
+    import lab4d.engine.model as model
+    import lab4d.utils.render_utils as ru
+    assert nerf.NeRF.forward is patch.nerf_forward and nerf.NeRF.query_field is patch.query_field
+    assert warping.SkinningWarp.forward is patch.skinning_forward and warping.ComposedWarp.forward is patch.composed_forward
+    assert model.dvr_model.render is patch.dvr_render and model.dvr_model.evaluate is patch.dvr_evaluate
+    from lab4d_amd import render_utils as RU
+    assert ru.render_pixel is RU.render_pixel and model.render_pixel is RU.render_pixel and nerf.sample_cam_rays is RU.sample_cam_rays
+    import lab4d_amd.quaternion as hq
+    assert sys.modules["quaternion"] is hq
+    assert "lab4d.engine.model.dvr_model.render" in names and len(names) >= 24
+    patch.unpatch()
+    assert nerf.NeRF.forward is not patch.nerf_forward and model.render_pixel is not RU.render_pixel
+
+
+def _fields(ns):
+    from lab4d_amd import synthetic
+    torch.manual_seed(0)
+    out = {}
+    for motion in ("skel-quad", "comp_skel-quad_dense"):
+        f = ns.deformable.Deformable(motion, ref_shim.synthetic_data_info(64), num_freq_dir=-1, appr_channels=32, num_inst=1, init_scale=0.2)
+        f.category = "fg"
+        out[motion] = f
+    b = ns.nerf.NeRF(ref_shim.synthetic_data_info(64), num_freq_xyz=6, num_freq_dir=0, appr_channels=0, init_scale=0.1)
+    b.category = "bg"
+    out["bg"] = b
+    return out
+
+
+def test_every_name_the_adapters_read_exists_in_the_reference_modules(ns):
+    from lab4d_amd import mlp, patch
+    fields = _fields(ns)
+    scalars_fg = ["logibeta", "logscale", "logsigma", "aabb", "warp.logibeta", "warp.skinning_model.log_gauss", "warp.skinning_model.symm_idx"]
+    nets_fg = [(mlp.NET_FG_BASE, ""), (mlp.NET_FG_COLOR, ""), (mlp.NET_VIS, ""), (mlp.NET_FEAT, ""), (mlp.NET_SKIN, "")]
+    for motion in ("skel-quad", "comp_skel-quad_dense"):
+        f = fields[motion]
+        assert patch.field_kind(f) == "fg"
+        P = patch.field_params(f)
+        nets = list(nets_fg)
+        if motion.startswith("comp_"):
+            assert patch.warp_kind(f) == "composed"
+            nets += [(mlp.NET_DENSE, "warp.post_warp.forward_map."), (mlp.NET_DENSE, "warp.post_warp.backward_map.")]
+        else:
+            assert patch.warp_kind(f) == "skinning"
+        for net, prefix in nets:
+            for b in mlp.bindings(net, prefix):
+                assert b.wname in P and b.bname in P, (motion, b.wname)
+                assert P[b.wname] is dict(f.named_parameters())[b.wname], "parameters must be the live tensors (autograd reaches them)"
+        for k in scalars_fg:
+            assert k in P, (motion, k)
+        # the warp-level view used by SkinningWarp.forward / ComposedWarp.forward names the same tensors under "warp."
+        Pw = patch._warp_params(f.warp)
+        for b in mlp.bindings(mlp.NET_SKIN, ""):
+            assert Pw[b.wname] is P[b.wname]
+    b = fields["bg"]
+    assert patch.field_kind(b) == "bg" and patch.warp_kind(b) == "rigid"
+    P = patch.field_params(b)
+    for net in (mlp.NET_BG_BASE, mlp.NET_BG_COLOR, mlp.NET_VIS):
+        for bd in mlp.bindings(net, ""):
+            assert bd.wname in P and bd.bname in P, bd.wname
+    for k in ("logibeta", "logscale", "aabb"):
+        assert k in P
+
+
+def test_per_frame_inputs_assembled_from_a_reference_field(ns):
+    from lab4d_amd import patch, synthetic
+    fields = _fields(ns)
+    M, N, res = 2, 5, 64
+    fr0 = synthetic.make_frames(3, M, res)
+    hxy = torch.cat([torch.rand(M, N, 2) * res, torch.ones(M, N, 1)], -1)
+    for motion in ("skel-quad", "comp_skel-quad_dense"):
+        f = fields[motion]
+        f.train()
+        sd = {"Kinv": fr0["Kinv"], "field2cam": fr0["field2cam"], "frame_id": torch.tensor([3, 4]), "inst_id": torch.zeros(M, dtype=torch.long),
+              "near_far": fr0["near_far"], "hxy": hxy, "feature": torch.randn(M, N, 16)}
+        sd["t_articulation"], sd["rest_articulation"] = f.warp.articulation.get_vals_and_mean(sd["frame_id"])
+        fr = patch._frames(f, sd)
+        B = 25
+        for k, shp in {"code_base": (M, 32), "code_color": (M, 32), "code_vis": (M, 32), "code_skin": (M, 32), "appr_code": (M, 32),
+                       "t_embed": (M, 128), "t_embed_mean": (1, 128)}.items():
+            assert tuple(fr[k].shape) == shp, (motion, k, fr[k].shape)
+        assert fr["t_articulation"][0].shape == (M, B, 4) and fr["rest_articulation"][1].shape == (M, B, 4)
+        if motion.startswith("comp_"):
+            assert tuple(fr["dense"]["t_embed"].shape) == (M, 128) and tuple(fr["dense"]["code_fw"].shape) == (M, 32)
+        else:
+            assert "dense" not in fr
+        # the same values the reference modules produce
+        assert torch.equal(fr["t_embed"], f.warp.skinning_model.time_embedding(sd["frame_id"]))
+        assert torch.equal(fr["appr_code"], f.appr_embedding.get_vals(sd["frame_id"]))
+    # inst_id None -> the mean instance code, one row per frame (base.py:130-134)
+    f = fields["skel-quad"]
+    c = patch.inst_code(f.basefield, None, 3, torch.device("cpu"))
+    assert c.shape == (3, 32) and torch.equal(c[0], f.basefield.inst_embedding.get_mean_embedding())
+
+
+def test_appearance_get_vals_equals_the_reference(ns):
+    from lab4d_amd import patch
+    f = _fields(ns)["skel-quad"]
+    ae = f.appr_embedding
+    with torch.no_grad():
+        for p in ae.parameters():  # away from the init (zero biases) so every term counts
+            p.add_(0.05 * torch.randn_like(p))
+    for fid in (torch.tensor([0, 7, 63]), torch.tensor([31]), None):
+        ref = ae.get_vals(fid)
+        out = patch.appearance_get_vals(ae, fid)
+        assert out.shape == ref.shape
+        assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6), float((out - ref).abs().max())
+    # gradients reach the reference's own parameters
+    g = torch.autograd.grad(patch.appearance_get_vals(ae, torch.tensor([5, 6])).sum(), [ae.output.weight, ae.time_embedding.mapping1.weight])
+    gr = torch.autograd.grad(ae.get_vals(torch.tensor([5, 6])).sum(), [ae.output.weight, ae.time_embedding.mapping1.weight])
+    for a, b in zip(g, gr):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_draw_rng_follows_the_reference_draw_order():
+    """multinomial (nerf.py:437-440) first, then randperm (feature.py:177): same generator state -> same draws."""
+    from lab4d_amd import patch
+    M, N, D = 2, 40, 8
+    torch.manual_seed(7)
+    eik = torch.multinomial(torch.ones(M * N), M * N // 16, replacement=False)
+    perm = torch.randperm(M * N * D)[:1024]
+    torch.manual_seed(7)
+    r = patch.draw_rng(M, N, D, torch.device("cpu"))
+    assert torch.equal(r["eik_inds"], eik) and torch.equal(r["match_perm"], perm)
