@@ -246,21 +246,26 @@ def test_sample_pdf_indices_and_samples(golden_dir):
     assert bool((s.cpu()[:, 1:] >= s.cpu()[:, :-1] - 1e-6).all()), "det=True samples must be monotone"
 
 
-# measured on MI355X (gpurun_out/parity_sample_pdf_*.json): mismatching searchsorted indices / total
-SAMPLE_PDF_MISMATCH_MAX = {"reference_golden": 0, "random_positive_weights": 64, "random_zero_weight_runs": 1000}
+# Bounds on searchsorted indices that differ from torch's, per case: (interior queries, the u = 1 end point).  Measured on MI355X
+# (profiles/r02_parity_sample_pdf_*.json).  The end point is special: the last cdf entry is sum(pdf) = 1 up to rounding, and
+# whether it is <= 1.0f decides between index n_w and n_w + 1.  That rounding depends on the order in which the row
+# normaliser sum(w + eps) is reduced -- torch's CPU kernel (vectorised, lane count depends on the AVX level of the build),
+# torch's GPU reduction and a sequential sum give normalisers that differ in the last ulp, so the reference does not agree
+# with ITSELF across its own platforms there; both choices interpolate to the same sample (bins[n_w]).  Interior queries can
+# differ only where a cdf entry is within 3 ulp of u; none does on these cases: the interior indices are bit-exact.
+SAMPLE_PDF_MISMATCH_MAX = {"reference_golden": (0, 0), "random_positive_weights": (0, 0.2), "random_zero_weight_runs": (0, 0.2)}  # measured: interior 0 of 315,040; end point 593 of 5,000 rows
 
 
 def _check_inds(inds, samples, bins, wts, n_imp, tag):
-    """Indices must equal torch's searchsorted(right=True) (the reference's own output for `reference_golden`) except at
-    ties created by the fp32 row normaliser, where torch's own CPU builds (AVX2 / AVX-512 lane order) and its GPU reduction
-    already disagree with each other: there u sits within 3 ulp of a cdf entry and the index moves by exactly one bin.
-    The measured count is reported and held to a per-case bound (not a blanket percentage)."""
+    """Indices vs torch.searchsorted(right=True) on torch's own cdf (`reference_golden`: the reference's stored output)."""
+    from parity_report import report
     s_ref, inds_ref = O.sample_pdf(bins, wts, n_imp, return_inds=True)
     mism = inds != inds_ref
-    n_bad = int(mism.sum())
-    from parity_report import report
-    report("sample_pdf_" + tag, {"mismatch_count": float(n_bad), "total": float(inds.numel()), "rate": n_bad / inds.numel()})
-    if n_bad:
+    n_end = int(mism[:, -1].sum())
+    n_int = int(mism[:, :-1].sum())
+    report("sample_pdf_" + tag, {"interior_mismatch_count": float(n_int), "interior_total": float(mism[:, :-1].numel()),
+                                 "endpoint_mismatch_count": float(n_end), "rows": float(len(inds))})
+    if mism.any():
         w = wts + 1e-5
         cdf = torch.cat([torch.zeros(len(w), 1), torch.cumsum(w / w.sum(-1, keepdim=True), -1)], -1)
         u = torch.linspace(0, 1, n_imp).expand(len(w), n_imp)
@@ -269,7 +274,8 @@ def _check_inds(inds, samples, bins, wts, n_imp, tag):
             j = min(int(inds[r, c]), int(inds_ref[r, c]))
             assert abs(int(inds[r, c]) - int(inds_ref[r, c])) == 1
             assert abs(float(cdf[r, j]) - float(u[r, c])) <= 3 * 1.2e-7 * max(1.0, float(u[r, c])), (r, c)
-    assert n_bad <= SAMPLE_PDF_MISMATCH_MAX[tag], (tag, n_bad, inds.numel())
+    max_int, max_end_frac = SAMPLE_PDF_MISMATCH_MAX[tag]
+    assert n_int <= max_int and n_end <= max_end_frac * len(inds), (tag, n_int, n_end, len(inds))
 
 
 def test_sample_pdf_random_draws_and_stratified_rays():
