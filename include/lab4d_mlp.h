@@ -140,5 +140,14 @@ int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream);
  * gradient or NULL (accumulated, zero-fill first).  When pf_db is given, db is NOT written: db = sum_m pf_db[m]. */
 int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int ld, int spf, const void* dz, const void* emb,
                     const void* act_prev, float* dW, float* db, float* pf_db, int M, void* stream);
+/* The same contraction with the result accumulated (atomically) straight into a gradient buffer in the REFERENCE layout --
+ * what autograd would otherwise build from the kernel-layout matrix with a zero-fill, a column scatter and an add into
+ * `weight.grad` (nnutils/base.py:65-78 layers; engine/trainer.py:343-350 accumulates them in .grad).  dW_ref: (mout, ld_ref)
+ * fp32, typically the parameter's .grad; col_map: (ke + kin) int32, kernel input column -> reference column or -1 (the map
+ * lab4d_mlp_pack takes); db: the reference bias gradient (mout entries, rows >= mout are not written) or NULL.
+ * col_map == NULL is lab4d_mlp_wgrad. */
+int lab4d_mlp_wgrad_mapped(int net, int layer, int precision, int S, int S_pad, int ld, int spf, const void* dz, const void* emb,
+                           const void* act_prev, float* dW_ref, int ld_ref, const int32_t* col_map, float* db, float* pf_db, int M,
+                           void* stream);
 
 #endif /* LAB4D_MLP_H */

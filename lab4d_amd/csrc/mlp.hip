@@ -12,10 +12,27 @@ namespace lab4d {
 // exactly once; each wave keeps its TM x 4 accumulator tiles in registers, prefetches the operands of its next
 // step while the MFMAs of the current one run, and at the end the 4 partial blocks are summed through LDS
 // (ds_add_f32) so that only one set of global atomics per workgroup is issued.
+// Where a weight-gradient element goes.  Default (cmap == NULL): the kernel-layout (mout_pad, K) scratch matrix.  Mapped: straight
+// into a gradient buffer in the REFERENCE layout (mout, ld) -- kernel column k is reference column cmap[k] (or -1: a padding /
+// conditioning slot that has no weight there), rows >= mout are padding -- so the caller needs no scatter pass and can hand in
+// the parameter's accumulated .grad itself (the adds are atomic).  db_rows: bias rows that exist in the db buffer.
+struct DwMap {
+  const int* cmap;
+  int ld, mout, db_rows;
+};
+__device__ __forceinline__ void dw_add(float* dW, int o, int k, int K, const DwMap& wm, float v) {
+  if (wm.cmap) {
+    const int c = wm.cmap[k];
+    if (c >= 0 && o < wm.mout) atomicAdd(dW + (size_t)o * wm.ld + c, v);
+  } else {
+    atomicAdd(dW + (size_t)o * K + k, v);
+  }
+}
+
 template <class P, int TM>
 __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __restrict__ dz, const typename P::store_t* __restrict__ emb,
                                                     const typename P::store_t* __restrict__ actp, int mo_tiles, int ke, int kin,
-                                                    int S_pad, int chunk, int spf, int cpf, float* __restrict__ dW, float* __restrict__ db) {
+                                                    int S_pad, int chunk, int spf, int cpf, float* __restrict__ dW, float* __restrict__ db, DwMap wm) {
   constexpr int TN = 4;
   constexpr int SPS = P::BF16 ? 16 : 8;  // samples per step
   __shared__ float red[TM * TN * 16 * 64];
@@ -138,14 +155,14 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
     if (to < mo_tiles && tk < nk_tiles) {
       const int o = 32 * to + drow(r, l2 >> 5);
       const int k = 32 * tk + (l2 & 31);
-      atomicAdd(dW + (size_t)o * K + k, red[e]);
+      dw_add(dW, o, k, K, wm, red[e]);
     }
   }
   if (kb == 0 && db) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const float v = rs[i] + __shfl_xor(rs[i], 32, 64);
-      if (h == 0 && av_[i]) atomicAdd(db + 32 * (ob * TM + i) + row, v);
+      if (h == 0 && av_[i] && 32 * (ob * TM + i) + row < wm.db_rows) atomicAdd(db + 32 * (ob * TM + i) + row, v);
     }
   }
 }
@@ -158,7 +175,7 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
 template <class P>
 __global__ void __launch_bounds__(256) k_mlp_wgrad_big(const typename P::store_t* __restrict__ dz, const typename P::store_t* __restrict__ emb,
                                                         const typename P::store_t* __restrict__ actp, int mo_tiles, int ke, int kin,
-                                                        int S_pad, int chunk, int spf, int cpf, float* __restrict__ dW, float* __restrict__ db) {
+                                                        int S_pad, int chunk, int spf, int cpf, float* __restrict__ dW, float* __restrict__ db, DwMap wm) {
   constexpr int TM = 4, TN = 4;
   constexpr int SPS = P::BF16 ? 16 : 8;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
@@ -260,12 +277,12 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_big(const typename P::store_t
         for (int r = 0; r < 16; ++r) {
           const int o = 32 * (ob * 8 + wr * 4 + i) + drow(r, h);
           const int k = 32 * (kb * 8 + wc * 4 + j) + row;
-          atomicAdd(dW + (size_t)o * K + k, acc[i][j][r]);
+          dw_add(dW, o, k, K, wm, acc[i][j][r]);
         }
       }
       if (do_db) {
         const float v = rs[i] + __shfl_xor(rs[i], 32, 64);
-        if (h == 0) atomicAdd(db + 32 * (ob * 8 + wr * 4 + i) + row, v);
+        if (h == 0 && 32 * (ob * 8 + wr * 4 + i) + row < wm.db_rows) atomicAdd(db + 32 * (ob * 8 + wr * 4 + i) + row, v);
       }
     }
   }
@@ -301,7 +318,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int MT, int NBW>
 __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __restrict__ dz, const unsigned short* __restrict__ emb,
                                                         const unsigned short* __restrict__ actp, int ke, int kin, int S_pad, int chunk,
-                                                        int spf, int cpf, float* __restrict__ dW, float* __restrict__ db) {
+                                                        int spf, int cpf, float* __restrict__ dW, float* __restrict__ db, DwMap wm) {
   using P = PBF16;
   constexpr int TM = MT / 2, TN = NBW, MO = 32 * MT, KB = 64 * NBW;
   constexpr int A_BYTES = MT * 2048, STAGE = A_BYTES + NBW * 4096;  // 32 samples x (MO + KB) rows x 2 B
@@ -449,12 +466,12 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
       for (int r = 0; r < 16; ++r) {
         const int o = 32 * (wr * TM + i) + drow(r, h);
         const int k = k0 + 32 * (wc * TN + j) + row;
-        atomicAdd(dW + (size_t)o * K + k, acc[i][j][r]);
+        dw_add(dW, o, k, K, wm, acc[i][j][r]);
       }
     }
     if (do_db) {
       const float v = rs[i] + __shfl_xor(rs[i], 32, 64);
-      if (h == 0) atomicAdd(db + 32 * (wr * TM + i) + row, v);
+      if (h == 0 && 32 * (wr * TM + i) + row < wm.db_rows) atomicAdd(db + 32 * (wr * TM + i) + row, v);
     }
   }
 }
@@ -639,11 +656,18 @@ extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
 
 extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int ld, int spf, const void* dz, const void* emb,
                                const void* act_prev, float* dW, float* db, float* pf_db, int M, void* stream) {
+  return lab4d_mlp_wgrad_mapped(net, layer, precision, S, S_pad, ld, spf, dz, emb, act_prev, dW, 0, nullptr, db, pf_db, M, stream);
+}
+
+extern "C" int lab4d_mlp_wgrad_mapped(int net, int layer, int precision, int S, int S_pad, int ld, int spf, const void* dz, const void* emb,
+                                      const void* act_prev, float* dW, int ld_ref, const int32_t* col_map, float* db, float* pf_db, int M,
+                                      void* stream) {
   lab4d_mlp_desc d;
   if (int e = lab4d_mlp_describe(net, &d)) return e;
   LAB4D_REQUIRE(layer >= 0 && layer < d.n_layers, "mlp_wgrad: bad layer %d", layer);
   const lab4d_mlp_layer& L = d.layers[layer];
   LAB4D_REQUIRE(dz && dW, "mlp_wgrad: null dz/dW");
+  LAB4D_REQUIRE(col_map == nullptr || ld_ref > 0, "mlp_wgrad_mapped: a column map needs the reference row stride");
   LAB4D_REQUIRE(L.ke == 0 || emb, "mlp_wgrad: layer %d needs the stored embedding", layer);
   LAB4D_REQUIRE(L.kin == 0 || act_prev, "mlp_wgrad: layer %d needs the previous activation", layer);
   LAB4D_REQUIRE(S_pad % 64 == 0 && S_pad >= S && ld >= S_pad && ld % 8 == 0, "mlp_wgrad: bad S_pad/ld");
@@ -674,13 +698,15 @@ extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_p
   const int jobs = ob_n * kb_n * nchunks;
   const dim3 grid(jobs), block(256);
   float* db_arg = fold_pf ? pf_db : db;
+  // mapped mode: db (when it is the target) is the reference bias (mout entries); the per-frame table keeps its padded rows
+  const DwMap wm = {col_map, ld_ref, L.mout, (col_map && !fold_pf) ? L.mout : L.mout_pad};
   hipStream_t st = (hipStream_t)stream;
 #define WG(P, TMV) hipLaunchKernelGGL((k_mlp_wgrad<P, TMV>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
-                                      (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
+                                      (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg, wm)
 #define WGB(P) hipLaunchKernelGGL((k_mlp_wgrad_big<P>), grid, block, 0, st, (const typename P::store_t*)dz, (const typename P::store_t*)emb, \
-                                  (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
+                                  (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg, wm)
 #define WGD(MTV, NBV) hipLaunchKernelGGL((k_mlp_wgrad_dma<MTV, NBV>), grid, block, 0, st, (const unsigned short*)dz, (const unsigned short*)emb, \
-                                         (const unsigned short*)act_prev, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg)
+                                         (const unsigned short*)act_prev, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg, wm)
 #define WGD_NB(MTV) do { if (nbw == 1) WGD(MTV, 1); else if (nbw == 2) WGD(MTV, 2); else if (nbw == 3) WGD(MTV, 3); else WGD(MTV, 4); } while (0)
   if (dma) {
     if (mo_tiles == 8) WGD_NB(8); else if (mo_tiles == 4) WGD_NB(4); else WGD_NB(2);

@@ -192,6 +192,144 @@ __device__ __forceinline__ unsigned tile_lane_offset(int row, int k) {
   return (unsigned)(row * 64) * (unsigned)sizeof(typename P::store_t) + 16u * (unsigned)k;
 }
 
+// ---- packed-bf16 epilogue helpers (bf16 path) ------------------------------------------------------------------------------------
+// The epilogue of an M-tile used to cost ~270 VALU instructions per 32 MFMAs (ReLU in fp32, sign bits by compare + select + or
+// per value, two fp32->bf16 packings, 4x4 quad transposes as separate DPP moves and selects) -- above the ~5 issue slots per
+// 32x32x16 MFMA a single wave per SIMD can hide (MI355X_MICROARCH.md).  Working on the PACKED pre-activation instead:
+//   w[t][k] = bf16x2(acc[t][2k], acc[t][2k+1])   one v_cvt_pk_bf16_f32 per pair, exactly the next layer's B-operand dword
+//   sign bits: bits = (bits >> 1) | (w & 0x80008000) per dword (v_lshrrev + v_and_or): 2 ops per PAIR
+//   ReLU: v_pk_max_i16(w, 0) -- a bf16 with the sign bit set is a negative int16 -- relu(round(x)) == round(relu(x))
+//   store dwords (two adjacent samples of one feature): one v_perm_b32 of the two n-tiles' packed words
+//   quad transposes: v_cndmask_b32_dpp (the DPP operand folded into the select), 32 per tile, in one asm block
+// the same conversion as an opaque instruction: with the builtin form the optimiser splits the pair again as soon as a bit
+// operation touches one half of it (it then converts every value on its own and re-joins them with v_perm: 3 ops per pair)
+__device__ __forceinline__ unsigned int pack2bf_op(float lo, float hi) {
+  unsigned int w;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
+  return w;
+}
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pk_relu_bf16(unsigned int w) {
+  const i16x2_t v = __builtin_bit_cast(i16x2_t, w), z = {0, 0};
+  return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(v, z));
+}
+// halves of w multiplied by the 0/1 halves of m01 (exact masking of a packed bf16 pair in one v_pk_mul_lo_u16)
+__device__ __forceinline__ unsigned int pk_mask_bf16(unsigned int w, unsigned int m01) {
+  return __builtin_bit_cast(unsigned int, __builtin_bit_cast(u16x2_t, w) * __builtin_bit_cast(u16x2_t, m01));
+}
+// ReLU sign mask of one tile in the packed layout: bit (8t + k + 16*odd) belongs to accumulator register r = 2k + odd of n-tile t;
+// 1 = the unit is ALIVE (pre-activation not negative).  w[t][k]: packed PRE-activation pairs.
+__device__ __forceinline__ unsigned int pk_alive_bits(const unsigned int (&w)[2][8]) {
+  unsigned int sb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    sb[t] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sb[t] = (sb[t] >> 1) | (w[t][k] & 0x80008000u);  // word k: low sign -> bit 8+k, high sign -> bit 24+k
+  }
+  return ~((sb[0] >> 8) | sb[1]);
+}
+__host__ __device__ __forceinline__ constexpr int pk_bit(int t, int r) { return 8 * t + (r >> 1) + 16 * (r & 1); }
+// position of (n-tile t, register r) in a stored ReLU mask word: packed layout for bf16 tiles, plain 16t + r for fp32 tiles
+template <class P>
+__host__ __device__ __forceinline__ constexpr int mask_bit(int t, int r) { return P::BF16 ? pk_bit(t, r) : 16 * t + r; }
+// 0/1 halves for packed word k of n-tile t from the alive bits
+__device__ __forceinline__ unsigned int pk_m01(unsigned int alive, int t, int k) { return (alive >> (8 * t + k)) & 0x00010001u; }
+
+// Four 4x4 dword transposes (one per 4-feature group of a 32-row tile) inside every lane quad: d[i][j], lane q of the quad ends up
+// with the dwords j = 0..3 that lanes 0..3 held at index q.  32 v_cndmask_b32_dpp + 4 s_mov_b64 in ONE asm block: VOP2
+// v_cndmask takes its condition from VCC only, so the four lane masks are switched in per phase, and the eight selects of a phase
+// are independent (a DPP read needs two wait states after the VALU write of its source: phases keep writers >= 7 slots away).
+// Results: c[i][0] = d[i][0], c[i][1] = d[i][2], c[i][2] = t2[i], c[i][3] = d[i][3] (returned through `out`).
+__device__ __forceinline__ void quad_transpose4(unsigned int (&d)[4][4], unsigned int (&out)[4][4]) {
+  unsigned int t0[4], t2[4];
+  const unsigned long long mE = 0x5555555555555555ull, mO = 0xAAAAAAAAAAAAAAAAull, mL = 0x3333333333333333ull, mH = 0xCCCCCCCCCCCCCCCCull;
+#define LAB4D_QP1 " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define LAB4D_QP2 " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+  // Four separate statements (the scheduler may put MFMAs between the phases; volatile keeps their order).  Every phase sets VCC
+  // itself.  A DPP read needs two wait states after the VALU write of its source: phase A reads registers the code in front
+  // of it has just written (s_mov + s_nop = 2 states), the later phases only read what an earlier phase wrote >= 8 slots back.
+  // phase A: t0 = even ? d0 : xor1(d1) ; t2 = even ? d2 : xor1(d3)
+  asm volatile("s_mov_b64 vcc, %[m]\n\ts_nop 0\n\t"
+               "v_cndmask_b32_dpp %[t00], %[d01], %[d00], vcc" LAB4D_QP1 "v_cndmask_b32_dpp %[t20], %[d03], %[d02], vcc" LAB4D_QP1
+               "v_cndmask_b32_dpp %[t01], %[d11], %[d10], vcc" LAB4D_QP1 "v_cndmask_b32_dpp %[t21], %[d13], %[d12], vcc" LAB4D_QP1
+               "v_cndmask_b32_dpp %[t02], %[d21], %[d20], vcc" LAB4D_QP1 "v_cndmask_b32_dpp %[t22], %[d23], %[d22], vcc" LAB4D_QP1
+               "v_cndmask_b32_dpp %[t03], %[d31], %[d30], vcc" LAB4D_QP1 "v_cndmask_b32_dpp %[t23], %[d33], %[d32], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+               : [t00] "=&v"(t0[0]), [t01] "=&v"(t0[1]), [t02] "=&v"(t0[2]), [t03] "=&v"(t0[3]), [t20] "=&v"(t2[0]), [t21] "=&v"(t2[1]),
+                 [t22] "=&v"(t2[2]), [t23] "=&v"(t2[3])
+               : [m] "s"(mE), [d00] "v"(d[0][0]), [d01] "v"(d[0][1]), [d02] "v"(d[0][2]), [d03] "v"(d[0][3]), [d10] "v"(d[1][0]), [d11] "v"(d[1][1]),
+                 [d12] "v"(d[1][2]), [d13] "v"(d[1][3]), [d20] "v"(d[2][0]), [d21] "v"(d[2][1]), [d22] "v"(d[2][2]), [d23] "v"(d[2][3]),
+                 [d30] "v"(d[3][0]), [d31] "v"(d[3][1]), [d32] "v"(d[3][2]), [d33] "v"(d[3][3])
+               : "vcc");
+  // phase B: d1 = odd ? d1 : xor1(d0) ; d3 = odd ? d3 : xor1(d2)
+  asm volatile("s_mov_b64 vcc, %[m]\n\t"
+               "v_cndmask_b32_dpp %[d01], %[d00], %[d01], vcc" LAB4D_QP1 "v_cndmask_b32_dpp %[d03], %[d02], %[d03], vcc" LAB4D_QP1
+               "v_cndmask_b32_dpp %[d11], %[d10], %[d11], vcc" LAB4D_QP1 "v_cndmask_b32_dpp %[d13], %[d12], %[d13], vcc" LAB4D_QP1
+               "v_cndmask_b32_dpp %[d21], %[d20], %[d21], vcc" LAB4D_QP1 "v_cndmask_b32_dpp %[d23], %[d22], %[d23], vcc" LAB4D_QP1
+               "v_cndmask_b32_dpp %[d31], %[d30], %[d31], vcc" LAB4D_QP1 "v_cndmask_b32_dpp %[d33], %[d32], %[d33], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+               : [d01] "+v"(d[0][1]), [d03] "+v"(d[0][3]), [d11] "+v"(d[1][1]), [d13] "+v"(d[1][3]), [d21] "+v"(d[2][1]), [d23] "+v"(d[2][3]),
+                 [d31] "+v"(d[3][1]), [d33] "+v"(d[3][3])
+               : [m] "s"(mO), [d00] "v"(d[0][0]), [d02] "v"(d[0][2]), [d10] "v"(d[1][0]), [d12] "v"(d[1][2]), [d20] "v"(d[2][0]), [d22] "v"(d[2][2]),
+                 [d30] "v"(d[3][0]), [d32] "v"(d[3][2])
+               : "vcc");
+  // phase C: c0 = low ? t0 : xor2(t2) ; c1 = low ? d1 : xor2(d3)
+  unsigned int c0[4], c1[4];
+  asm volatile("s_mov_b64 vcc, %[m]\n\t"
+               "v_cndmask_b32_dpp %[c00], %[t20], %[t00], vcc" LAB4D_QP2 "v_cndmask_b32_dpp %[c10], %[d03], %[d01], vcc" LAB4D_QP2
+               "v_cndmask_b32_dpp %[c01], %[t21], %[t01], vcc" LAB4D_QP2 "v_cndmask_b32_dpp %[c11], %[d13], %[d11], vcc" LAB4D_QP2
+               "v_cndmask_b32_dpp %[c02], %[t22], %[t02], vcc" LAB4D_QP2 "v_cndmask_b32_dpp %[c12], %[d23], %[d21], vcc" LAB4D_QP2
+               "v_cndmask_b32_dpp %[c03], %[t23], %[t03], vcc" LAB4D_QP2 "v_cndmask_b32_dpp %[c13], %[d33], %[d31], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+               : [c00] "=&v"(c0[0]), [c01] "=&v"(c0[1]), [c02] "=&v"(c0[2]), [c03] "=&v"(c0[3]), [c10] "=&v"(c1[0]), [c11] "=&v"(c1[1]),
+                 [c12] "=&v"(c1[2]), [c13] "=&v"(c1[3])
+               : [m] "s"(mL), [t00] "v"(t0[0]), [t01] "v"(t0[1]), [t02] "v"(t0[2]), [t03] "v"(t0[3]), [t20] "v"(t2[0]), [t21] "v"(t2[1]), [t22] "v"(t2[2]),
+                 [t23] "v"(t2[3]), [d01] "v"(d[0][1]), [d03] "v"(d[0][3]), [d11] "v"(d[1][1]), [d13] "v"(d[1][3]), [d21] "v"(d[2][1]), [d23] "v"(d[2][3]),
+                 [d31] "v"(d[3][1]), [d33] "v"(d[3][3])
+               : "vcc");
+  // phase D: c2 = high ? t2 : xor2(t0) ; c3 = high ? d3 : xor2(d1)
+  asm volatile("s_mov_b64 vcc, %[m]\n\t"
+               "v_cndmask_b32_dpp %[t20], %[t00], %[t20], vcc" LAB4D_QP2 "v_cndmask_b32_dpp %[d03], %[d01], %[d03], vcc" LAB4D_QP2
+               "v_cndmask_b32_dpp %[t21], %[t01], %[t21], vcc" LAB4D_QP2 "v_cndmask_b32_dpp %[d13], %[d11], %[d13], vcc" LAB4D_QP2
+               "v_cndmask_b32_dpp %[t22], %[t02], %[t22], vcc" LAB4D_QP2 "v_cndmask_b32_dpp %[d23], %[d21], %[d23], vcc" LAB4D_QP2
+               "v_cndmask_b32_dpp %[t23], %[t03], %[t23], vcc" LAB4D_QP2 "v_cndmask_b32_dpp %[d33], %[d31], %[d33], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+               : [t20] "+v"(t2[0]), [t21] "+v"(t2[1]), [t22] "+v"(t2[2]), [t23] "+v"(t2[3]), [d03] "+v"(d[0][3]), [d13] "+v"(d[1][3]), [d23] "+v"(d[2][3]),
+                 [d33] "+v"(d[3][3])
+               : [m] "s"(mH), [t00] "v"(t0[0]), [t01] "v"(t0[1]), [t02] "v"(t0[2]), [t03] "v"(t0[3]), [d01] "v"(d[0][1]), [d11] "v"(d[1][1]), [d21] "v"(d[2][1]),
+                 [d31] "v"(d[3][1])
+               : "vcc");
+#undef LAB4D_QP1
+#undef LAB4D_QP2
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[i][0] = c0[i];
+    out[i][1] = c1[i];
+    out[i][2] = t2[i];
+    out[i][3] = d[i][3];
+  }
+}
+
+// store one 32-row tile from the packed words of both n-tiles: w[t][k] = bf16x2(value of register 2k, value of register 2k+1)
+__device__ __forceinline__ void store_tile_packed(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, const unsigned int (&w)[2][8]) {
+#ifdef LAB4D_ABL_L2STORE  // kernel experiment (timing only): every wave keeps writing the same 2048-sample window, so the stores never reach HBM
+  s0 &= 0x7ff;
+#endif
+  const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
+  GLOBAL_AS char* base = (GLOBAL_AS char*)buf + tile_base_offset<PBF16>(F, s0, 32 * mt);
+  const unsigned lo = tile_lane_offset<PBF16>(4 * h + q, k);
+  unsigned int d[4][4], c[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // register r = 4i + j: dword = (sample 2n of n-tile 0, sample 2n+1 of n-tile 1) of that feature
+      const int r = 4 * i + j;
+      d[i][j] = __builtin_amdgcn_perm(w[1][r >> 1], w[0][r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
+    }
+  quad_transpose4(d, c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gst16(base + (lo + tile_lane_offset<PBF16>(8 * i, 0)), c[i][0], c[i][1], c[i][2], c[i][3]);
+}
+
 template <class P>
 __device__ __forceinline__ void store_tile(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
   const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
@@ -307,7 +445,11 @@ constexpr int ACACHE_G = 14;  // 2 x 14 KiB: leaves 4 KiB of the 160 KiB unalloc
 __device__ __forceinline__ void wg_step_barrier() {
   // LDS writes of this wave visible + everybody arrived.  Raw s_barrier: __syncthreads() would also drain the
   // outstanding activation stores (vmcnt(0)), a full HBM round trip per step.
+#ifdef LAB4D_ABL_NOBAR  // kernel experiment (timing only, results wrong): no lock-step
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // ---- layer kinds ----------------------------------------------------------------------------------
@@ -641,18 +783,22 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       // workgroup-shared A groups (see wg_step_barrier): wave w moves groups w, w+4, ... (clamped: a duplicate fetch of the
       // last group keeps the code branch-free when GL is not a multiple of 4)
       auto a_fetch = [&](int mt, uint4 (&stg)[NQ]) {
+#ifndef LAB4D_ABL_NOAFETCH
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
           stg[i] = load_a(Wl, G, mt, g, lane);
         }
+#endif
       };
       auto a_stash = [&](int buf, const uint4 (&stg)[NQ]) {
+#ifndef LAB4D_ABL_NOAFETCH
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
           abuf[(buf * ACACHE_G + g) * 64 + lane] = stg[i];
         }
+#endif
       };
       auto a_grab = [&](int buf, uint4 (&A)[G]) {
 #pragma unroll
@@ -667,7 +813,34 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         if constexpr (ls.add_ext != 0 && !TAN) load_tile_raw<P>((const GLOBAL_AS void*)a.ext, 32 * MT, s0, mt, lane, ext_raw);
       };
       // ---- epilogue of one M-tile: ReLU (+ sign mask), ext add, activation store, hand-over to the next layer
-      auto epilogue = [&](int mt, f32x16_t (&acc)[NT]) {
+      // Packed tiles keep their global stores for `flush`, which the step issues AFTER the weight loads of the tile after next:
+      // the CU's vector-memory queue is a FIFO, and a weight load queued behind a tile's 5 KB of activation stores (17 KB per CU
+      // and step, drained at the HBM rate) came back later than the step that needed it (measured: removing the weight stream
+      // made the forward 19 % faster although it is 3 % of the bytes).  Loads first, stores last: a load now only has the
+      // stores of the PREVIOUS step in front of it, issued a whole step earlier.
+      constexpr bool PACKED = P::BF16 && !TAN && ls.add_ext == 0 && !LAST;
+      auto epilogue = [&](int mt, f32x16_t (&acc)[NT], unsigned int (&w)[2][8], unsigned int& wbits) {
+        if constexpr (PACKED) {
+          // packed-bf16 epilogue (see pk_* helpers): everything after the one fp32 -> bf16 conversion works on the 16 packed dwords
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[t][k] = pack2bf_op(acc[t][2 * k], acc[t][2 * k + 1]);
+          if constexpr (ls.relu != 0) {
+#ifndef LAB4D_ABL_NOMASK
+            if constexpr (ST) wbits = pk_alive_bits(w);
+#endif
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int k = 0; k < 8; ++k) w[t][k] = pk_relu_bf16(w[t][k]);
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) slab[(t * UW + 2 * mt + q) * 64] = make_uint4(w[t][4 * q], w[t][4 * q + 1], w[t][4 * q + 2], w[t][4 * q + 3]);
+          return;
+        }
         if constexpr (ls.relu != 0) {
           // ReLU + its sign bits (1 dword per lane per tile): the backward masks with these instead of re-reading
           // the whole activation tile (16x less traffic, 31 fewer live registers)
@@ -677,16 +850,18 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
               for (int r = 0; r < 16; ++r)
-                acc[t][r] = __uint_as_float(__float_as_uint(acc[t][r]) & (unsigned int)__builtin_amdgcn_sbfe((int)bits, 16 * t + r, 1));
+                acc[t][r] = __uint_as_float(__float_as_uint(acc[t][r]) & (unsigned int)__builtin_amdgcn_sbfe((int)bits, mask_bit<P>(t, r), 1));
           } else {
+#ifndef LAB4D_ABL_NOMASK
             if constexpr (ST && !LAST) {
               unsigned int bits = 0;
 #pragma unroll
               for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bits |= (acc[t][r] > 0.f ? 1u : 0u) << (16 * t + r);
+                for (int r = 0; r < 16; ++r) bits |= (acc[t][r] > 0.f ? 1u : 0u) << mask_bit<P>(t, r);
               maskl[((size_t)tile * MT + mt) * 64 + lane] = bits;
             }
+#endif
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -702,7 +877,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
             for (int r = 0; r < 16; ++r) acc[t][r] += e[t][r];
         }
         if constexpr (ST) {
+#ifndef LAB4D_ABL_NOSTORE
           if constexpr (!LAST) store_tile<P>(actl, 32 * MT, s0, mt, lane, acc);
+#endif
         } else if constexpr (fwd_any_export<Net>(R)) {
           if (actl) store_tile<P>(actl, 32 * MT, s0, mt, lane, acc);  // inference: only the layer another net consumes
         }
@@ -725,6 +902,20 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
             }
         }
       };
+      auto flush = [&](int mt, const unsigned int (&w)[2][8], unsigned int wbits) {
+        if constexpr (PACKED) {
+          if constexpr (ST) {
+#ifndef LAB4D_ABL_NOMASK
+            if constexpr (ls.relu != 0) maskl[((size_t)tile * MT + mt) * 64 + lane] = wbits;
+#endif
+#ifndef LAB4D_ABL_NOSTORE
+            store_tile_packed(actl, 32 * MT, s0, mt, lane, w);
+#endif
+          } else if constexpr (fwd_any_export<Net>(R)) {
+            if (actl) store_tile_packed(actl, 32 * MT, s0, mt, lane, w);  // inference: only the layer another net consumes
+          }
+        }
+      };
       // Software pipeline over the M-tiles (one wave per SIMD: nothing else hides the epilogue): step k issues the
       // MFMAs of tile k+1 into the second accumulator set and, in the same basic block, runs the epilogue of tile k, so
       // the VALU / LDS / store work of one tile overlaps the matrix pipe of the next.  Accumulator sets alternate, hence
@@ -732,8 +923,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       uint4 A[G], stg[NQ];
       f32x16_t bv[NB];
       f32x16_t acc0[NT], acc1[NT];
+      unsigned int pw[2][8], pbits = 0;  // packed tile + ReLU bits waiting for `flush`
       // prologue: tiles 0 and 1 into the two LDS buffers (the barrier in front keeps a fast wave from overwriting groups
-      // a slow one still has to read for the previous layer)
+      // a slow one still has to read for the previous layer), tile 2 requested into the staging registers
       wg_step_barrier();
       a_fetch(0, stg);
       a_stash(0, stg);
@@ -741,6 +933,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
         a_fetch(1, stg);
         a_stash(1, stg);
       }
+      a_fetch(MT > 2 ? 2 : MT - 1, stg);
 #pragma unroll
       for (int g = GL; g < G; ++g) A[g] = load_a(Wl, G, 0, g, lane);
       load_bias(0, bv);
@@ -752,33 +945,39 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       if constexpr (NPAIR > 0) {
 #pragma nounroll
         for (int k = 0; k < 2 * NPAIR; k += 2) {
-          // step k: A(k+1) is in buffer (k+1)&1 = 1; fetch A(k+2) for buffer 0 (read last in step k-1)
+          // step k: A(k+1) is in buffer 1; the staging registers hold A(k+2) (requested during the previous step), which goes
+          // to buffer 0 (read last in step k-1); then A(k+3) is requested, and only then tile k's stores are issued
           wg_step_barrier();
           a_grab(1, A);
-          a_fetch(k + 2 < MT ? k + 2 : MT - 1, stg);
           mfma_tile(std::true_type{}, k + 2 < MT ? k + 2 : MT - 1, A, bv, acc1);  // tile k+1
-          epilogue(k, acc0);
+          epilogue(k, acc0, pw, pbits);
           prefetch(k + 1);
           a_stash(0, stg);
+          a_fetch(k + 3 < MT ? k + 3 : MT - 1, stg);
+          flush(k, pw, pbits);
           // step k+1
           wg_step_barrier();
           a_grab(0, A);
-          a_fetch(k + 3 < MT ? k + 3 : MT - 1, stg);
           mfma_tile(std::true_type{}, k + 3 < MT ? k + 3 : MT - 1, A, bv, acc0);  // tile k+2
-          epilogue(k + 1, acc1);
+          epilogue(k + 1, acc1, pw, pbits);
           prefetch(k + 2 < MT ? k + 2 : MT - 1);
           a_stash(1, stg);
+          a_fetch(k + 4 < MT ? k + 4 : MT - 1, stg);
+          flush(k + 1, pw, pbits);
         }
       }
       if constexpr (NSTEP % 2 == 1) {
         wg_step_barrier();
         a_grab(1, A);
         mfma_tile(std::false_type{}, 0, A, bv, acc1);  // tile MT-1
-        epilogue(MT - 2, acc0);
+        epilogue(MT - 2, acc0, pw, pbits);
+        flush(MT - 2, pw, pbits);
         prefetch(MT - 1);
-        epilogue(MT - 1, acc1);
+        epilogue(MT - 1, acc1, pw, pbits);
+        flush(MT - 1, pw, pbits);
       } else {
-        epilogue(MT - 1, acc0);
+        epilogue(MT - 1, acc0, pw, pbits);
+        flush(MT - 1, pw, pbits);
       }
     });
   }
@@ -876,18 +1075,22 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
         }
       };
       auto a_fetch = [&](int mt, uint4 (&stg)[NQ]) {
+#ifndef LAB4D_ABL_NOAFETCH
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
           stg[i] = load_a(Wt, GK, mt, g, lane);
         }
+#endif
       };
       auto a_stash = [&](int buf, const uint4 (&stg)[NQ]) {
+#ifndef LAB4D_ABL_NOAFETCH
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
           abuf[(buf * ACACHE_G + g) * 64 + lane] = stg[i];
         }
+#endif
       };
       auto a_grab = [&](int buf, uint4 (&A)[GK]) {
 #pragma unroll
@@ -896,11 +1099,12 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
       // Software pipeline over N row tiles starting at tile0 (same scheme as the forward chain): step k issues the MFMAs
       // of tile k+1 into the other accumulator set in the same basic block as the epilogue of tile k.
       // pre(j) requests the HBM inputs of epi(j) (mask bits, stored embedding / external gradient tile) one step ahead.
-      auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi) {
+      auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi, auto&& fl) {
         constexpr int N = decltype(n_c)::value;
         if constexpr (N > 0) {
           uint4 A[GK], stg[NQ];
           f32x16_t acc0[NT], acc1[NT];
+          unsigned int pw[2][8];  // packed tile waiting for its store (see the forward kernel: weight loads first, stores last)
           wg_step_barrier();  // nobody still reads the buffers for the previous pipeline
           a_fetch(tile0, stg);
           a_stash(0, stg);
@@ -908,6 +1112,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
             a_fetch(tile0 + 1, stg);
             a_stash(1, stg);
           }
+          a_fetch(tile0 + (N > 2 ? 2 : N - 1), stg);
 #pragma unroll
           for (int g = GL; g < GK; ++g) A[g] = load_a(Wt, GK, tile0, g, lane);
           pre(0);
@@ -920,29 +1125,34 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
             for (int k = 0; k < 2 * NPAIR; k += 2) {
               wg_step_barrier();
               a_grab(1, A);
-              a_fetch(tile0 + (k + 2 < N ? k + 2 : N - 1), stg);
               mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), A, acc1);
-              epi(k, acc0);
+              epi(k, acc0, pw);
               pre(k + 1);
               a_stash(0, stg);
+              a_fetch(tile0 + (k + 3 < N ? k + 3 : N - 1), stg);
+              fl(k, pw);
               wg_step_barrier();
               a_grab(0, A);
-              a_fetch(tile0 + (k + 3 < N ? k + 3 : N - 1), stg);
               mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), A, acc0);
-              epi(k + 1, acc1);
+              epi(k + 1, acc1, pw);
               pre(k + 2 < N ? k + 2 : N - 1);
               a_stash(1, stg);
+              a_fetch(tile0 + (k + 4 < N ? k + 4 : N - 1), stg);
+              fl(k + 1, pw);
             }
           }
           if constexpr (NSTEP % 2 == 1) {
             wg_step_barrier();
             a_grab(1, A);
             mfma_tile(std::false_type{}, 0, A, acc1);
-            epi(N - 2, acc0);
+            epi(N - 2, acc0, pw);
+            fl(N - 2, pw);
             pre(N - 1);
-            epi(N - 1, acc1);
+            epi(N - 1, acc1, pw);
+            fl(N - 1, pw);
           } else {
-            epi(N - 1, acc0);
+            epi(N - 1, acc0, pw);
+            fl(N - 1, pw);
           }
         }
       };
@@ -956,7 +1166,8 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
         if constexpr (lp.ext_grad != 0) load_tile_raw<P>((const GLOBAL_AS void*)a.ext_gin, pad32(lp.mout), s0, j, lane, raw);
       };
       // (a) gradient wrt the embedding slots -> input gradient
-      auto epi_emb = [&](int mt, f32x16_t (&acc)[NT]) {
+      auto no_flush = [&](int, const unsigned int (&)[2][8]) {};
+      auto epi_emb = [&](int mt, f32x16_t (&acc)[NT], unsigned int (&)[2][8]) {
         if constexpr (Net::EMB == 0) {
           f32x16_t e[NT];
           tile_from_raw<P>(raw, lane, e);
@@ -998,7 +1209,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
         }
       };
       // (b) gradient wrt the previous layer's output -> masked dZ_{l-1}
-      auto epi_act = [&](int j, f32x16_t (&acc)[NT]) {
+      auto epi_act = [&](int j, f32x16_t (&acc)[NT], unsigned int (&w)[2][8]) {
         const unsigned int bits = mbits;
         if constexpr (lp.ext_grad != 0) {
           f32x16_t eg[NT];
@@ -1011,9 +1222,31 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
         if constexpr (lp.add_ext != 0) {
           store_tile<P>((GLOBAL_AS void*)a.ext_gout, pad32(lp.mout), s0, j, lane, acc);  // y = relu(z) + ext  ->  dL/dext = dL/dy
         }
-        // ReLU mask and the zero of the padded tail samples in one AND per value: bit -> all-ones / zero word (v_bfe_i32),
-        // then v_and with the fp32 bits (was: bit test + compare + select + a scalar AND per value)
-        {
+        if constexpr (P::BF16) {
+          // packed path: one conversion, the ReLU mask and the zero of the padded tail samples applied to the packed pairs with
+          // v_pk_mul_lo_u16 by 0/1 halves (3 ops per pair instead of 2 per value), packed store and hand-over
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[t][k] = pack2bf_op(acc[t][2 * k], acc[t][2 * k + 1]);
+#ifndef LAB4D_ABL_NOMASK
+          {
+            unsigned int alive = lp.relu != 0 ? bits : 0xffffffffu;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              if (sidx[t] >= a.S) alive &= ~(0x00ff00ffu << (8 * t));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int k = 0; k < 8; ++k) w[t][k] = pk_mask_bf16(w[t][k], pk_m01(alive, t, k));
+          }
+#endif
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) slab[(t * UW + 2 * j + q) * 64] = make_uint4(w[t][4 * q], w[t][4 * q + 1], w[t][4 * q + 2], w[t][4 * q + 3]);
+        } else {
+          // fp32 tiles: ReLU mask and the zero of the padded tail samples in one AND per value (v_bfe_i32 + v_and)
           unsigned int keep = lp.relu != 0 ? bits : 0xffffffffu;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -1023,26 +1256,33 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               acc[t][r] = __uint_as_float(__float_as_uint(acc[t][r]) & (unsigned int)__builtin_amdgcn_sbfe((int)keep, 16 * t + r, 1));
+          store_tile<P>(dzp, pad32(lp.mout), s0, j, lane, acc);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            uint4 u[P::UPT];
+            tile_to_units<P>(acc[t], u);
+#pragma unroll
+            for (int q = 0; q < P::UPT; ++q) slab[(t * UW + P::UPT * j + q) * 64] = u[q];
+          }
         }
-        store_tile<P>(dzp, pad32(lp.mout), s0, j, lane, acc);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          uint4 u[P::UPT];
-          tile_to_units<P>(acc[t], u);
-#pragma unroll
-          for (int q = 0; q < P::UPT; ++q) slab[(t * UW + P::UPT * j + q) * 64] = u[q];
+      };
+      auto flush_act = [&](int j, const unsigned int (&w)[2][8]) {
+        if constexpr (P::BF16) {
+#ifndef LAB4D_ABL_NOSTORE
+          store_tile_packed(dzp, pad32(lp.mout), s0, j, lane, w);
+#endif
         }
       };
       // embedding row tiles come first in W^T; they are skipped when no input gradient is wanted
       if constexpr (MTE > 0) {
         if (a.d_x != nullptr) {
-          pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb);
+          pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb, no_flush);
           // raw-input nets: the (TILE, CIN) input-gradient tile sits in the wave's staging area (the slab is idle while the
           // last layer's embedding tiles are processed); one contiguous coalesced copy, rows >= S dropped
           if constexpr (Net::EMB != 0) stage_out(stagef, a.d_x, (long)s0 * Net::CIN, TILE * Net::CIN, (long)a.S * Net::CIN - 1, lane);
         }
       }
-      if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act);
+      if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act, flush_act);
     });
 
     if constexpr (Net::EMB == 0) {

@@ -52,6 +52,7 @@ _lib.register("lab4d_mlp_forward", [ctypes.POINTER(FwdArgs), vp])
 _lib.register("lab4d_mlp_backward", [ctypes.POINTER(BwdArgs), vp])
 _lib.register("lab4d_mlp_forward_tangent", [ctypes.POINTER(FwdArgs), vp])
 _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp])
+_lib.register("lab4d_mlp_wgrad_mapped", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
 
 NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color"}
@@ -215,6 +216,20 @@ def col_map(net, layer, device):
     return _COLMAP[key]
 
 
+# Fused gradient accumulation (the training loop's switch): when a weight / bias already HAS a .grad buffer (the optimizer's
+# flat gradient views, lab4d_amd.optim.FlatAdamW), the weight-gradient kernels add into it directly, in reference layout
+# (lab4d_mlp_wgrad_mapped), and autograd is handed None for that input -- no zero-fill, no column scatter, no AccumulateGrad add
+# per layer and use.  Off (default): gradients are returned to autograd like any other Function.
+FUSED_GRAD_ACCUM = False
+
+
+def _grad_sink(p):
+    g = p.grad if FUSED_GRAD_ACCUM else None
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
+
+
 ALWAYS_PACK = False  # set while capturing a hipGraph: the pack kernels must be part of the graph (weights change between replays)
 _COLIDX = {}
 
@@ -248,17 +263,40 @@ def packed_weights(net, layer, prec, W, transposed):
     hit = per.get(key)
     if hit is not None and hit[0] == ver and hit[1].device == W.device and not ALWAYS_PACK:
         return hit[1]
+    out = _pack_into(net, layer, prec, W, transposed, hit[1] if (hit is not None and hit[1].device == W.device) else None)
+    if not ALWAYS_PACK:
+        per[key] = (ver, out)
+    return out
+
+
+def _pack_into(net, layer, prec, W, transposed, out=None):
+    """Run the pack kernel; `out` (a previous packed buffer of the same layer) is overwritten in place so that its address
+    -- which a captured hipGraph may hold -- stays valid across optimizer steps."""
     d = describe(net)
     L = d.layers[layer]
     Wc = W.detach().contiguous()
     _lib.require_device(Wc)
-    out = torch.empty(L.mout_pad * (L.ke + L.kin), dtype=store_dtype(prec), device=W.device)
+    if out is None or ALWAYS_PACK:
+        out = torch.empty(L.mout_pad * (L.ke + L.kin), dtype=store_dtype(prec), device=W.device)
     cm = col_map(net, layer, W.device)
     _lib.check(_lib.lib().lab4d_mlp_pack(net, layer, prec, 1 if transposed else 0, _lib.ptr(Wc), Wc.shape[1], _lib.ptr(cm),
                                          _lib.ptr(out), _lib.stream()), "mlp_pack")
-    if not ALWAYS_PACK:
-        per[key] = (ver, out)
     return out
+
+
+def repack_all():
+    """Refresh, in place, every cached packed copy whose parameter changed since it was packed (call after an optimizer step when
+    the kernels that consume the copies are replayed from a captured hipGraph and therefore never come through packed_weights)."""
+    n = 0
+    for ref, per in list(_PACK_CACHE.values()):
+        W = ref()
+        if W is None:
+            continue
+        for key, (ver, buf) in list(per.items()):
+            if ver != W._version:
+                per[key] = (W._version, _pack_into(key[0], key[1], key[2], W, key[3], buf))
+                n += 1
+    return n
 
 
 def clear_caches():
@@ -363,7 +401,7 @@ class MlpChain(Function):
         a.out = out.data_ptr()
         # algorithmic HBM bytes of this launch: every stored tensor written once, inputs read once
         nbytes = sum(t.numel() * t.element_size() for t in acts + masks + [emb, ext, out, x] if t is not None)
-        with _lib.timed("k_mlp_fwd<%s>" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], float(nbytes))):
+        with _lib.timed("k_mlp_fwd<%s>%s" % (KERNEL_NET[net], "" if need_grad else " inference"), (2.0 * S * NET_MACS[net], float(nbytes))):
             _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
         ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
@@ -431,11 +469,18 @@ class MlpChain(Function):
         # weight / bias gradients
         M = (S + spf - 1) // spf
         grads_pf, grads_params = [], []
-        # one zero-filled arena for every accumulated output of the wgrad launches (one fill instead of ~3 per layer)
-        sizes = []
+        # one zero-filled arena for every accumulated output of the wgrad launches (one fill instead of ~3 per layer); layers
+        # whose weight has a gradient sink (FUSED_GRAD_ACCUM) need no scratch matrix at all
+        sizes, sinks = [], []
         for l in range(NL):
             L = d.layers[l]
-            sizes.append((L.mout_pad * (L.ke + L.kin), L.mout_pad, M * L.mout_pad if L.pf_bias else 0))
+            need_w = ctx.needs_input_grad[9 + n_pf + 2 * l]
+            need_b = ctx.needs_input_grad[9 + n_pf + 2 * l + 1]
+            sw = _grad_sink(Ws[l]) if need_w else None
+            sb = _grad_sink(bs[l]) if (need_b and sw is not None and not L.pf_bias) else None
+            sinks.append((sw, sb))
+            sizes.append((0 if sw is not None else L.mout_pad * (L.ke + L.kin), 0 if sb is not None else L.mout_pad,
+                          M * L.mout_pad if L.pf_bias else 0))
         arena = torch.zeros(sum(sum(t) for t in sizes), device=dev)
         aoff = 0
         for l in range(NL):
@@ -447,18 +492,25 @@ class MlpChain(Function):
             gW = gb = None
             if need_w or need_b or need_pf:
                 n0, n1, n2 = sizes[l]
-                dWk = arena[aoff:aoff + n0].view(L.mout_pad, K)
-                dbk = arena[aoff + n0:aoff + n0 + n1]
+                sw, sb = sinks[l]
+                dWk = arena[aoff:aoff + n0].view(L.mout_pad, K) if sw is None else None
+                dbk = arena[aoff + n0:aoff + n0 + n1] if sb is None else None
                 pfd = arena[aoff + n0 + n1:aoff + n0 + n1 + n2].view(M, L.mout_pad) if need_pf else None
                 prev = ctx.acts[l - 1] if L.kin else None
                 with _lib.timed(wgrad_kernel_name(L, prec), wgrad_work(L, S_pad, prec)):
-                  _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, ld, spf, _lib.ptr(dz[l]), _lib.ptr(ctx.emb), _lib.ptr(prev),
-                                                      _lib.ptr(dWk), _lib.ptr(dbk), _lib.ptr(pfd), M, _lib.stream()), "mlp_wgrad")
-                if need_w:
+                    if sw is not None:
+                        _lib.check(_lib.lib().lab4d_mlp_wgrad_mapped(net, l, prec, S, S_pad, ld, spf, _lib.ptr(dz[l]), _lib.ptr(ctx.emb), _lib.ptr(prev),
+                                                                     _lib.ptr(sw), sw.shape[1], _lib.ptr(col_map(net, l, dev)),
+                                                                     _lib.ptr(sb if sb is not None else dbk), _lib.ptr(pfd), M, _lib.stream()),
+                                   "mlp_wgrad_mapped")
+                    else:
+                        _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, ld, spf, _lib.ptr(dz[l]), _lib.ptr(ctx.emb), _lib.ptr(prev),
+                                                              _lib.ptr(dWk), _lib.ptr(dbk), _lib.ptr(pfd), M, _lib.stream()), "mlp_wgrad")
+                if need_w and sw is None:
                     kcols, rcols = col_index(net, l, dev)
                     gW = torch.zeros_like(Ws[l], dtype=torch.float32)
                     gW[:, rcols] = dWk[:L.mout][:, kcols]
-                if need_b:
+                if need_b and sb is None:
                     gb = (pfd.sum(0) if need_pf else dbk)[:L.mout].reshape(bs[l].shape)
                 if need_pf:
                     grads_pf.append(pfd)
@@ -598,7 +650,8 @@ class EikonalSdf(Function):
         temb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
         a.emb = temb.data_ptr()
         _lib.check(_lib.lib().lab4d_mlp_forward_tangent(ctypes.byref(a), _lib.stream()), "mlp_forward_tangent")
-        sizes = [d.layers[l].mout_pad * (d.layers[l].ke + d.layers[l].kin) for l in range(NL)]
+        sinks = [(_grad_sink(Ws[l]) if ctx.needs_input_grad[7 + 2 * l] else None) for l in range(NL)]
+        sizes = [0 if sinks[l] is not None else d.layers[l].mout_pad * (d.layers[l].ke + d.layers[l].kin) for l in range(NL)]
         arena = torch.zeros(sum(sizes), device=dev)
         off = 0
         grads = []
@@ -606,14 +659,20 @@ class EikonalSdf(Function):
             L = d.layers[l]
             gW = None
             if ctx.needs_input_grad[7 + 2 * l]:
-                dWk = arena[off:off + sizes[l]].view(L.mout_pad, L.ke + L.kin)
                 prev = tact[l - 1] if L.kin else None
                 with _lib.timed(wgrad_kernel_name(L, prec) + "@eik", wgrad_work(L, S_pad, prec)):
-                    _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, S_pad, spf, _lib.ptr(dz[l]), _lib.ptr(temb), _lib.ptr(prev),
-                                                          _lib.ptr(dWk), None, None, 0, _lib.stream()), "mlp_wgrad(eikonal)")
-                kcols, rcols = col_index(net, l, dev)
-                gW = torch.zeros_like(Ws[l], dtype=torch.float32)
-                gW[:, rcols] = dWk[:L.mout][:, kcols]
+                    if sinks[l] is not None:
+                        _lib.check(_lib.lib().lab4d_mlp_wgrad_mapped(net, l, prec, S, S_pad, S_pad, spf, _lib.ptr(dz[l]), _lib.ptr(temb), _lib.ptr(prev),
+                                                                     _lib.ptr(sinks[l]), sinks[l].shape[1], _lib.ptr(col_map(net, l, dev)), None, None, 0,
+                                                                     _lib.stream()), "mlp_wgrad_mapped(eikonal)")
+                    else:
+                        dWk = arena[off:off + sizes[l]].view(L.mout_pad, L.ke + L.kin)
+                        _lib.check(_lib.lib().lab4d_mlp_wgrad(net, l, prec, S, S_pad, S_pad, spf, _lib.ptr(dz[l]), _lib.ptr(temb), _lib.ptr(prev),
+                                                              _lib.ptr(dWk), None, None, 0, _lib.stream()), "mlp_wgrad(eikonal)")
+                if sinks[l] is None:
+                    kcols, rcols = col_index(net, l, dev)
+                    gW = torch.zeros_like(Ws[l], dtype=torch.float32)
+                    gW[:, rcols] = dWk[:L.mout][:, kcols]
             off += sizes[l]
             grads += [gW, None]
         return (None, None, None, None, None, None, None, *grads)

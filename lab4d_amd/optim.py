@@ -25,7 +25,8 @@ class FlatAdamW:
         self.params = list(params)
         if not self.params:
             raise RuntimeError("FlatAdamW: no parameters")
-        _lib.require_device(*[p.detach().contiguous() for p in self.params])
+        # the flat layout (and with it the all-reduce bucket `flat_grad`) is plain tensor bookkeeping and works on any device
+        # -- the CPU tests of the data-parallel path use exactly this object; step() / grad_norm_clip() need the HIP library
         dev = self.params[0].device
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         ends, off = [], 0
@@ -66,12 +67,14 @@ class FlatAdamW:
 
     def grad_norm_clip(self, max_norm):
         """Global gradient norm and clip_grad_norm_'s coefficient, both left on the device (no host sync); returns the norm."""
+        _lib.require_device(self.flat_grad)
         _lib.check(_lib.lib().lab4d_grad_norm_clip(_lib.ptr(self.flat_grad), self.n, float(max_norm), _lib.ptr(self.work), _lib.ptr(self.norm),
                                                    _lib.ptr(self.coef), _lib.stream()), "grad_norm_clip")
         return self.norm
 
     def step(self, max_norm=None):
         """One AdamW step; with max_norm the gradients are scaled by min(1, max_norm / (norm + 1e-6)) inside the update."""
+        _lib.require_device(self.flat, self.flat_grad)
         if max_norm is not None:
             self.grad_norm_clip(max_norm)
         self.steps += 1

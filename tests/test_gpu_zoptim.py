@@ -55,3 +55,70 @@ def test_grad_norm_at_scale():
     ref = float(x.double().norm())
     assert abs(float(norm) - ref) <= 1e-5 * ref
     assert abs(float(coef) - min(1.0, 5.0 / (ref + 1e-6))) <= 1e-5
+
+
+@pytest.mark.parametrize("prec_name", ["f32", "bf16"])
+def test_fused_gradient_accumulation_equals_autograd(golden_dir, prec_name):
+    """mlp.FUSED_GRAD_ACCUM (the training loop's mode: weight-gradient kernels add straight into the optimizer's flat gradient
+    views, in reference layout, lab4d_mlp_wgrad_mapped) gives the same gradients as handing them to autograd -- over the whole
+    training graph of the reference fixture, two accumulation passes (gradient accumulation over chunks), every parameter."""
+    import os
+    from lab4d_amd import deformable as DF
+    from lab4d_amd import mlp, optim, synthetic
+    prec = mlp.PREC_F32 if prec_name == "f32" else mlp.PREC_BF16
+    g = torch.load(os.path.join(golden_dir, "train_small.pt"), weights_only=False)
+    meta = g["meta"]
+
+    def run(fused):
+        P = synthetic.to_device(synthetic.make_weights(meta["seed"]), DEV)
+        for k, v in P.items():
+            if v.dtype.is_floating_point and k != "aabb":
+                v.requires_grad_(True)
+        params = [v for v in P.values() if v.requires_grad]
+        opt = optim.FlatAdamW(params, 5e-4)
+        opt.zero_grad()
+        mlp.FUSED_GRAD_ACCUM = fused
+        try:
+            for _ in range(2):
+                fr = synthetic.add_codes(synthetic.to_device(dict(g["frames"]), DEV), P)
+                batch = synthetic.to_device(g["batch"], DEV)
+                fr["feature"] = batch["feature"]
+                res = DF.render_train(P, fr, g["hxy"].to(DEV), synthetic.to_device(g["rng"], DEV), flow_thresh=meta["flow_thresh"], n_depth=meta["D"],
+                                      alpha=meta["alpha"], prec=prec)
+                sum(DF.losses_fg(res, batch, meta["res"], DF.DEFAULT_LOSS_WT).values()).backward()
+        finally:
+            mlp.FUSED_GRAD_ACCUM = False
+        return {k: v.grad.clone() for k, v in P.items() if v.requires_grad}, opt.flat_grad.clone()
+
+    ga, fa = run(False)
+    gb, fb = run(True)
+    worst = 0.0
+    for k in ga:
+        denom = float(ga[k].abs().max()) + 1e-20
+        e = float((ga[k] - gb[k]).abs().max()) / denom
+        worst = max(worst, e)
+        assert e < 2e-5, (k, e)  # same kernels, same operands: only the order of the fp32 atomic adds differs
+    assert float(fa.abs().sum()) > 0 and torch.allclose(fa, fb, rtol=1e-3, atol=1e-6 * float(fa.abs().max()))
+
+
+def test_repack_all_refreshes_packed_weights_in_place():
+    """After an optimizer step the packed bf16 copies a captured hipGraph reads are refreshed IN PLACE (same device address):
+    mlp.repack_all() re-packs exactly the copies whose parameter changed, and a forward pass then sees the new weights."""
+    from lab4d_amd import mlp, synthetic
+    P = synthetic.to_device(synthetic.make_weights(5), DEV)
+    fr = synthetic.add_codes(synthetic.to_device(synthetic.make_frames(6, 2, 64), DEV), P)
+    x = (torch.rand(512, 3, device=DEV) - 0.5) * 0.2
+    mlp.clear_caches()
+    with torch.no_grad():
+        y0 = mlp.run_chain(mlp.NET_VIS, mlp.PREC_BF16, P, x, 256, conds={0: fr["code_vis"]}).clone()
+        W = P["vis_mlp.basefield.linear_2.0.weight"]
+        buf = mlp.packed_weights(mlp.NET_VIS, 1, mlp.PREC_BF16, W, False)
+        addr, before = buf.data_ptr(), buf.clone()
+        assert mlp.repack_all() == 0  # nothing changed yet
+        W.mul_(1.5)  # in-place update bumps the version counter, like an optimizer step
+        n = mlp.repack_all()
+        assert n >= 1
+        buf2 = mlp.packed_weights(mlp.NET_VIS, 1, mlp.PREC_BF16, W, False)
+        assert buf2.data_ptr() == addr and not torch.equal(buf2, before)
+        y1 = mlp.run_chain(mlp.NET_VIS, mlp.PREC_BF16, P, x, 256, conds={0: fr["code_vis"]})
+        assert float((y1 - y0).abs().max()) > 1e-4
