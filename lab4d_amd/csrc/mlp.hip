@@ -20,12 +20,15 @@ struct DwMap {
   const int* cmap;
   int ld, mout, db_rows;
 };
-__device__ __forceinline__ void dw_add(float* dW, int o, int k, int K, const DwMap& wm, float v) {
+// destination column of kernel column k (resolved ONCE per column a lane owns: a lookup per accumulator element made the 256x256
+// ring kernel 39 % slower) ...
+__device__ __forceinline__ int dw_col(int k, const DwMap& wm) { return wm.cmap ? wm.cmap[k] : k; }
+// ... and the add of one element of row o into that column
+__device__ __forceinline__ void dw_add(float* dW, int o, int c, int K, const DwMap& wm, float v) {
   if (wm.cmap) {
-    const int c = wm.cmap[k];
     if (c >= 0 && o < wm.mout) atomicAdd(dW + (size_t)o * wm.ld + c, v);
   } else {
-    atomicAdd(dW + (size_t)o * K + k, v);
+    atomicAdd(dW + (size_t)o * K + c, v);
   }
 }
 
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(const typename P::store_t* __
     if (to < mo_tiles && tk < nk_tiles) {
       const int o = 32 * to + drow(r, l2 >> 5);
       const int k = 32 * tk + (l2 & 31);
-      dw_add(dW, o, k, K, wm, red[e]);
+      dw_add(dW, o, dw_col(k, wm), K, wm, red[e]);
     }
   }
   if (kb == 0 && db) {
@@ -273,11 +276,11 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_big(const typename P::store_t
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (!bv_[j]) continue;
+        const int c = dw_col(32 * (kb * 8 + wc * 4 + j) + row, wm);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = 32 * (ob * 8 + wr * 4 + i) + drow(r, h);
-          const int k = 32 * (kb * 8 + wc * 4 + j) + row;
-          dw_add(dW, o, k, K, wm, acc[i][j][r]);
+          dw_add(dW, o, c, K, wm, acc[i][j][r]);
         }
       }
       if (do_db) {
@@ -462,11 +465,11 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       if (!bv_[j]) continue;
+      const int c = dw_col(k0 + 32 * (wc * TN + j) + row, wm);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = 32 * (wr * TM + i) + drow(r, h);
-        const int k = k0 + 32 * (wc * TN + j) + row;
-        dw_add(dW, o, k, K, wm, acc[i][j][r]);
+        dw_add(dW, o, c, K, wm, acc[i][j][r]);
       }
     }
     if (do_db) {

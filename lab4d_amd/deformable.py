@@ -10,6 +10,8 @@ inputs produced by the per-frame modules (camera / articulation / appearance / t
 Heavy per-sample work runs in liblab4d_hip.so; what is left in torch here is per-frame or per-ray glue plus
 a handful of element-wise epilogues that DESIGN.md lists as not yet folded into kernels.
 """
+import ctypes
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -299,8 +301,104 @@ def mask_balance_wt(mask, vis2d, is_detected):
     return torch.where(both, wt, torch.ones_like(wt))
 
 
+LOSS_TERMS = ["mask", "feature", "feat_reproj", "rgb", "depth", "flow", "vis", "reg_gauss_mask", "reg_eikonal", "reg_deform_cyc", "reg_delta_skin",
+              "reg_skin_entropy"]
+
+
+class _LossInputs(ctypes.Structure):
+    _fields_ = [(n, vp) for n in ("mask", "feature", "xy_reproj", "rgb", "depth", "flow", "vis", "gauss_mask", "eikonal", "cyc_dist", "delta_skin",
+                                  "skin_entropy", "t_mask", "t_feature", "t_hxy", "t_rgb", "t_depth", "t_flow", "t_flow_uct", "t_vis2d", "t_detected",
+                                  "balance_wt")] + [("hxy_ld", ci), ("dense_uses_mask", ci)]
+
+
+class _LossGrads(ctypes.Structure):
+    _fields_ = [(n, vp) for n in ("mask", "feature", "xy_reproj", "rgb", "depth", "flow", "vis", "gauss_mask", "eikonal", "cyc_dist", "delta_skin",
+                                  "skin_entropy")]
+
+
+_lib.register("lab4d_ray_losses_forward", [ctypes.POINTER(_LossInputs), ci, ci, ctypes.POINTER(cf * 12), vp, vp, vp])
+_lib.register("lab4d_ray_losses_backward", [ctypes.POINTER(_LossInputs), ci, ci, ctypes.POINTER(cf * 12), vp, vp, ctypes.POINTER(_LossGrads), vp])
+_RENDERED = ("mask", "feature", "xy_reproj", "rgb", "depth", "flow", "vis", "gauss_mask", "eikonal", "cyc_dist", "delta_skin", "skin_entropy")
+_TARGETS = ("t_mask", "t_feature", "t_hxy", "t_rgb", "t_depth", "t_flow", "t_flow_uct", "t_vis2d", "t_detected", "balance_wt")
+
+
+class RayLosses(Function):
+    """All per-ray loss terms in one pass each way (include/lab4d_loss.h).  apply(N, weights (12 floats), *rendered (12), *targets
+    (10)) -> (13,): the weighted terms in LOSS_TERMS order, then their total."""
+
+    @staticmethod
+    def forward(ctx, N, weights, *tensors):
+        rendered = [None if t is None else t.contiguous().float() for t in tensors[:12]]
+        targets = [None if t is None else t.contiguous().float() for t in tensors[12:]]
+        _lib.require_device(*[t for t in rendered + targets if t is not None])
+        ref = next(t for t in rendered if t is not None)
+        R = targets[_TARGETS.index("t_vis2d")].numel()
+        a = _LossInputs()
+        for n, t in zip(_RENDERED + _TARGETS, rendered + targets):
+            setattr(a, n, None if t is None else t.data_ptr())
+        a.hxy_ld = targets[2].shape[-1] if targets[2] is not None else 0
+        a.dense_uses_mask = 1
+        w = (cf * 12)(*[float(x) for x in weights])
+        acc = torch.empty(24, device=ref.device)
+        loss = torch.empty(13, device=ref.device)
+        _lib.check(_lib.lib().lab4d_ray_losses_forward(ctypes.byref(a), R, int(N), ctypes.byref(w), _lib.ptr(acc), _lib.ptr(loss), _lib.stream()),
+                   "ray_losses_forward")
+        ctx.keep = (rendered, targets, acc, [float(x) for x in weights], R, int(N), a.hxy_ld)
+        ctx.shapes = [None if t is None else t.shape for t in tensors[:12]]
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        rendered, targets, acc, weights, R, N, hxy_ld = ctx.keep
+        a = _LossInputs()
+        for n, t in zip(_RENDERED + _TARGETS, rendered + targets):
+            setattr(a, n, None if t is None else t.data_ptr())
+        a.hxy_ld, a.dense_uses_mask = hxy_ld, 1
+        g_loss = (g[:12] + g[12]).contiguous()
+        gr = _LossGrads()
+        outs = []
+        for i, (n, t) in enumerate(zip(_RENDERED, rendered)):
+            o = torch.empty_like(t) if (t is not None and ctx.needs_input_grad[2 + i]) else None
+            outs.append(o)
+            setattr(gr, n, None if o is None else o.data_ptr())
+        w = (cf * 12)(*weights)
+        _lib.check(_lib.lib().lab4d_ray_losses_backward(ctypes.byref(a), R, N, ctypes.byref(w), _lib.ptr(acc), _lib.ptr(g_loss), ctypes.byref(gr),
+                                                        _lib.stream()), "ray_losses_backward")
+        return (None, None) + tuple(None if o is None else o.view(s) for o, s in zip(outs, ctx.shapes)) + (None,) * 10
+
+
+class LossDict(dict):
+    """{term: scalar}; `.total` is their sum, formed by the kernel (summing the dict's values costs one launch per term)."""
+    total = None
+
+
 def losses_fg(results, batch, train_res, weights):
-    """compute_recon_loss + mask_losses + rendered regularisers + apply_loss_weights for field_type "fg"."""
+    """compute_recon_loss + mask_losses + rendered regularisers + apply_loss_weights for field_type "fg" (engine/model.py:
+    401-611): every term's masked sum / positive count in one kernel pass over the rays, the gradients of all rendered
+    inputs in one more (csrc/losses.hip).  `batch["mask_balance_wt"]` (get_mask_balance_wt, model.py:401-424, a function of
+    the targets only) is used when the caller precomputed it."""
+    r, a = results["rendered"], results["aux_dict"]["fg"]
+    bal = batch.get("mask_balance_wt")
+    if bal is None:
+        bal = mask_balance_wt(batch["mask"], batch["vis2d"], batch["is_detected"])
+    wt = []
+    for k in LOSS_TERMS:
+        w = 1.0 if weights is None or k + "_wt" not in weights else float(weights[k + "_wt"])
+        wt.append(w / train_res if k in ("flow", "feat_reproj") else w)
+    rendered = [r["mask"], a["feature"], a["xy_reproj"], r["rgb"], r["depth"], r["flow"], a["vis"], a["gauss_mask"], r["eikonal"], a["cyc_dist"],
+                a["delta_skin"], a["skin_entropy"]]
+    targets = [batch["mask"], batch["feature"], batch["hxy"], batch["rgb"], batch["depth"], batch["flow"], batch["flow_uct"], batch["vis2d"],
+               batch["is_detected"], bal]
+    vec = RayLosses.apply(r["mask"].shape[1], wt, *rendered, *targets)
+    out = LossDict((k, vec[i]) for i, k in enumerate(LOSS_TERMS))
+    out.total = vec[12]
+    return out
+
+
+def losses_fg_reference_ops(results, batch, train_res, weights):
+    """The same terms written with element-wise tensor operations, one term at a time like the reference -- kept as the
+    readable statement of what RayLosses computes (tests compare the two); not used by the renderer."""
     r, a = results["rendered"], results["aux_dict"]["fg"]
     L = {}
     L["mask"] = (r["mask"] - batch["mask"].float()).pow(2) * mask_balance_wt(batch["mask"], batch["vis2d"], batch["is_detected"])

@@ -70,7 +70,7 @@ def test_training_graph_matches_reference_goldens(golden_dir, case):
     for k, v in g["aux_fg"].items():
         assert rel(res["aux_dict"]["fg"][k], v) < 2e-4, f"aux_fg.{k}: {rel(res['aux_dict']['fg'][k], v):.3e}"
     # PSNR of the rendered colour against the reference render (north_star: "matched PSNR")
-    mse = float(((res["rendered"]["rgb"].cpu() - g["rendered"]["rgb"]) ** 2).mean())
+    mse = float(((res["rendered"]["rgb"].detach().cpu() - g["rendered"]["rgb"]) ** 2).mean())
     assert mse < 1e-9, f"rgb PSNR {(-10 * torch.log10(torch.tensor(mse))).item():.1f} dB"
     losses = DF.losses_fg(res, batch, meta["res"], DF.DEFAULT_LOSS_WT)
     for k, v in g["loss"].items():
@@ -200,7 +200,7 @@ def test_bf16_training_graph_is_close_to_fp32(golden_dir):
     fr["feature"] = batch["feature"]
     res = DF.render_train(Pd, fr, g["hxy"].to(DEV), synthetic.to_device(g["rng"], DEV), flow_thresh=meta["flow_thresh"], n_depth=meta["D"],
                           alpha=meta["alpha"], prec=mlp.PREC_BF16)
-    mse = float(((res["rendered"]["rgb"].cpu() - g["rendered"]["rgb"]) ** 2).mean())
+    mse = float(((res["rendered"]["rgb"].detach().cpu() - g["rendered"]["rgb"]) ** 2).mean())
     psnr = -10 * torch.log10(torch.tensor(mse)).item()
     assert psnr > 35, psnr
     assert rel(res["rendered"]["mask"], g["rendered"]["mask"]) < 3e-2
