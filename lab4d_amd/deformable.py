@@ -20,7 +20,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib, mlp
 from . import quat_utils as Q
 from . import render_utils as RU
-from .warping import composed_warp, skinning_warp
+from .warping import composed_warp, skinning_warp, skinning_warp_forward_multi
 
 vp, ci, cf = _lib.vp, _lib.ci, _lib.cf
 _lib.register("lab4d_gauss_density_forward", [vp, vp, ci, vp, ci, vp, vp, vp])
@@ -244,7 +244,15 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     fd["rgb"], fd["density"], fd["density_fg"], fd["vis"] = rgb, density, density, vis
     # flow: canonical points into the pair partner's camera (nerf.py:948-997)
     nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam", "t_articulation", "rest_articulation"]})
-    xyz_next, _ = warp(xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"], False, partner=True)
+    shared = fr.get("dense") is None and fr.get("rest_shared_in_pair", True)
+    if shared:
+        # both forward warps of the canonical samples (into the partner's frame here, into the own frame for the cycle term
+        # below) see the same skinning field: the rest articulation is a per-instance quantity and pair partners are frames
+        # of one video (rest_articulation == its flip_pair), so it is evaluated once (warping.skinning_warp_forward_multi)
+        (xyz_next, _), (xyz_cyc, cyc_aux) = skinning_warp_forward_multi(P, xyz, [nxt["t_articulation"], fr["t_articulation"]], fr["rest_articulation"],
+                                                                        fr["t_embed_mean"], fr["code_skin"], prec)
+    else:
+        xyz_next, _ = warp(xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"], False, partner=True)
     xyz_cam_next = rigid_apply(nxt["field2cam"][0], nxt["field2cam"][1], xyz_next)
     hxy_next = pinhole_projection(Q.kmatinv(nxt["Kinv"]), xyz_cam_next)
     flow = (hxy_next - hxy.unsqueeze(-2))[..., :2]
@@ -253,7 +261,8 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
         valid = valid & (flow.norm(dim=-1, keepdim=True) < float(flow_thresh))
     fd["flow"] = torch.cat([flow, valid.to(flow.dtype)], -1)
     # cycle consistency (deformable.py:173-198)
-    xyz_cyc, cyc_aux = warp(xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
+    if not shared:
+        xyz_cyc, cyc_aux = warp(xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
     fd["cyc_dist"] = (xyz_cyc - xyz_t).norm(2, -1, keepdim=True)
     for k in ["skin_entropy", "delta_skin"]:
         fd[k] = (cyc_aux[k] + bw_aux[k]) / 2

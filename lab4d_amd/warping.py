@@ -111,15 +111,28 @@ def get_gauss(P):
     return lg.exp()
 
 
+def _spf(shape):
+    spf = 1
+    for d in shape[1:-1]:
+        spf *= d
+    return spf
+
+
+def skin_logits(P, x, art, t_embed, code, M, spf, prec):
+    """The delta-skin field of SkinningField.forward (skinning.py:89-124) at the articulation `art`: gaussian-scaled bone
+    coordinates -> delta-skin MLP.  x (S,3).  Returns the raw (S,B) MLP output and gauss (B,3)."""
+    gauss = get_gauss(P)
+    bone = BoneCoords.apply(x, art[0], art[1], gauss, spf)  # (S,3B): input of the delta-skin MLP only
+    cond = torch.cat([t_embed.expand(M, -1), code], -1)
+    return mlp.run_chain(mlp.NET_SKIN, prec, P, bone, spf, conds={0: cond}), gauss
+
+
 def skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, prec=mlp.PREC_F32):
     """SkinningWarp.forward (warping.py:277-336).  xyz: (M,N,D,3).  Returns warped xyz and
     {"skin_entropy","delta_skin"} (M,N,D,1).  t_embed: (M,128) per-frame (backward warp) or (1,128)
     mean embedding (forward warp, frame_id=None: warping.py:314)."""
     shape = xyz.shape
-    M = shape[0]
-    spf = 1
-    for d in shape[1:-1]:
-        spf *= d
+    M, spf = shape[0], _spf(shape)
     if backward:
         se3 = Q.dual_quaternion_mul(rest_articulation, Q.dual_quaternion_inverse(t_articulation))
         art = t_articulation
@@ -127,12 +140,30 @@ def skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, back
         se3 = Q.dual_quaternion_mul(t_articulation, Q.dual_quaternion_inverse(rest_articulation))
         art = rest_articulation
     x = xyz.reshape(-1, 3)
-    gauss = get_gauss(P)
-    bone = BoneCoords.apply(x, art[0], art[1], gauss, spf)  # (S,3B): input of the delta-skin MLP only
-    cond = torch.cat([t_embed.expand(M, -1), code], -1)
-    raw = mlp.run_chain(mlp.NET_SKIN, prec, P, bone, spf, conds={0: cond})
+    raw, gauss = skin_logits(P, x, art, t_embed, code, M, spf, prec)
     out, ent, dsk = SkinBlend.apply(x, raw, art[0], art[1], gauss, se3[0], se3[1], spf)
     return out.view(shape), {"skin_entropy": ent.view(shape[:-1] + (1,)), "delta_skin": dsk.view(shape[:-1] + (1,))}
+
+
+def skinning_warp_forward_multi(P, xyz, t_articulations, rest_articulation, t_embed_mean, code, prec=mlp.PREC_F32):
+    """Several FORWARD warps of the same canonical points to different target articulations (SkinningWarp.forward with
+    backward=False, warping.py:306-333).  In the forward direction the skinning weights depend only on the points, the REST
+    articulation, the mean time embedding and the instance code (warping.py:311-314: articulation = rest_articulation,
+    frame_id = None) -- not on the target -- so the bone coordinates and the delta-skin MLP are evaluated ONCE and only the
+    dual-quaternion blend runs per target.  The training graph warps every canonical sample forward twice (compute_flow into
+    the pair partner's frame, nerf.py:966-973; cycle_loss into its own, deformable.py:173-198): the reference evaluates the
+    skinning field twice with identical inputs, this evaluates it once.  Returns [(warped xyz, aux), ...]."""
+    shape = xyz.shape
+    M, spf = shape[0], _spf(shape)
+    x = xyz.reshape(-1, 3)
+    raw, gauss = skin_logits(P, x, rest_articulation, t_embed_mean, code, M, spf, prec)
+    rest_inv = Q.dual_quaternion_inverse(rest_articulation)
+    outs = []
+    for t_art in t_articulations:
+        se3 = Q.dual_quaternion_mul(t_art, rest_inv)
+        out, ent, dsk = SkinBlend.apply(x, raw, rest_articulation[0], rest_articulation[1], gauss, se3[0], se3[1], spf)
+        outs.append((out.view(shape), {"skin_entropy": ent.view(shape[:-1] + (1,)), "delta_skin": dsk.view(shape[:-1] + (1,))}))
+    return outs
 
 
 def dense_warp(P, xyz, t_embed, code, backward, prec=mlp.PREC_F32, prefix="warp.post_warp."):

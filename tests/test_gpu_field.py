@@ -83,12 +83,41 @@ def test_training_graph_matches_reference_goldens(golden_dir, case):
     for k, gv in zip(names + ["frame:" + k for k in fnames], grads):
         ref = g["grads"][k]
         assert gv is not None, k
-        if "full" in ref:
+        if k.startswith("frame:rest_articulation"):
+            # The two forward warps of a training query share one evaluation of the skinning field (deformable.query_field_train,
+            # "rest_shared_in_pair"): the rest articulation is the same tensor for both frames of a pair (the fixtures', like
+            # any reference batch's, is identical row for row), so what is defined is the gradient summed over the pair --
+            # the reference attributes the flow branch's share to the partner's copy of the row, this path to the own copy.
+            pair = lambda t: t.reshape(t.shape[0] // 2, 2, -1).sum(1)
+            e = rel(pair(gv), pair(ref["full"]))
+        elif "full" in ref:
             e = rel(gv, ref["full"])
         else:
             e = rel(gv.flatten()[:: ref["stride"]], ref["sub"])
         worst = max(worst, e)
         assert e < 5e-3, f"grad {k}: {e:.3e}"
+
+
+def test_unshared_forward_warps_give_the_reference_rows(golden_dir):
+    """With fr["rest_shared_in_pair"] = False both forward warps evaluate their own skinning field, exactly like the reference:
+    the per-ROW gradient of rest_articulation then matches the fixture as well (the shared path only matches the pair sums)."""
+    from lab4d_amd import deformable as DF
+    g, P = load_case(golden_dir, "train_small.pt")
+    meta = g["meta"]
+    Pd = synthetic.to_device(P, DEV)
+    fr = synthetic.to_device(dict(g["frames"]), DEV)
+    rest = tuple(t.clone().requires_grad_(True) for t in fr["rest_articulation"])
+    fr["rest_articulation"] = rest
+    fr = synthetic.add_codes(fr, Pd)
+    batch = synthetic.to_device(g["batch"], DEV)
+    fr["feature"] = batch["feature"]
+    fr["rest_shared_in_pair"] = False
+    res = DF.render_train(Pd, fr, g["hxy"].to(DEV), synthetic.to_device(g["rng"], DEV), flow_thresh=meta["flow_thresh"], n_depth=meta["D"], alpha=meta["alpha"])
+    for k, v in g["rendered"].items():
+        assert rel(res["rendered"][k], v) < 2e-4, k
+    grads = torch.autograd.grad(DF.losses_fg(res, batch, meta["res"], DF.DEFAULT_LOSS_WT).total, list(rest))
+    for i, gv in enumerate(grads):
+        assert rel(gv, g["grads"]["frame:rest_articulation.%d" % i]["full"]) < 5e-3, i
 
 
 def test_training_graph_multi_instance(golden_dir):
