@@ -95,6 +95,23 @@ int lab4d_sample_pdf_u(const float* bins, const float* weights, const float* u_s
 int lab4d_sort_depth(const float* a, int na, const float* b, int nb, int R, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 2b. Valid-sample compaction of the evaluation path -- nnutils/nerf.py:495-528 (get_valid_idx), 769-819 (query_nerf);
+ *     utils/geom_utils.py:409-422 (extend_aabb), 506-517 (check_inside_aabb, strict inequalities).
+ *     valid_mask: mask[s] = xyz[s] strictly inside aabb (2,3) AND (t_aabb == NULL or xyz_t[s] strictly inside t_aabb (2,3)); uint8.
+ *     compact: idx[0..count) = ascending indices of the set mask bytes, *count = how many -- BOTH stay on the device (the
+ *       reference's `valid_idx.sum()` and boolean indexing each cost a host round trip); work: lab4d_compact_work_ints(S) ints.
+ *     gather_rows / scatter_rows / frame_of take that device-side count: rows j < *count are moved, gather zero-fills the rest
+ *       of its n_rows-row output, scatter leaves the other rows of dst as the caller filled them (zeros, nerf.py:812-816),
+ *       frame_of writes idx[j] / spf (the frame a compacted sample belongs to: lab4d_mlp_fwd_args.frame_idx).
+ * ------------------------------------------------------------------------------------------ */
+int lab4d_valid_mask(const float* xyz, const float* xyz_t, const float* aabb, const float* t_aabb, long S, unsigned char* mask, void* stream);
+long lab4d_compact_work_ints(long S);
+int lab4d_compact(const unsigned char* mask, long S, int* idx, int* count, int* work, void* stream);
+int lab4d_gather_rows(const float* src, const int* idx, const int* count, long n_rows, int C, float* dst, void* stream);
+int lab4d_scatter_rows(const float* src, const int* idx, const int* count, long n_rows, int C, float* dst, void* stream);
+int lab4d_frame_of(const int* idx, const int* count, long n_rows, int spf, int* frame, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 3. Compositing -- utils/render_utils.py:59-184 (render_pixel / compute_weights / integrate).
  *    One launch renders every per-sample field of a ray batch.  R = M*N rays, D samples.
  *    fields[i]: (R,D,channels[i]) fp32; modes[i]: 0 = normalised weights w/(sum w+1e-6),

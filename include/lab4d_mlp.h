@@ -106,6 +106,10 @@ typedef struct {
   const void* ext;                  /* [mout_pad][ld] tensor added at the add_ext layer                 */
   float* out;                       /* (S, c_out) raw head output, fp32                                    */
   const float* x2;                  /* LAB4D_NET_BG_COLOR: (S,3) second per-sample input (view direction, nerf.py:196); else NULL */
+  const int32_t* S_dev;             /* evaluation path only: device-side sample count -- only the first min(S, *S_dev) samples are
+                                       processed (stream-compacted valid samples, nnutils/nerf.py:782-819, whose count stays on the
+                                       device); NULL: all S                                                                       */
+  const int32_t* frame_idx;         /* (S) int32 frame of every sample, or NULL: frame of sample s = s / spf                       */
 } lab4d_mlp_fwd_args;
 int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream);
 

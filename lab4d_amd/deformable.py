@@ -103,6 +103,11 @@ def gauss_density(P, xyz, rest_articulation):
     return out.view(xyz.shape[:-1] + (1,))
 
 
+def _flip_yz(n):
+    """normal * [1, -1, -1] (nerf.py:489-491) without building a constant on the host (hipGraph-capturable)."""
+    return torch.cat([n[..., :1], -n[..., 1:]], -1)
+
+
 def posenc_window(alpha, n_freq, device):
     """PosEmbedding.apply_annealing window (embedding.py:112-125)."""
     if alpha is None:
@@ -495,41 +500,62 @@ def importance_sampling(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
     return RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, depth=depth_all), inds
 
 
+def nerf_forward_compacted(P, x_k, fr, frame_k, count, prec, alpha=None):
+    """NeRF.forward on the stream-compacted valid samples (NeRF.query_nerf, nerf.py:782-808): x_k (S,3) with the valid samples
+    in its first *count rows, frame_k (S) int32 their frames.  Returns (rgb (S,3), density (S,1)); rows >= *count are undefined."""
+    dev = x_k.device
+    sdf, feat = mlp.run_chain_compacted(mlp.NET_FG_BASE, prec, P, x_k, frame_k, count, conds={0: fr["code_base"], 4: fr["code_base"]},
+                                        export_layer=8, freq_w=posenc_window(alpha, 10, dev))
+    ibeta = P["logibeta"].exp()
+    density = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta
+    rgb = mlp.run_chain_compacted(mlp.NET_FG_COLOR, prec, P, x_k, frame_k, count, conds={0: fr["code_color"], 3: fr["appr_code"]}, ext=feat,
+                                  freq_w=posenc_window(alpha, 12, dev))
+    return torch.sigmoid(rgb), density
+
+
 def query_field_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
-    """Eval-mode Deformable.query_field (train-only fields return {}, decorator.py:4-17)."""
+    """Eval-mode Deformable.query_field (train-only fields return {}, decorator.py:4-17): importance sampling, backward warp,
+    visibility, get_valid_idx + query_nerf (the field's colour / density only on the VALID samples: mask, stream compaction and
+    scatter on the device, no host synchronisation -- nerf.py:495-528, 769-819), normals / eikonal on every sample
+    (compute_normal, nerf.py:455-493)."""
     (xyz_cam, dir_cam, deltas, depth, _, _), inds = importance_sampling(P, fr, hxy, n_depth, alpha, prec)
     # normals need d sdf / d xyz_cam through the rigid transform and the warp (nerf.py:455-493): one first-order
-    # backward pass through the same kernels, so the forward below is run under autograd with xyz_cam as the leaf.
+    # backward pass through the same kernels, so the sdf pass below is run under autograd with xyz_cam as the leaf.
     # Only d sdf / d xyz_cam is wanted: parameters and per-frame inputs are detached, otherwise the backward below would
     # also run every weight-gradient kernel (needs_input_grad follows requires_grad, not what autograd.grad asked for)
     det = lambda v: tuple(t.detach() for t in v) if isinstance(v, tuple) else (v.detach() if torch.is_tensor(v) else v)
     P = {k: det(v) for k, v in P.items()}
-    fr = {k: det(v) for k, v in fr.items()}
+    fr = {k: (det(v) if not isinstance(v, dict) else {a: det(b) for a, b in v.items()}) for k, v in fr.items()}
     with torch.enable_grad():
         xc = xyz_cam.detach().requires_grad_(True)
         qi, ti = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
         xyz_t = rigid_apply(qi, ti, xc)
         xyz, _ = _warp_fn(P, fr, prec)(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
-        rgb, sdf = nerf_forward(P, xyz, fr, prec, get_density=False, alpha=alpha)
+        sdf = nerf_forward(P, xyz, fr, prec, with_color=False, get_density=False, alpha=alpha)
         (g,) = torch.autograd.grad(sdf, xc, torch.ones_like(sdf))
     with torch.no_grad():
-        xyz, xyz_t, rgb, sdf = xyz.detach(), xyz_t.detach(), rgb.detach(), sdf.detach()
-        ibeta = P["logibeta"].exp()
-        density = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta
+        xyz, xyz_t = xyz.detach(), xyz_t.detach()
+        shape = xyz.shape[:-1]
+        S, spf = xyz.numel() // 3, _spf(xyz)
         vis = vis_field(P, xyz, fr, prec)
-        valid = get_valid_idx(P, xyz, xyz_t, fr["t_articulation"])
-        # query_nerf (nerf.py:782-819) evaluates the field on the valid samples only and scatters into zeros; here the
-        # field is evaluated everywhere and masked (same result; the compaction itself is future work, DESIGN.md s.7)
-        rgb = rgb * valid[..., None]
-        density = density * valid[..., None]
+        # get_valid_idx (nerf.py:495-528): inside the field's aabb (+10 %) and, in time-t space, inside the box of frame 0's bones (x2)
+        _, tb = Q.dual_quaternion_to_quaternion_translation(fr["t_articulation"])
+        t_aabb = extend_aabb(torch.stack([tb[0].min(0)[0], tb[0].max(0)[0]], 0), factor=1.0)
+        mask = RU.valid_mask(xyz, xyz_t, extend_aabb(P["aabb"]), t_aabb)
+        # query_nerf (nerf.py:782-819): the field on the valid samples only, scattered into zeros
+        idx, count = RU.compact(mask)
+        x_k = RU.gather_rows(xyz.reshape(-1, 3), idx, count)
+        rgb_k, dens_k = nerf_forward_compacted(P, x_k, fr, RU.frame_of(idx, count, spf), count, prec, alpha)
+        rgb = RU.scatter_rows(rgb_k, idx, count, S).view(shape + (3,))
+        density = RU.scatter_rows(dens_k, idx, count, S).view(shape + (1,))
         fd = {"rgb": rgb, "density": density, "density_fg": density, "vis": vis}
         fd["eikonal"] = (g.norm(2, dim=-1, keepdim=True) - 1) ** 2
-        fd["normal"] = F.normalize(g, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=g.device)
+        fd["normal"] = _flip_yz(F.normalize(g, dim=-1))
         fd["xyz"] = xyz
         fd["xyz_cam"] = xyz_cam
         fd["depth"] = depth / P["logscale"].exp()
         fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
-    return fd, deltas, {"valid": valid, "inds": inds}
+    return fd, deltas, {"valid": mask.view(shape).bool(), "inds": inds, "valid_count": count}
 
 
 @torch.no_grad()
@@ -580,7 +606,7 @@ def query_field_eval_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32, p
         for k in ("cyc_dist", "delta_skin", "skin_entropy"):
             fd[k] = torch.zeros_like(density)
         fd["eikonal"] = (g.norm(2, dim=-1, keepdim=True) - 1) ** 2
-        fd["normal"] = F.normalize(g, dim=-1) * torch.tensor([1.0, -1.0, -1.0], device=g.device)
+        fd["normal"] = _flip_yz(F.normalize(g, dim=-1))
         fd["xyz"] = xyz
         fd["xyz_cam"] = xyz_cam
         fd["depth"] = depth / P[prefix + "logscale"].exp()

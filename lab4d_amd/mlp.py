@@ -37,7 +37,7 @@ class NetDesc(ctypes.Structure):
 class FwdArgs(ctypes.Structure):
     _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("S_pad", ci), ("ld", ci), ("spf", ci), ("x", vp), ("freq_w", vp),
                 ("W", vp * MAXL), ("bias", vp * MAXL), ("pf_bias", vp * MAXL), ("act", vp * MAXL), ("mask", vp * MAXL), ("emb", vp),
-                ("ext", vp), ("out", vp), ("x2", vp)]
+                ("ext", vp), ("out", vp), ("x2", vp), ("S_dev", vp), ("frame_idx", vp)]
 
 
 class BwdArgs(ctypes.Structure):
@@ -533,6 +533,58 @@ def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_la
         params += [P[bd[l].wname], P[bd[l].bname]]
     return MlpChain.apply(net, prec, spf, x, ext, freq_w, -1 if export_layer is None else export_layer, len(pfs), x2, *pfs, *params)
 
+
+
+@torch.no_grad()
+def run_chain_compacted(net, prec, P, x, frame_idx, count, conds=None, ext=None, freq_w=None, export_layer=None, prefix=""):
+    """Inference-mode chain on a stream-compacted sample list (NeRF.query_nerf, nerf.py:782-808): x (S,3) holds the valid samples
+    in its first *count rows (count: int32 device scalar -- it never visits the host), frame_idx (S) int32 names the frame each
+    of them belongs to (compacted samples are not frame-contiguous, so `s // spf` no longer works; the per-frame bias tables keep
+    their M rows instead of being expanded per sample as nerf.py:795-798 does).  Tiles beyond the count are skipped by the kernel;
+    rows >= *count of the result are not written.  Returns out or (out, exported activation)."""
+    d = describe(net)
+    bd = bindings(net, prefix)
+    x = x.contiguous()
+    _lib.require_device(x, frame_idx, count)
+    if frame_idx.dtype != torch.int32 or count.dtype != torch.int32:
+        raise RuntimeError("run_chain_compacted: frame_idx and count must be int32")
+    S = x.shape[0]
+    S_pad = s_pad_of(S)
+    dev, sdt = x.device, store_dtype(prec)
+    a = FwdArgs()
+    a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, S_pad, 1
+    a.x, a.S_dev, a.frame_idx = x.data_ptr(), count.data_ptr(), frame_idx.data_ptr()
+    keep = []
+    if freq_w is not None:
+        freq_w = freq_w.contiguous().float()
+        a.freq_w = freq_w.data_ptr()
+    exported = None
+    for l in range(d.n_layers):
+        L = d.layers[l]
+        W, b = P[bd[l].wname], P[bd[l].bname].detach().float()
+        pw = packed_weights(net, l, prec, W, False)
+        a.W[l] = pw.data_ptr()
+        if b.numel() != L.mout_pad:
+            b = torch.nn.functional.pad(b, (0, L.mout_pad - b.numel()))
+        b = b.contiguous()
+        a.bias[l] = b.data_ptr()
+        keep += [pw, b]
+        if L.pf_bias:
+            pf = (pf_bias_of(net, l, W, conds[l]).float() + b[None]).contiguous()
+            a.pf_bias[l] = pf.data_ptr()
+            keep.append(pf)
+        if l == export_layer:
+            exported = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
+            a.act[l] = exported.data_ptr()
+    if ext is not None:
+        if ext.dtype != sdt:
+            raise RuntimeError("ext must be stored as %s" % sdt)
+        a.ext = ext.data_ptr()
+    out = torch.empty(S, d.c_out, device=dev)
+    a.out = out.data_ptr()
+    with _lib.timed("k_mlp_fwd<%s> inference" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], 0.0)):
+        _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(compacted)")
+    return (out, exported) if exported is not None else out
 
 
 class EikonalSdf(Function):

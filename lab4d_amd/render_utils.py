@@ -1,6 +1,8 @@
 """Host-side mirror of lab4d/utils/render_utils.py -- same function names and signatures
 (sample_cam_rays, render_pixel, compute_weights, integrate, sample_pdf), executed by the
 gfx950 kernels of liblab4d_hip.so (csrc/raymarch.hip, csrc/composite.hip)."""
+import ctypes
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -307,4 +309,69 @@ def sort_depth(a, b):
     out = torch.empty(R, a.shape[1] + b.shape[1], device=a.device)
     _lib.check(_lib.lib().lab4d_sort_depth(_lib.ptr(a), a.shape[1], _lib.ptr(b), b.shape[1], R, _lib.ptr(out), _lib.stream()),
                "sort_depth")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# valid-sample compaction of the evaluation path (include/lab4d_hip.h section 2b; nerf.py:495-528, 769-819)
+# ---------------------------------------------------------------------------------------------------
+_lib.register("lab4d_valid_mask", [_lib.vp] * 4 + [ctypes.c_long, _lib.vp, _lib.vp])
+_lib.register("lab4d_compact", [_lib.vp, ctypes.c_long, _lib.vp, _lib.vp, _lib.vp, _lib.vp])
+_lib.register("lab4d_gather_rows", [_lib.vp] * 3 + [ctypes.c_long, _lib.ci, _lib.vp, _lib.vp])
+_lib.register("lab4d_scatter_rows", [_lib.vp] * 3 + [ctypes.c_long, _lib.ci, _lib.vp, _lib.vp])
+_lib.register("lab4d_frame_of", [_lib.vp] * 2 + [ctypes.c_long, _lib.ci, _lib.vp, _lib.vp])
+
+
+@torch.no_grad()
+def valid_mask(xyz, xyz_t, aabb, t_aabb=None):
+    """uint8 (S): xyz strictly inside aabb (2,3) and (if t_aabb is given) xyz_t strictly inside t_aabb (2,3)."""
+    x = xyz.reshape(-1, 3).contiguous()
+    xt = xyz_t.reshape(-1, 3).contiguous() if t_aabb is not None else None
+    aabb = aabb.contiguous().float()
+    t_aabb = None if t_aabb is None else t_aabb.contiguous().float()
+    _lib.require_device(x, xt, aabb, t_aabb)
+    mask = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().lab4d_valid_mask(_lib.ptr(x), _lib.ptr(xt), _lib.ptr(aabb), _lib.ptr(t_aabb), x.shape[0], _lib.ptr(mask), _lib.stream()),
+               "valid_mask")
+    return mask
+
+
+@torch.no_grad()
+def compact(mask):
+    """Stream compaction of a uint8 mask (S): (idx int32 (S): ascending indices of the set entries in its first `count` slots,
+    count int32 device scalar).  Nothing is synchronised with the host."""
+    mask = mask.contiguous()
+    _lib.require_device(mask)
+    S = mask.numel()
+    idx = torch.empty(S, dtype=torch.int32, device=mask.device)
+    count = torch.empty(1, dtype=torch.int32, device=mask.device)
+    work = torch.empty((S + 1023) // 1024 + 1, dtype=torch.int32, device=mask.device)
+    _lib.check(_lib.lib().lab4d_compact(_lib.ptr(mask), S, _lib.ptr(idx), _lib.ptr(count), _lib.ptr(work), _lib.stream()), "compact")
+    return idx, count
+
+
+@torch.no_grad()
+def gather_rows(src, idx, count):
+    """(S,C) -> (S,C): row j = src[idx[j]] for j < count, zeros after."""
+    src = src.contiguous().float()
+    out = torch.empty_like(src)
+    _lib.check(_lib.lib().lab4d_gather_rows(_lib.ptr(src), _lib.ptr(idx), _lib.ptr(count), src.shape[0], src.shape[1], _lib.ptr(out), _lib.stream()),
+               "gather_rows")
+    return out
+
+
+@torch.no_grad()
+def scatter_rows(src, idx, count, n_rows):
+    """zeros (n_rows,C) with row idx[j] = src[j] for j < count (query_nerf's scatter into zeros, nerf.py:812-816)."""
+    src = src.contiguous().float()
+    out = torch.zeros(n_rows, src.shape[1], device=src.device)
+    _lib.check(_lib.lib().lab4d_scatter_rows(_lib.ptr(src), _lib.ptr(idx), _lib.ptr(count), src.shape[0], src.shape[1], _lib.ptr(out), _lib.stream()),
+               "scatter_rows")
+    return out
+
+
+@torch.no_grad()
+def frame_of(idx, count, spf):
+    out = torch.empty_like(idx)
+    _lib.check(_lib.lib().lab4d_frame_of(_lib.ptr(idx), _lib.ptr(count), idx.numel(), int(spf), _lib.ptr(out), _lib.stream()), "frame_of")
     return out

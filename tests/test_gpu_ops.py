@@ -396,3 +396,74 @@ def test_compose_fields_matches_oracle_and_reference_golden(golden_dir):
     assert torch.equal(dd.cpu(), rd)
     for k in rg:
         assert torch.equal(dg[k].cpu(), rg[k]), k
+
+
+@pytest.mark.parametrize("S,p", [(1, 1.0), (63, 0.5), (1024, 0.0), (1025, 1.0), (65573, 0.176), (4 * 1024 * 1024 + 17, 0.3)])
+def test_stream_compaction_matches_nonzero(S, p):
+    """lab4d_compact (wave ballot + popcount, block counts, one-block scan, wave-prefix write): the index list equals
+    torch.nonzero of the mask -- ascending, bit-exact -- and the count stays on the device; gather / scatter / frame_of honour it."""
+    from lab4d_amd import render_utils as RU
+    g = gen(S % 1000 + 5)
+    mask = (torch.rand(S, generator=g) < p).to(torch.uint8)
+    idx, count = RU.compact(mask.to(DEV))
+    ref = torch.nonzero(mask).flatten().int()
+    assert count.dtype == torch.int32 and int(count) == ref.numel()
+    assert torch.equal(idx.cpu()[: ref.numel()], ref)
+    src = torch.randn(S, 3, generator=g)
+    gat = RU.gather_rows(src.to(DEV), idx, count).cpu()
+    assert torch.equal(gat[: ref.numel()], src[ref.long()]) and float(gat[ref.numel():].abs().sum()) == 0.0
+    sc = RU.scatter_rows(gat.to(DEV), idx, count, S).cpu()
+    assert torch.equal(sc, src * mask[:, None].float())
+    fr = RU.frame_of(idx, count, 7).cpu()
+    assert torch.equal(fr[: ref.numel()], ref // 7) and int(fr[ref.numel():].abs().sum()) == 0
+
+
+def test_valid_mask_is_bit_exact_at_the_box_faces():
+    """check_inside_aabb uses strict inequalities (geom_utils.py:506-517): points exactly on a face are outside."""
+    from lab4d_amd import render_utils as RU
+    g = gen(31)
+    aabb = torch.tensor([[-0.1, -0.2, -0.3], [0.2, 0.1, 0.4]])
+    t_aabb = torch.tensor([[-0.5, -0.5, -0.5], [0.0, 0.5, 0.5]])
+    x = torch.rand(5000, 3, generator=g) - 0.5
+    xt = torch.rand(5000, 3, generator=g) * 1.2 - 0.6
+    x[:6] = torch.tensor([[-0.1, 0, 0], [0.2, 0, 0], [0, -0.2, 0], [0, 0.1, 0], [0, 0, -0.3], [0, 0, 0.4]])  # on the six faces
+    x[6] = torch.tensor([0.19999999, 0.0999999, 0.39999998])
+    xt[7] = torch.tensor([0.0, 0.0, 0.0])  # on a face of the second box
+    x[7] = 0.0
+    ins = lambda p, b: ((p > b[:1]) & (p < b[1:])).all(-1)
+    m = RU.valid_mask(x.to(DEV), xt.to(DEV), aabb.to(DEV), t_aabb.to(DEV)).cpu().bool()
+    assert torch.equal(m, ins(x, aabb) & ins(xt, t_aabb))
+    assert not m[:6].any() and not m[7]
+    m1 = RU.valid_mask(x.to(DEV), None, aabb.to(DEV)).cpu().bool()
+    assert torch.equal(m1, ins(x, aabb))
+
+
+def test_compacted_chain_equals_the_chain_on_gathered_samples():
+    """run_chain_compacted (device-side sample count, per-sample frame index) == run_chain on the same samples in frame order."""
+    from lab4d_amd import mlp, render_utils as RU, synthetic
+    P = synthetic.to_device(synthetic.make_weights(9), DEV)
+    fr = synthetic.add_codes(synthetic.to_device(synthetic.make_frames(10, 2, 64), DEV), P)
+    g = gen(33)
+    M, spf = 2, 700
+    x = ((torch.rand(M * spf, 3, generator=g) - 0.5) * 0.3).to(DEV)
+    mask = (torch.rand(M * spf, generator=g) < 0.3).to(torch.uint8).to(DEV)
+    idx, count = RU.compact(mask)
+    K = int(count)
+    x_k = RU.gather_rows(x, idx, count)
+    frame_k = RU.frame_of(idx, count, spf)
+    for prec in (mlp.PREC_F32, mlp.PREC_BF16):
+        with torch.no_grad():
+            full = mlp.run_chain(mlp.NET_VIS, prec, P, x, spf, conds={0: fr["code_vis"]})
+            comp = mlp.run_chain_compacted(mlp.NET_VIS, prec, P, x_k, frame_k, count, conds={0: fr["code_vis"]})
+            assert torch.allclose(comp[:K], full[idx[:K].long()], rtol=1e-5, atol=1e-6)
+            sdf_f, feat_f = mlp.run_chain(mlp.NET_FG_BASE, prec, P, x, spf, conds={0: fr["code_base"], 4: fr["code_base"]}, export_layer=8)
+            sdf_c, feat_c = mlp.run_chain_compacted(mlp.NET_FG_BASE, prec, P, x_k, frame_k, count, conds={0: fr["code_base"], 4: fr["code_base"]},
+                                                    export_layer=8)
+            assert torch.allclose(sdf_c[:K], sdf_f[idx[:K].long()], rtol=1e-5, atol=1e-6)
+            rgb_f = mlp.run_chain(mlp.NET_FG_COLOR, prec, P, x, spf, conds={0: fr["code_color"], 3: fr["appr_code"]}, ext=feat_f)
+            rgb_c = mlp.run_chain_compacted(mlp.NET_FG_COLOR, prec, P, x_k, frame_k, count, conds={0: fr["code_color"], 3: fr["appr_code"]}, ext=feat_c)
+            assert torch.allclose(rgb_c[:K], rgb_f[idx[:K].long()], rtol=1e-5, atol=1e-6)
+    # an empty selection: nothing is processed, nothing is written
+    idx0, count0 = RU.compact(torch.zeros_like(mask))
+    out = mlp.run_chain_compacted(mlp.NET_VIS, mlp.PREC_BF16, P, x_k, RU.frame_of(idx0, count0, spf), count0, conds={0: fr["code_vis"]})
+    assert int(count0) == 0 and out.shape == (M * spf, 1)
