@@ -111,7 +111,7 @@ def register(name, argtypes):
     if _LIB is not None:
         fn = getattr(_LIB, name)
         fn.argtypes = argtypes
-        fn.restype = ci
+        fn.restype = ctypes.c_int64 if name in ("lab4d_mlp_packed_bytes", "lab4d_compact_work_ints") else ci
 
 
 def lib():
@@ -128,7 +128,7 @@ def lib():
         for name, at in SIGNATURES.items():
             fn = getattr(_LIB, name)
             fn.argtypes = at
-            fn.restype = ctypes.c_int64 if name == "lab4d_mlp_packed_bytes" else ci
+            fn.restype = ctypes.c_int64 if name in ("lab4d_mlp_packed_bytes", "lab4d_compact_work_ints") else ci
     return _LIB
 
 

@@ -565,6 +565,7 @@ int with_net(int net, F&& f) {
     case LAB4D_NET_VIS: return f(NetVis{});
     case LAB4D_NET_FEAT: return f(NetFeat{});
     case LAB4D_NET_SKIN: return f(NetSkin{});
+    case LAB4D_NET_SKIN18: return f(NetSkin18{});
     case LAB4D_NET_DENSE: return f(NetDense{});
     case LAB4D_NET_BG_BASE: return f(NetBgBase{});
     case LAB4D_NET_BG_COLOR: return f(NetBgColor{});

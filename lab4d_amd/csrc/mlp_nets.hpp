@@ -42,6 +42,11 @@ struct NetSkin {
   static constexpr int ID = LAB4D_NET_SKIN, NL = 3, EMB = 1, NFREQ = 0, CIN = 75, SLOTS = 75, KE = 96, COUT = 25, AUX3 = 0;
   static constexpr LS L[NL] = {{96, 0, 64, 1, 1, 0, 0}, {0, 64, 64, 1, 0, 0, 0}, {0, 64, 25, 0, 0, 0, 0}};
 };
+// the same network for the 18 joints of skel-human (utils/skel_utils.py:348-349; BASELINE configs[2]): 54 coordinates -> 64 -> 64 -> 18
+struct NetSkin18 {
+  static constexpr int ID = LAB4D_NET_SKIN18, NL = 3, EMB = 1, NFREQ = 0, CIN = 54, SLOTS = 54, KE = 64, COUT = 18, AUX3 = 0;
+  static constexpr LS L[NL] = {{64, 0, 64, 1, 1, 0, 0}, {0, 64, 64, 1, 0, 0, 0}, {0, 64, 18, 0, 0, 0, 0}};
+};
 
 // warping.py:105-170,445-483 : DenseWarp(D=2,W=256) post-warp of ComposedWarp: PosEmbedding(3,6)=39 (+128 time embedding
 // +32 instance code as per-frame bias) -> 256 -> 256 -> 3 ; one table serves forward_map and backward_map

@@ -21,7 +21,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 MAXL = 12
-NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE, NET_BG_BASE, NET_BG_COLOR = 0, 1, 2, 3, 4, 5, 6, 7
+NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE, NET_BG_BASE, NET_BG_COLOR, NET_SKIN18 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 PREC_F32, PREC_BF16 = 0, 1
 vp, ci = ctypes.c_void_p, ctypes.c_int
 
@@ -55,14 +55,14 @@ _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp
 _lib.register("lab4d_mlp_wgrad_mapped", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
 
-NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color"}
+NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color", 8: "skin18"}
 # algorithmic MACs per sample (real layer shapes incl. conditioning columns)
 NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736, 5: 39 * 256 + 256 * 256 + 256 * 3,
-            6: 100096 + 128, 7: 43392 + 8576}
+            6: 100096 + 128, 7: 43392 + 8576, 8: (54 + 160) * 64 + 64 * 64 + 64 * 18}
 
 
 
-KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor"}  # template argument names in csrc/mlp_nets.hpp
+KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor", 8: "Skin18"}  # template argument names in csrc/mlp_nets.hpp
 
 
 def wgrad_kernel_name(L, prec):
@@ -156,9 +156,9 @@ def bindings(net, prefix=""):
         b.append(LayerBinding(q + "linear_5.0.weight", q + "linear_5.0.bias", emb0=0, prev0=39))
         b.append(LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0))
         return b
-    if net == NET_SKIN:  # skinning.py:70-86: [3B bone coords | 128 time embedding | 32 instance code]
+    if net in (NET_SKIN, NET_SKIN18):  # skinning.py:70-86: [3B bone coords | 128 time embedding | 32 instance code], B = 25 / 18
         q = p + "warp.skinning_model.delta_field."
-        return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(75, 160)),
+        return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(75 if net == NET_SKIN else 54, 160)),
                 LayerBinding(q + "linear_2.0.weight", q + "linear_2.0.bias", prev0=0),
                 LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0)]
     if net == NET_DENSE:  # warping.py:123-141: [39 posenc | 128 time embedding | 32 instance code]; prefix selects the map,
@@ -181,6 +181,15 @@ def bindings(net, prefix=""):
                 LayerBinding(p + "rgb.0.weight", p + "rgb.0.bias", prev0=0, aux0=128),
                 LayerBinding(p + "rgb.2.weight", p + "rgb.2.bias", prev0=0)]
     raise ValueError(net)
+
+
+def skin_net_for(n_bones):
+    """The delta-skin network instantiation of a skeleton: 25 bones (bob, skel-quad) or 18 (skel-human)."""
+    if n_bones == 25:
+        return NET_SKIN
+    if n_bones == 18:
+        return NET_SKIN18
+    raise NotImplementedError("lab4d_amd: the delta-skin network is instantiated for 25 and 18 bones (got %d)" % n_bones)
 
 
 _COLMAP = {}

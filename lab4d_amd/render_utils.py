@@ -317,6 +317,7 @@ def sort_depth(a, b):
 # ---------------------------------------------------------------------------------------------------
 _lib.register("lab4d_valid_mask", [_lib.vp] * 4 + [ctypes.c_long, _lib.vp, _lib.vp])
 _lib.register("lab4d_compact", [_lib.vp, ctypes.c_long, _lib.vp, _lib.vp, _lib.vp, _lib.vp])
+_lib.register("lab4d_compact_work_ints", [ctypes.c_long])
 _lib.register("lab4d_gather_rows", [_lib.vp] * 3 + [ctypes.c_long, _lib.ci, _lib.vp, _lib.vp])
 _lib.register("lab4d_scatter_rows", [_lib.vp] * 3 + [ctypes.c_long, _lib.ci, _lib.vp, _lib.vp])
 _lib.register("lab4d_frame_of", [_lib.vp] * 2 + [ctypes.c_long, _lib.ci, _lib.vp, _lib.vp])
@@ -345,7 +346,7 @@ def compact(mask):
     S = mask.numel()
     idx = torch.empty(S, dtype=torch.int32, device=mask.device)
     count = torch.empty(1, dtype=torch.int32, device=mask.device)
-    work = torch.empty((S + 1023) // 1024 + 1, dtype=torch.int32, device=mask.device)
+    work = torch.empty(int(_lib.lib().lab4d_compact_work_ints(S)), dtype=torch.int32, device=mask.device)
     _lib.check(_lib.lib().lab4d_compact(_lib.ptr(mask), S, _lib.ptr(idx), _lib.ptr(count), _lib.ptr(work), _lib.stream()), "compact")
     return idx, count
 

@@ -18,6 +18,9 @@ NUM_BONES = 25  # skel-quad (lab4d/utils/skel_utils.py quad skeleton)
 # left<->right bone permutation of the quad skeleton (skel_utils.py:349-357 QUAD_SYMM_IDX, 0-based);
 # SkinningField.get_gauss averages log_gauss over it (skinning.py:142-153)
 QUAD_SYMM_IDX = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15, 16, 21, 22, 23, 24, 17, 18, 19, 20]
+# the 18-joint human skeleton (skel_utils.py:348-349 HUMAN_SYMM_IDX, 0-based): fg_motion "skel-human" (BASELINE configs[2])
+HUMAN_SYMM_IDX = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 15, 16, 17, 12, 13, 14]
+SYMM_IDX = {25: QUAD_SYMM_IDX, 18: HUMAN_SYMM_IDX}
 
 # (name, out, in) for every per-sample Linear on the fg hot path (SURVEY.md 8a notes)
 FG_LINEARS = [
@@ -111,11 +114,14 @@ def add_bg_codes(fr, P):
     return fr
 
 
-def make_weights(seed=0, num_inst=1, sdf_bias=None):
+def make_weights(seed=0, num_inst=1, sdf_bias=None, num_bones=NUM_BONES):
     """Flat dict of fp32 CPU tensors keyed by the reference's state_dict names."""
     g = torch.Generator().manual_seed(seed)
     P = {}
     for name, o, i in FG_LINEARS:
+        if name.startswith("warp.skinning_model.delta_field") and num_bones != NUM_BONES:  # skinning.py:70-86: sized by the skeleton
+            i = 3 * num_bones + 160 if name.endswith("linear_1.0") else i
+            o = num_bones if name.endswith("linear_final") else o
         bound = 1.0 / math.sqrt(i)
         P[name + ".weight"] = (torch.rand(o, i, generator=g) * 2 - 1) * bound
         P[name + ".bias"] = (torch.rand(o, generator=g) * 2 - 1) * bound
@@ -125,9 +131,9 @@ def make_weights(seed=0, num_inst=1, sdf_bias=None):
     P["logscale"] = torch.tensor([math.log(0.2)])  # nerf.py:147-148, init_scale=0.2
     P["logsigma"] = torch.tensor([0.0])  # feature.py:86-87
     P["warp.logibeta"] = torch.tensor([-math.log(0.01)])  # warping.py:273-275
-    P["warp.skinning_model.log_gauss"] = torch.full((NUM_BONES, 3), math.log(0.03))  # skinning.py:62-66
-    P["warp.skinning_model.log_gauss"] += 0.1 * torch.randn(NUM_BONES, 3, generator=g)
-    P["warp.skinning_model.symm_idx"] = torch.tensor(QUAD_SYMM_IDX, dtype=torch.long)
+    P["warp.skinning_model.log_gauss"] = torch.full((num_bones, 3), math.log(0.03))  # skinning.py:62-66
+    P["warp.skinning_model.log_gauss"] += 0.1 * torch.randn(num_bones, 3, generator=g)
+    P["warp.skinning_model.symm_idx"] = torch.tensor(SYMM_IDX[num_bones], dtype=torch.long)
     P["aabb"] = torch.tensor([[-0.12, -0.12, -0.12], [0.12, 0.12, 0.12]])  # proxy sphere r=0.12
     if sdf_bias is not None:
         P["sdf.bias"] = torch.tensor([float(sdf_bias)])
@@ -154,7 +160,7 @@ def _qt_to_dq(q, t):
     return q, 0.5 * _qmul(tq, q)
 
 
-def make_frames(seed, M, res, num_inst=1):
+def make_frames(seed, M, res, num_inst=1, num_bones=NUM_BONES):
     """Per-frame inputs for M frames (M even: consecutive frames form a pair, nerf.py:929-946)."""
     g = torch.Generator().manual_seed(seed)
     fr = {}
@@ -167,12 +173,12 @@ def make_frames(seed, M, res, num_inst=1):
     fr["field2cam"] = (q.contiguous(), t.contiguous())
     fr["near_far"] = torch.stack([t[:, 2] - 0.18, t[:, 2] + 0.18], -1).contiguous()
     # bones: rest centres inside the r=0.1 ball, identity rest rotation; time-t = small motion
-    centres = 0.06 * torch.randn(NUM_BONES, 3, generator=g)
-    rest_q = torch.tensor([1.0, 0, 0, 0]).repeat(M, NUM_BONES, 1)
+    centres = 0.06 * torch.randn(num_bones, 3, generator=g)
+    rest_q = torch.tensor([1.0, 0, 0, 0]).repeat(M, num_bones, 1)
     rest_t = centres[None].repeat(M, 1, 1)
     fr["rest_articulation"] = tuple(x.contiguous() for x in _qt_to_dq(rest_q, rest_t))
-    dq_q = _rand_unit_quat(g, M * NUM_BONES, 0.6).view(M, NUM_BONES, 4)
-    t_t = rest_t + 0.01 * torch.randn(M, NUM_BONES, 3, generator=g)
+    dq_q = _rand_unit_quat(g, M * num_bones, 0.6).view(M, num_bones, 4)
+    t_t = rest_t + 0.01 * torch.randn(M, num_bones, 3, generator=g)
     fr["t_articulation"] = tuple(x.contiguous() for x in _qt_to_dq(dq_q, t_t))
     fr["t_embed"] = 0.5 * torch.randn(M, 128, generator=g)
     fr["t_embed_mean"] = 0.5 * torch.randn(1, 128, generator=g)

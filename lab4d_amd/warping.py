@@ -124,7 +124,7 @@ def skin_logits(P, x, art, t_embed, code, M, spf, prec):
     gauss = get_gauss(P)
     bone = BoneCoords.apply(x, art[0], art[1], gauss, spf)  # (S,3B): input of the delta-skin MLP only
     cond = torch.cat([t_embed.expand(M, -1), code], -1)
-    return mlp.run_chain(mlp.NET_SKIN, prec, P, bone, spf, conds={0: cond}), gauss
+    return mlp.run_chain(mlp.skin_net_for(art[0].shape[1]), prec, P, bone, spf, conds={0: cond}), gauss
 
 
 def skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, prec=mlp.PREC_F32):

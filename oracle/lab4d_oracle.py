@@ -971,3 +971,33 @@ DEFAULT_LOSS_WT = {
     "reg_gauss_skin_wt": 1e-3, "reg_cam_prior_wt": 0.1, "reg_skel_prior_wt": 0.1,
     "reg_gauss_mask_wt": 0.01, "reg_soft_deform_wt": 100.0,
 }
+
+
+# ----------------------------------------------------------------------------
+# proxy-geometry refresh: nnutils/nerf.py:303-376, utils/geom_utils.py:344-362,392-476
+# ----------------------------------------------------------------------------
+def sample_grid(aabb, grid_size):
+    """geom_utils.sample_grid (geom_utils.py:392-406)."""
+    ax = [torch.linspace(float(aabb[0][i]), float(aabb[1][i]), grid_size) for i in range(3)]
+    return torch.cartesian_prod(*ax)
+
+
+def grid_query(P, aabb, grid_size, code_base, code_vis, extend=0.5):
+    """The volume extract_canonical_mesh hands to marching cubes (nerf.py:327-343, geom_utils.py:467-476): sdf and visibility > 0
+    on the dense grid of extend_aabb(aabb, extend), one instance code for every point."""
+    box = extend_aabb(aabb, extend) if extend else aabb
+    pts = sample_grid(box, grid_size)
+    n = pts.shape[0]
+    sdf = nerf_forward(P, pts[None], {"basefield": code_base}, with_color=False, get_density=False)[0]
+    vis = vis_field(P, pts[None], code_vis)[0] > 0
+    G = grid_size
+    return sdf.view(G, G, G), vis.view(G, G, G), box
+
+
+def get_near_far(pts, quat, trans, tol_fac=1.5):
+    """geom_utils.get_near_far (geom_utils.py:344-362), cameras as (quat, trans)."""
+    z = quaternion_translation_apply(quat[:, None].expand(-1, pts.shape[0], -1), trans[:, None].expand(-1, pts.shape[0], -1),
+                                     pts[None].expand(quat.shape[0], -1, -1))[..., 2]
+    pmax, pmin = z.max(-1)[0], z.min(-1)[0]
+    delta = (pmax - pmin) * (tol_fac - 1)
+    return torch.stack([pmin - delta, pmax + delta], -1).clamp(min=1e-3)

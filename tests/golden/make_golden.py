@@ -50,7 +50,7 @@ def build_reference_field(ns, P, num_inst=1, fg_motion="skel-quad"):
     missing = [k for k in P if k not in f.state_dict() and k != "warp.skinning_model.symm_idx"]
     assert not missing, missing
     f.load_state_dict(sd, strict=False)
-    assert list(f.warp.skinning_model.symm_idx) == synthetic.QUAD_SYMM_IDX
+    assert list(f.warp.skinning_model.symm_idx) == synthetic.SYMM_IDX[len(f.warp.skinning_model.symm_idx)]
     return f
 
 
@@ -94,14 +94,15 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
               rows=None):
     """num_inst > 1 / inst_id: the multi-instance configuration (BASELINE config 4): per-instance codes in every CondMLP
     (base.py:123-150), frames of one pair share their video's instance id."""
-    P = synthetic.make_weights(seed, num_inst=num_inst)
+    num_bones = 18 if "skel-human" in fg_motion else 25  # utils/skel_utils.py:348-351
+    P = synthetic.make_weights(seed, num_inst=num_inst, num_bones=num_bones)
     if fg_motion.startswith("comp_"):  # fg_motion "comp_skel-quad_dense" (BASELINE configs 2-3): skinning + dense post-warp
         P = synthetic.add_dense_weights(P, seed, num_inst)
     f = build_reference_field(ns, P, num_inst, fg_motion)
     f.train()
     f.pos_embedding.set_alpha(alpha)
     f.pos_embedding_color.set_alpha(alpha)
-    fr = synthetic.make_frames(seed + 1, M, res)
+    fr = synthetic.make_frames(seed + 1, M, res, num_bones=num_bones)
     if inst_id is not None:
         fr["inst_id"] = torch.tensor(inst_id, dtype=torch.long)
     if frame_id is not None:
@@ -503,6 +504,8 @@ def main(only=None):
         ("train_small", lambda: gen_train(ns, "small", M=2, N=6, D=8, res=64, seed=11)),
         ("train_alpha", lambda: gen_train(ns, "alpha", M=4, N=5, D=6, res=64, seed=21, alpha=0.45)),
         ("train_compmotion", lambda: gen_train(ns, "compmotion", M=2, N=6, D=8, res=64, seed=51, fg_motion="comp_skel-quad_dense", frame_id=[3, 4])),
+        # BASELINE configs[2]'s fg field: the 18-joint human skeleton with the dense post-warp (fg_motion "comp_skel-human_dense")
+        ("train_human", lambda: gen_train(ns, "human", M=2, N=6, D=8, res=64, seed=81, fg_motion="comp_skel-human_dense", frame_id=[10, 11])),
         ("train_multi", lambda: gen_train(ns, "multi", M=4, N=5, D=6, res=64, seed=31, num_inst=3, inst_id=[1, 1, 2, 2], frame_id=[22, 23, 44, 45])),
         # BASELINE config 0: 64x64 crop x 64 samples
         ("train_c1", lambda: gen_train(ns, "c1", M=2, N=None, D=64, res=64, seed=41, full_grid_stride=16)),

@@ -31,13 +31,14 @@ EVAL_INDEX_MISMATCH_MAX = 2  # measured: 1 of 128
 
 def load_case(golden_dir, name):
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
-    P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"))
+    P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"),
+                               num_bones=18 if "skel-human" in g["meta"].get("fg_motion", "") else 25)
     if g["meta"].get("fg_motion", "skel-quad").startswith("comp_"):
         P = synthetic.add_dense_weights(P, g["meta"]["seed"], g["meta"].get("num_inst", 1))
     return g, P
 
 
-@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_compmotion.pt"])
+@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_compmotion.pt", "train_human.pt"])
 def test_training_graph_matches_reference_goldens(golden_dir, case):
     from lab4d_amd import deformable as DF
     g, P = load_case(golden_dir, case)

@@ -35,7 +35,8 @@ def patch_f32():
 def _load(golden_dir, name):
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
     meta = g["meta"]
-    P = synthetic.make_weights(meta["seed"], num_inst=meta.get("num_inst", 1), sdf_bias=meta.get("sdf_bias"))
+    P = synthetic.make_weights(meta["seed"], num_inst=meta.get("num_inst", 1), sdf_bias=meta.get("sdf_bias"),
+                               num_bones=18 if "skel-human" in meta.get("fg_motion", "") else 25)
     composed = meta.get("fg_motion", "skel-quad").startswith("comp_")
     if composed:
         P = synthetic.add_dense_weights(P, meta["seed"], meta.get("num_inst", 1))
@@ -59,7 +60,7 @@ def _model(field):
     return m
 
 
-@pytest.mark.parametrize("case", ["train_small.pt", "train_compmotion.pt"])
+@pytest.mark.parametrize("case", ["train_small.pt", "train_compmotion.pt", "train_human.pt"])
 def test_query_field_and_render_samples_match_the_reference(golden_dir, patch_f32, case):
     """Deformable.query_field -> dvr_model.render_samples_chunk through the adapters, training mode, vs the reference's own
     outputs for the same rays / weights / random draws; gradients reach the stand-in module's parameters."""

@@ -88,7 +88,8 @@ def test_compose_fields(ops):
 
 def _load_case(golden_dir, name):
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
-    P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"))
+    P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"),
+                               num_bones=18 if "skel-human" in g["meta"].get("fg_motion", "") else 25)
     if g["meta"].get("fg_motion", "skel-quad").startswith("comp_"):
         P = synthetic.add_dense_weights(P, g["meta"]["seed"], g["meta"].get("num_inst", 1))
     chk = float(sum(v.double().abs().sum() for k, v in sorted(P.items()) if v.dtype.is_floating_point))
@@ -97,7 +98,7 @@ def _load_case(golden_dir, name):
     return g, P, fr
 
 
-@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_multi.pt", "train_compmotion.pt"])
+@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_multi.pt", "train_compmotion.pt", "train_human.pt"])
 def test_training_graph_against_reference(golden_dir, case):
     """train_multi: BASELINE config 4's shape -- 3 instances, two frame pairs from different videos, per-instance codes.
     train_compmotion: fg_motion "comp_skel-quad_dense" (BASELINE configs 2-3): every warp of the graph is the ComposedWarp."""
@@ -469,3 +470,23 @@ def test_training_graph_at_baseline_sizes(golden_dir, name):
         else:
             close(gv.flatten()[:: ref["stride"]], ref["sub"], "grad." + k, rtol=5e-3, atol=2e-4 * float(ref["sub"].abs().max()) + 1e-10)
             assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 2e-3 * float(ref["norm"]) + 1e-12, k
+
+
+def test_proxy_geometry_refresh_against_reference(golden_dir):
+    """the dense sdf / visibility grid extract_canonical_mesh hands to marching cubes, get_near_far and the EMA
+    updates -- the oracle's restatement against the reference's own outputs (tests/golden/proxy.pt)."""
+    g = torch.load(os.path.join(golden_dir, "proxy.pt"), weights_only=False)
+    meta = g["meta"]
+    P = synthetic.make_weights(meta["seed"], sdf_bias=meta["sdf_bias"])
+    G = meta["grid_size"]
+    mean = lambda k: P[k].mean(0, keepdim=True)
+    sdf, vis, box = O.grid_query(P, g["aabb"], G, mean("basefield.inst_embedding.mapping.weight"), mean("vis_mlp.basefield.inst_embedding.mapping.weight"))
+    assert torch.allclose(box, g["box"], atol=1e-7) and torch.allclose(O.sample_grid(box, G), g["grid"], atol=1e-7)
+    close(sdf, g["sdf"], "grid sdf")
+    assert int((vis != g["vis"]).sum()) <= 1
+    close(O.get_near_far(g["verts"], g["cam_quat"], g["cam_trans"]), g["get_near_far"], "get_near_far")
+    nf = g["near_far_before"].clone()
+    nf[g["frame_mapping"]] = nf[g["frame_mapping"]] * 0.9 + O.get_near_far(g["verts"], g["cam_quat"], g["cam_trans"]) * 0.1
+    close(nf, g["near_far_after"], "update_near_far")
+    bounds = torch.stack([g["verts"].min(0)[0], g["verts"].max(0)[0]], 0)
+    close(g["aabb_before"] * 0.9 + bounds * 0.1, g["aabb_after"], "update_aabb")
