@@ -149,6 +149,28 @@ int lab4d_composite_backward(const float* density, const float* deltas, const la
                              float* g_gauss_density, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 3a. Per-sample epilogues of the training query.
+ *   flow_cyc -- NeRF.compute_flow (nnutils/nerf.py:948-997: field_to_cam with the pair partner's pose, utils/geom_utils.py:14-27
+ *     pinhole_projection, flow = projection - pixel, valid = z > 1e-6 [and |flow| < flow_thresh; pass a negative thresh for None])
+ *     and Deformable.cycle_loss' distance (nnutils/deformable.py:189-193), one kernel each way.
+ *     xyz_next (S,3): canonical samples forward-warped into the partner's object space; q (M,4), t (M,3): the partner's
+ *     field-to-camera pose (row m serves samples [m*spf, (m+1)*spf)); K (M,3,3): its intrinsics (Kmatinv(Kinv)); hxy (S/D,3): pixel of
+ *     every ray; xyz_cyc / xyz_t (S,3) or NULL: the forward-warped and the time-t points of the cycle term.
+ *     -> flow (S,3) = (u, v, valid), cyc (S) = |xyz_cyc - xyz_t|.
+ *     backward: g_flow (S,3; the valid channel is ignored), g_cyc (S) -> g_xyz_next (S,3), g_per_frame (M,16) = [g_q 4 | g_t 3 | g_K 9]
+ *     (zero-filled by the call), g_xyz_cyc, g_xyz_t (S,3) or NULL.
+ *   volsdf -- the VolSDF density of NeRF.forward (nerf.py:186-192): density = (0.5 + 0.5 sign(sdf) expm1(-|sdf| ibeta)) ibeta with
+ *     ibeta a 1-element device tensor; backward gives g_sdf (S) and g_ibeta (1, zero-filled by the call; may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+int lab4d_flow_cyc_forward(const float* xyz_next, const float* q, const float* t, const float* K, const float* hxy, const float* xyz_cyc,
+                           const float* xyz_t, long S, int spf, int D, float flow_thresh, float* flow, float* cyc, void* stream);
+int lab4d_flow_cyc_backward(const float* xyz_next, const float* q, const float* t, const float* K, const float* xyz_cyc, const float* xyz_t,
+                            const float* g_flow, const float* g_cyc, long S, int spf, int M, float* g_xyz_next, float* g_per_frame,
+                            float* g_xyz_cyc, float* g_xyz_t, void* stream);
+int lab4d_volsdf_forward(const float* sdf, const float* ibeta, long S, float* density, void* stream);
+int lab4d_volsdf_backward(const float* sdf, const float* ibeta, const float* g_density, long S, float* g_sdf, float* g_ibeta, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 3b. Field composition -- nnutils/multifields.py:339-398 (MultiFields.compose_fields, "comp" configs).
  *    The samples of two fields (fg: Da per ray, bg: Db per ray) are concatenated along the depth axis, z-sorted
  *    (argsort of the concatenated depth) and every per-sample key is gathered with that permutation.

@@ -27,6 +27,10 @@ _lib.register("lab4d_gauss_density_forward", [vp, vp, ci, vp, ci, vp, vp, vp])
 _lib.register("lab4d_gauss_density_backward", [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp])
 _lib.register("lab4d_l2_normalize_forward", [vp, ci, ci, vp, vp])
 _lib.register("lab4d_l2_normalize_backward", [vp, vp, ci, ci, vp, vp])
+_lib.register("lab4d_flow_cyc_forward", [vp] * 7 + [ctypes.c_long, ci, ci, cf, vp, vp, vp])
+_lib.register("lab4d_flow_cyc_backward", [vp] * 8 + [ctypes.c_long, ci, ci, vp, vp, vp, vp, vp])
+_lib.register("lab4d_volsdf_forward", [vp, vp, ctypes.c_long, vp, vp])
+_lib.register("lab4d_volsdf_backward", [vp, vp, vp, ctypes.c_long, vp, vp, vp])
 
 
 def flip_pair(x):
@@ -108,6 +112,78 @@ def _flip_yz(n):
     return torch.cat([n[..., :1], -n[..., 1:]], -1)
 
 
+class FlowCyc(Function):
+    """compute_flow's projection into the pair partner's camera (nerf.py:948-997) and cycle_loss' distance
+    (deformable.py:189-193) in one kernel each way (csrc/flow.hip).  xyz_next (M,N,D,3), q (M,4), t (M,3), Kmat (M,3,3): the
+    partner's pose / intrinsics, hxy (M,N,3), xyz_cyc / xyz_t (M,N,D,3) or None -> flow (M,N,D,3) = (u, v, valid), cyc (M,N,D,1)."""
+
+    @staticmethod
+    def forward(ctx, xyz_next, q, t, Kmat, hxy, xyz_cyc, xyz_t, flow_thresh):
+        xyz_next, q, t, Kmat, hxy = [x.contiguous().float() for x in (xyz_next, q, t, Kmat, hxy)]
+        has_cyc = xyz_cyc is not None
+        if has_cyc:
+            xyz_cyc, xyz_t = xyz_cyc.contiguous().float(), xyz_t.contiguous().float()
+        _lib.require_device(xyz_next, q, t, Kmat, hxy, xyz_cyc, xyz_t)
+        M, N, D = xyz_next.shape[:3]
+        S = M * N * D
+        flow = torch.empty(M, N, D, 3, device=xyz_next.device)
+        cyc = torch.empty(M, N, D, 1, device=xyz_next.device) if has_cyc else None
+        _lib.check(_lib.lib().lab4d_flow_cyc_forward(_lib.ptr(xyz_next), _lib.ptr(q), _lib.ptr(t), _lib.ptr(Kmat), _lib.ptr(hxy), _lib.ptr(xyz_cyc),
+                                                     _lib.ptr(xyz_t), S, N * D, D, -1.0 if flow_thresh is None else float(flow_thresh), _lib.ptr(flow),
+                                                     _lib.ptr(cyc), _lib.stream()), "flow_cyc_forward")
+        ctx.save_for_backward(xyz_next, q, t, Kmat, xyz_cyc, xyz_t)
+        ctx.dims = (M, N, D)
+        return (flow, cyc) if has_cyc else (flow, None)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_flow, g_cyc):
+        xyz_next, q, t, Kmat, xyz_cyc, xyz_t = ctx.saved_tensors
+        M, N, D = ctx.dims
+        S = M * N * D
+        has_cyc = xyz_cyc is not None
+        g_flow = g_flow.contiguous()
+        if has_cyc:
+            g_cyc = torch.zeros(M, N, D, 1, device=g_flow.device) if g_cyc is None else g_cyc.contiguous()
+        g_next = torch.empty_like(xyz_next)
+        g_pf = torch.empty(M, 16, device=g_flow.device)
+        g_xc = torch.empty_like(xyz_cyc) if has_cyc else None
+        g_xt = torch.empty_like(xyz_t) if has_cyc else None
+        _lib.check(_lib.lib().lab4d_flow_cyc_backward(_lib.ptr(xyz_next), _lib.ptr(q), _lib.ptr(t), _lib.ptr(Kmat), _lib.ptr(xyz_cyc), _lib.ptr(xyz_t),
+                                                      _lib.ptr(g_flow), _lib.ptr(g_cyc) if has_cyc else None, S, N * D, M, _lib.ptr(g_next), _lib.ptr(g_pf),
+                                                      _lib.ptr(g_xc), _lib.ptr(g_xt), _lib.stream()), "flow_cyc_backward")
+        return g_next, g_pf[:, :4], g_pf[:, 4:7], g_pf[:, 7:].reshape(M, 3, 3), None, g_xc, g_xt, None
+
+
+class VolSdfDensity(Function):
+    """The VolSDF density of NeRF.forward (nerf.py:186-192) in one kernel each way (the reference: 8 element-wise launches)."""
+
+    @staticmethod
+    def forward(ctx, sdf, ibeta):
+        sdf_c, ib = sdf.contiguous().float(), ibeta.reshape(1).contiguous().float()
+        _lib.require_device(sdf_c, ib)
+        out = torch.empty_like(sdf_c)
+        _lib.check(_lib.lib().lab4d_volsdf_forward(_lib.ptr(sdf_c), _lib.ptr(ib), sdf_c.numel(), _lib.ptr(out), _lib.stream()), "volsdf_forward")
+        ctx.save_for_backward(sdf_c, ib)
+        ctx.ib_shape = ibeta.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        sdf, ib = ctx.saved_tensors
+        g = g.contiguous()
+        g_sdf = torch.empty_like(sdf)
+        g_ib = torch.empty(1, device=sdf.device) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.lib().lab4d_volsdf_backward(_lib.ptr(sdf), _lib.ptr(ib), _lib.ptr(g), sdf.numel(), _lib.ptr(g_sdf), _lib.ptr(g_ib), _lib.stream()),
+                   "volsdf_backward")
+        return g_sdf, None if g_ib is None else g_ib.view(ctx.ib_shape)
+
+
+def volsdf_density(sdf, logibeta):
+    return VolSdfDensity.apply(sdf, logibeta.exp())
+
+
 def posenc_window(alpha, n_freq, device):
     """PosEmbedding.apply_annealing window (embedding.py:112-125)."""
     if alpha is None:
@@ -126,8 +202,7 @@ def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None
                               freq_w=posenc_window(alpha, 10, dev))
     sdf = sdf.view(shape[:-1] + (1,))
     if get_density:
-        ibeta = P["logibeta"].exp()
-        out = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta  # VolSDF (nerf.py:186-192)
+        out = volsdf_density(sdf, P["logibeta"])  # VolSDF (nerf.py:186-192)
     else:
         out = sdf
     if not with_color:
@@ -149,8 +224,7 @@ def nerf_forward_bg(P, xyz, dir, codes, prec, get_density=True, alpha=None, pref
                               freq_w=posenc_window(alpha, 6, dev), prefix=prefix)
     sdf = sdf.view(shape[:-1] + (1,))
     if get_density:
-        ibeta = P[prefix + "logibeta"].exp()
-        out = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta
+        out = volsdf_density(sdf, P[prefix + "logibeta"])
     else:
         out = sdf
     if dir is None:
@@ -258,17 +332,11 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
                                                                         fr["t_embed_mean"], fr["code_skin"], prec)
     else:
         xyz_next, _ = warp(xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"], False, partner=True)
-    xyz_cam_next = rigid_apply(nxt["field2cam"][0], nxt["field2cam"][1], xyz_next)
-    hxy_next = pinhole_projection(Q.kmatinv(nxt["Kinv"]), xyz_cam_next)
-    flow = (hxy_next - hxy.unsqueeze(-2))[..., :2]
-    valid = xyz_cam_next[..., -1:] > 1e-6
-    if flow_thresh is not None:
-        valid = valid & (flow.norm(dim=-1, keepdim=True) < float(flow_thresh))
-    fd["flow"] = torch.cat([flow, valid.to(flow.dtype)], -1)
     # cycle consistency (deformable.py:173-198)
     if not shared:
         xyz_cyc, cyc_aux = warp(xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
-    fd["cyc_dist"] = (xyz_cyc - xyz_t).norm(2, -1, keepdim=True)
+    # projection into the partner's camera, flow, validity and the cycle distance: one kernel each way (csrc/flow.hip)
+    fd["flow"], fd["cyc_dist"] = FlowCyc.apply(xyz_next, nxt["field2cam"][0], nxt["field2cam"][1], Q.kmatinv(nxt["Kinv"]), hxy, xyz_cyc, xyz_t, flow_thresh)
     for k in ["skin_entropy", "delta_skin"]:
         fd[k] = (cyc_aux[k] + bw_aux[k]) / 2
     fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha, prec)
@@ -506,8 +574,7 @@ def nerf_forward_compacted(P, x_k, fr, frame_k, count, prec, alpha=None):
     dev = x_k.device
     sdf, feat = mlp.run_chain_compacted(mlp.NET_FG_BASE, prec, P, x_k, frame_k, count, conds={0: fr["code_base"], 4: fr["code_base"]},
                                         export_layer=8, freq_w=posenc_window(alpha, 10, dev))
-    ibeta = P["logibeta"].exp()
-    density = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta
+    density = volsdf_density(sdf, P["logibeta"])
     rgb = mlp.run_chain_compacted(mlp.NET_FG_COLOR, prec, P, x_k, frame_k, count, conds={0: fr["code_color"], 3: fr["appr_code"]}, ext=feat,
                                   freq_w=posenc_window(alpha, 12, dev))
     return torch.sigmoid(rgb), density
@@ -625,13 +692,7 @@ def query_field_train_bg(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=No
     rgb, density = nerf_forward_bg(P, xyz, dirs, codes, prec, alpha=alpha, prefix=prefix)
     fd["rgb"], fd["density"], fd["density_bg"], fd["vis"] = rgb, density, density, vis
     nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam"]})
-    xyz_cam_next = rigid_apply(nxt["field2cam"][0], nxt["field2cam"][1], xyz)
-    hxy_next = pinhole_projection(Q.kmatinv(nxt["Kinv"]), xyz_cam_next)
-    flow = (hxy_next - hxy.unsqueeze(-2))[..., :2]
-    valid = xyz_cam_next[..., -1:] > 1e-6
-    if flow_thresh is not None:
-        valid = valid & (flow.norm(dim=-1, keepdim=True) < float(flow_thresh))
-    fd["flow"] = torch.cat([flow, valid.to(flow.dtype)], -1)
+    fd["flow"], _ = FlowCyc.apply(xyz, nxt["field2cam"][0], nxt["field2cam"][1], Q.kmatinv(nxt["Kinv"]), hxy, None, None, flow_thresh)
     for k in ("cyc_dist", "delta_skin", "skin_entropy"):
         fd[k] = torch.zeros_like(density)
     fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds_bg"), alpha, prec, net=mlp.NET_BG_BASE, prefix=prefix)
