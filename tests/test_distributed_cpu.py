@@ -71,7 +71,8 @@ def _worker(rank, world, port, res, q):
     _rank_loss(params, rank, world, res).backward()
     assert all(p.grad.data_ptr() >= opt.flat_grad.data_ptr() for p in params), "autograd must accumulate into the flat buffer"
     bench.allreduce_flat(opt.flat_grad, world)
-    q.put((rank, opt.flat_grad.clone(), [p.grad.clone() for p in params]))
+    # by value (numpy), not as shared-memory tensors: the parent may pick the item up after this process has exited
+    q.put((rank, opt.flat_grad.numpy().copy(), [p.grad.numpy().copy() for p in params]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,8 +85,8 @@ def test_flat_gradient_allreduce_is_the_mean_of_the_rank_gradients(world, res, p
     [p.start() for p in ps]
     got = {}
     for _ in range(world):
-        r, flat, grads = q.get(timeout=300)
-        got[r] = (flat, grads)
+        r, flat, grads = q.get(timeout=600)
+        got[r] = (torch.from_numpy(flat), [torch.from_numpy(g) for g in grads])
     [p.join(60) for p in ps]
     for r in range(1, world):
         assert torch.equal(got[r][0], got[0][0]), "every rank holds the same reduced bucket"

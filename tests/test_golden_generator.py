@@ -57,9 +57,8 @@ def test_make_golden_reproduces_the_committed_fixtures(tmp_path, golden_dir, nam
 def test_every_generator_job_is_importable_and_named():
     """Every fixture under tests/golden/ has a job in a generator (no orphan .pt whose recipe is lost)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    src = "".join(open(os.path.join(ROOT, "tests", "golden", f)).read() for f in ("make_golden.py", "make_pose_golden.py", "make_reg_golden.py",
-                                                                                 "make_bench_golden.py")
-                  if os.path.exists(os.path.join(ROOT, "tests", "golden", f)))
+    src = "".join(open(os.path.join(ROOT, "tests", "golden", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "tests", "golden")))
+                  if f.startswith("make_") and f.endswith(".py"))
     for f in os.listdir(os.path.join(ROOT, "tests", "golden")):
         if f.endswith(".pt"):
             stem = f[:-3]
