@@ -260,7 +260,11 @@ _PACK_CACHE = {}  # id(weight tensor) -> (weakref to it, {(net, layer, prec, tra
 def packed_weights(net, layer, prec, W, transposed):
     """Pack one layer's weights for the chain kernels.  Cached per weight *object* and invalidated by its
     autograd version counter (an in-place optimizer step bumps it); never keyed on addresses, which the
-    caching allocator recycles."""
+    caching allocator recycles.
+
+    INVARIANT for callers: a weight update must bump `W._version` -- every in-place torch op on the parameter and
+    FlatAdamW.step (increment_version) do; writes through `p.data`, `.detach()` aliases or raw pointers do NOT, and must be
+    followed by `clear_caches()` (or `repack_all(force=True)` under a captured graph)."""
     key = (net, layer, prec, transposed)
     ver = W._version
     ent = _PACK_CACHE.get(id(W))
@@ -293,16 +297,17 @@ def _pack_into(net, layer, prec, W, transposed, out=None):
     return out
 
 
-def repack_all():
+def repack_all(force=False):
     """Refresh, in place, every cached packed copy whose parameter changed since it was packed (call after an optimizer step when
-    the kernels that consume the copies are replayed from a captured hipGraph and therefore never come through packed_weights)."""
+    the kernels that consume the copies are replayed from a captured hipGraph and therefore never come through packed_weights).
+    force=True repacks regardless of the version counters (after an update that did not bump them)."""
     n = 0
     for ref, per in list(_PACK_CACHE.values()):
         W = ref()
         if W is None:
             continue
         for key, (ver, buf) in list(per.items()):
-            if ver != W._version:
+            if force or ver != W._version:
                 per[key] = (W._version, _pack_into(key[0], key[1], key[2], W, key[3], buf))
                 n += 1
     return n
@@ -692,7 +697,8 @@ class EikonalSdf(Function):
         Ws = ctx.params[0::2]
         dev, sdt = x.device, store_dtype(prec)
         # dL/dg, then u = J_e(x) dL/dg in embedding-slot order [ (f, a, {sin,cos}) pairs | x | pad ]
-        dLdg = ge * 2 * (gn - 1) / gn * g
+        # zero sdf gradient (every unit of a layer dead): torch's norm backward takes the zero subgradient there, not 0/0
+        dLdg = ge * torch.where(gn > 0, 2 * (gn - 1) / gn.clamp_min(1e-38), torch.zeros_like(gn)) * g
         freq = 2.0 ** torch.arange(L0, dtype=torch.float32, device=dev)
         wf = freq if fw is None else freq * fw
         ang = x[:, None, :] * freq[None, :, None]

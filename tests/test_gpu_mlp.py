@@ -208,6 +208,35 @@ def test_eikonal_value_and_weight_gradients(prec, tol):
         assert cosine(a, b) > 0.97, f"{k}: cosine {cosine(a, b):.4f}"
 
 
+def test_eikonal_with_a_dead_layer_keeps_gradients_finite():
+    """Every unit of the last hidden layer dead => d sdf/dx == 0 exactly: the loss is 1 per sample and its weight gradients are
+    finite (the zero subgradient of the norm, as torch's norm backward takes it), not 0/0 spread through the wgrad GEMM."""
+    from lab4d_amd import deformable as DF
+    M, N, D = 2, 8, 8
+    P, fr, xyz, g = setup(12, M, N, D)
+    P = dict(P)
+    P["basefield.linear_8.0.bias"] = torch.full_like(P["basefield.linear_8.0.bias"], -1e3)
+    inds = torch.tensor([0, 3, 9, 15])
+    keys = [k for k in P if k.startswith(("basefield.", "sdf.")) and P[k].dtype.is_floating_point and k.endswith(("weight", "bias"))]
+
+    def run(dev):
+        Pl = {k: (v.to(dev).clone().requires_grad_(True) if v.dtype.is_floating_point else v.to(dev)) for k, v in P.items()}
+        e = (O.compute_eikonal(Pl, xyz, fr["code_base"], inds) if dev == "cpu"
+             else DF.eikonal_subsample(Pl, xyz.to(dev), fr["code_base"].to(dev), inds.to(dev), prec=0))
+        gs = torch.autograd.grad(e.sum(), [Pl[k] for k in keys], allow_unused=True)
+        return e, gs
+
+    re, rg = run("cpu")
+    de, dg = run(DEV)
+    assert torch.equal(re, torch.ones_like(re)) and torch.equal(de.cpu(), re)
+    for k, a, b in zip(keys, dg, rg):
+        if a is None:
+            continue
+        assert bool(torch.isfinite(a).all()), k
+        ref = torch.zeros_like(a.cpu()) if b is None else b
+        assert float((a.cpu() - ref).abs().max()) == 0.0, k
+
+
 def test_bg_field_forward_backward_matches_oracle():
     """Background NeRF (LAB4D_NET_BG_BASE / LAB4D_NET_BG_COLOR, the view direction as the second per-sample input) vs the
     oracle: rgb, density, and every gradient incl. d/d dir, fp32; bf16 stays close."""
