@@ -299,6 +299,12 @@ def rank_main(a):
             eval_result = {"value": None, "error": repr(e)[:300]}
         torch.cuda.empty_cache()
 
+    # per-frame prologue: camera inverses, bone transforms, per-frame bias tables -- functions of (weights, frames) only, evaluated
+    # once per step; the chunks read them from static leaves and the summed leaf gradients go back through it after the last chunk
+    prologue = DF.FramePrologue(P, fr)
+    fr = prologue.refresh()
+    prologue.outs = None  # no autograd graph of the prologue (and none of its AccumulateGrad nodes) alive while the chunk is captured
+
     M, N0 = inputs[0][0].shape[:2]
     S0 = M * N0 * spp
     uniform = all(h.shape == inputs[0][0].shape for h, _ in inputs)
@@ -323,11 +329,13 @@ def rank_main(a):
         with torch.cuda.graph(graph):
             st_loss = train_chunk(DF, P, fr, st_hxy, st_batch, st_rng, spp, res, prec)
     opt.zero_grad()
+    prologue.zero_grad()  # the eager warm-up / capture passes accumulated into the leaves
     ar_events = []
 
     def step():
         opt.zero_grad()
         last = None
+        prologue.refresh()
         for hxy, batch in inputs:
             if graph is not None:
                 st_hxy.copy_(hxy)
@@ -340,6 +348,7 @@ def rank_main(a):
             else:
                 last = train_chunk(DF, P, fr, hxy, batch, draw_rng(hxy.shape[0], hxy.shape[1], hxy.shape[0] * hxy.shape[1] * spp, dev, gen),
                                    spp, res, prec)
+        prologue.backward()
         if world > 1:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

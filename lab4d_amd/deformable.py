@@ -99,10 +99,13 @@ class GaussDensity(Function):
         return gx, gc, gi
 
 
-def gauss_density(P, xyz, rest_articulation):
+def gauss_density(P, xyz, rest_articulation, ft=None):
     """Deformable.compute_gauss_density (deformable.py:329-356): bones of frame 0 at rest."""
-    _, centre = Q.dual_quaternion_to_quaternion_translation((rest_articulation[0][:1], rest_articulation[1][:1]))
-    ibeta = P["warp.logibeta"].exp()
+    if ft is not None:
+        centre, ibeta = ft["gauss_centre"], ft["gauss_ibeta"]
+    else:
+        _, centre = Q.dual_quaternion_to_quaternion_translation((rest_articulation[0][:1], rest_articulation[1][:1]))
+        ibeta = P["warp.logibeta"].exp()
     out = GaussDensity.apply(xyz.reshape(-1, 3), centre[0], ibeta)
     return out.view(xyz.shape[:-1] + (1,))
 
@@ -192,14 +195,15 @@ def posenc_window(alpha, n_freq, device):
     return 0.5 * (1 + torch.cos(torch.pi * w + torch.pi))
 
 
-def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None):
-    """NeRF.forward (nerf.py:167-215), fg configuration (no view dependence, appearance code in the rgb head)."""
+def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None, ft=None):
+    """NeRF.forward (nerf.py:167-215), fg configuration (no view dependence, appearance code in the rgb head).
+    ft: the step's per-frame terms (frame_terms) -- the per-frame bias tables are taken from there instead of being re-formed."""
     shape = xyz.shape
     spf = _spf(xyz)
     x = xyz.reshape(-1, 3)
     dev = x.device
     sdf, feat = mlp.run_chain(mlp.NET_FG_BASE, prec, P, x, spf, conds={0: fr["code_base"], 4: fr["code_base"]}, export_layer=8,
-                              freq_w=posenc_window(alpha, 10, dev))
+                              freq_w=posenc_window(alpha, 10, dev), pfs_pre=None if ft is None else {0: ft["pf.base0"], 4: ft["pf.base4"]})
     sdf = sdf.view(shape[:-1] + (1,))
     if get_density:
         out = volsdf_density(sdf, P["logibeta"])  # VolSDF (nerf.py:186-192)
@@ -208,7 +212,7 @@ def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None
     if not with_color:
         return out
     rgb = mlp.run_chain(mlp.NET_FG_COLOR, prec, P, x, spf, conds={0: fr["code_color"], 3: fr["appr_code"]}, ext=feat,
-                        freq_w=posenc_window(alpha, 12, dev))
+                        freq_w=posenc_window(alpha, 12, dev), pfs_pre=None if ft is None else {0: ft["pf.color0"], 3: ft["pf.color3"]})
     return torch.sigmoid(rgb).view(shape[:-1] + (3,)), out
 
 
@@ -234,9 +238,10 @@ def nerf_forward_bg(P, xyz, dir, codes, prec, get_density=True, alpha=None, pref
     return torch.sigmoid(rgb).view(shape[:-1] + (3,)), out
 
 
-def vis_field(P, xyz, fr, prec):
+def vis_field(P, xyz, fr, prec, ft=None):
     """VisField.forward (visibility.py:53-63)."""
-    out = mlp.run_chain(mlp.NET_VIS, prec, P, xyz.reshape(-1, 3), _spf(xyz), conds={0: fr["code_vis"]})
+    out = mlp.run_chain(mlp.NET_VIS, prec, P, xyz.reshape(-1, 3), _spf(xyz), conds={0: fr["code_vis"]},
+                        pfs_pre=None if ft is None else {0: ft["pf.vis0"]})
     return out.view(xyz.shape[:-1] + (1,))
 
 
@@ -279,19 +284,104 @@ def global_match(P, feat_px, feat_canonical, xyz_canonical, perm):
     return (prob @ xc).view(shape[:-1] + (3,))
 
 
-def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32, net=mlp.NET_FG_BASE, prefix=""):
+def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32, net=mlp.NET_FG_BASE, prefix="", pf_tables=None):
     """NeRF.compute_eikonal (nerf.py:416-453) on the host-drawn 1/16 ray subset: (|d sdf/dx| - 1)^2 with gradients to the
-    basefield / sdf weights, via the primal + tangent-mode chain kernels (mlp.EikonalSdf) -- no second-order autograd."""
+    basefield / sdf weights, via the primal + tangent-mode chain kernels (mlp.EikonalSdf) -- no second-order autograd.
+    pf_tables = (pf0, pf4): the (M, mout) per-frame bias tables of layers 0 and 4 from the step's prologue; the per-ray rows are
+    gathered from them (cond[idx] @ W^T == (cond @ W^T)[idx])."""
     M, N, D, _ = xyz.shape
     pts = xyz.reshape(M * N, D, 3)
     out = torch.zeros(M * N, D, device=xyz.device)
     if rand_inds is None:
         rand_inds = torch.arange(M * N, device=xyz.device)
-    ray_code = code[torch.div(rand_inds, N, rounding_mode="floor")]
+    ray_frame = torch.div(rand_inds, N, rounding_mode="floor")
     x = pts[rand_inds].detach().reshape(-1, 3)
-    e = mlp.eikonal_sdf(P, x, ray_code, D, prec, freq_w=posenc_window(alpha, mlp.describe(net).n_freq, xyz.device), prefix=prefix, net=net)
+    if pf_tables is not None:
+        ray_code, pf_rows = None, (pf_tables[0].index_select(0, ray_frame), pf_tables[1].index_select(0, ray_frame))
+    else:
+        ray_code, pf_rows = code[ray_frame], None
+    e = mlp.eikonal_sdf(P, x, ray_code, D, prec, freq_w=posenc_window(alpha, mlp.describe(net).n_freq, xyz.device), prefix=prefix, net=net,
+                        pf_rows=pf_rows)
     out = out.index_put((rand_inds,), e.view(-1, D))
     return out.reshape(M, N, D, 1)
+
+
+def frame_terms(P, fr):
+    """Everything the training-mode query derives from the weights and the per-frame inputs ALONE -- camera inverses, the
+    bone transforms of the three skinning warps, the gaussian bone scales, the per-frame bias tables code @ W[:, cond]^T of
+    every conditioned layer -- as a flat dict of tensors.  None of it depends on the rays, so a training step evaluates it ONCE
+    (FramePrologue) instead of once per ray chunk; called inline (ft=None paths) it is the same arithmetic in the same order.
+    SkinningWarp foreground only: with a dense post-warp (fr["dense"]) the warp terms stay inline."""
+    from .warping import get_gauss, skin_cond
+    ft = {}
+    M = fr["field2cam"][0].shape[0]
+    ft["cam2field.q"], ft["cam2field.t"] = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
+    nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam", "t_articulation"]})
+    ft["Kmat"], ft["Kmat_next"] = Q.kmatinv(fr["Kinv"]), Q.kmatinv(nxt["Kinv"])
+    ft["field2cam_next.q"], ft["field2cam_next.t"] = nxt["field2cam"][0].contiguous(), nxt["field2cam"][1].contiguous()
+    ft["scale"] = P["logscale"].exp()
+    _, centre = Q.dual_quaternion_to_quaternion_translation((fr["rest_articulation"][0][:1], fr["rest_articulation"][1][:1]))
+    ft["gauss_centre"], ft["gauss_ibeta"] = centre, P["warp.logibeta"].exp()
+    W = lambda net, l: P[mlp.bindings(net)[l].wname]
+    ft["pf.base0"] = mlp.pf_bias_of(mlp.NET_FG_BASE, 0, W(mlp.NET_FG_BASE, 0), fr["code_base"])
+    ft["pf.base4"] = mlp.pf_bias_of(mlp.NET_FG_BASE, 4, W(mlp.NET_FG_BASE, 4), fr["code_base"])
+    ft["pf.color0"] = mlp.pf_bias_of(mlp.NET_FG_COLOR, 0, W(mlp.NET_FG_COLOR, 0), fr["code_color"])
+    ft["pf.color3"] = mlp.pf_bias_of(mlp.NET_FG_COLOR, 3, W(mlp.NET_FG_COLOR, 3), fr["appr_code"])
+    ft["pf.vis0"] = mlp.pf_bias_of(mlp.NET_VIS, 0, W(mlp.NET_VIS, 0), fr["code_vis"])
+    if fr.get("dense") is None:
+        t_art, rest = fr["t_articulation"], fr["rest_articulation"]
+        skin = mlp.skin_net_for(t_art[0].shape[1])
+        ft["gauss"] = get_gauss(P)
+        ft["se3_bw.r"], ft["se3_bw.d"] = Q.dual_quaternion_mul(rest, Q.dual_quaternion_inverse(t_art))
+        rest_inv = Q.dual_quaternion_inverse(rest)
+        ft["se3_next.r"], ft["se3_next.d"] = Q.dual_quaternion_mul(nxt["t_articulation"], rest_inv)
+        ft["se3_own.r"], ft["se3_own.d"] = Q.dual_quaternion_mul(t_art, rest_inv)
+        ft["pf.skin_bw"] = mlp.pf_bias_of(skin, 0, W(skin, 0), skin_cond(fr["t_embed"], fr["code_skin"], M))
+        ft["pf.skin_fw"] = mlp.pf_bias_of(skin, 0, W(skin, 0), skin_cond(fr["t_embed_mean"], fr["code_skin"], M))
+    return ft
+
+
+class FramePrologue:
+    """The per-frame prologue / epilogue of one training step whose rays are rendered chunk by chunk.
+
+        fr_step = prologue.refresh()        # once per step: frame_terms(P, fr) with its autograd graph; values -> static leaves
+        for chunk: render_train(P, fr_step, ...); loss.backward()    # chunks read the leaves, their gradients add up in leaf.grad
+        prologue.backward()                 # once per step: the summed leaf gradients flow back to the weights / per-frame inputs
+
+    The leaves keep their addresses across steps, so the chunk can be a captured hipGraph that is replayed."""
+
+    def __init__(self, P, fr):
+        self.P, self.fr = P, fr
+        self.outs, self.leaves = None, None
+
+    def refresh(self):
+        self.outs = frame_terms(self.P, self.fr)
+        if self.leaves is None:
+            self.leaves = {}
+            for k, v in self.outs.items():
+                leaf = v.detach().clone().contiguous()
+                if v.requires_grad:
+                    leaf.requires_grad_(True)
+                    leaf.grad = torch.zeros_like(leaf)
+                self.leaves[k] = leaf
+        else:
+            with torch.no_grad():
+                for k, v in self.outs.items():
+                    self.leaves[k].copy_(v)
+        return dict(self.fr, frame_terms=self.leaves)
+
+    def zero_grad(self):
+        for leaf in (self.leaves or {}).values():
+            if leaf.grad is not None:
+                leaf.grad.zero_()
+
+    def backward(self):
+        ks = [k for k, v in self.outs.items() if v.requires_grad]
+        if ks:
+            torch.autograd.backward([self.outs[k] for k in ks], [self.leaves[k].grad for k in ks])
+            for k in ks:
+                self.leaves[k].grad.zero_()
+        self.outs = None
 
 
 def _warp_fn(P, fr, prec):
@@ -314,44 +404,58 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     oracle.lab4d_oracle.query_field_train).  With fr["dense"] = {"t_embed", "code_fw", "code_bw"} every warp is the
     ComposedWarp of fg_motion "comp_skel-*_dense" (skinning composed with the dense post-warp, warping.py:445-483)."""
     warp = _warp_fn(P, fr, prec)
-    cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
+    ft = fr.get("frame_terms")  # the step's prologue (FramePrologue.refresh), or evaluated here: same arithmetic either way
+    if ft is None:
+        ft = frame_terms(P, fr)
+    skinning = fr.get("dense") is None
+    cam2field = (ft["cam2field.q"], ft["cam2field.t"])
     xyz_cam, dir_cam, deltas, depth, xyz_t, _ = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=n_depth)
-    xyz, bw_aux = warp(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
+    if skinning:
+        xyz, bw_aux = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, prec,
+                                    pre={"se3": (ft["se3_bw.r"], ft["se3_bw.d"]), "gauss": ft["gauss"], "pf": ft["pf.skin_bw"]})
+    else:
+        xyz, bw_aux = warp(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
     fd = {}
-    vis = vis_field(P, xyz, fr, prec)
-    rgb, density = nerf_forward(P, xyz, fr, prec, alpha=alpha)
+    vis = vis_field(P, xyz, fr, prec, ft)
+    rgb, density = nerf_forward(P, xyz, fr, prec, alpha=alpha, ft=ft)
     fd["rgb"], fd["density"], fd["density_fg"], fd["vis"] = rgb, density, density, vis
     # flow: canonical points into the pair partner's camera (nerf.py:948-997)
     nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam", "t_articulation", "rest_articulation"]})
-    shared = fr.get("dense") is None and fr.get("rest_shared_in_pair", True)
+    shared = skinning and fr.get("rest_shared_in_pair", True)
+    fw_pre = {"gauss": ft["gauss"], "pf": ft["pf.skin_fw"]} if skinning else None
     if shared:
         # both forward warps of the canonical samples (into the partner's frame here, into the own frame for the cycle term
         # below) see the same skinning field: the rest articulation is a per-instance quantity and pair partners are frames
         # of one video (rest_articulation == its flip_pair), so it is evaluated once (warping.skinning_warp_forward_multi)
         (xyz_next, _), (xyz_cyc, cyc_aux) = skinning_warp_forward_multi(P, xyz, [nxt["t_articulation"], fr["t_articulation"]], fr["rest_articulation"],
-                                                                        fr["t_embed_mean"], fr["code_skin"], prec)
+                                                                        fr["t_embed_mean"], fr["code_skin"], prec,
+                                                                        pre=dict(fw_pre, se3s=[(ft["se3_next.r"], ft["se3_next.d"]), (ft["se3_own.r"], ft["se3_own.d"])]))
     else:
         xyz_next, _ = warp(xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"], False, partner=True)
     # cycle consistency (deformable.py:173-198)
     if not shared:
         xyz_cyc, cyc_aux = warp(xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
     # projection into the partner's camera, flow, validity and the cycle distance: one kernel each way (csrc/flow.hip)
-    fd["flow"], fd["cyc_dist"] = FlowCyc.apply(xyz_next, nxt["field2cam"][0], nxt["field2cam"][1], Q.kmatinv(nxt["Kinv"]), hxy, xyz_cyc, xyz_t, flow_thresh)
+    fd["flow"], fd["cyc_dist"] = FlowCyc.apply(xyz_next, ft["field2cam_next.q"], ft["field2cam_next.t"], ft["Kmat_next"], hxy, xyz_cyc, xyz_t, flow_thresh)
     for k in ["skin_entropy", "delta_skin"]:
         fd[k] = (cyc_aux[k] + bw_aux[k]) / 2
-    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha, prec)
+    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha, prec, pf_tables=(ft["pf.base0"], ft["pf.base4"]))
     fd["xyz"] = xyz
     fd["xyz_cam"] = xyz_cam
-    fd["depth"] = depth / P["logscale"].exp()
+    fd["depth"] = depth / ft["scale"]
     fd["feature"] = compute_feat(P, xyz, prec)
     aux = {}
     xyz_matches = global_match(P, fr["feature"], fd["feature"], xyz, rng["match_perm"])
-    xm_next, _ = warp(xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
+    if skinning:
+        xm_next, _ = skinning_warp(P, xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], fr["code_skin"], False,
+                                   prec, pre=dict(fw_pre, se3=(ft["se3_own.r"], ft["se3_own.d"])))
+    else:
+        xm_next, _ = warp(xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
     xyz_reproj = rigid_apply(fr["field2cam"][0], fr["field2cam"][1], xm_next)[:, :, 0]
     aux["xyz_matches"] = xyz_matches
     aux["xyz_reproj"] = xyz_reproj
-    aux["xy_reproj"] = pinhole_projection(Q.kmatinv(fr["Kinv"]), xyz_reproj)[..., :2]
-    fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
+    aux["xy_reproj"] = pinhole_projection(ft["Kmat"], xyz_reproj)[..., :2]
+    fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"], ft)
     return fd, deltas, aux
 
 

@@ -423,7 +423,10 @@ class MlpChain(Function):
         ctx.x_shape = x.shape
         ctx.has_x2 = x2 is not None
         if export_layer is not None and export_layer >= 0:
-            return out, acts[export_layer]
+            # a separate tensor object over the same storage: returning ctx.acts[export_layer] itself would make the node own a
+            # tensor whose grad_fn is the node -- a reference cycle that keeps every stored activation of the chunk alive until
+            # the cyclic garbage collector runs (measured: +0.7 GiB per chunk at 128^2 x 32, 140 GiB per chunk at the bench size)
+            return out, acts[export_layer].view(-1)
         return out
 
     @staticmethod
@@ -533,15 +536,17 @@ class MlpChain(Function):
         return (None, None, None, d_x, ext_g, None, None, None, d_x2, *grads_pf, *grads_params)
 
 
-def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_layer=None, prefix="", x2=None):
+def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_layer=None, prefix="", x2=None, pfs_pre=None):
     """Convenience wrapper: P maps reference state_dict names -> device tensors; conds maps layer index ->
-    (M, C) per-frame conditioning input of that layer.  Returns out or (out, exported activation)."""
+    (M, C) per-frame conditioning input of that layer.  pfs_pre maps layer index -> an already evaluated per-frame bias
+    pf_bias_of(net, l, W, conds[l]) (the per-frame prologue of a training step, deformable.frame_terms: the table does not
+    depend on the rays, so it is formed once per step, not once per chunk).  Returns out or (out, exported activation)."""
     d = describe(net)
     bd = bindings(net, prefix)
     pfs = []
     for l in range(d.n_layers):
         if d.layers[l].pf_bias:
-            pfs.append(pf_bias_of(net, l, P[bd[l].wname], conds[l]))
+            pfs.append(pfs_pre[l] if pfs_pre is not None and l in pfs_pre else pf_bias_of(net, l, P[bd[l].wname], conds[l]))
     params = []
     for l in range(d.n_layers):
         params += [P[bd[l].wname], P[bd[l].bname]]
@@ -745,12 +750,16 @@ class EikonalSdf(Function):
         return (None, None, None, None, None, None, None, *grads)
 
 
-def eikonal_sdf(P, x, ray_code, spf, prec, freq_w=None, prefix="", net=NET_FG_BASE):
+def eikonal_sdf(P, x, ray_code, spf, prec, freq_w=None, prefix="", net=NET_FG_BASE, pf_rows=None):
     """(|d sdf/dx| - 1)^2 at detached points x (S,3); ray_code (S/spf, 32) = instance code of the ray each group of `spf`
-    consecutive samples belongs to.  net = NET_FG_BASE or NET_BG_BASE (both condition layers 0 and 4 on the code)."""
+    consecutive samples belongs to.  net = NET_FG_BASE or NET_BG_BASE (both condition layers 0 and 4 on the code).
+    pf_rows = (pf0, pf4) already evaluated per ray (rows of the per-frame tables, deformable.frame_terms) replaces ray_code."""
     bd = bindings(net, prefix)
-    pf0 = pf_bias_of(net, 0, P[bd[0].wname], ray_code)
-    pf4 = pf_bias_of(net, 4, P[bd[4].wname], ray_code)
+    if pf_rows is not None:
+        pf0, pf4 = pf_rows
+    else:
+        pf0 = pf_bias_of(net, 0, P[bd[0].wname], ray_code)
+        pf4 = pf_bias_of(net, 4, P[bd[4].wname], ray_code)
     params = []
     for l in range(describe(net).n_layers):
         params += [P[bd[l].wname], P[bd[l].bname]]

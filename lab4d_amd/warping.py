@@ -118,34 +118,46 @@ def _spf(shape):
     return spf
 
 
-def skin_logits(P, x, art, t_embed, code, M, spf, prec):
+def skin_cond(t_embed, code, M):
+    """Conditioning input of the delta-skin MLP's first layer: [time embedding | instance code] per frame."""
+    return torch.cat([t_embed.expand(M, -1), code], -1)
+
+
+def skin_logits(P, x, art, t_embed, code, M, spf, prec, pre=None):
     """The delta-skin field of SkinningField.forward (skinning.py:89-124) at the articulation `art`: gaussian-scaled bone
-    coordinates -> delta-skin MLP.  x (S,3).  Returns the raw (S,B) MLP output and gauss (B,3)."""
-    gauss = get_gauss(P)
+    coordinates -> delta-skin MLP.  x (S,3).  Returns the raw (S,B) MLP output and gauss (B,3).
+    pre = {"gauss", "pf"}: the per-frame terms already evaluated by the step's prologue (deformable.frame_terms)."""
+    gauss = pre["gauss"] if pre is not None else get_gauss(P)
     bone = BoneCoords.apply(x, art[0], art[1], gauss, spf)  # (S,3B): input of the delta-skin MLP only
-    cond = torch.cat([t_embed.expand(M, -1), code], -1)
-    return mlp.run_chain(mlp.skin_net_for(art[0].shape[1]), prec, P, bone, spf, conds={0: cond}), gauss
+    net = mlp.skin_net_for(art[0].shape[1])
+    if pre is not None:
+        return mlp.run_chain(net, prec, P, bone, spf, pfs_pre={0: pre["pf"]}), gauss
+    return mlp.run_chain(net, prec, P, bone, spf, conds={0: skin_cond(t_embed, code, M)}), gauss
 
 
-def skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, prec=mlp.PREC_F32):
+def skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, prec=mlp.PREC_F32, pre=None):
     """SkinningWarp.forward (warping.py:277-336).  xyz: (M,N,D,3).  Returns warped xyz and
     {"skin_entropy","delta_skin"} (M,N,D,1).  t_embed: (M,128) per-frame (backward warp) or (1,128)
-    mean embedding (forward warp, frame_id=None: warping.py:314)."""
+    mean embedding (forward warp, frame_id=None: warping.py:314).
+    pre = {"se3", "gauss", "pf"}: per-frame terms of this warp evaluated by the step's prologue (deformable.frame_terms)."""
     shape = xyz.shape
     M, spf = shape[0], _spf(shape)
-    if backward:
+    if pre is not None:
+        se3 = pre["se3"]
+        art = t_articulation if backward else rest_articulation
+    elif backward:
         se3 = Q.dual_quaternion_mul(rest_articulation, Q.dual_quaternion_inverse(t_articulation))
         art = t_articulation
     else:
         se3 = Q.dual_quaternion_mul(t_articulation, Q.dual_quaternion_inverse(rest_articulation))
         art = rest_articulation
     x = xyz.reshape(-1, 3)
-    raw, gauss = skin_logits(P, x, art, t_embed, code, M, spf, prec)
+    raw, gauss = skin_logits(P, x, art, t_embed, code, M, spf, prec, pre)
     out, ent, dsk = SkinBlend.apply(x, raw, art[0], art[1], gauss, se3[0], se3[1], spf)
     return out.view(shape), {"skin_entropy": ent.view(shape[:-1] + (1,)), "delta_skin": dsk.view(shape[:-1] + (1,))}
 
 
-def skinning_warp_forward_multi(P, xyz, t_articulations, rest_articulation, t_embed_mean, code, prec=mlp.PREC_F32):
+def skinning_warp_forward_multi(P, xyz, t_articulations, rest_articulation, t_embed_mean, code, prec=mlp.PREC_F32, pre=None):
     """Several FORWARD warps of the same canonical points to different target articulations (SkinningWarp.forward with
     backward=False, warping.py:306-333).  In the forward direction the skinning weights depend only on the points, the REST
     articulation, the mean time embedding and the instance code (warping.py:311-314: articulation = rest_articulation,

@@ -1,0 +1,80 @@
+"""The per-frame prologue of a training step (deformable.FramePrologue): evaluating the ray-independent terms once per step and
+sending the chunks' summed gradients back through them afterwards must give the gradients of the chunk-by-chunk inline graph."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _problem():
+    import bench
+    from lab4d_amd import synthetic
+    res, spp = 32, 16
+    P = synthetic.to_device(synthetic.make_weights(3), DEV)
+    for k, v in P.items():
+        if v.dtype.is_floating_point and k != "aabb":
+            v.requires_grad_(True)
+    fr = synthetic.to_device(synthetic.add_codes(synthetic.make_frames(4, 2, res), synthetic.make_weights(3)), DEV)
+    # per-frame inputs that carry gradients (in a training run they are outputs of the pose / articulation modules)
+    for k in ("t_articulation", "rest_articulation", "field2cam"):
+        fr[k] = tuple(t.clone().requires_grad_(True) for t in fr[k])
+    for k in ("t_embed", "appr_code"):
+        fr[k] = fr[k].clone().requires_grad_(True)
+    chunks = [bench.chunk_inputs(res, y, 8, DEV, seed=7 + y) for y in (8, 16)]
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    rngs = [bench.draw_rng(2, h.shape[1], 2 * h.shape[1] * spp, DEV, gen) for h, _ in chunks]
+    return bench, P, fr, chunks, rngs, res, spp
+
+
+def _leaves(P, fr):
+    out = {k: v for k, v in P.items() if v.dtype.is_floating_point and v.requires_grad}
+    for k in ("t_articulation", "rest_articulation", "field2cam"):
+        out[k + ".0"], out[k + ".1"] = fr[k]
+    out["t_embed"], out["appr_code"] = fr["t_embed"], fr["appr_code"]
+    return out
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_prologue_gradients_equal_the_inline_graph(prec):
+    from lab4d_amd import deformable as DF
+    bench, P, fr, chunks, rngs, res, spp = _problem()
+    leaves = _leaves(P, fr)
+
+    def grads():
+        g = {k: (v.grad.clone() if v.grad is not None else None) for k, v in leaves.items()}
+        for v in leaves.values():
+            v.grad = None
+        return g
+
+    losses_a = [float(bench.train_chunk(DF, P, fr, h, b, r, spp, res, prec)) for (h, b), r in zip(chunks, rngs)]
+    ga = grads()
+    pro = DF.FramePrologue(P, fr)
+    for step in range(2):  # second step: leaves refreshed in place, leaf gradients start from zero again
+        fr_step = pro.refresh()
+        losses_b = [float(bench.train_chunk(DF, P, fr_step, h, b, r, spp, res, prec)) for (h, b), r in zip(chunks, rngs)]
+        pro.backward()
+        gb = grads()
+        assert losses_a == losses_b
+        for k in ga:
+            assert (ga[k] is None) == (gb[k] is None), k
+            if ga[k] is None:
+                continue
+            scale = float(ga[k].abs().max())
+            # the split only re-associates sums over chunks (leaf gradients are added before, not after, the per-frame backward)
+            assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * scale + 1e-12, (k, step, float((ga[k] - gb[k]).abs().max()), scale)
+
+
+def test_prologue_leaves_keep_their_addresses_and_follow_the_weights():
+    from lab4d_amd import deformable as DF
+    bench, P, fr, chunks, rngs, res, spp = _problem()
+    pro = DF.FramePrologue(P, fr)
+    a = pro.refresh()["frame_terms"]
+    ptrs = {k: v.data_ptr() for k, v in a.items()}
+    before = a["pf.base0"].clone()
+    with torch.no_grad():
+        P["basefield.linear_1.0.weight"].mul_(1.5)
+    b = pro.refresh()["frame_terms"]
+    assert {k: v.data_ptr() for k, v in b.items()} == ptrs
+    assert not torch.equal(before, b["pf.base0"])
+    assert torch.equal(b["pf.base0"], DF.frame_terms(P, fr)["pf.base0"])

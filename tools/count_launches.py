@@ -13,6 +13,8 @@ mlp.FUSED_GRAD_ACCUM = True                                                     
 gen = torch.Generator(device=dev).manual_seed(0)
 M, N = hxy.shape[:2]
 rng = bench.draw_rng(M, N, M * N * 128, dev, gen)
+prologue = DF.FramePrologue(P, fr)   # as in bench.py: the per-frame terms are formed once per step, outside the chunk
+fr = prologue.refresh()
 for _ in range(2):
     bench.train_chunk(DF, P, fr, hxy, batch, rng, 128, 512, mlp.PREC_BF16)
 torch.cuda.synchronize()
@@ -31,3 +33,17 @@ tot = 0
 print("top CPU-side ops by call count (aten ops launching kernels):")
 for k, c, t in rows[:70]:
     print(f"{k[:60]:60s} {c:6d} {t/1e3:9.2f} ms self device")
+
+# attribution: which line of the host layer issues the kernel-launching torch ops (aten ops with device time of their own)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof2:
+    bench.train_chunk(DF, P, fr, hxy, batch, rng, 128, 512, mlp.PREC_BF16)
+    torch.cuda.synchronize()
+by_line = collections.Counter()
+for e in prof2.key_averages(group_by_stack_n=12):
+    if e.device_type == torch.autograd.DeviceType.CUDA or e.self_device_time_total <= 0 or not e.key.startswith("aten::"):
+        continue
+    where = next((f for f in e.stack if "lab4d_amd/" in f or "bench.py" in f), "(autograd engine / backward of torch ops)")
+    by_line[where.split("/root/repo/")[-1][:110]] += e.count
+print("\nkernel-launching aten ops by issuing line:")
+for k, c in by_line.most_common(60):
+    print(f"{c:5d}  {k}")
