@@ -318,16 +318,29 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // MT = row tiles of dz (MO = 32*MT output features: 256 / 128 / 64); NBW = 64-row blocks of X one workgroup contracts
 // against (B operand = 64*NBW rows).  Waves 2x2: wave (wr, wc) owns MT/2 x NBW tiles.
-template <int MT, int NBW>
-__global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __restrict__ dz, const unsigned short* __restrict__ emb,
+// NW = waves per workgroup: 4 (2 x 2 wave grid, TM = MT/2 row tiles per wave) or 8 (4 x 2, TM = MT/4).  The 256-row layers run with
+// 8 waves: the same 32-KiB stages in the same LDS ring, but two waves per SIMD (128-160 accumulator registers each instead of
+// 256), so the DMA issue, the LDS reads and the barrier wait of one wave overlap the MFMAs of the other, and a 320-column
+// operand (the skip layer: embedding + activation) fits ONE job (TN = 5) instead of two that each re-read dZ.
+#ifdef LAB4D_ABL_WGRAD4
+#define LAB4D_WGRAD_NB5 0
+#else
+#define LAB4D_WGRAD_NB5 1
+#endif
+template <int MT, int NBW, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) k_mlp_wgrad_dma(const unsigned short* __restrict__ dz, const unsigned short* __restrict__ emb,
                                                         const unsigned short* __restrict__ actp, int ke, int kin, int S_pad, int chunk,
                                                         int spf, int cpf, float* __restrict__ dW, float* __restrict__ db, DwMap wm) {
   using P = PBF16;
-  constexpr int TM = MT / 2, TN = NBW, MO = 32 * MT, KB = 64 * NBW;
+  static_assert(NW == 4 || NW == 8, "wave grid");
+  constexpr int TM = 2 * MT / NW, TN = NBW, MO = 32 * MT, KB = 64 * NBW;
+  static_assert(TM >= 1 && TM * (NW / 2) == MT, "row tiles per wave");
   constexpr int A_BYTES = MT * 2048, STAGE = A_BYTES + NBW * 4096;  // 32 samples x (MO + KB) rows x 2 B
   constexpr int NS0 = 65536 / STAGE, NSTAGE = NS0 < 4 ? 4 : (NS0 > 8 ? 8 : NS0);  // ring depth: >= 64 KiB in flight per CU
-  constexpr int PA = MT / 2, PW = PA + NBW;  // transfers per wave per stage (exact: the counted waits rely on it)
+  constexpr int PA = 2 * MT / NW, PB = (4 * NBW + NW - 1) / NW, PW = PA + PB;  // transfers per wave per stage (exact: the counted waits rely on it)
+  static_assert(PA * NW == 2 * MT, "A pieces per wave");
   static_assert(PW * (NSTAGE - 2) <= 63, "vmcnt range");
+  static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), row = lane & 31, h = lane >> 5;
   const int wr = wid >> 1, wc = wid & 1;
@@ -378,15 +391,15 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
     const unsigned char* ga = reinterpret_cast<const unsigned char*>(dz + (size_t)blk * block_stride(MO)) + half * 64 + lane_src;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const int piece = wid + 4 * p;
+      const int piece = wid + NW * p;
       dma_1k(ga + piece * 2048, st + piece * 1024);
     }
     unsigned char* sb = st + A_BYTES;
     const unsigned char* g1 = reinterpret_cast<const unsigned char*>(emb + (size_t)blk * block_stride(ke) + (size_t)k0 * 64) + half * 64 + lane_src;
     const unsigned char* g2 = reinterpret_cast<const unsigned char*>(actp + (size_t)blk * block_stride(kin) + (size_t)r2 * 64) + half * 64 + lane_src;
 #pragma unroll
-    for (int p = 0; p < NBW; ++p) {
-      int q = wid + 4 * p;
+    for (int p = 0; p < PB; ++p) {
+      int q = wid + NW * p;
       q = q < nbp ? q : nbp - 1;
       const int r0 = 16 * q;  // first row of the piece inside the B operand
       const unsigned char* src = r0 < n1 ? g1 + (size_t)r0 * 128 : g2 + (size_t)(r0 - n1) * 128;
@@ -410,7 +423,8 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad_dma(const unsigned short* __r
       if constexpr (TM == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]));
       else if constexpr (TM == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4[0]), "+v"(a4[1]));
       else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4[0]));
-      if constexpr (TN == 4) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
+      if constexpr (TN == 5) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]), "+v"(b4[4]));
+      else if constexpr (TN == 4) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
       else if constexpr (TN == 3) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]));
       else if constexpr (TN == 2) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]));
       else asm volatile("" : "+v"(b4[0]));
@@ -683,7 +697,8 @@ extern "C" int lab4d_mlp_wgrad_mapped(int net, int layer, int precision, int S, 
   // bf16 layers of 64 / 128 / 256 output features run the LDS-DMA ring; NBW = 64-row blocks of X per workgroup
   const bool dma = precision == LAB4D_PREC_BF16 && (mo_tiles == 8 || mo_tiles == 4 || mo_tiles == 2);
   const int Kt = L.ke + L.kin;
-  const int nbw = Kt <= 64 ? 1 : (Kt <= 128 ? 2 : (Kt <= 192 ? 3 : (Kt <= 256 ? 4 : 3)));  // K = 320 -> 192 + 128
+  // K = 320 (skip layer): one 320-column job with the 8-wave kernel of the 256-row layers, 192 + 128 otherwise
+  const int nbw = Kt <= 64 ? 1 : (Kt <= 128 ? 2 : (Kt <= 192 ? 3 : (Kt <= 256 ? 4 : (LAB4D_WGRAD_NB5 && mo_tiles == 8 && Kt <= 320 ? 5 : 3))));
   const int TM = mo_tiles >= 4 ? 4 : (mo_tiles >= 2 ? 2 : 1);
   const int ob_n = dma ? 1 : (big ? div_up(mo_tiles, 8) : div_up(mo_tiles, TM));
   const int kb_n = dma ? div_up(Kt, 64 * nbw) : (big ? div_up(nk_tiles, 8) : div_up(nk_tiles, 4));
@@ -702,7 +717,7 @@ extern "C" int lab4d_mlp_wgrad_mapped(int net, int layer, int precision, int S, 
     nchunks = div_up(S_pad, chunk);
   }
   const int jobs = ob_n * kb_n * nchunks;
-  const dim3 grid(jobs), block(256);
+  const dim3 grid(jobs), block(256), block8(512);
   float* db_arg = fold_pf ? pf_db : db;
   // mapped mode: db (when it is the target) is the reference bias (mout entries); the per-frame table keeps its padded rows
   const DwMap wm = {col_map, ld_ref, L.mout, (col_map && !fold_pf) ? L.mout : L.mout_pad};
@@ -713,11 +728,20 @@ extern "C" int lab4d_mlp_wgrad_mapped(int net, int layer, int precision, int S, 
                                   (const typename P::store_t*)act_prev, mo_tiles, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg, wm)
 #define WGD(MTV, NBV) hipLaunchKernelGGL((k_mlp_wgrad_dma<MTV, NBV>), grid, block, 0, st, (const unsigned short*)dz, (const unsigned short*)emb, \
                                          (const unsigned short*)act_prev, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg, wm)
+#define WGD8(NBV) hipLaunchKernelGGL((k_mlp_wgrad_dma<8, NBV, 8>), grid, block8, 0, st, (const unsigned short*)dz, (const unsigned short*)emb, \
+                                     (const unsigned short*)act_prev, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg, wm)
 #define WGD_NB(MTV) do { if (nbw == 1) WGD(MTV, 1); else if (nbw == 2) WGD(MTV, 2); else if (nbw == 3) WGD(MTV, 3); else WGD(MTV, 4); } while (0)
   if (dma) {
-    if (mo_tiles == 8) WGD_NB(8); else if (mo_tiles == 4) WGD_NB(4); else WGD_NB(2);
+    if (mo_tiles == 8) {
+#ifdef LAB4D_ABL_WGRAD4
+      WGD_NB(8);
+#else
+      if (nbw == 1) WGD8(1); else if (nbw == 2) WGD8(2); else if (nbw == 3) WGD8(3); else if (nbw == 4) WGD8(4); else WGD8(5);
+#endif
+    } else if (mo_tiles == 4) WGD_NB(4); else WGD_NB(2);
   }
 #undef WGD_NB
+#undef WGD8
 #undef WGD
   else if (precision == LAB4D_PREC_BF16) { if (big) WGB(PBF16); else if (TM == 4) WG(PBF16, 4); else if (TM == 2) WG(PBF16, 2); else WG(PBF16, 1); }
   else if (precision == LAB4D_PREC_F32) { if (big) WGB(PF32); else if (TM == 4) WG(PF32, 4); else if (TM == 2) WG(PF32, 2); else WG(PF32, 1); }

@@ -9,10 +9,10 @@ int launch_mlp_fwd_tangent<NetFgBase>(int precision, const FwdK& k0, int S, hipS
   FwdK k = k0;
   if (precision == LAB4D_PREC_BF16) {
     k.ntiles = k.S_pad / PBF16::TILE;
-    hipLaunchKernelGGL((k_mlp_fwd<NetFgBase, PBF16, true, true>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);
+    LAB4D_MLP_LAUNCH((k_mlp_fwd<NetFgBase, PBF16, true, true>), k, st);
   } else if (precision == LAB4D_PREC_F32) {
     k.ntiles = k.S_pad / PF32::TILE;
-    hipLaunchKernelGGL((k_mlp_fwd<NetFgBase, PF32, true, true>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);
+    LAB4D_MLP_LAUNCH((k_mlp_fwd<NetFgBase, PF32, true, true>), k, st);
   } else {
     set_error("mlp_forward_tangent: bad precision %d", precision);
     return LAB4D_EINVAL;

@@ -66,6 +66,19 @@ __device__ __forceinline__ float relu1(float x) {
   return y;
 }
 
+// Hazard fence between the MFMAs that produced an accumulator tile and INLINE ASM that reads it.  On gfx950 a VALU read of an
+// MFMA result needs software wait states (passes + 3: 11 for the 8-pass 32x32x16, 19 for a 16-pass shape); the compiler inserts
+// them in front of instructions it can see, but not in front of an inline-asm statement.  While the accumulators lived in AGPRs a
+// compiler-visible v_accvgpr_read always sat in between; built for two waves per SIMD (<= 256 registers, no AGPRs) the packed
+// epilogue read the MFMA's destination VGPRs directly and, depending on the schedule, got stale values (found on hardware:
+// visibility / feature nets wrong at occupancy 2, right at occupancy 1).  The fence takes the tile as in/out operands, so every
+// asm consumer depends on it; 20 wait states, only ever exposed when the tile's last MFMA has just issued.
+__device__ __forceinline__ void acc_fence(f32x16_t& c) {
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]),
+                 "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]));
+}
+
 // feature (row) held by accumulator register r of lane-half h inside a 32-row tile
 __host__ __device__ __forceinline__ constexpr int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -450,6 +463,27 @@ __device__ __forceinline__ void emb_pair(int pair, const float* x /* [6]: point,
 // ds_read_b128, conflict-free).  Up to ACACHE_G groups go through LDS (2 buffers x 16 KiB: with the four 32 KiB slabs
 // that is the CU's whole 160 KiB); the few groups beyond (skip-layer embedding columns) keep the direct path.
 constexpr int ACACHE_G = 14;  // 2 x 14 KiB: leaves 4 KiB of the 160 KiB unallocated (a kernel that needs ALL of the LDS cannot be co-scheduled with anything, e.g. a profiler's helper)
+// The narrow fg nets (feature 128 wide, visibility 64 wide; bf16) are built for TWO workgroups per CU (two waves per SIMD from independent, not lock-stepped
+// workgroups: while one waits at its barrier / on a store the other issues MFMAs): <= 256 registers per lane
+// (__launch_bounds__(256, 2)) and <= 78 KiB of LDS (4 x 16 KiB slabs + 2 x 7 KiB of shared A groups).
+template <class Net, class P>
+constexpr int want_occ() {
+#ifdef LAB4D_ABL_OCC1
+  return 1;
+#else
+  return (P::BF16 && (Net::ID == LAB4D_NET_FEAT || Net::ID == LAB4D_NET_VIS)) ? 2 : 1;  // the bg nets (per-frame bias in two layers) spill 25-53 registers at 256
+#endif
+}
+template <class Net, class P>
+constexpr int acache_g() {
+#ifdef LAB4D_ABL_ACG14
+  return ACACHE_G;
+#elif defined(LAB4D_ABL_ACG7)
+  return (P::BF16 && (Net::ID == LAB4D_NET_FEAT || Net::ID == LAB4D_NET_VIS)) ? 7 : ACACHE_G;
+#else
+  return want_occ<Net, P>() == 2 ? 7 : ACACHE_G;
+#endif
+}
 __device__ __forceinline__ void wg_step_barrier() {
   // LDS writes of this wave visible + everybody arrived.  Raw s_barrier: __syncthreads() would also drain the
   // outstanding activation stores (vmcnt(0)), a full HBM round trip per step.
@@ -582,10 +616,11 @@ __device__ __forceinline__ void stage_out(const float* __restrict__ stage, float
 // a runtime branch makes the compiler's s_waitcnt vmcnt(N) bookkeeping assume the store-free path: the wait for the
 // prefetched A groups of the next tile then also waits for this tile's activation stores (a full HBM round trip per tile).
 template <class Net, class P, bool TAN = false, bool ST = false>
-__global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
+__global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
   constexpr int NT = P::NT, TILE = P::TILE, KE = Net::KE, UE = KE / P::FPG, UW = Slab<Net, P>::UW;
+  constexpr int ACG = acache_g<Net, P>();
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
-  __shared__ uint4 abuf[2 * ACACHE_G * 64];  // workgroup-shared A groups of the current / next M-tile step
+  __shared__ uint4 abuf[2 * ACG * 64];  // workgroup-shared A groups of the current / next M-tile step
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
   // the wave index is the same in all lanes, but the compiler only knows that after a readfirstlane: with it the tile
   // index and every tile base address are scalar (SGPR) values instead of 64-bit per-lane VGPR pairs
@@ -746,7 +781,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       constexpr bool LAST = (R == Net::NL - 1);
       constexpr int MT = pad32(ls.mout) / 32;
       constexpr int GE = ls.ke / P::FPG, GA = ls.kin / P::FPG, G = GE + GA;
-      constexpr int GL = G < ACACHE_G ? G : ACACHE_G, NQ = (GL + 3) / 4;  // A groups shared through LDS / fetched per wave
+      constexpr int GL = G < ACG ? G : ACG, NQ = (GL + 3) / 4;  // A groups shared through LDS / fetched per wave
       const GLOBAL_AS void* Wl = KARG_PTR(FwdK, const void*, W, l);
       const GLOBAL_AS float* bl = KARG_PTR(FwdK, const float*, bias, l);
       const GLOBAL_AS float* pfl = KARG_PTR(FwdK, const float*, pf_bias, l);
@@ -813,13 +848,13 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
-          abuf[(buf * ACACHE_G + g) * 64 + lane] = stg[i];
+          abuf[(buf * ACG + g) * 64 + lane] = stg[i];
         }
 #endif
       };
       auto a_grab = [&](int buf, uint4 (&A)[G]) {
 #pragma unroll
-        for (int g = 0; g < GL; ++g) A[g] = abuf[(buf * ACACHE_G + g) * 64 + lane];
+        for (int g = 0; g < GL; ++g) A[g] = abuf[(buf * ACG + g) * 64 + lane];
       };
       // ---- HBM inputs of an epilogue (tangent mode: the primal's sign bits; colour net: the basefield feature tile) are
       // requested one pipeline step ahead, like the A groups
@@ -837,6 +872,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(FwdK a) {
       // stores of the PREVIOUS step in front of it, issued a whole step earlier.
       constexpr bool PACKED = P::BF16 && !TAN && ls.add_ext == 0 && !LAST;
       auto epilogue = [&](int mt, f32x16_t (&acc)[NT], unsigned int (&w)[2][8], unsigned int& wbits) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc_fence(acc[t]);
         if constexpr (PACKED) {
           // packed-bf16 epilogue (see pk_* helpers): everything after the one fp32 -> bf16 conversion works on the 16 packed dwords
 #pragma unroll
@@ -1011,11 +1048,12 @@ constexpr int emb_layer_count() {
 }
 
 template <class Net, class P>
-__global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
+__global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
   static_assert(Net::EMB == 0 || emb_layer_count<Net>() == 1, "raw-input nets may use the input in one layer only");
   constexpr int NT = P::NT, TILE = P::TILE, NL = Net::NL, UW = Slab<Net, P>::UW;
+  constexpr int ACG = acache_g<Net, P>();
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
-  __shared__ uint4 abuf[2 * ACACHE_G * 64];  // workgroup-shared A groups (see wg_step_barrier)
+  __shared__ uint4 abuf[2 * ACG * 64];  // workgroup-shared A groups (see wg_step_barrier)
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint4* slab = slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE + lane;
@@ -1062,7 +1100,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
       constexpr LS ls = Net::L[R];
       constexpr LS lp = Net::L[R > 0 ? R - 1 : 0];
       constexpr int GK = pad32(ls.mout) / P::FPG;        // K units = out features of layer l
-      constexpr int GL = GK < ACACHE_G ? GK : ACACHE_G, NQ = (GL + 3) / 4;  // A groups shared through LDS / fetched per wave
+      constexpr int GL = GK < ACG ? GK : ACG, NQ = (GL + 3) / 4;  // A groups shared through LDS / fetched per wave
       constexpr int MTE = ls.ke / 32, MTA = ls.kin / 32;  // row tiles: embedding slots, then previous activation
       constexpr bool DO_ACT = (R > 0 && MTA > 0);
       const int lm1 = l > 0 ? l - 1 : 0;
@@ -1105,13 +1143,13 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
-          abuf[(buf * ACACHE_G + g) * 64 + lane] = stg[i];
+          abuf[(buf * ACG + g) * 64 + lane] = stg[i];
         }
 #endif
       };
       auto a_grab = [&](int buf, uint4 (&A)[GK]) {
 #pragma unroll
-        for (int g = 0; g < GL; ++g) A[g] = abuf[(buf * ACACHE_G + g) * 64 + lane];
+        for (int g = 0; g < GL; ++g) A[g] = abuf[(buf * ACG + g) * 64 + lane];
       };
       // Software pipeline over N row tiles starting at tile0 (same scheme as the forward chain): step k issues the MFMAs
       // of tile k+1 into the other accumulator set in the same basic block as the epilogue of tile k.
@@ -1228,6 +1266,8 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(BwdK a) {
       // (b) gradient wrt the previous layer's output -> masked dZ_{l-1}
       auto epi_act = [&](int j, f32x16_t (&acc)[NT], unsigned int (&w)[2][8]) {
         const unsigned int bits = mbits;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc_fence(acc[t]);
         if constexpr (lp.ext_grad != 0) {
           f32x16_t eg[NT];
           tile_from_raw<P>(raw, lane, eg);
@@ -1336,11 +1376,28 @@ int launch_mlp_bwd(int precision, const BwdK& k, int S, hipStream_t st);
 template <class Net>
 int launch_mlp_fwd_tangent(int precision, const FwdK& k, int S, hipStream_t st);
 
+// persistent grid: as many 4-wave workgroups as fit the chip at once (one per CU for the wide nets, whose slabs take most of the
+// CU's LDS; two for the narrow ones), asked of the runtime once per kernel
+template <auto kernel>
 inline int mlp_grid(int ntiles) {
+  static int per_cu = 0, n_cu = 0;  // per kernel instantiation
+  if (per_cu == 0) {
+    int nb = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) nb = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    per_cu = nb > 2 ? 2 : nb;
+  }
   int g = (ntiles + 3) / 4;
-  if (g > 256) g = 256;  // persistent: one 4-wave block per CU (the slab takes most of the CU's LDS)
+  if (g > n_cu * per_cu) g = n_cu * per_cu;
   return g < 1 ? 1 : g;
 }
+#define LAB4D_MLP_LAUNCH(KERNEL, k, st)                                                              \
+  do {                                                                                               \
+    constexpr auto kfn = &KERNEL;                                                                    \
+    hipLaunchKernelGGL(kfn, dim3(mlp_grid<kfn>((k).ntiles)), dim3(256), 0, st, k);                   \
+  } while (0)
 
 #define LAB4D_MLP_INSTANTIATE(Net)                                                                                        \
   namespace lab4d {                                                                                                       \
@@ -1349,12 +1406,12 @@ inline int mlp_grid(int ntiles) {
     FwdK k = k0;                                                                                                          \
     if (precision == LAB4D_PREC_BF16) {                                                                                   \
       k.ntiles = k.S_pad / PBF16::TILE; /* padded tail tiles are processed too: they zero-fill dz */                                                                                  \
-      if (k.emb) hipLaunchKernelGGL((k_mlp_fwd<Net, PBF16, false, true>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);  \
-      else hipLaunchKernelGGL((k_mlp_fwd<Net, PBF16, false, false>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);       \
+      if (k.emb) LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PBF16, false, true>), k, st);  \
+      else LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PBF16, false, false>), k, st);       \
     } else if (precision == LAB4D_PREC_F32) {                                                                             \
       k.ntiles = k.S_pad / PF32::TILE;                                                                                   \
-      if (k.emb) hipLaunchKernelGGL((k_mlp_fwd<Net, PF32, false, true>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);   \
-      else hipLaunchKernelGGL((k_mlp_fwd<Net, PF32, false, false>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);        \
+      if (k.emb) LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PF32, false, true>), k, st);   \
+      else LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PF32, false, false>), k, st);        \
     } else {                                                                                                              \
       set_error("mlp_forward: bad precision %d", precision);                                                              \
       return LAB4D_EINVAL;                                                                                                \
@@ -1366,10 +1423,10 @@ inline int mlp_grid(int ntiles) {
     BwdK k = k0;                                                                                                          \
     if (precision == LAB4D_PREC_BF16) {                                                                                   \
       k.ntiles = k.S_pad / PBF16::TILE; /* padded tail tiles are processed too: they zero-fill dz */                                                                                  \
-      hipLaunchKernelGGL((k_mlp_bwd<Net, PBF16>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);                         \
+      LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16>), k, st);                         \
     } else if (precision == LAB4D_PREC_F32) {                                                                             \
       k.ntiles = k.S_pad / PF32::TILE;                                                                                   \
-      hipLaunchKernelGGL((k_mlp_bwd<Net, PF32>), dim3(mlp_grid(k.ntiles)), dim3(256), 0, st, k);                          \
+      LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PF32>), k, st);                          \
     } else {                                                                                                              \
       set_error("mlp_backward: bad precision %d", precision);                                                             \
       return LAB4D_EINVAL;                                                                                                \
