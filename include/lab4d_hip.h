@@ -223,6 +223,11 @@ int lab4d_l2_normalize_backward(const float* x, const float* g, int S, int C, fl
  * ------------------------------------------------------------------------------------------ */
 #include "lab4d_hashgrid.h"
 
+/* ------------------------------------------------------------------------------------------
+ * 9. Batch ingestion -- dataloader/vidloader.py:217-358, utils/numpy_utils.py:97-122.  See lab4d_ingest.h.
+ * ------------------------------------------------------------------------------------------ */
+#include "lab4d_ingest.h"
+
 #ifdef __cplusplus
 }
 #endif

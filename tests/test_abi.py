@@ -39,6 +39,7 @@ def test_python_signatures_cover_the_header():
     import lab4d_amd.deformable  # noqa: F401  (registers the mlp / skinning / gauss-density signatures)
     import lab4d_amd.mlp  # noqa: F401
     import lab4d_amd.hashgrid  # noqa: F401
+    import lab4d_amd.ingest  # noqa: F401
     import lab4d_amd.multifields  # noqa: F401
     import lab4d_amd.optim  # noqa: F401
     import lab4d_amd.pose  # noqa: F401
