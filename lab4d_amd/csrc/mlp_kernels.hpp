@@ -818,7 +818,10 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
       };
       // ---- MFMA phase of one M-tile: acc = bias + W[mt] x.  `pre` = tile whose A groups / bias are requested behind it
       // (each group's registers are re-loaded as soon as its MFMAs have issued), or -1.
-      auto mfma_tile = [&](auto has_pre, int pre, uint4 (&A)[G], f32x16_t (&bv)[NB], f32x16_t (&acc)[NT]) {
+      // rbuf >= 0 (progressive reload): the LDS-shared groups of tile `pre` are read back from buffer rbuf group by group, each
+      // right after the MFMAs that consumed the register it overwrites -- the LDS round trip of the next tile's weights hides
+      // behind this tile's matrix work instead of sitting between the barrier and the first MFMA of every step.
+      auto mfma_tile = [&](auto has_pre, int pre, int rbuf, uint4 (&A)[G], f32x16_t (&bv)[NB], f32x16_t (&acc)[NT]) {
         constexpr bool PRE = decltype(has_pre)::value;
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = bv[NB == 1 ? 0 : t];
@@ -828,6 +831,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
           for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], g < GE ? emb[t][g < GE ? g : 0] : bin[t][g >= GE ? g - GE : 0]);
           if constexpr (PRE) {
             if (g >= GL) A[g] = load_a(Wl, G, pre, g, lane);  // groups beyond the LDS-shared ones (g is unrolled)
+            else if (rbuf >= 0) A[g] = abuf[(rbuf * ACG + g) * 64 + lane];
           }
         }
         if constexpr (PRE) load_bias(pre, bv);
@@ -994,8 +998,51 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
       prefetch(0);
       wg_step_barrier();
       a_grab(0, A);
-      mfma_tile(std::bool_constant<(MT > 1)>{}, 1, A, bv, acc0);
       constexpr int NSTEP = MT - 1, NPAIR = NSTEP / 2;
+#ifdef LAB4D_PROG_FWD  // measured: -3..-6 % on the backward chains, but the forward chains (which also hold the embedding and the bias tile) spill 26-73 registers with it and get 7-10 % slower: backward only
+      // Progressive weight reload.  Step of tile T: the A registers hold tile T; each group is re-read from buffer (T+1)&1
+      // (tile T+1, stashed during the previous step) right behind its MFMAs; the staging registers (tile T+2) go to buffer T&1,
+      // which was last read during the previous step; tile T+3 is requested.  One barrier per step as before: it orders
+      // "everybody has read buffer T&1" before this step's stash and "stash of tile T+1 visible" before this step's reads.
+      mfma_tile(std::bool_constant<(MT > 1)>{}, 1, 1, A, bv, acc0);  // tile 0, reloading tile 1 from buffer 1
+      if constexpr (MT > 1) {
+        wg_step_barrier();  // every wave has grabbed tile 0 out of buffer 0
+        a_stash(0, stg);    // tile 2
+        a_fetch(MT > 3 ? 3 : MT - 1, stg);
+      }
+      if constexpr (NPAIR > 0) {
+#pragma nounroll
+        for (int k = 0; k < 2 * NPAIR; k += 2) {
+          wg_step_barrier();
+          mfma_tile(std::true_type{}, k + 2 < MT ? k + 2 : MT - 1, 0, A, bv, acc1);  // tile k+1, reloading tile k+2 from buffer 0
+          epilogue(k, acc0, pw, pbits);
+          prefetch(k + 1);
+          a_stash(1, stg);  // tile k+3
+          a_fetch(k + 4 < MT ? k + 4 : MT - 1, stg);
+          flush(k, pw, pbits);
+          wg_step_barrier();
+          mfma_tile(std::true_type{}, k + 3 < MT ? k + 3 : MT - 1, 1, A, bv, acc0);  // tile k+2, reloading tile k+3 from buffer 1
+          epilogue(k + 1, acc1, pw, pbits);
+          prefetch(k + 2 < MT ? k + 2 : MT - 1);
+          a_stash(0, stg);  // tile k+4
+          a_fetch(k + 5 < MT ? k + 5 : MT - 1, stg);
+          flush(k + 1, pw, pbits);
+        }
+      }
+      if constexpr (NSTEP % 2 == 1) {
+        wg_step_barrier();
+        mfma_tile(std::false_type{}, 0, -1, A, bv, acc1);  // tile MT-1
+        epilogue(MT - 2, acc0, pw, pbits);
+        flush(MT - 2, pw, pbits);
+        prefetch(MT - 1);
+        epilogue(MT - 1, acc1, pw, pbits);
+        flush(MT - 1, pw, pbits);
+      } else {
+        epilogue(MT - 1, acc0, pw, pbits);
+        flush(MT - 1, pw, pbits);
+      }
+#else
+      mfma_tile(std::bool_constant<(MT > 1)>{}, 1, -1, A, bv, acc0);
       if constexpr (NPAIR > 0) {
 #pragma nounroll
         for (int k = 0; k < 2 * NPAIR; k += 2) {
@@ -1003,7 +1050,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
           // to buffer 0 (read last in step k-1); then A(k+3) is requested, and only then tile k's stores are issued
           wg_step_barrier();
           a_grab(1, A);
-          mfma_tile(std::true_type{}, k + 2 < MT ? k + 2 : MT - 1, A, bv, acc1);  // tile k+1
+          mfma_tile(std::true_type{}, k + 2 < MT ? k + 2 : MT - 1, -1, A, bv, acc1);  // tile k+1
           epilogue(k, acc0, pw, pbits);
           prefetch(k + 1);
           a_stash(0, stg);
@@ -1012,7 +1059,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
           // step k+1
           wg_step_barrier();
           a_grab(0, A);
-          mfma_tile(std::true_type{}, k + 3 < MT ? k + 3 : MT - 1, A, bv, acc0);  // tile k+2
+          mfma_tile(std::true_type{}, k + 3 < MT ? k + 3 : MT - 1, -1, A, bv, acc0);  // tile k+2
           epilogue(k + 1, acc1, pw, pbits);
           prefetch(k + 2 < MT ? k + 2 : MT - 1);
           a_stash(1, stg);
@@ -1023,7 +1070,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
       if constexpr (NSTEP % 2 == 1) {
         wg_step_barrier();
         a_grab(1, A);
-        mfma_tile(std::false_type{}, 0, A, bv, acc1);  // tile MT-1
+        mfma_tile(std::false_type{}, 0, -1, A, bv, acc1);  // tile MT-1
         epilogue(MT - 2, acc0, pw, pbits);
         flush(MT - 2, pw, pbits);
         prefetch(MT - 1);
@@ -1033,6 +1080,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
         epilogue(MT - 1, acc0, pw, pbits);
         flush(MT - 1, pw, pbits);
       }
+#endif
     });
   }
 }
@@ -1114,7 +1162,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
         for (int u = 0; u < GK; ++u) bin[t][u] = slab[(t * UW + u) * 64];
 
       // MFMA phase of one row tile of W^T: acc = W^T[mt] dz.  pre = row tile whose A groups are requested behind it.
-      auto mfma_tile = [&](auto has_pre, int pre, uint4 (&A)[GK], f32x16_t (&acc)[NT]) {
+      auto mfma_tile = [&](auto has_pre, int pre, int rbuf, uint4 (&A)[GK], f32x16_t (&acc)[NT]) {
         constexpr bool PRE = decltype(has_pre)::value;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -1126,6 +1174,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
           for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], bin[t][g]);
           if constexpr (PRE) {
             if (g >= GL) A[g] = load_a(Wt, GK, pre, g, lane);  // groups beyond the LDS-shared ones (g is unrolled)
+            else if (rbuf >= 0) A[g] = abuf[(rbuf * ACG + g) * 64 + lane];  // progressive reload (see the forward kernel)
           }
         }
       };
@@ -1173,14 +1222,53 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
           pre(0);
           wg_step_barrier();
           a_grab(0, A);
-          mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, A, acc0);
           constexpr int NSTEP = N - 1, NPAIR = NSTEP / 2;
+#ifndef LAB4D_ABL_NOPROG
+          mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, 1, A, acc0);  // tile 0, reloading tile 1 from buffer 1
+          if constexpr (N > 1) {
+            wg_step_barrier();  // every wave has grabbed tile 0 out of buffer 0
+            a_stash(0, stg);    // tile 2
+            a_fetch(tile0 + (N > 3 ? 3 : N - 1), stg);
+          }
+          if constexpr (NPAIR > 0) {
+#pragma nounroll
+            for (int k = 0; k < 2 * NPAIR; k += 2) {
+              wg_step_barrier();
+              mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), 0, A, acc1);
+              epi(k, acc0, pw);
+              pre(k + 1);
+              a_stash(1, stg);
+              a_fetch(tile0 + (k + 4 < N ? k + 4 : N - 1), stg);
+              fl(k, pw);
+              wg_step_barrier();
+              mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), 1, A, acc0);
+              epi(k + 1, acc1, pw);
+              pre(k + 2 < N ? k + 2 : N - 1);
+              a_stash(0, stg);
+              a_fetch(tile0 + (k + 5 < N ? k + 5 : N - 1), stg);
+              fl(k + 1, pw);
+            }
+          }
+          if constexpr (NSTEP % 2 == 1) {
+            wg_step_barrier();
+            mfma_tile(std::false_type{}, 0, -1, A, acc1);
+            epi(N - 2, acc0, pw);
+            fl(N - 2, pw);
+            pre(N - 1);
+            epi(N - 1, acc1, pw);
+            fl(N - 1, pw);
+          } else {
+            epi(N - 1, acc0, pw);
+            fl(N - 1, pw);
+          }
+#else
+          mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, -1, A, acc0);
           if constexpr (NPAIR > 0) {
 #pragma nounroll
             for (int k = 0; k < 2 * NPAIR; k += 2) {
               wg_step_barrier();
               a_grab(1, A);
-              mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), A, acc1);
+              mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), -1, A, acc1);
               epi(k, acc0, pw);
               pre(k + 1);
               a_stash(0, stg);
@@ -1188,7 +1276,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
               fl(k, pw);
               wg_step_barrier();
               a_grab(0, A);
-              mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), A, acc0);
+              mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), -1, A, acc0);
               epi(k + 1, acc1, pw);
               pre(k + 2 < N ? k + 2 : N - 1);
               a_stash(1, stg);
@@ -1199,7 +1287,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
           if constexpr (NSTEP % 2 == 1) {
             wg_step_barrier();
             a_grab(1, A);
-            mfma_tile(std::false_type{}, 0, A, acc1);
+            mfma_tile(std::false_type{}, 0, -1, A, acc1);
             epi(N - 2, acc0, pw);
             fl(N - 2, pw);
             pre(N - 1);
@@ -1209,6 +1297,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
             epi(N - 1, acc0, pw);
             fl(N - 1, pw);
           }
+#endif
         }
       };
       uint4 raw[4];            // prefetched tile: stored embedding (epi_emb) or external gradient (epi_act)
