@@ -33,9 +33,9 @@ PEAK_BF16 = 2.5e15  # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
 # algorithmic GEMM FLOPs of the fg training graph per sample, fwd+bwd: 3 x 2 x 918,912 MAC
 FLOP_PER_SAMPLE = 5513472.0
-# device memory per sample of a training chunk (stored activations, dZ, masks, per-sample fields): measured 152 GiB for a
-# 4.19 M-sample chunk (profiles/r01_bench.json) -- used by --dry-ranks to check that a rank's chunk fits
-BYTES_PER_SAMPLE = 152 * 2**30 / (2 * 32 * 512 * 128)
+# device memory per sample of a training chunk (stored activations, dZ, masks, per-sample fields): measured 126.1 GiB peak for an
+# 8.39 M-sample chunk (64 rows x 2 frames, profiles/r02_bench.json) -- used by --dry-ranks to check that a rank's chunk fits
+BYTES_PER_SAMPLE = 126.1 * 2**30 / (2 * 64 * 512 * 128)
 
 
 def parse():
@@ -45,13 +45,17 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=128)
-    ap.add_argument("--chunk-rows", type=int, default=32, help="image rows per frame per chunk (32 rows x 512 = 16384 rays/frame; ~150 GiB of HBM)")
+    ap.add_argument("--chunk-rows", type=int, default=None, help="image rows per frame per chunk (64 rows x 512 = 32768 rays/frame = 8.4 M samples per chunk; ~126 GiB of the 288 GB: "
+                                                                "fewer, larger launches -- 32-row chunks measured 5.8 %% slower, 128 rows do not fit)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays per frame of one CPU-baseline pass (1 warm-up + 3 timed passes)")
     ap.add_argument("--dry-ranks", type=int, default=0, help="no GPU work: print every rank's row band, chunk list and memory estimate for --gpus N")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.chunk_rows is None:
+        a.chunk_rows = 64 if a.dtype == "bf16" else 32  # fp32 activations are twice the size
+    return a
 
 
 def make_problem(res, device):
