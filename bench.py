@@ -11,7 +11,10 @@ A *step* is one pass of the hot path over one batch of synthetic input: one 512x
 feature MLP + matching -> gaussian-bone density -> compositing -> losses -> backward to every weight and
 per-frame input), gradients all-reduced across ranks (RCCL) and applied with AdamW.  Rays are processed in
 chunks with gradient accumulation (per-chunk loss normalisers = the reference's per-rank DDP semantics).
-With --gpus N the frame pair is split into N row bands (strong scaling, same total work).
+With --gpus N the rows of the frame pair are dealt out to the N ranks round-robin (strong scaling, same total work), and a rank deals
+its rows out to its chunks the same way: every chunk then sees the whole image (object and background) like one of the
+reference's random pixel batches, instead of a band of empty background at the top of the frame whose masked loss terms have no
+positive element (their mean over an empty selection is NaN in the reference, engine/model.py:602, and would poison the step).
 
 Prints ONE JSON line on rank 0.
 """
@@ -48,6 +51,9 @@ def parse():
     ap.add_argument("--chunk-rows", type=int, default=None, help="image rows per frame per chunk (64 rows x 512 = 32768 rays/frame = 8.4 M samples per chunk; ~126 GiB of the 288 GB: "
                                                                 "fewer, larger launches -- 32-row chunks measured 5.8 %% slower, 128 rows do not fit)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--config", default="fg", choices=["fg", "comp"],
+                    help="fg: BASELINE configs[1] (the headline metric).  comp: BASELINE configs[2]'s per-GPU shape -- fg field with the 18-joint human skeleton and "
+                         "composed motion (comp_skel-human_dense) + background field, compose_fields, comp losses; spp/2 samples per field")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays per frame of one CPU-baseline pass (1 warm-up + 3 timed passes)")
@@ -58,8 +64,20 @@ def parse():
     return a
 
 
-def make_problem(res, device):
+def make_problem(res, device, comp=False):
     from lab4d_amd import synthetic
+    if comp:  # MultiFields(field_type="comp", fg_motion="comp_skel-human_dense"): 18 bones + dense post-warp
+        w = synthetic.add_dense_weights(synthetic.make_weights(0, num_bones=18), 0)
+        P = synthetic.to_device(w, device)
+        for k, v in P.items():
+            if v.dtype.is_floating_point and k != "aabb":
+                v.requires_grad_(True)
+        fr = synthetic.to_device(synthetic.add_codes(synthetic.make_frames(1, 2, res, num_bones=18), w), device)
+        Pb = synthetic.to_device(synthetic.make_bg_weights(0), device)
+        for v in Pb.values():
+            v.requires_grad_(True)
+        frb = synthetic.add_bg_codes(synthetic.to_device(synthetic.make_bg_frames(1, 2, res), device), Pb)
+        return P, fr, Pb, frb
     P = synthetic.to_device(synthetic.make_weights(0), device)
     for k, v in P.items():
         if v.dtype.is_floating_point and k != "aabb":
@@ -69,8 +87,9 @@ def make_problem(res, device):
 
 
 def chunk_inputs(res, row0, rows, device, seed):
+    """Resident inputs of one chunk: rows = a list of image rows, or (with row0) the length of a contiguous band."""
     from lab4d_amd import deformable as DF, synthetic
-    hxy = synthetic.make_rays(res, 2, rows=(row0, row0 + rows))
+    hxy = synthetic.make_rays(res, 2, rows=(row0, row0 + rows) if isinstance(rows, int) else list(rows))
     batch = synthetic.to_device(synthetic.make_targets(seed, 2, hxy.shape[1], res, hxy), device)
     # get_mask_balance_wt (engine/model.py:401-424) depends on the targets only: part of the resident input, not of the timed step
     batch["mask_balance_wt"] = DF.mask_balance_wt(batch["mask"], batch["vis2d"], batch["is_detected"])
@@ -99,6 +118,22 @@ def train_chunk(DF, P, fr, hxy, batch, rng, spp, res, prec):
     return total.detach()
 
 
+# algorithmic GEMM FLOPs of the comp training graph per RAY at D samples per field, fwd+bwd: fg 918,912 MAC/sample + three
+# dense post-warps of 117,248 MAC (backward map once, forward map twice), bg 162,432 MAC/sample
+def comp_flop_per_ray(d_field):
+    return 3 * 2 * d_field * (918912 + 3 * 117248 + 162432)
+
+
+def train_chunk_comp(DF, P, fr, Pb, frb, hxy, batch, rng, spp, res, prec):
+    f = dict(fr)
+    f["feature"] = batch["feature"]
+    r = dict(rng, eik_inds_bg=rng["eik_inds"])
+    out = DF.render_train_comp(P, f, Pb, frb, hxy, r, flow_thresh=float(res), n_depth=spp // 2, prec=prec)
+    total = sum(DF.losses_comp(out, batch, res, DF.DEFAULT_LOSS_WT).values())
+    total.backward()
+    return total.detach()
+
+
 def eval_rate(DF, P, fr, inputs, spp, prec, use_graph):
     """Forward-only rate of the renderer: render_eval = importance sampling (spp/2 coarse samples -> density -> inverse-CDF
     -> spp samples), backward warp, visibility, normals / eikonal on every sample (one first-order backward of the sdf chain), colour /
@@ -107,7 +142,7 @@ def eval_rate(DF, P, fr, inputs, spp, prec, use_graph):
     dense bf16 peak."""
     half = inputs[0][0].shape[1] // 2
     n_ev = min(4, len(inputs))
-    pick = [inputs[(2 * i + 1) * len(inputs) // (2 * n_ev)] for i in range(n_ev)]  # row bands spread over the frame (top rows see no valid sample)
+    pick = [inputs[(2 * i + 1) * len(inputs) // (2 * n_ev)] for i in range(n_ev)]  # each chunk's rows are spread over the whole frame
     ev_in = [h[:, :half].contiguous() for h, _ in pick]
     st = ev_in[0].clone()
     counts = []
@@ -218,10 +253,15 @@ def cpu_baseline(res, spp, n_rays):
     return out
 
 
-def row_band(rank, world, res):
-    """Strong scaling: rank r renders image rows [r0, r1) of both frames; the last rank takes the remainder."""
-    rows_per_rank = res // world
-    return rank * rows_per_rank, ((rank + 1) * rows_per_rank if rank < world - 1 else res)
+def rank_rows(rank, world, res):
+    """Strong scaling: rank r renders image rows r, r + world, r + 2 world, ... of both frames (round-robin: every rank sees the whole
+    image; the first res % world ranks hold one row more)."""
+    return list(range(rank, res, world))
+
+
+def chunk_rows_of(rows, n_chunks):
+    """A rank's rows dealt out to its chunks round-robin (chunk c takes rows[c::n_chunks])."""
+    return [rows[c::n_chunks] for c in range(n_chunks)]
 
 
 def allreduce_flat(flat_grad, world):
@@ -232,12 +272,14 @@ def allreduce_flat(flat_grad, world):
 
 
 def rank_plan(rank, world, res, chunk_rows, spp):
-    """Row band, chunk list and device-memory estimate of one rank (also what --dry-ranks prints for every rank)."""
-    r0, r1 = row_band(rank, world, res)
-    chunks = [(y, min(chunk_rows, r1 - y)) for y in range(r0, r1, chunk_rows)]
-    samples = max(2 * n * res * spp for _, n in chunks)
-    return {"rank": rank, "rows": [r0, r1], "chunks": chunks, "uniform": len({n for _, n in chunks}) == 1,
-            "rays_per_step": 2 * res * (r1 - r0), "peak_chunk_samples": samples,
+    """Rows, chunk list and device-memory estimate of one rank (also what --dry-ranks prints for every rank)."""
+    rows = rank_rows(rank, world, res)
+    n_chunks = max(1, -(-len(rows) // chunk_rows))
+    chunks = chunk_rows_of(rows, n_chunks)
+    samples = max(2 * len(c) * res * spp for c in chunks)
+    return {"rank": rank, "rows": "%d::%d (%d rows)" % (rank, world, len(rows)), "n_rows": len(rows), "chunks": chunks,
+            "chunk_sizes": [len(c) for c in chunks], "uniform": len({len(c) for c in chunks}) == 1,
+            "rays_per_step": 2 * res * len(rows), "peak_chunk_samples": samples,
             "est_peak_hbm_gib": round(samples * BYTES_PER_SAMPLE / 2**30, 1)}
 
 
@@ -245,12 +287,13 @@ def dry_ranks(a):
     """De-risk --gpus N without the hardware: every rank's plan, and the invariants the multi-process run relies on."""
     world = a.dry_ranks
     plans = [rank_plan(r, world, a.res, a.chunk_rows, a.spp) for r in range(world)]
-    rows = sorted(sum(([p["rows"]] for p in plans), []))
-    assert rows[0][0] == 0 and rows[-1][1] == a.res and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1)), "bands must tile the frame"
+    rows = sorted(y for p in plans for c in p["chunks"] for y in c)
+    assert rows == list(range(a.res)), "the ranks' chunks must partition the rows of the frame"
     assert sum(p["rays_per_step"] for p in plans) == 2 * a.res * a.res
     for p in plans:
-        p["launch"] = "hipGraph replay per chunk" if p["uniform"] else "eager (chunk_rows does not divide the band: chunks differ in shape)"
+        p["launch"] = "hipGraph replay per chunk" if p["uniform"] else "eager (chunk_rows does not divide the rank's rows: chunks differ in shape)"
         assert p["est_peak_hbm_gib"] < 250, "rank %d would not fit 288 GB" % p["rank"]
+        p["chunks"] = ["%d::%d" % (c[0], c[1] - c[0]) if len(c) > 1 else str(c) for c in p["chunks"]]  # first row :: stride
     print(json.dumps({"world": world, "collective": "1 x all_reduce of the flat fp32 gradient per step", "plans": plans}))
 
 
@@ -276,8 +319,13 @@ def rank_main(a):
     _lib.lib()
     prec = mlp.PREC_BF16 if a.dtype == "bf16" else mlp.PREC_F32
     res, spp = a.res, a.spp
-    P, fr = make_problem(res, dev)
-    params = [v for k, v in P.items() if v.dtype.is_floating_point and v.requires_grad]
+    comp = a.config == "comp"
+    Pb = frb = None
+    if comp:
+        P, fr, Pb, frb = make_problem(res, dev, comp=True)
+    else:
+        P, fr = make_problem(res, dev)
+    params = [v for k, v in P.items() if v.dtype.is_floating_point and v.requires_grad] + (list(Pb.values()) if comp else [])
     # the reference's optimizer step (trainer.py:164-190,349-350,581-604): clip_grad_norm_(params, 5.0) + AdamW, one learning rate
     # per parameter -- here three launches over one flat buffer; p.grad are views of opt.flat_grad, which is also the all-reduce bucket
     from lab4d_amd.optim import FlatAdamW
@@ -285,18 +333,18 @@ def rank_main(a):
     mlp.FUSED_GRAD_ACCUM = True  # weight-gradient kernels add straight into those views (no scatter / AccumulateGrad per layer)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
-    # strong scaling: this rank renders rows [r0, r1) of both frames
+    # strong scaling: this rank renders rows rank::world of both frames, its chunks interleave those rows again
     plan = rank_plan(rank, world, res, a.chunk_rows, spp)
     chunks = plan["chunks"]
     # pre-build the inputs (resident in HBM before the timed region)
-    inputs = [chunk_inputs(res, y, n, dev, seed=100 + i) for i, (y, n) in enumerate(chunks)]
+    inputs = [chunk_inputs(res, None, rows, dev, seed=100 + i) for i, rows in enumerate(chunks)]
     rays_per_step = 2 * res * res
 
     # SURVEY 8d also asks for the forward-only rate: eval-mode render (importance sampling -> 128 samples, field, normals
     # through one first-order backward, compositing) of the same rays.  Measured before the training graph is captured
     # (its 150 GiB private pool would leave the allocator thrashing), eager launches, half a training chunk per call.
     eval_result = None
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not comp:
         try:
             eval_result = eval_rate(DF, P, fr, inputs, spp, prec, not a.no_graph)
         except Exception as e:  # an extra, never the headline: report the failure instead of losing the bench line
@@ -308,9 +356,19 @@ def rank_main(a):
     prologue = DF.FramePrologue(P, fr)
     fr = prologue.refresh()
     prologue.outs = None  # no autograd graph of the prologue (and none of its AccumulateGrad nodes) alive while the chunk is captured
+    prologue_bg = None
+    if comp:
+        prologue_bg = DF.BgPrologue(Pb, frb)
+        frb = prologue_bg.refresh()
+        prologue_bg.outs = None
 
+    if comp:
+        def train_chunk_(DF_, P_, fr_, hxy_, batch_, rng_, spp_, res_, prec_):
+            return train_chunk_comp(DF_, P_, fr_, Pb, frb, hxy_, batch_, rng_, spp_, res_, prec_)
+    else:
+        train_chunk_ = train_chunk
     M, N0 = inputs[0][0].shape[:2]
-    S0 = M * N0 * spp
+    S0 = M * N0 * (spp // 2 if comp else spp)
     uniform = all(h.shape == inputs[0][0].shape for h, _ in inputs)
     use_graph = (not a.no_graph) and uniform
     graph = None
@@ -327,19 +385,23 @@ def rank_main(a):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):  # eager warm-up on the capture stream: allocator pools, rocBLAS workspaces, column maps, packed weights
-                train_chunk(DF, P, fr, st_hxy, st_batch, st_rng, spp, res, prec)
+                train_chunk_(DF, P, fr, st_hxy, st_batch, st_rng, spp, res, prec)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            st_loss = train_chunk(DF, P, fr, st_hxy, st_batch, st_rng, spp, res, prec)
+            st_loss = train_chunk_(DF, P, fr, st_hxy, st_batch, st_rng, spp, res, prec)
     opt.zero_grad()
     prologue.zero_grad()  # the eager warm-up / capture passes accumulated into the leaves
+    if comp:
+        prologue_bg.zero_grad()
     ar_events = []
 
     def step():
         opt.zero_grad()
         last = None
         prologue.refresh()
+        if comp:
+            prologue_bg.refresh()
         for hxy, batch in inputs:
             if graph is not None:
                 st_hxy.copy_(hxy)
@@ -350,9 +412,11 @@ def rank_main(a):
                 graph.replay()
                 last = st_loss
             else:
-                last = train_chunk(DF, P, fr, hxy, batch, draw_rng(hxy.shape[0], hxy.shape[1], hxy.shape[0] * hxy.shape[1] * spp, dev, gen),
+                last = train_chunk_(DF, P, fr, hxy, batch, draw_rng(hxy.shape[0], hxy.shape[1], hxy.shape[0] * hxy.shape[1] * (spp // 2 if comp else spp), dev, gen),
                                    spp, res, prec)
         prologue.backward()
+        if comp:
+            prologue_bg.backward()
         if world > 1:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -388,7 +452,7 @@ def rank_main(a):
         _lib.PROF = {}
         n_prof_chunks = min(4, len(inputs))
         for hxy, batch in inputs[:n_prof_chunks]:
-            train_chunk(DF, P, fr, hxy, batch, draw_rng(M, N0, S0, dev, gen), spp, res, prec)
+            train_chunk_(DF, P, fr, hxy, batch, draw_rng(M, N0, S0, dev, gen), spp, res, prec)
         torch.cuda.synchronize()
         prof_src = "HIP events around every launch of the family in an eager re-run of %d chunks right after the timed region " \
                    "(the timed region replays a captured hipGraph, which cannot host events)" % n_prof_chunks
@@ -439,27 +503,33 @@ def rank_main(a):
             "metric": "rendered rays/sec (fwd+bwd) at 512\u00b2 \u00d7 128 samples; PSNR vs ref", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "cat-pikachu fg NeRF (Deformable skel-quad, 25 bones), %dx%d frame pair, %d samples/ray, training graph fwd+bwd+AdamW"
+            "config": {"workload": ("human-48-shaped fg+bg composite (MultiFields comp: fg Deformable comp_skel-human_dense, 18 bones + dense post-warp; bg NeRF), "
+                                    "%dx%d frame pair, %d + %d samples/ray composed, training graph fwd+bwd+AdamW" % (res, res, spp // 2, spp // 2)) if comp else
+                                   "cat-pikachu fg NeRF (Deformable skel-quad, 25 bones), %dx%d frame pair, %d samples/ray, training graph fwd+bwd+AdamW"
                                    % (res, res, spp), "rays_per_step": rays_per_step, "chunk_rays": 2 * a.chunk_rows * res,
-                       "parallelism": "ray-band x%d, one RCCL all-reduce of the flat fp32 gradient (%d elements) per step" % (world, opt.n),
+                       "parallelism": "rows dealt round-robin to %d rank(s) and to each rank's chunks, one RCCL all-reduce of the flat fp32 gradient (%d elements) per step" % (world, opt.n),
                        "launch": "hipGraph replay per chunk" if graph is not None else "eager",
                        "optimizer": "lab4d_amd.optim.FlatAdamW: clip_grad_norm_(5.0) + AdamW in 3 launches over one flat buffer; "
                                     "weight gradients accumulated into it by the wgrad kernels"},
             "rank_ms_per_step": [round(x, 2) for x in rank_ms], "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
-            "rank_plan": {k: plan[k] for k in ("rows", "rays_per_step", "est_peak_hbm_gib")},
+            "rank_plan": {k: plan[k] for k in ("rows", "chunk_sizes", "rays_per_step", "est_peak_hbm_gib")},
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-            "whole_graph_tflops": round(value * spp * FLOP_PER_SAMPLE / 1e12, 2),
-            "whole_graph_frac_of_peak": round(value * spp * FLOP_PER_SAMPLE / peak, 4),
+            "whole_graph_tflops": round(value * (comp_flop_per_ray(spp // 2) if comp else spp * FLOP_PER_SAMPLE) / 1e12, 2),
+            "whole_graph_frac_of_peak": round(value * (comp_flop_per_ray(spp // 2) if comp else spp * FLOP_PER_SAMPLE) / peak, 4),
             "roofline": roofline,
+            # sanity of the timed work: the loss of the last chunk and whether every parameter is still finite after the timed optimizer steps
+            "loss_last_chunk": float(last), "params_finite": bool(all(bool(torch.isfinite(p).all()) for p in params)),
         }
         if eval_result is not None:
             out["eval_forward_only"] = eval_result
-        if world == 1:
+        if comp:
+            out["metric"] = "rendered rays/sec (fwd+bwd), fg+bg composite at 512\u00b2 (BASELINE configs[2] per-GPU shape; not the headline metric)"
+        if world == 1 and not comp:
             try:
                 out["psnr_vs_ref_db"] = psnr_vs_reference(dev)
             except Exception as e:
                 out["psnr_vs_ref_db"] = {"error": repr(e)[:200]}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not comp:
             out["cpu_baseline"] = cpu_baseline(res, spp, a.cpu_rays)
         print(json.dumps(out))
     if world > 1:

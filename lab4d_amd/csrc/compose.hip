@@ -20,9 +20,15 @@ __global__ void __launch_bounds__(256) k_compose_order(const float* __restrict__
     for (int i = threadIdx.x; i < Dt; i += blockDim.x) {
       const float d = sd[i];
       int rank = 0;
+      // total order with NaN last (torch.sort's convention): without it every NaN depth ranks 0, slots of `order` stay unwritten
+      // and the gathers read wild indices -- a NaN (e.g. weights gone NaN upstream) must stay a NaN, not become a memory fault
+      const bool dn = d != d;
       for (int j = 0; j < Dt; ++j) {
         const float e = sd[j];
-        rank += (e < d) || (e == d && j < i);
+        const bool en = e != e;
+        const bool lt = dn ? !en : (e < d);
+        const bool eq = dn ? en : (e == d);
+        rank += lt || (eq && j < i);
       }
       order[(size_t)r * Dt + rank] = i;
       pos[(size_t)r * Dt + i] = rank;

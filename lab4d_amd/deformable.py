@@ -384,6 +384,30 @@ class FramePrologue:
         self.outs = None
 
 
+class BgPrologue(FramePrologue):
+    """The same once-per-step pattern for the background field of the `comp` configurations: its only ray-independent terms are the
+    instance-code lookups (embedding.py:246-264) that feed the per-frame biases."""
+    KEYS = {"code_base": "basefield.inst_embedding.mapping.weight", "code_color": "colorfield.inst_embedding.mapping.weight",
+            "code_vis": "vis_mlp.basefield.inst_embedding.mapping.weight"}
+
+    def refresh(self):
+        idx = lambda w: self.fr["inst_id"] if w.shape[0] > 1 else torch.zeros_like(self.fr["inst_id"])  # noqa: E731
+        self.outs = {k: self.P[n][idx(self.P[n])] for k, n in self.KEYS.items()}
+        if self.leaves is None:
+            self.leaves = {}
+            for k, v in self.outs.items():
+                leaf = v.detach().clone().contiguous()
+                if v.requires_grad:
+                    leaf.requires_grad_(True)
+                    leaf.grad = torch.zeros_like(leaf)
+                self.leaves[k] = leaf
+        else:
+            with torch.no_grad():
+                for k, v in self.outs.items():
+                    self.leaves[k].copy_(v)
+        return dict(self.fr, **self.leaves)
+
+
 def _warp_fn(P, fr, prec):
     """The fg field's warp as a closure over its per-frame inputs: SkinningWarp, or ComposedWarp when fr carries the dense
     post-warp's inputs.  partner=True: the warp into the pair partner's frame (compute_flow, nerf.py:966-973) -- the

@@ -209,8 +209,9 @@ def make_rays(res, M, rows=None):
     """Full pixel grid hxy (M, N, 3) = (x+0.5?, ...) -- the reference's create_xy_grid
     (trainer.py:493-506) uses integer pixel coordinates [0,res) with homogeneous 1."""
     ys, xs = torch.meshgrid(torch.arange(res, dtype=torch.float32), torch.arange(res, dtype=torch.float32), indexing="ij")
-    if rows is not None:
-        ys, xs = ys[rows[0]:rows[1]], xs[rows[0]:rows[1]]
+    if rows is not None:  # (first, last+1) of a contiguous band, or an explicit list / tensor of row indices
+        sel = slice(rows[0], rows[1]) if isinstance(rows, tuple) else torch.as_tensor(rows, dtype=torch.long)
+        ys, xs = ys[sel], xs[sel]
     hxy = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(xs.numel())], -1)
     return hxy[None].repeat(M, 1, 1).contiguous()
 

@@ -1,4 +1,4 @@
-"""The N>1 path on CPU (gloo; world_size 2 and 8, one process per rank like the GPU job): bench.py's own row-band partition and
+"""The N>1 path on CPU (gloo; world_size 2 and 8, one process per rank like the GPU job): bench.py's own round-robin row partition and
 its ONE collective -- `bench.allreduce_flat` over the optimizer's flat gradient buffer (`lab4d_amd.optim.FlatAdamW.flat_grad`,
 the product's bucket: parameters of different shapes, each padded to 4 elements) -- reproduce the data-parallel semantics of the
 reference (DDP: every rank normalises its loss over its own rays, gradients are averaged over ranks), including an
@@ -19,15 +19,16 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (the sharding / all-reduce helpers of the real bench, not a copy)
 
 
-def bands(res, world):
-    return [bench.row_band(r, world, res) for r in range(world)]
-
-
-def test_row_bands_partition_the_frame():
+def test_rank_rows_and_chunks_partition_the_frame():
     for res, world in [(512, 1), (512, 2), (512, 8), (500, 8), (64, 3)]:
-        b = bands(res, world)
-        assert b[0][0] == 0 and b[-1][1] == res
-        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        rows = [bench.rank_rows(r, world, res) for r in range(world)]
+        assert sorted(y for rr in rows for y in rr) == list(range(res))
+        assert max(len(rr) for rr in rows) - min(len(rr) for rr in rows) <= 1
+        for rr in rows:  # a rank's rows dealt out to its chunks: a partition again, every chunk spread over the whole image
+            for n in (1, 2, 4):
+                ch = bench.chunk_rows_of(rr, n)
+                assert sorted(y for c in ch for y in c) == rr
+                assert all(c and max(c) - min(c) >= res - 2 * world * n for c in ch)
 
 
 def test_dry_ranks_plans():
@@ -40,7 +41,7 @@ def test_dry_ranks_plans():
         assert d["world"] == world and len(d["plans"]) == world
         assert sum(p["rays_per_step"] for p in d["plans"]) == 2 * res * res
         if res == 512:
-            assert all(p["uniform"] and p["est_peak_hbm_gib"] <= 152.0 for p in d["plans"])
+            assert all(p["uniform"] and p["est_peak_hbm_gib"] <= 152.0 and sum(p["chunk_sizes"]) == p["n_rows"] for p in d["plans"])
 
 
 def _params():
@@ -49,13 +50,12 @@ def _params():
 
 
 def _rank_loss(params, rank, world, res):
-    """A stand-in for one rank's training loss: its band of rows, normalised over ITS rows (per-rank normaliser)."""
+    """A stand-in for one rank's training loss: its rows, normalised over ITS rows (per-rank normaliser)."""
     from oracle import lab4d_oracle as O
     W, b, V, c = params
     g = torch.Generator().manual_seed(1)
     x_all = torch.randn(res, 3, generator=g)
-    r0, r1 = bench.row_band(rank, world, res)
-    e = O.pos_embedding(x_all[r0:r1], 10)
+    e = O.pos_embedding(x_all[bench.rank_rows(rank, world, res)], 10)
     return (e @ W.t()).pow(2).mean() + (b * (rank + 1)).sum() + (e[:, :7] @ V.t()).abs().mean() * c.sum()
 
 
@@ -90,7 +90,7 @@ def test_flat_gradient_allreduce_is_the_mean_of_the_rank_gradients(world, res, p
     [p.join(60) for p in ps]
     for r in range(1, world):
         assert torch.equal(got[r][0], got[0][0]), "every rank holds the same reduced bucket"
-    # expected: mean over ranks of each rank's own gradient (uneven last band at res=500: 62 rows x 7 ranks + 66)
+    # expected: mean over ranks of each rank's own gradient (uneven shares at res=500: 63 rows for the first four ranks, 62 for the others)
     expect = None
     for r in range(world):
         params = _params()
@@ -98,13 +98,13 @@ def test_flat_gradient_allreduce_is_the_mean_of_the_rank_gradients(world, res, p
         expect = [g / world for g in gs] if expect is None else [e + g / world for e, g in zip(expect, gs)]
     for g, e in zip(got[0][1], expect):
         assert torch.allclose(g, e, rtol=1e-5, atol=1e-7)
-    if res % world == 0:  # equal bands: mean of per-band means == global mean (the single-process gradient)
+    if res % world == 0:  # equal shares: mean of per-rank means == global mean (the single-process gradient)
         params = _params()
         W = params[0]
         from oracle import lab4d_oracle as O
         x_all = torch.randn(res, 3, generator=torch.Generator().manual_seed(1))
         (gW,) = torch.autograd.grad((O.pos_embedding(x_all, 10) @ W.t()).pow(2).mean(), [W])
-        part = torch.autograd.grad(sum((O.pos_embedding(x_all[slice(*bench.row_band(r, world, res))], 10) @ W.t()).pow(2).mean() for r in range(world)) / world, [W])[0]
+        part = torch.autograd.grad(sum((O.pos_embedding(x_all[bench.rank_rows(r, world, res)], 10) @ W.t()).pow(2).mean() for r in range(world)) / world, [W])[0]
         assert torch.allclose(gW, part, rtol=1e-5, atol=1e-7)
     # padding slots of the bucket (parameters are padded to 4 elements) stay zero through the reduction
     flat = got[0][0]

@@ -467,3 +467,24 @@ def test_compacted_chain_equals_the_chain_on_gathered_samples():
     idx0, count0 = RU.compact(torch.zeros_like(mask))
     out = mlp.run_chain_compacted(mlp.NET_VIS, mlp.PREC_BF16, P, x_k, RU.frame_of(idx0, count0, spf), count0, conds={0: fr["code_vis"]})
     assert int(count0) == 0 and out.shape == (M * spf, 1)
+
+
+def test_compose_order_with_nan_depths_is_still_a_permutation():
+    """A NaN depth (e.g. parameters gone NaN upstream) must come out as NaN values, never as a wild gather index: NaNs sort last,
+    like torch.sort, and `order` stays a permutation of every ray's samples."""
+    from lab4d_amd import multifields
+    g = torch.Generator().manual_seed(9)
+    M, N, Da, Db = 2, 33, 64, 64
+    a, b = torch.rand(M, N, Da, 1, generator=g), torch.rand(M, N, Db, 1, generator=g)
+    a[0, 3, 5:9] = float("nan")
+    b[1, 7, :] = float("nan")
+    a[1, 8, :] = float("nan")
+    b[1, 8, :] = float("nan")
+    order, pos = multifields.compose_order(a.to(DEV), b.to(DEV))
+    order, pos = order.cpu().long(), pos.cpu().long()
+    R, Dt = M * N, Da + Db
+    assert torch.equal(torch.sort(order, 1)[0], torch.arange(Dt).expand(R, Dt))
+    assert torch.equal(torch.gather(pos, 1, order), torch.arange(Dt).expand(R, Dt))
+    cat = torch.cat([a, b], 2).reshape(R, Dt)
+    ref = torch.sort(cat, stable=True, dim=1)[1]
+    assert torch.equal(order, ref)
