@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays per frame of one CPU-baseline pass (1 warm-up + 3 timed passes)")
+    ap.add_argument("--emulate-rank-of", type=int, default=0,
+                    help="single process, no collective: run rank 0's share of an N-rank job (its rows, chunks, prologue, optimizer step) -- the per-rank step "
+                         "time an N-GPU run cannot beat; reported under 'emulated', the headline fields stay those of the work actually done")
     ap.add_argument("--dry-ranks", type=int, default=0, help="no GPU work: print every rank's row band, chunk list and memory estimate for --gpus N")
     a = ap.parse_args()
     if a.chunk_rows is None:
@@ -334,11 +337,11 @@ def rank_main(a):
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
     # strong scaling: this rank renders rows rank::world of both frames, its chunks interleave those rows again
-    plan = rank_plan(rank, world, res, a.chunk_rows, spp)
+    plan = rank_plan(rank, world, res, a.chunk_rows, spp) if not a.emulate_rank_of else rank_plan(0, a.emulate_rank_of, res, a.chunk_rows, spp)
     chunks = plan["chunks"]
     # pre-build the inputs (resident in HBM before the timed region)
     inputs = [chunk_inputs(res, None, rows, dev, seed=100 + i) for i, rows in enumerate(chunks)]
-    rays_per_step = 2 * res * res
+    rays_per_step = 2 * res * res if not a.emulate_rank_of else plan["rays_per_step"]
 
     # SURVEY 8d also asks for the forward-only rate: eval-mode render (importance sampling -> 128 samples, field, normals
     # through one first-order backward, compositing) of the same rays.  Measured before the training graph is captured
@@ -518,6 +521,8 @@ def rank_main(a):
             "whole_graph_frac_of_peak": round(value * (comp_flop_per_ray(spp // 2) if comp else spp * FLOP_PER_SAMPLE) / peak, 4),
             "roofline": roofline,
             # sanity of the timed work: the loss of the last chunk and whether every parameter is still finite after the timed optimizer steps
+            "emulated": None if not a.emulate_rank_of else {"rank_0_of": a.emulate_rank_of, "note": "rank 0's share of the strong-scaling job on one GPU, no collective: "
+                         "ms_per_step is the per-rank time an %d-GPU run is bounded by (plus its all-reduce of %.1f MB)" % (a.emulate_rank_of, opt.n * 4 / 1e6)},
             "loss_last_chunk": float(last), "params_finite": bool(all(bool(torch.isfinite(p).all()) for p in params)),
         }
         if eval_result is not None:
