@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays per frame of one CPU-baseline pass (1 warm-up + 3 timed passes)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the gradient all-reduce even at world size 1 "
+                                                              "(exercises init order, graph capture next to RCCL's buffers and the collective call on a 1-GPU box)")
     ap.add_argument("--emulate-rank-of", type=int, default=0,
                     help="single process, no collective: run rank 0's share of an N-rank job (its rows, chunks, prologue, optimizer step) -- the per-rank step "
                          "time an N-GPU run cannot beat; reported under 'emulated', the headline fields stay those of the work actually done")
@@ -311,8 +313,12 @@ def rank_main(a):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl")  # RCCL on ROCm
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -420,7 +426,7 @@ def rank_main(a):
         prologue.backward()
         if comp:
             prologue_bg.backward()
-        if world > 1:
+        if use_dist:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             allreduce_flat(opt.flat_grad, world)
@@ -435,7 +441,7 @@ def rank_main(a):
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -463,7 +469,7 @@ def rank_main(a):
     _lib.PROF = None
     rank_ms = [dt / a.steps * 1e3]
     allreduce_ms = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev)
         ts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(ts, t)
@@ -537,7 +543,7 @@ def rank_main(a):
         if world == 1 and not a.no_cpu_baseline and not comp:
             out["cpu_baseline"] = cpu_baseline(res, spp, a.cpu_rays)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
