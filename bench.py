@@ -310,6 +310,11 @@ def main():
 
 
 def rank_main(a):
+    # stdout carries exactly ONE line, the JSON.  Native libraries write banners to file descriptor 1 (RCCL prints its version block there
+    # on first use): fd 1 is pointed at stderr for the run, the JSON goes to a private duplicate of the original stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -542,9 +547,12 @@ def rank_main(a):
                 out["psnr_vs_ref_db"] = {"error": repr(e)[:200]}
         if world == 1 and not a.no_cpu_baseline and not comp:
             out["cpu_baseline"] = cpu_baseline(res, spp, a.cpu_rays)
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
 
 
 if __name__ == "__main__":
