@@ -1,5 +1,6 @@
 // Host API of the fused MLP stack (include/lab4d_mlp.h) + weight-gradient GEMM + weight packing.
 // The chain kernels live in mlp_kernels.hpp / mlp_inst_*.hip.
+#include <cstdlib>
 #include "mlp_kernels.hpp"
 
 namespace lab4d {
@@ -702,8 +703,13 @@ extern "C" int lab4d_mlp_wgrad_mapped(int net, int layer, int precision, int S, 
   const int TM = mo_tiles >= 4 ? 4 : (mo_tiles >= 2 ? 2 : 1);
   const int ob_n = dma ? 1 : (big ? div_up(mo_tiles, 8) : div_up(mo_tiles, TM));
   const int kb_n = dma ? div_up(Kt, 64 * nbw) : (big ? div_up(nk_tiles, 8) : div_up(nk_tiles, 4));
-  // ~1024 workgroups in total (4 per CU); chunks are multiples of 256 samples (one 64-sample step per wave)
-  int nchunks = 1024 / (ob_n * kb_n); if (nchunks < 1) nchunks = 1;
+  // One resident wave of workgroups (256 CUs x 1 for the 256-row layers and the <= 32-row heads, x 2 for the 64 / 128-row rings), each
+  // streaming ONE long sample range: every workgroup ends with an fp32 atomic add of its whole dW block into the same addresses
+  // (256 KiB for a 256 x 256 layer), and pays one ring fill; with 1024 workgroups (round 1) those two fixed costs were 11 % of the
+  // 256-row launch (0.90 -> 0.80 ms at 4.2 M samples).  Chunks are multiples of 256 samples (one 64-sample step per wave).
+  static const int jobs_env = getenv("LAB4D_WGRAD_JOBS") ? atoi(getenv("LAB4D_WGRAD_JOBS")) : 0;  // kernel experiments
+  const int jobs_target = jobs_env > 0 ? jobs_env : ((dma && mo_tiles < 8) ? 512 : 256);
+  int nchunks = jobs_target / (ob_n * kb_n); if (nchunks < 1) nchunks = 1;
   int chunk = div_up(div_up(S_pad, nchunks), 256) * 256; if (chunk < 1024) chunk = 1024;
   // per-frame bias gradient folded into this kernel when frames are 256-sample aligned: chunks never straddle a
   // frame and the row sums of dz go straight to pf_db (saves a second pass over dz)
