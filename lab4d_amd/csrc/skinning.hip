@@ -23,6 +23,59 @@ __device__ __forceinline__ void qrot_gq(float w, V3 v, V3 p, V3 g, float& gw, V3
   gv = v * (-2.f * gp) + p * (2.f * gvv) + g * (2.f * vp) + cross(p, g) * (2.f * w);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// (S, C) fp32 rows staged through LDS.  One thread per sample reading its own C-float row straight from global memory touches one
+// 128-byte line per lane and instruction (a wave's 64 rows span 64*C*4 bytes; every line is re-fetched for each of the C column
+// steps once 16 waves per CU have pushed it out of the 32 KiB L1; partial-line writes are worse).  Instead a block's 256
+// consecutive rows -- ONE contiguous 256*C*4-byte region -- move between global memory and LDS with 16-byte-per-lane accesses,
+// and a thread reads / writes its row in LDS (row stride C | 1 floats: odd, hence bank-conflict-free).
+// ---------------------------------------------------------------------------------------------
+template <int C>
+struct RowTile {
+  static constexpr int CP = C | 1;            // odd row stride (floats)
+  static constexpr int FLOATS = 256 * CP;
+  // rows [s0, s0 + n) of g (row-major, C floats per row) -> tile; block-cooperative, all 256 threads call it
+  static __device__ __forceinline__ void load(const float* __restrict__ g, long s0, int n, float* __restrict__ tile) {
+    const float* src = g + s0 * C;
+    const int total = n * C;
+    if ((((size_t)src) & 15) == 0) {
+      for (int e = 4 * (int)threadIdx.x; e < total; e += 1024) {
+        if (e + 3 < total) {
+          const float4 v = *reinterpret_cast<const float4*>(src + e);
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const int r = (e + k) / C; tile[r * CP + (e + k) - r * C] = vv[k]; }
+        } else {
+          for (int k = 0; e + k < total; ++k) { const int r = (e + k) / C; tile[r * CP + (e + k) - r * C] = src[e + k]; }
+        }
+      }
+    } else {
+      for (int e = threadIdx.x; e < total; e += 256) { const int r = e / C; tile[r * CP + e - r * C] = src[e]; }
+    }
+  }
+  static __device__ __forceinline__ void store(float* __restrict__ g, long s0, int n, const float* __restrict__ tile) {
+    float* dst = g + s0 * C;
+    const int total = n * C;
+    if ((((size_t)dst) & 15) == 0) {
+      for (int e = 4 * (int)threadIdx.x; e < total; e += 1024) {
+        if (e + 3 < total) {
+          float vv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const int r = (e + k) / C; vv[k] = tile[r * CP + (e + k) - r * C]; }
+          *reinterpret_cast<float4*>(dst + e) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+          for (int k = 0; e + k < total; ++k) { const int r = (e + k) / C; dst[e + k] = tile[r * CP + (e + k) - r * C]; }
+        }
+      }
+    } else {
+      for (int e = threadIdx.x; e < total; e += 256) { const int r = e / C; dst[e] = tile[r * CP + e - r * C]; }
+    }
+  }
+};
+// frame of sample s: 32-bit division (a 64-bit division by a runtime value costs ~100 instructions per thread)
+__device__ __forceinline__ int frame_of(long s, int spf) { return (int)((unsigned)s / (unsigned)spf); }
+
 // ---------------------------------------------------------------------------------------------
 // bone coordinates
 // ---------------------------------------------------------------------------------------------
@@ -36,16 +89,30 @@ __device__ __forceinline__ V3 bone_apply(float w, V3 v, float dw, V3 dv, V3 x) {
 template <int B>
 __global__ void __launch_bounds__(256) k_bone_fwd(const float* __restrict__ xyz, const float* __restrict__ ar, const float* __restrict__ ad,
                                                    const float* __restrict__ gauss, long S, int spf, float* __restrict__ out) {
+  // one thread per (sample, bone); a block's 256 results are 768 consecutive floats of `out`: staged in LDS and written as float4
+  // (three 4-byte stores per thread at a 12-byte stride were three partial writes of every line)
+  __shared__ float tile[768];
   const long total = S * B;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long s = i / B;
-    const int b = (int)(i - s * B);
-    const int m = (int)(s / spf);
-    const float* r = ar + ((size_t)m * B + b) * 4;
-    const float* d = ad + ((size_t)m * B + b) * 4;
-    const V3 y = bone_apply(r[0], ldv3(r + 1), d[0], ldv3(d + 1), ldv3(xyz + s * 3));
-    const V3 gs = ldv3(gauss + 3 * b);
-    stv3(out + i * 3, {y.x / gs.x, y.y / gs.y, y.z / gs.z});
+  for (long i0 = (long)blockIdx.x * 256; i0 < total; i0 += (long)gridDim.x * 256) {
+    const long i = i0 + threadIdx.x;
+    if (i < total) {
+      const unsigned iu = (unsigned)i;  // S * B < 2^32 (host-checked)
+      const unsigned s = iu / (unsigned)B;
+      const int b = (int)(iu - s * (unsigned)B);
+      const int m = (int)(s / (unsigned)spf);
+      const float* r = ar + ((size_t)m * B + b) * 4;
+      const float* d = ad + ((size_t)m * B + b) * 4;
+      const V3 y = bone_apply(r[0], ldv3(r + 1), d[0], ldv3(d + 1), ldv3(xyz + (size_t)s * 3));
+      const V3 gs = ldv3(gauss + 3 * b);
+      stv3(tile + 3 * threadIdx.x, {y.x / gs.x, y.y / gs.y, y.z / gs.z});
+    }
+    __syncthreads();
+    const long rem = total - i0;
+    const int n = (int)(rem < 256 ? rem : 256) * 3;
+    float* dst = out + i0 * 3;  // i0 * 3 floats: a multiple of 768 floats, 16-byte aligned with the buffer
+    if (threadIdx.x * 4 + 3 < n) *reinterpret_cast<float4*>(dst + 4 * threadIdx.x) = *reinterpret_cast<const float4*>(tile + 4 * threadIdx.x);
+    else for (int e = 4 * threadIdx.x; e < n && e < 4 * (int)threadIdx.x + 4; ++e) dst[e] = tile[e];
+    __syncthreads();
   }
 }
 
@@ -53,17 +120,28 @@ __global__ void __launch_bounds__(256) k_bone_fwd(const float* __restrict__ xyz,
 template <int B>
 __global__ void __launch_bounds__(256) k_bone_bwd_x(const float* __restrict__ ar, const float* __restrict__ gauss,
                                                      const float* __restrict__ g_bone, long S, int spf, float* __restrict__ g_xyz) {
-  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(s / spf);
-    V3 acc = {0, 0, 0};
+  using T = RowTile<3 * B>;
+  __shared__ float tile[T::FLOATS];
+  for (long s0 = (long)blockIdx.x * 256; s0 < S; s0 += (long)gridDim.x * 256) {
+    const long rem = S - s0;
+    const int n = (int)(rem < 256 ? rem : 256);
+    T::load(g_bone, s0, n, tile);
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+      const long s = s0 + threadIdx.x;
+      const int m = frame_of(s, spf);
+      const float* row = tile + threadIdx.x * T::CP;
+      V3 acc = {0, 0, 0};
 #pragma unroll 5
-    for (int b = 0; b < B; ++b) {
-      const float* r = ar + ((size_t)m * B + b) * 4;
-      const V3 gs = ldv3(gauss + 3 * b);
-      const V3 g = ldv3(g_bone + (s * B + b) * 3);
-      acc = acc + qrot_t(r[0], ldv3(r + 1) * -1.f, {g.x / gs.x, g.y / gs.y, g.z / gs.z});
+      for (int b = 0; b < B; ++b) {
+        const float* r = ar + ((size_t)m * B + b) * 4;
+        const V3 gs = ldv3(gauss + 3 * b);
+        const V3 g = ldv3(row + 3 * b);
+        acc = acc + qrot_t(r[0], ldv3(r + 1) * -1.f, {g.x / gs.x, g.y / gs.y, g.z / gs.z});
+      }
+      stv3(g_xyz + s * 3, acc);
     }
-    stv3(g_xyz + s * 3, acc);
+    __syncthreads();
   }
 }
 
@@ -257,25 +335,35 @@ __device__ __forceinline__ V3 dq_apply(float w, V3 v, float dw, V3 dv, V3 x) {
   return qrot(w, v, x) + (v * -dw + dv * w + cross(v, dv)) * 2.f;
 }
 
-template <int B>
+template <int B, bool UNI>
 __global__ void __launch_bounds__(256) k_blend_fwd(const float* __restrict__ xyz, const float* __restrict__ aff, const float* __restrict__ raw,
                                                     const float* __restrict__ sr, const float* __restrict__ sd, long S, int spf,
                                                     float* __restrict__ out, float* __restrict__ ent, float* __restrict__ dskin) {
-  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(s / spf);
-    const V3 x = ldv3(xyz + s * 3);
-    Blend<B> bl;
-    blend_forward<B>(x, aff + (size_t)m * B * 12, raw + s * B, sr + (size_t)m * B * 4, sd + (size_t)m * B * 4, bl);
-    const float i = bl.inv;
-    const V3 y = dq_apply(bl.rw[0] * i, V3{bl.rw[1], bl.rw[2], bl.rw[3]} * i, bl.dw4[0] * i, V3{bl.dw4[1], bl.dw4[2], bl.dw4[3]} * i, x);
-    stv3(out + s * 3, y);
-    if (ent) ent[s] = bl.lse_minus_max;
-    if (dskin) {
-      float q = 0.f;
+  using T = RowTile<B>;
+  __shared__ float tile[T::FLOATS];
+  for (long s0 = (long)blockIdx.x * 256; s0 < S; s0 += (long)gridDim.x * 256) {
+    const long rem = S - s0;
+    const int n = (int)(rem < 256 ? rem : 256);
+    T::load(raw, s0, n, tile);
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+      const long s = s0 + threadIdx.x;
+      const int m = UNI ? __builtin_amdgcn_readfirstlane(frame_of(s0, spf)) : frame_of(s, spf);
+      const V3 x = ldv3(xyz + s * 3);
+      Blend<B> bl;
+      blend_forward<B>(x, aff + (size_t)m * B * 12, tile + threadIdx.x * T::CP, sr + (size_t)m * B * 4, sd + (size_t)m * B * 4, bl);
+      const float i = bl.inv;
+      const V3 y = dq_apply(bl.rw[0] * i, V3{bl.rw[1], bl.rw[2], bl.rw[3]} * i, bl.dw4[0] * i, V3{bl.dw4[1], bl.dw4[2], bl.dw4[3]} * i, x);
+      stv3(out + s * 3, y);
+      if (ent) ent[s] = bl.lse_minus_max;
+      if (dskin) {
+        float q = 0.f;
 #pragma unroll
-      for (int b = 0; b < B; ++b) q += bl.dl[b] * bl.dl[b];
-      dskin[s] = q / (float)B;   // warping.py:332
+        for (int b = 0; b < B; ++b) q += bl.dl[b] * bl.dl[b];
+        dskin[s] = q / (float)B;   // warping.py:332
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -285,76 +373,121 @@ __global__ void __launch_bounds__(256) k_blend_fwd(const float* __restrict__ xyz
 // of materialising an (S,3B) gradient it is (a) pushed to the point here (g_xyz += sum_b Abar_b[:, :3]^T (gsk_b c_b)) and
 // (b) reduced per frame as second moments Q_b = sum_s gsk_sb [x,1][x,1]^T (c_b is affine in x), from which
 // k_bone_gram_from_moments rebuilds the Gram matrix the parameter chain rule needs.
-template <int B>
+// UNI: spf is a multiple of 256, so a block's 256 samples share ONE frame: the frame index is wave-uniform (readfirstlane) and the
+// per-frame tables (25 x (12 + 4 + 4) floats) are fetched with scalar loads instead of being held in ~200 vector registers.
+template <int B, bool UNI>
 __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz, const float* __restrict__ aff, const float* __restrict__ raw,
                                                     const float* __restrict__ sr, const float* __restrict__ sd, const float* __restrict__ g_out,
                                                     const float* __restrict__ g_ent, const float* __restrict__ g_dskin, long S, int spf,
                                                     float* __restrict__ g_xyz, float* __restrict__ g_raw, float* __restrict__ work) {
-  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(s / spf);
-    const float* srm = sr + (size_t)m * B * 4;
-    const float* sdm = sd + (size_t)m * B * 4;
-    const float* affm = aff + (size_t)m * B * 12;
-    const V3 x = ldv3(xyz + s * 3), g = ldv3(g_out + s * 3);
+  // The (S,B) operands -- raw in; coef, gsk, g_raw out -- go through ONE LDS tile of 256 rows, one after the other (RowTile): the
+  // per-thread row accesses of the first version ran this kernel at 1.7 TB/s (a third of what its 516 bytes per sample allow).
+  using T = RowTile<B>;
+  __shared__ float tile[T::FLOATS];
+  for (long s0 = (long)blockIdx.x * 256; s0 < S; s0 += (long)gridDim.x * 256) {
+    const long rem = S - s0;
+    const int n = (int)(rem < 256 ? rem : 256);
+    const bool active = (int)threadIdx.x < n;
+    const long s = s0 + threadIdx.x;
+    float* row = tile + threadIdx.x * T::CP;
+    T::load(raw, s0, n, tile);
+    __syncthreads();
     Blend<B> bl;
-    blend_forward<B>(x, affm, raw + s * B, srm, sdm, bl);
-    const float i = bl.inv;
-    const float w = bl.rw[0] * i, dw = bl.dw4[0] * i;
-    const V3 v = V3{bl.rw[1], bl.rw[2], bl.rw[3]} * i, dv = V3{bl.dw4[1], bl.dw4[2], bl.dw4[3]} * i;
-    V3 gx = qrot_t(w, v, g);
-    float gqw; V3 gqv;
-    qrot_gq(w, v, x, g, gqw, gqv);
-    // t = 2 (-dw v + w dv + v x dv)
-    const float gn_w = gqw + 2.f * dot(dv, g);
-    const V3 gn_v = gqv + g * (-2.f * dw) + cross(dv, g) * 2.f;
-    const float gd_w = -2.f * dot(v, g);
-    const V3 gd_v = g * (2.f * w) + cross(g, v) * 2.f;
-    // normalisation: qn = rw * inv, dn = dw4 * inv, inv = 1/|rw|
-    const float qg = w * gn_w + dot(v, gn_v);           // qn . g_qn
-    const float dg = dw * gd_w + dot(dv, gd_v);          // dn . g_dn
-    float grw[4], gdw[4];
-    grw[0] = i * (gn_w - w * qg) - w * i * dg;
-    grw[1] = i * (gn_v.x - v.x * qg) - v.x * i * dg;
-    grw[2] = i * (gn_v.y - v.y * qg) - v.y * i * dg;
-    grw[3] = i * (gn_v.z - v.z * qg) - v.z * i * dg;
-    gdw[0] = i * gd_w; gdw[1] = i * gd_v.x; gdw[2] = i * gd_v.y; gdw[3] = i * gd_v.z;
-    float* wk = work + s * B;            // coef[s][b] = p_b * sign_b
-    float* wg = work + S * B + s * 8;    // [g_rw (4) | g_dw (4)]
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { wg[k] = grw[k]; wg[4 + k] = gdw[k]; }
-    // softmax / entropy / delta adjoint
     float gp[B];
-    float pg = 0.f;
+    float pg = 0.f, ge = 0.f, gds = 0.f;
+    unsigned rawpos = 0;  // bit b: raw[s][b] > 0 (the ReLU of the delta-skin head, skinning.py:119)
+    const float* affm = aff;
+    V3 x = {0, 0, 0};
+    if (active) {
+      const int m = UNI ? __builtin_amdgcn_readfirstlane(frame_of(s0, spf)) : frame_of(s, spf);
+      const float* srm = sr + (size_t)m * B * 4;
+      const float* sdm = sd + (size_t)m * B * 4;
+      affm = aff + (size_t)m * B * 12;
+      x = ldv3(xyz + s * 3);
+      const V3 g = ldv3(g_out + s * 3);
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const float* r = srm + 4 * b;
-      const float* d = sdm + 4 * b;
-      gp[b] = bl.sg[b] * (r[0] * grw[0] + r[1] * grw[1] + r[2] * grw[2] + r[3] * grw[3] + d[0] * gdw[0] + d[1] * gdw[1] + d[2] * gdw[2] + d[3] * gdw[3]);
-      pg += bl.p[b] * gp[b];
-      wk[b] = bl.p[b] * bl.sg[b];
-    }
-    const float ge = g_ent ? g_ent[s] : 0.f;
-    const float gds = g_dskin ? g_dskin[s] * (2.f / (float)B) : 0.f;
-    float* wq = work + S * (B + 8) + s * B;  // gsk[s][b]
+      for (int b_ = 0; b_ < B; ++b_) rawpos |= (row[b_] > 0.f ? 1u : 0u) << b_;
+      blend_forward<B>(x, affm, row, srm, sdm, bl);
+      const float i = bl.inv;
+      const float w = bl.rw[0] * i, dw = bl.dw4[0] * i;
+      const V3 v = V3{bl.rw[1], bl.rw[2], bl.rw[3]} * i, dv = V3{bl.dw4[1], bl.dw4[2], bl.dw4[3]} * i;
+      V3 gx = qrot_t(w, v, g);
+      float gqw; V3 gqv;
+      qrot_gq(w, v, x, g, gqw, gqv);
+      // t = 2 (-dw v + w dv + v x dv)
+      const float gn_w = gqw + 2.f * dot(dv, g);
+      const V3 gn_v = gqv + g * (-2.f * dw) + cross(dv, g) * 2.f;
+      const float gd_w = -2.f * dot(v, g);
+      const V3 gd_v = g * (2.f * w) + cross(g, v) * 2.f;
+      // normalisation: qn = rw * inv, dn = dw4 * inv, inv = 1/|rw|
+      const float qg = w * gn_w + dot(v, gn_v);           // qn . g_qn
+      const float dg = dw * gd_w + dot(dv, gd_v);          // dn . g_dn
+      float grw[4], gdw[4];
+      grw[0] = i * (gn_w - w * qg) - w * i * dg;
+      grw[1] = i * (gn_v.x - v.x * qg) - v.x * i * dg;
+      grw[2] = i * (gn_v.y - v.y * qg) - v.y * i * dg;
+      grw[3] = i * (gn_v.z - v.z * qg) - v.z * i * dg;
+      gdw[0] = i * gd_w; gdw[1] = i * gd_v.x; gdw[2] = i * gd_v.y; gdw[3] = i * gd_v.z;
+      float4* wg = reinterpret_cast<float4*>(work + S * B + s * 8);    // [g_rw (4) | g_dw (4)]: 32 contiguous bytes per sample
+      wg[0] = make_float4(grw[0], grw[1], grw[2], grw[3]);
+      wg[1] = make_float4(gdw[0], gdw[1], gdw[2], gdw[3]);
+      // softmax / entropy / delta adjoint
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      // skin_b = -(dist2_b + delta_b);  entropy = lse(skin) - max(skin)
-      const float gskin = bl.p[b] * (gp[b] - pg) + ge * (bl.p[b] - (b == bl.anchor ? 1.f : 0.f));
-      const float gdelta = -gskin + gds * bl.dl[b];
-      g_raw[s * B + b] = raw[s * B + b] > 0.f ? 0.1f * gdelta : 0.f;
-      const float gsk = -2.f * gskin;
-      wq[b] = gsk;
+      for (int b_ = 0; b_ < B; ++b_) {
+        const float* r = srm + 4 * b_;
+        const float* d = sdm + 4 * b_;
+        gp[b_] = bl.sg[b_] * (r[0] * grw[0] + r[1] * grw[1] + r[2] * grw[2] + r[3] * grw[3] + d[0] * gdw[0] + d[1] * gdw[1] + d[2] * gdw[2] + d[3] * gdw[3]);
+        pg += bl.p[b_] * gp[b_];
+      }
+      ge = g_ent ? g_ent[s] : 0.f;
+      gds = g_dskin ? g_dskin[s] * (2.f / (float)B) : 0.f;
       // dL/dx through c_b = Abar_b [x,1]:  Abar_b[:, :3]^T (gsk * c_b)
-      const Aff A = ld_aff(affm + 12 * b);
-      const V3 c = bone_coord(A, x);
-      const float u0 = gsk * c.x, u1 = gsk * c.y, u2 = gsk * c.z;
-      gx = gx + V3{A.r0.x * u0 + A.r1.x * u1 + A.r2.x * u2, A.r0.y * u0 + A.r1.y * u1 + A.r2.y * u2, A.r0.z * u0 + A.r1.z * u1 + A.r2.z * u2};
+#pragma unroll
+      for (int b_ = 0; b_ < B; ++b_) {
+        const float gskin = bl.p[b_] * (gp[b_] - pg) + ge * (bl.p[b_] - (b_ == bl.anchor ? 1.f : 0.f));
+        const float gsk = -2.f * gskin;
+        const Aff A = ld_aff(affm + 12 * b_);
+        const V3 c = bone_coord(A, x);
+        const float u0 = gsk * c.x, u1 = gsk * c.y, u2 = gsk * c.z;
+        gx = gx + V3{A.r0.x * u0 + A.r1.x * u1 + A.r2.x * u2, A.r0.y * u0 + A.r1.y * u1 + A.r2.y * u2, A.r0.z * u0 + A.r1.z * u1 + A.r2.z * u2};
+      }
+      stv3(g_xyz + s * 3, gx);
+      float* xx = work + S * (2 * B + 8) + s * 10;  // upper triangle of [x,1][x,1]^T, row-major
+      xx[0] = x.x * x.x; xx[1] = x.x * x.y; xx[2] = x.x * x.z; xx[3] = x.x;
+      xx[4] = x.y * x.y; xx[5] = x.y * x.z; xx[6] = x.y;
+      xx[7] = x.z * x.z; xx[8] = x.z; xx[9] = 1.f;
     }
-    stv3(g_xyz + s * 3, gx);
-    float* xx = work + S * (2 * B + 8) + s * 10;  // upper triangle of [x,1][x,1]^T, row-major
-    xx[0] = x.x * x.x; xx[1] = x.x * x.y; xx[2] = x.x * x.z; xx[3] = x.x;
-    xx[4] = x.y * x.y; xx[5] = x.y * x.z; xx[6] = x.y;
-    xx[7] = x.z * x.z; xx[8] = x.z; xx[9] = 1.f;
+    // the three (S,B) outputs, one pass each through the tile (values re-derived from the registers of the pass above)
+    // skin_b = -(dist2_b + delta_b);  entropy = lse(skin) - max(skin)
+    __syncthreads();  // every thread has read its raw row
+    if (active) {
+#pragma unroll
+      for (int b_ = 0; b_ < B; ++b_) row[b_] = bl.p[b_] * bl.sg[b_];  // coef[s][b] = p_b * sign_b
+    }
+    __syncthreads();
+    T::store(work, s0, n, tile);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int b_ = 0; b_ < B; ++b_) {
+        const float gskin = bl.p[b_] * (gp[b_] - pg) + ge * (bl.p[b_] - (b_ == bl.anchor ? 1.f : 0.f));
+        row[b_] = -2.f * gskin;  // gsk[s][b]
+      }
+    }
+    __syncthreads();
+    T::store(work + S * (B + 8), s0, n, tile);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int b_ = 0; b_ < B; ++b_) {
+        const float gskin = bl.p[b_] * (gp[b_] - pg) + ge * (bl.p[b_] - (b_ == bl.anchor ? 1.f : 0.f));
+        const float gdelta = -gskin + gds * bl.dl[b_];
+        row[b_] = ((rawpos >> b_) & 1u) ? 0.1f * gdelta : 0.f;
+      }
+    }
+    __syncthreads();
+    T::store(g_raw, s0, n, tile);
+    __syncthreads();
   }
 }
 
@@ -522,7 +655,8 @@ extern "C" int lab4d_skin_blend_forward(const float* xyz, const float* art_r, co
   if (S == 0) return LAB4D_OK;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_bone_affine, dim3(div_up(M * B, 64)), dim3(64), 0, st, art_r, art_d, gauss, M, B, work);
-  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_fwd<NB>), dim3(sgrid(S)), dim3(256), 0, st, xyz, work, raw, sr, sd, (long)S, spf, out, ent, dskin));
+  if (spf % 256 == 0) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_fwd<NB, true>), dim3(sgrid(S)), dim3(256), 0, st, xyz, work, raw, sr, sd, (long)S, spf, out, ent, dskin)); }
+  else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_fwd<NB, false>), dim3(sgrid(S)), dim3(256), 0, st, xyz, work, raw, sr, sd, (long)S, spf, out, ent, dskin)); }
   return check_launch("skin_blend_forward");
 }
 
@@ -539,8 +673,10 @@ extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* art_r, c
   float* aff = work;
   float* ws = work + (size_t)M * B * 12;
   hipLaunchKernelGGL(k_bone_affine, dim3(div_up(M * B, 64)), dim3(64), 0, st, art_r, art_d, gauss, M, B, aff);
-  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
-                                      (long)S, spf, g_xyz, g_raw, ws));
+  if (spf % 256 == 0) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, true>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
+                                      (long)S, spf, g_xyz, g_raw, ws)); }
+  else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, false>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
+                                      (long)S, spf, g_xyz, g_raw, ws)); }
   if (int e = check_launch("skin_blend_backward")) return e;
   if (g_se3)
     if (int e = lab4d_gram_per_frame(ws, B, ws + (size_t)S * B, 8, S, spf, M, g_se3, stream)) return e;
