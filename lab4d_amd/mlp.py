@@ -69,7 +69,7 @@ def wgrad_kernel_name(L, prec):
     """Which kernel lab4d_mlp_wgrad dispatches to for this layer (mirrors the dispatch in csrc/mlp.hip)."""
     if prec == PREC_BF16 and L.mout_pad in (64, 128, 256):
         K = L.ke + L.kin
-        nbw = 1 if K <= 64 else (2 if K <= 128 else (3 if K <= 192 else (4 if K <= 256 else 3)))
+        nbw = 1 if K <= 64 else (2 if K <= 128 else (3 if K <= 192 else (4 if K <= 256 else (5 if (L.mout_pad == 256 and K <= 320) else 3))))
         return "k_mlp_wgrad_dma<%d,%d>" % (L.mout_pad // 32, nbw)
     if L.mout_pad >= 256:
         return "k_mlp_wgrad_big"
