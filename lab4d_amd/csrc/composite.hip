@@ -41,6 +41,45 @@ __device__ __forceinline__ void ray_weights(const float* density, const float* d
   rw.mask = wave_sum(msum);
 }
 
+
+// ---- per-sample fields with C channels, read / written as ONE contiguous (D*C)-float run per ray ----------------------------
+// The first version walked a field channel by channel (lane d reads v[(base+d)*C + c]: a 4*C-byte stride, every line touched C times
+// and every gradient line written C times in 4-byte pieces): k_composite_bwd ran at 1.0 TB/s.  Here lane l handles the flattened
+// elements e = l, l+64, ... (d = e / C, c = e % C), the per-sample weights come from a wave-private LDS copy, and the per-sample
+// reduction over the channels (dL/dw_hat) goes through LDS (shuffles when C divides 64, ds_add_f32 otherwise).
+constexpr int kMaxD = 64 * 4;
+// e / C for e < 2^15 without an integer division: shift for powers of two, multiply-shift for 3 (exact below 2^16)
+__device__ __forceinline__ int div_c(int e, int C, int sh) { return sh >= 0 ? (e >> sh) : (C == 3 ? (int)(((unsigned)e * 43691u) >> 17) : e / C); }
+__device__ __forceinline__ int shift_of(int C) { return (C & (C - 1)) == 0 ? __ffs(C) - 1 : -1; }
+
+// out_c = sum_d wl[d] * v[d][c]  -> written by the lanes c < C
+template <int NC>
+__device__ __forceinline__ void field_reduce(const float* __restrict__ v, int D, int C, const float* wl, int lane, float* __restrict__ out_c) {
+  const int n = D * C, sh = shift_of(C);
+  if ((64 % C) == 0) {
+    float s = 0.f;
+    for (int e = lane; e < n; e += 64) s += wl[e >> sh] * v[e];
+    for (int o = C; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (lane < C) out_c[lane] = s;
+  } else if (C == 3) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int e = lane; e < n; e += 64) {
+      const int d = div_c(e, 3, -1), c = e - 3 * d;
+      const float x = wl[d] * v[e];
+      s0 += c == 0 ? x : 0.f; s1 += c == 1 ? x : 0.f; s2 += c == 2 ? x : 0.f;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { out_c[0] = s0; out_c[1] = s1; out_c[2] = s2; }
+  } else {
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+      for (int d = lane; d < D; d += 64) s += wl[d] * v[d * C + c];
+      s = wave_sum(s);
+      if (lane == 0) out_c[c] = s;
+    }
+  }
+}
+
 template <int NC>
 __global__ void __launch_bounds__(256) k_composite_fwd(const float* __restrict__ density, const float* __restrict__ deltas,
                                                         lab4d_field_list fl, const float* __restrict__ flow,
@@ -51,11 +90,15 @@ __global__ void __launch_bounds__(256) k_composite_fwd(const float* __restrict__
                                                         float* __restrict__ t_sum, float* __restrict__ gauss_mask) {
   const int lane = threadIdx.x & 63;
   constexpr int nchunk = NC;
+  __shared__ float wl_all[4][64 * NC];
+  float* wl = wl_all[threadIdx.x >> 6];  // wave-private: normalised weights of the current ray
   for (long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6); ray < R; ray += (long)gridDim.x * 4) {
     const long base = ray * D;
     RayWeights<NC> rw;
     ray_weights(density, deltas, base, D, lane, rw);
     const float inv = 1.f / (rw.mask + 1e-6f);
+    _Pragma("unroll") for (int j = 0; j < nchunk; ++j) wl[lane + 64 * j] = rw.w[j] * inv;
+    __builtin_amdgcn_wave_barrier();
     if (weights || transmit) {
       _Pragma("unroll") for (int j = 0; j < nchunk; ++j) {
         const int d = lane + 64 * j;
@@ -71,25 +114,15 @@ __global__ void __launch_bounds__(256) k_composite_fwd(const float* __restrict__
       const int C = fl.channels[f];
       const float* v = fl.fields[f];
       const int mode = fl.modes[f];
+      const float* vr = v + base * C;  // this ray's (D, C) block: D*C contiguous floats
       if (mode == 2) {  // mean over (D, C)
         float s = 0.f;
-        _Pragma("unroll") for (int j = 0; j < nchunk; ++j) {
-          const int d = lane + 64 * j;
-          if (d < D) for (int c = 0; c < C; ++c) s += v[(base + d) * C + c];
-        }
+        for (int e = lane; e < D * C; e += 64) s += vr[e];
         s = wave_sum(s);
         if (lane == 0) out[ray * sumC + co] = s / (float)(D * C);
         co += 1;
       } else {
-        for (int c = 0; c < C; ++c) {
-          float s = 0.f;
-          _Pragma("unroll") for (int j = 0; j < nchunk; ++j) {
-            const int d = lane + 64 * j;
-            if (d < D) s += (rw.w[j] * inv) * v[(base + d) * C + c];
-          }
-          s = wave_sum(s);
-          if (lane == 0) out[ray * sumC + co + c] = s;
-        }
+        field_reduce<NC>(vr, D, C, wl, lane, out + ray * sumC + co);
         co += C;
       }
     }
@@ -142,6 +175,9 @@ __global__ void __launch_bounds__(256) k_composite_bwd(const float* __restrict__
                                                         float* __restrict__ g_gdens) {
   const int lane = threadIdx.x & 63;
   constexpr int nchunk = NC;
+  __shared__ float wl_all[4][64 * NC], al_all[4][64 * NC];
+  float* wl = wl_all[threadIdx.x >> 6];  // wave-private: normalised weights w_d / Z of the current ray
+  float* al = al_all[threadIdx.x >> 6];  // wave-private: dL/d(w_hat)_d accumulated over the mode-0 channels
   for (long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6); ray < R; ray += (long)gridDim.x * 4) {
     const long base = ray * D;
     RayWeights<NC> rw;
@@ -150,34 +186,50 @@ __global__ void __launch_bounds__(256) k_composite_bwd(const float* __restrict__
     float gw[NC];   // dL/dw_d
     float A[NC];    // dL/d(w_hat)_d = sum over mode-0 channels of g_c v_dc
 #pragma unroll
-    for (int j = 0; j < NC; ++j) { gw[j] = 0.f; A[j] = 0.f; }
+    for (int j = 0; j < NC; ++j) { gw[j] = 0.f; A[j] = 0.f; wl[lane + 64 * j] = rw.w[j] * inv; al[lane + 64 * j] = 0.f; }
+    __builtin_amdgcn_wave_barrier();
     int co = 0;
     for (int f = 0; f < fl.n_fields; ++f) {
       const int C = fl.channels[f];
       const float* v = fl.fields[f];
       float* gv = gf.fields[f];
       const int mode = fl.modes[f];
+      const float* vr = v + base * C;
+      float* gvr = gv ? gv + base * C : nullptr;
+      const int n = D * C;
       if (mode == 2) {
         const float g = g_out ? g_out[ray * sumC + co] / (float)(D * C) : 0.f;
-        if (gv) _Pragma("unroll") for (int j = 0; j < nchunk; ++j) {
-          const int d = lane + 64 * j;
-          if (d < D) for (int c = 0; c < C; ++c) gv[(base + d) * C + c] = g;
-        }
+        if (gvr) for (int e = lane; e < n; e += 64) gvr[e] = g;
         co += 1;
       } else {
-        for (int c = 0; c < C; ++c) {
-          const float g = g_out ? g_out[ray * sumC + co + c] : 0.f;
-          _Pragma("unroll") for (int j = 0; j < nchunk; ++j) {
-            const int d = lane + 64 * j;
-            if (d < D) {
-              if (mode == 0) A[j] += g * v[(base + d) * C + c];
-              if (gv) gv[(base + d) * C + c] = g * rw.w[j] * inv;
+        const float* gc = g_out ? g_out + ray * sumC + co : nullptr;
+        const int sh = shift_of(C);
+        if ((64 % C) == 0) {
+          const int c = lane & (C - 1);
+          const float g = gc ? gc[c] : 0.f;
+          for (int e = lane; e < n; e += 64) {
+            const int d = e >> sh;
+            if (gvr) gvr[e] = g * wl[d];
+            if (mode == 0) {
+              float a = g * vr[e];
+              for (int o = 1; o < C; o <<= 1) a += __shfl_xor(a, o, 64);  // the C lanes of one sample
+              if (c == 0) al[d] += a;
             }
+          }
+        } else {
+          for (int e = lane; e < n; e += 64) {
+            const int d = div_c(e, C, sh), c = e - d * C;
+            const float g = gc ? gc[c] : 0.f;
+            if (gvr) gvr[e] = g * wl[d];
+            if (mode == 0) atomicAdd(&al[d], g * vr[e]);  // ds_add_f32
           }
         }
         co += C;
       }
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NC; ++j) A[j] = al[lane + 64 * j];
     // w_hat = w / Z:  dL/dw_d = A_d / Z - (sum_j A_j w_j) / Z^2 + g_mask
     float aw = 0.f;
 #pragma unroll

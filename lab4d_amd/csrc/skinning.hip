@@ -35,11 +35,33 @@ template <int C>
 struct RowTile {
   static constexpr int CP = C | 1;            // odd row stride (floats)
   static constexpr int FLOATS = 256 * CP;
-  // rows [s0, s0 + n) of g (row-major, C floats per row) -> tile; block-cooperative, all 256 threads call it
+  // rows [s0, s0 + n) of g (row-major, C floats per row) -> tile; block-cooperative, all 256 threads call it.
+  // Full tiles issue ALL their global loads before the first LDS write (a load -> write loop pays one memory latency per pass:
+  // 19 passes for the 75-float rows, at two blocks per CU that was the whole kernel time).
   static __device__ __forceinline__ void load(const float* __restrict__ g, long s0, int n, float* __restrict__ tile) {
     const float* src = g + s0 * C;
     const int total = n * C;
     if ((((size_t)src) & 15) == 0) {
+      constexpr int TRIPS = (256 * C + 1023) / 1024;
+      if (n == 256) {
+        float4 v[TRIPS];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+          const int e = 4 * (int)threadIdx.x + 1024 * t;
+          if (e + 3 < 256 * C) v[t] = *reinterpret_cast<const float4*>(src + e);
+        }
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+          const int e = 4 * (int)threadIdx.x + 1024 * t;
+          if (e + 3 < 256 * C) {
+            const float vv[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int r = (e + k) / C; tile[r * CP + (e + k) - r * C] = vv[k]; }
+          }
+        }
+        static_assert((256 * C) % 4 == 0, "a full tile is a whole number of float4");
+        return;
+      }
       for (int e = 4 * (int)threadIdx.x; e < total; e += 1024) {
         if (e + 3 < total) {
           const float4 v = *reinterpret_cast<const float4*>(src + e);
@@ -86,38 +108,40 @@ __device__ __forceinline__ V3 bone_apply(float w, V3 v, float dw, V3 dv, V3 x) {
   return qrot(w, v * -1.f, x) + t;
 }
 
-template <int B>
+// One thread per sample; the (S,3B) rows leave through an LDS tile as coalesced float4 stores (RowTile).  UNI (spf % 256 == 0): the
+// block's samples share one frame, so the bone tables are wave-uniform and come through SCALAR loads -- the first version gave every
+// (sample, bone) its own thread and fetched the 11 table floats of its bone with per-lane gather loads: 14 vector-memory
+// instructions per 12 bytes of output, bound by the texture addresser (2.4 TB/s).
+template <int B, bool UNI>
 __global__ void __launch_bounds__(256) k_bone_fwd(const float* __restrict__ xyz, const float* __restrict__ ar, const float* __restrict__ ad,
                                                    const float* __restrict__ gauss, long S, int spf, float* __restrict__ out) {
-  // one thread per (sample, bone); a block's 256 results are 768 consecutive floats of `out`: staged in LDS and written as float4
-  // (three 4-byte stores per thread at a 12-byte stride were three partial writes of every line)
-  __shared__ float tile[768];
-  const long total = S * B;
-  for (long i0 = (long)blockIdx.x * 256; i0 < total; i0 += (long)gridDim.x * 256) {
-    const long i = i0 + threadIdx.x;
-    if (i < total) {
-      const unsigned iu = (unsigned)i;  // S * B < 2^32 (host-checked)
-      const unsigned s = iu / (unsigned)B;
-      const int b = (int)(iu - s * (unsigned)B);
-      const int m = (int)(s / (unsigned)spf);
-      const float* r = ar + ((size_t)m * B + b) * 4;
-      const float* d = ad + ((size_t)m * B + b) * 4;
-      const V3 y = bone_apply(r[0], ldv3(r + 1), d[0], ldv3(d + 1), ldv3(xyz + (size_t)s * 3));
-      const V3 gs = ldv3(gauss + 3 * b);
-      stv3(tile + 3 * threadIdx.x, {y.x / gs.x, y.y / gs.y, y.z / gs.z});
+  using T = RowTile<3 * B>;
+  __shared__ float tile[T::FLOATS];
+  for (long s0 = (long)blockIdx.x * 256; s0 < S; s0 += (long)gridDim.x * 256) {
+    const long rem = S - s0;
+    const int n = (int)(rem < 256 ? rem : 256);
+    if ((int)threadIdx.x < n) {
+      const long s = s0 + threadIdx.x;
+      const int m = UNI ? __builtin_amdgcn_readfirstlane(frame_of(s0, spf)) : frame_of(s, spf);
+      const V3 x = ldv3(xyz + s * 3);
+      float* row = tile + threadIdx.x * T::CP;
+#pragma unroll 5
+      for (int b = 0; b < B; ++b) {
+        const float* r = ar + ((size_t)m * B + b) * 4;
+        const float* d = ad + ((size_t)m * B + b) * 4;
+        const V3 y = bone_apply(r[0], ldv3(r + 1), d[0], ldv3(d + 1), x);
+        const V3 gs = ldv3(gauss + 3 * b);
+        stv3(row + 3 * b, {y.x / gs.x, y.y / gs.y, y.z / gs.z});
+      }
     }
     __syncthreads();
-    const long rem = total - i0;
-    const int n = (int)(rem < 256 ? rem : 256) * 3;
-    float* dst = out + i0 * 3;  // i0 * 3 floats: a multiple of 768 floats, 16-byte aligned with the buffer
-    if (threadIdx.x * 4 + 3 < n) *reinterpret_cast<float4*>(dst + 4 * threadIdx.x) = *reinterpret_cast<const float4*>(tile + 4 * threadIdx.x);
-    else for (int e = 4 * threadIdx.x; e < n && e < 4 * (int)threadIdx.x + 4; ++e) dst[e] = tile[e];
+    T::store(out, s0, n, tile);
     __syncthreads();
   }
 }
 
 // g_xyz[s] = sum_b R_b^T (g_bone[s,b] / gauss_b): one thread per sample
-template <int B>
+template <int B, bool UNI>
 __global__ void __launch_bounds__(256) k_bone_bwd_x(const float* __restrict__ ar, const float* __restrict__ gauss,
                                                      const float* __restrict__ g_bone, long S, int spf, float* __restrict__ g_xyz) {
   using T = RowTile<3 * B>;
@@ -129,7 +153,7 @@ __global__ void __launch_bounds__(256) k_bone_bwd_x(const float* __restrict__ ar
     __syncthreads();
     if ((int)threadIdx.x < n) {
       const long s = s0 + threadIdx.x;
-      const int m = frame_of(s, spf);
+      const int m = UNI ? __builtin_amdgcn_readfirstlane(frame_of(s0, spf)) : frame_of(s, spf);
       const float* row = tile + threadIdx.x * T::CP;
       V3 acc = {0, 0, 0};
 #pragma unroll 5
@@ -618,7 +642,8 @@ extern "C" int lab4d_bone_coords_forward(const float* xyz, const float* ar, cons
   LAB4D_REQUIRE(xyz && ar && ad && gauss && out, "bone_coords_forward: null pointer");
   LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "bone_coords_forward: M*spf < S");
   if (S == 0) return LAB4D_OK;
-  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_fwd<NB>), dim3(sgrid((long)S * B)), dim3(256), 0, (hipStream_t)stream, xyz, ar, ad, gauss, (long)S, spf, out));
+  if (spf % 256 == 0) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_fwd<NB, true>), dim3(sgrid(S)), dim3(256), 0, (hipStream_t)stream, xyz, ar, ad, gauss, (long)S, spf, out)); }
+  else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_fwd<NB, false>), dim3(sgrid(S)), dim3(256), 0, (hipStream_t)stream, xyz, ar, ad, gauss, (long)S, spf, out)); }
   return check_launch("bone_coords_forward");
 }
 
@@ -628,7 +653,10 @@ extern "C" int lab4d_bone_coords_backward(const float* xyz, const float* ar, con
   LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "bone_coords_backward: M*spf < S");
   if (S == 0) return LAB4D_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (g_xyz) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_x<NB>), dim3(sgrid(S)), dim3(256), 0, st, ar, gauss, g_bone, (long)S, spf, g_xyz)); }
+  if (g_xyz) {
+    if (spf % 256 == 0) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_x<NB, true>), dim3(sgrid(S)), dim3(256), 0, st, ar, gauss, g_bone, (long)S, spf, g_xyz)); }
+    else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_x<NB, false>), dim3(sgrid(S)), dim3(256), 0, st, ar, gauss, g_bone, (long)S, spf, g_xyz)); }
+  }
   if (g_ar || g_ad || g_gauss) {
     LAB4D_REQUIRE(g_ar && g_ad && g_gauss, "bone_coords_backward: parameter gradients must be requested together");
     const int chunk = 8192;

@@ -126,10 +126,15 @@ class _Composite(Function):
         vis_num = torch.empty(M, N, 1, device=dev) if vis is not None else None
         t_sum = torch.empty(M, N, 1, device=dev) if vis is not None else None
         gmask = torch.empty(M, N, 1, device=dev) if gdens is not None else None
-        _lib.check(_lib.lib().lab4d_composite_forward(
-            _lib.ptr(density), _lib.ptr(deltas), fl, _lib.ptr(flow), _lib.ptr(vis), _lib.ptr(gdens), R, D, _lib.ptr(weights),
-            _lib.ptr(transmit), _lib.ptr(mask), _lib.ptr(out), _lib.ptr(flow_out), _lib.ptr(vis_num), _lib.ptr(t_sum),
-            _lib.ptr(gmask), _lib.stream()), "composite_forward")
+        # algorithmic bytes: (2 + sum C) floats read per sample (+ flow 3, vis 1, gauss density 1), weights / transmittance written
+        extra = (3 if flow is not None else 0) + (1 if vis is not None else 0) + (1 if gdens is not None else 0)
+        chans = sum(f.shape[-1] for f in fields)
+        ctx.chans = chans + extra
+        with _lib.timed("k_composite_fwd", (0.0, 4.0 * R * D * (2 + chans + extra + 2))):
+            _lib.check(_lib.lib().lab4d_composite_forward(
+                _lib.ptr(density), _lib.ptr(deltas), fl, _lib.ptr(flow), _lib.ptr(vis), _lib.ptr(gdens), R, D, _lib.ptr(weights),
+                _lib.ptr(transmit), _lib.ptr(mask), _lib.ptr(out), _lib.ptr(flow_out), _lib.ptr(vis_num), _lib.ptr(t_sum),
+                _lib.ptr(gmask), _lib.stream()), "composite_forward")
         ctx.save_for_backward(density, deltas, flow, vis, gdens, *fields)
         ctx.modes = tuple(modes)
         ctx.dims = (M, N, D, sumC)
@@ -166,10 +171,11 @@ class _Composite(Function):
         g_flow = torch.empty_like(flow) if (flow is not None and ctx.needs_input_grad[2]) else None
         g_vis = torch.empty_like(vis) if (vis is not None and ctx.needs_input_grad[3]) else None
         g_gd = torch.empty_like(gdens) if (gdens is not None and ctx.needs_input_grad[4]) else None
-        _lib.check(_lib.lib().lab4d_composite_backward(
-            _lib.ptr(density), _lib.ptr(deltas), fl, _lib.ptr(flow), _lib.ptr(vis), _lib.ptr(gdens), R, D, _lib.ptr(g_mask),
-            _lib.ptr(g_out), _lib.ptr(g_flow_out), _lib.ptr(g_vis_num), _lib.ptr(g_gmask), _lib.ptr(g_density),
-            _lib.ptr(g_deltas), gf, _lib.ptr(g_flow), _lib.ptr(g_vis), _lib.ptr(g_gd), _lib.stream()), "composite_backward")
+        with _lib.timed("k_composite_bwd", (0.0, 4.0 * R * D * 2 * (2 + ctx.chans))):  # every per-sample field read once, its gradient written once
+            _lib.check(_lib.lib().lab4d_composite_backward(
+                _lib.ptr(density), _lib.ptr(deltas), fl, _lib.ptr(flow), _lib.ptr(vis), _lib.ptr(gdens), R, D, _lib.ptr(g_mask),
+                _lib.ptr(g_out), _lib.ptr(g_flow_out), _lib.ptr(g_vis_num), _lib.ptr(g_gmask), _lib.ptr(g_density),
+                _lib.ptr(g_deltas), gf, _lib.ptr(g_flow), _lib.ptr(g_vis), _lib.ptr(g_gd), _lib.stream()), "composite_backward")
         return (g_density, g_deltas, g_flow, g_vis, g_gd, None, *gfields)
 
 

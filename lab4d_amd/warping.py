@@ -26,8 +26,9 @@ class BoneCoords(Function):
         _lib.require_device(xyz, art_r, art_d, gauss)
         S, (M, B) = xyz.shape[0], art_r.shape[:2]
         out = torch.empty(S, 3 * B, device=xyz.device)
-        _lib.check(_lib.lib().lab4d_bone_coords_forward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), S, spf, M, B,
-                                                        _lib.ptr(out), _lib.stream()), "bone_coords_forward")
+        with _lib.timed("k_bone_fwd", (0.0, 4.0 * S * (3 + 3 * B))):  # algorithmic bytes: xyz read, (S,3B) written
+            _lib.check(_lib.lib().lab4d_bone_coords_forward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), S, spf, M, B,
+                                                            _lib.ptr(out), _lib.stream()), "bone_coords_forward")
         ctx.save_for_backward(xyz, art_r, art_d, gauss)
         ctx.spf = spf
         return out
@@ -39,15 +40,17 @@ class BoneCoords(Function):
         S, (M, B) = xyz.shape[0], art_r.shape[:2]
         g = g.contiguous()
         gx = torch.empty_like(xyz)
-        _lib.check(_lib.lib().lab4d_bone_coords_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(g), S, ctx.spf,
-                                                         M, B, _lib.ptr(gx), None, None, None, _lib.stream()), "bone_coords_backward")
+        with _lib.timed("k_bone_bwd_x", (0.0, 4.0 * S * (3 + 3 * B))):
+            _lib.check(_lib.lib().lab4d_bone_coords_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(g), S, ctx.spf,
+                                                             M, B, _lib.ptr(gx), None, None, None, _lib.stream()), "bone_coords_backward")
         # parameter gradients: out[s,b,:] = (R_b x_s + t_b) / gauss_b is affine in x_s, so every one of them is a function
         # of the per-frame Gram matrix G[m,b,k,j] = sum_{s in m} g[s,b,k] [x_s,1]_j: one tall-skinny product on the device
         if not any(ctx.needs_input_grad[1:4]):
             return gx, None, None, None, None
         xh = torch.cat([xyz, torch.ones_like(xyz[:, :1])], -1)
         G = torch.zeros(M, 3 * B, 4, device=xyz.device)
-        _lib.check(_lib.lib().lab4d_gram_per_frame(_lib.ptr(g), 3 * B, _lib.ptr(xh), 4, S, ctx.spf, M, _lib.ptr(G), _lib.stream()), "gram_per_frame")
+        with _lib.timed("k_gram_pf_rb(bone)", (2.0 * S * 3 * B * 4, 4.0 * S * (3 * B + 4))):
+            _lib.check(_lib.lib().lab4d_gram_per_frame(_lib.ptr(g), 3 * B, _lib.ptr(xh), 4, S, ctx.spf, M, _lib.ptr(G), _lib.stream()), "gram_per_frame")
         # (M,B)-sized chain rule: one thread per (frame, bone) (csrc/skinning.hip k_bone_param_from_gram)
         need_r, need_d, need_g = ctx.needs_input_grad[1:4]
         gar = torch.empty_like(art_r) if need_r else None
@@ -73,9 +76,10 @@ class SkinBlend(Function):
         ent = torch.empty(S, 1, device=xyz.device)
         dsk = torch.empty(S, 1, device=xyz.device)
         work = torch.empty(M * B * 12, device=xyz.device)
-        _lib.check(_lib.lib().lab4d_skin_blend_forward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
-                                                       _lib.ptr(se3_r), _lib.ptr(se3_d), S, spf, M, B, _lib.ptr(out), _lib.ptr(ent), _lib.ptr(dsk),
-                                                       _lib.ptr(work), _lib.stream()), "skin_blend_forward")
+        with _lib.timed("k_blend_fwd", (0.0, 4.0 * S * (3 + B + 3 + 2))):  # xyz + raw read; out, entropy, delta_skin written
+            _lib.check(_lib.lib().lab4d_skin_blend_forward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
+                                                           _lib.ptr(se3_r), _lib.ptr(se3_d), S, spf, M, B, _lib.ptr(out), _lib.ptr(ent), _lib.ptr(dsk),
+                                                           _lib.ptr(work), _lib.stream()), "skin_blend_forward")
         ctx.save_for_backward(xyz, raw, art_r, art_d, gauss, se3_r, se3_d)
         ctx.spf = spf
         return out, ent, dsk
@@ -95,10 +99,13 @@ class SkinBlend(Function):
         gad = torch.empty_like(art_d) if need_p else None
         gg = torch.zeros_like(gauss) if need_p else None
         work = torch.empty(S * (2 * B + 18) + M * B * 34, device=xyz.device)
-        _lib.check(_lib.lib().lab4d_skin_blend_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
-                                                        _lib.ptr(se3_r), _lib.ptr(se3_d), _lib.ptr(g_out), _lib.ptr(g_ent), _lib.ptr(g_dsk), S,
-                                                        ctx.spf, M, B, _lib.ptr(gx), _lib.ptr(gr), _lib.ptr(gse3), _lib.ptr(gar), _lib.ptr(gad),
-                                                        _lib.ptr(gg), _lib.ptr(work), _lib.stream()), "skin_blend_backward")
+        # one entry for the whole adjoint (k_blend_bwd + its two per-frame Gram reductions): reads xyz, raw, g_out, g_ent, g_dskin; writes
+        # g_xyz, g_raw and the (S, 2B+18) work arrays, which the Gram reductions read once more
+        with _lib.timed("k_blend_bwd+gram", (0.0, 4.0 * S * ((3 + B + 3 + 2) + (3 + B) + 2 * (2 * B + 18)))):
+            _lib.check(_lib.lib().lab4d_skin_blend_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
+                                                            _lib.ptr(se3_r), _lib.ptr(se3_d), _lib.ptr(g_out), _lib.ptr(g_ent), _lib.ptr(g_dsk), S,
+                                                            ctx.spf, M, B, _lib.ptr(gx), _lib.ptr(gr), _lib.ptr(gse3), _lib.ptr(gar), _lib.ptr(gad),
+                                                            _lib.ptr(gg), _lib.ptr(work), _lib.stream()), "skin_blend_backward")
         return gx, gr, gar, gad, gg, gse3[..., :4].contiguous(), gse3[..., 4:].contiguous(), None
 
 
