@@ -389,6 +389,39 @@ def dvr_evaluate(self, batch, is_pair=True):
 
 
 # ---------------------------------------------------------------------------------------------------
+# per-frame articulation: the kinematic tree behind every SkinningWarp call
+# ---------------------------------------------------------------------------------------------------
+def articulation_skel_forward(self, t_embed, inst_id, return_so3=False, override_so3=None, override_log_bone_len=None,
+                              override_local_rest_joints=None):
+    """ArticulationSkelMLP.forward (nnutils/pose.py:417-470).  The time MLP and the two heads stay device GEMMs on M rows; the
+    bone lengths, the forward kinematics over the tree (`fk_se3`: a Python loop of clone + matmul + index_put per joint in the
+    reference), `matrix_to_quaternion` and `shift_joints_to_bones_dq` are ONE launch each way (csrc/fk.hip)."""
+    from . import pose
+    P = params_of(self, "a.")
+    if override_so3 is None:
+        lead = t_embed.shape[:-1]
+        so3 = pose.articulation_so3(P, "a", t_embed.reshape(-1, t_embed.shape[-1])).reshape(*lead, self.num_se3, 3)
+    else:
+        so3 = override_so3
+    if return_so3:
+        return so3
+    lead = so3.shape[:-2]
+    so3_rows = so3.reshape(-1, self.num_se3, 3)
+    if override_local_rest_joints is not None:  # reanimation: the caller supplies the parent-to-child offsets (pose.py:455-456)
+        local = override_local_rest_joints.expand(*lead, self.num_se3, 3).reshape(-1, self.num_se3, 3)
+        qr, qd = pose.fk_bones(local.contiguous(), so3_rows, self.edges, shift=P["a.shift"])
+    else:
+        if override_log_bone_len is not None:
+            ll = override_log_bone_len.reshape(-1, self.num_se3)
+        else:
+            ii = None if inst_id is None else inst_id.reshape(-1)
+            ll = pose.log_bone_len(P, "a.log_bone_len", ii, 1 if ii is None else ii.shape[0])
+        skel = {"edges": self.edges, "symm_idx": self.symm_idx, "rest_joints": self.rest_joints}
+        qr, qd = pose.skel_bones(so3_rows, ll, P["a.logscale"], skel, P["a.shift"])
+    return qr.reshape(*lead, self.num_se3, 4), qd.reshape(*lead, self.num_se3, 4)
+
+
+# ---------------------------------------------------------------------------------------------------
 # binding
 # ---------------------------------------------------------------------------------------------------
 # (module path, class name or None for module-level, attribute, replacement, is_static)
@@ -415,6 +448,7 @@ def bindings():
         ("lab4d.nnutils.warping", "ComposedWarp", "forward", composed_forward, False),
         ("lab4d.nnutils.multifields", "MultiFields", "compose_fields", compose_fields, True),
         ("lab4d.nnutils.appearance", "AppearanceEmbedding", "get_vals", appearance_get_vals, False),
+        ("lab4d.nnutils.pose", "ArticulationSkelMLP", "forward", articulation_skel_forward, False),
         ("lab4d.engine.model", "dvr_model", "render", dvr_render, False),
         ("lab4d.engine.model", "dvr_model", "evaluate", dvr_evaluate, False),
         ("lab4d.engine.model", "dvr_model", "render_samples", dvr_render_samples, False),

@@ -122,3 +122,35 @@ def test_flat_articulation_and_intrinsics_match_the_reference(pose_fx):
     for k, g in pose_fx["intr"]["grads"].items():
         assert rel(P["intr." + k].grad, g) < 3e-4, k
     assert rel(pose.intrinsics_vals(P, "intr", None, info_k), pose_fx["intr"]["all_frames"]) < 1e-4
+
+
+def test_articulation_adapter_with_a_stand_in_module(pose_fx):
+    """lab4d_amd.patch.articulation_skel_forward (what patch() binds to ArticulationSkelMLP.forward) driven by a stand-in module
+    with the reference's parameter names: outputs incl. the return_so3 / override branches vs the reference-generated fixture."""
+    from lab4d_amd import patch, pose
+    from standins import Node, _tree
+    ref, skel = pose_fx["art"], pose_fx["skel"]
+    state = {k: v.to(DEV) for k, v in pose_fx["art_state"].items()}
+    m = _tree(Node(), {k: v for k, v in state.items() if v.dtype.is_floating_point and k != "rest_joints"})
+    m.register_buffer("rest_joints", skel["rest_joints"].to(DEV))
+    m.edges, m.symm_idx, m.num_se3 = skel["edges"], skel["symm_idx"], skel["rest_joints"].shape[0]
+    info = dev_info(pose_fx["time_info"])
+    P = {"art." + k: v for k, v in state.items()}
+    fid = pose_fx["frame_id"].to(DEV)
+    te = pose.time_embedding(P, "art.time_embedding", fid, info)
+    inst = info["raw_fid_to_vid"][fid]
+    so3 = patch.articulation_skel_forward(m, te, inst, return_so3=True)
+    assert rel(so3, ref["so3"]) < 1e-4
+    qr, qd = patch.articulation_skel_forward(m, te, inst)
+    assert rel(qr, ref["t"][0]) < 1e-4 and rel(qd, ref["t"][1]) < 1e-4
+    # overrides (reanimation, pose.py:442-456): given joint angles, given bone-length increments, given local rest joints
+    q2 = patch.articulation_skel_forward(m, te, inst, override_so3=ref["so3"].to(DEV))
+    assert rel(q2[0], ref["t"][0]) < 1e-4 and rel(q2[1], ref["t"][1]) < 1e-4
+    ll = pose.log_bone_len(P, "art.log_bone_len", inst, inst.shape[0])
+    q3 = patch.articulation_skel_forward(m, te, inst, override_log_bone_len=ll)
+    assert rel(q3[0], ref["t"][0]) < 1e-4 and rel(q3[1], ref["t"][1]) < 1e-4
+    bl = (ll + P["art.logscale"]).exp()
+    bl = (bl + bl[..., torch.as_tensor(skel["symm_idx"], device=DEV)]) / 2
+    local = pose.rest_joints_to_local(m.rest_joints, skel["edges"])[None] * bl[..., None]
+    q4 = patch.articulation_skel_forward(m, te, inst, override_local_rest_joints=local)
+    assert rel(q4[0], ref["t"][0]) < 1e-4 and rel(q4[1], ref["t"][1]) < 1e-4
