@@ -61,9 +61,9 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
 // max(x, 0) in ONE v_max_f32: fmaxf() first canonicalises its argument (a second v_max) to quiet signalling NaNs, which an
 // MFMA result never is
 __device__ __forceinline__ float relu1(float x) {
-  float y;
-  asm("v_max_f32_e32 %0, 0, %1" : "=v"(y) : "v"(x));
-  return y;
+  // one v_med3_f32 the compiler can see (its hazard recognizer then places the wait states an MFMA result needs in front of a VALU
+  // read; the inline-asm v_max it replaces was invisible to it, see acc_fence)
+  return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff());
 }
 
 // Hazard fence between the MFMAs that produced an accumulator tile and INLINE ASM that reads it.  On gfx950 a VALU read of an
@@ -349,6 +349,60 @@ __device__ __forceinline__ void store_tile_packed(GLOBAL_AS void* buf, int F, in
   for (int i = 0; i < 4; ++i) gst16(base + (lo + tile_lane_offset<PBF16>(8 * i, 0)), c[i][0], c[i][1], c[i][2], c[i][3]);
 }
 
+
+// ---- tile store through the LDS transpose-read (round 2, second session) ----------------------------------------------------------
+// The packed units of a finished tile sit in the wave's slab anyway ([n-tile][unit][lane] 16 B: 8 features of one sample).  gfx950's
+// ds_read_b64_tr_b16 is a free 4x4 16-bit transpose with ARBITRARY per-lane chunk addresses (tools/probes/tr_probe.hip, verified on
+// hardware: inside a 16-lane group, lane i's element j is element i&3 of the 8-byte chunk addressed by lane (i>>2) + 4j).  With lane
+// c = (m = c&3, j = c>>2) of group G = (h = G&1, S = G>>1) pointing at sample 32S + 8m + j (and + 4 for a second read), lane i
+// receives samples 32S + 8(i>>2) + 0..7 of ONE feature = exactly a 16-byte piece of the [feature][64 samples] row: 8 reads + 4 stores per
+// 32 x 64 tile and NO VALU work (the DPP network it replaces: 16 v_perm + 32 v_cndmask_dpp per tile).  The reads are issued right
+// after the slab writes and waited for in `flush`, behind the next tile's weight requests.
+// Measured on the shipped one-wave-per-SIMD kernels (-DLAB4D_TRSTORE): parity-green, forward unchanged (6.71 vs 6.74 ms), backward
+// slower (8.42 vs 7.91 ms): with nothing to switch to, 8 more LDS round trips per step cost more than 48 VALU slots save -- so the
+// DPP network stays the default HERE.  The path is kept because it is what makes 32-sample tiles (two waves per SIMD for the
+// 256-wide nets) practical: a 32 x 32 tile needs an 8 x 8 16-bit transpose in registers, but only 4 of these reads.
+struct TrTile {
+  unsigned long long a[4], b[4];  // [2q + a]: first / second read of a pair
+};
+__device__ __forceinline__ unsigned tr_lane_base(unsigned slab_lds, int UW, int lane) {
+  // LDS byte address of this lane's supplier chunk for (mt = 0, q = 0, a = 0, first read)
+  const int i = lane & 15, G = lane >> 4, h = G & 1, S = G >> 1, m = i & 3, j = i >> 2;
+  const int sigma = 32 * S + 8 * m + j, n = sigma >> 1, t = sigma & 1;
+  return slab_lds + (unsigned)(((t * UW) * 64 + 32 * h + n) * 16);
+}
+__device__ __forceinline__ void tr_issue(unsigned addr /* tr_lane_base + mt * 2048 */, TrTile& r) {
+  // second read of a pair: samples + 4 = lane n + 2 = + 32 bytes; q: next unit = + 1024 bytes; a: + 8 bytes
+  asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+               "ds_read_b64_tr_b16 %4, %8 offset:32\n\t"
+               "ds_read_b64_tr_b16 %1, %8 offset:8\n\t"
+               "ds_read_b64_tr_b16 %5, %8 offset:40\n\t"
+               "ds_read_b64_tr_b16 %2, %8 offset:1024\n\t"
+               "ds_read_b64_tr_b16 %6, %8 offset:1056\n\t"
+               "ds_read_b64_tr_b16 %3, %8 offset:1032\n\t"
+               "ds_read_b64_tr_b16 %7, %8 offset:1064"
+               : "=&v"(r.a[0]), "=&v"(r.a[1]), "=&v"(r.a[2]), "=&v"(r.a[3]), "=&v"(r.b[0]), "=&v"(r.b[1]), "=&v"(r.b[2]), "=&v"(r.b[3])
+               : "v"(addr)
+               : "memory");
+}
+__device__ __forceinline__ void tr_wait(TrTile& r) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]));
+}
+__device__ __forceinline__ void tr_store(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, const TrTile& r) {
+#ifdef LAB4D_ABL_L2STORE
+  s0 &= 0x7ff;
+#endif
+  const int i = lane & 15, G = lane >> 4, h = G & 1, S = G >> 1;
+  GLOBAL_AS char* base = (GLOBAL_AS char*)buf + tile_base_offset<PBF16>(F, s0, 32 * mt);
+  const unsigned lo = (unsigned)((4 * h + (i & 3)) * 128 + (32 * S + 8 * (i >> 2)) * 2);
+#pragma unroll
+  for (int qa = 0; qa < 4; ++qa) {  // qa = 2q + a: rows 16q + 8a + 4h + (i&3)
+    const unsigned long long A = r.a[qa], B = r.b[qa];
+    gst16(base + (lo + (unsigned)((16 * (qa >> 1) + 8 * (qa & 1)) * 128)), (unsigned)A, (unsigned)(A >> 32), (unsigned)B, (unsigned)(B >> 32));
+  }
+}
+
 template <class P>
 __device__ __forceinline__ void store_tile(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
   const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
@@ -627,6 +681,9 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint4* slab = slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE + lane;  // + (t*UW + u)*64
   const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
+  // LDS byte address of this lane's chunk for the transposing tile store (see tr_issue)
+  const unsigned tr_base = tr_lane_base((unsigned)(size_t)(__attribute__((address_space(3))) uint4*)(slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE), UW, lane);
+  TrTile trt;
 
   // device-side sample count: only the first *S_dev samples exist (stream-compacted evaluation); tiles beyond them are skipped
   int S_eff = a.S, ntiles = a.ntiles;
@@ -876,9 +933,9 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
       // stores of the PREVIOUS step in front of it, issued a whole step earlier.
       constexpr bool PACKED = P::BF16 && !TAN && ls.add_ext == 0 && !LAST;
       auto epilogue = [&](int mt, f32x16_t (&acc)[NT], unsigned int (&w)[2][8], unsigned int& wbits) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc_fence(acc[t]);
         if constexpr (PACKED) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc_fence(acc[t]);  // the packing below is inline asm
           // packed-bf16 epilogue (see pk_* helpers): everything after the one fp32 -> bf16 conversion works on the 16 packed dwords
 #pragma unroll
           for (int t = 0; t < 2; ++t)
@@ -897,6 +954,9 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int q = 0; q < 2; ++q) slab[(t * UW + 2 * mt + q) * 64] = make_uint4(w[t][4 * q], w[t][4 * q + 1], w[t][4 * q + 2], w[t][4 * q + 3]);
+#if defined(LAB4D_TRSTORE) && !defined(LAB4D_ABL_NOSTORE)
+          if constexpr (ST || fwd_any_export<Net>(R)) tr_issue(tr_base + (unsigned)mt * 2048u, trt);  // read back transposed, stored in `flush`
+#endif
           return;
         }
         if constexpr (ls.relu != 0) {
@@ -967,10 +1027,20 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
             if constexpr (ls.relu != 0) maskl[((size_t)tile * MT + mt) * 64 + lane] = wbits;
 #endif
 #ifndef LAB4D_ABL_NOSTORE
+#ifndef LAB4D_TRSTORE
             store_tile_packed(actl, 32 * MT, s0, mt, lane, w);
+#else
+            tr_wait(trt);
+            tr_store(actl, 32 * MT, s0, mt, lane, trt);
+#endif
 #endif
           } else if constexpr (fwd_any_export<Net>(R)) {
+#ifndef LAB4D_TRSTORE
             if (actl) store_tile_packed(actl, 32 * MT, s0, mt, lane, w);  // inference: only the layer another net consumes
+#else
+            tr_wait(trt);
+            if (actl) tr_store(actl, 32 * MT, s0, mt, lane, trt);
+#endif
           }
         }
       };
@@ -1107,6 +1177,8 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
   uint4* slab = slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE + lane;
   float* stagef = reinterpret_cast<float*>(slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE);  // wave-private staging (raw-input nets)
   const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
+  const unsigned tr_base = tr_lane_base((unsigned)(size_t)(__attribute__((address_space(3))) uint4*)(slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE), UW, lane);
+  TrTile trt;
 
   for (int tile = wave; tile < a.ntiles; tile += nwaves) {
     const int s0 = tile * TILE;
@@ -1355,8 +1427,10 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
       // (b) gradient wrt the previous layer's output -> masked dZ_{l-1}
       auto epi_act = [&](int j, f32x16_t (&acc)[NT], unsigned int (&w)[2][8]) {
         const unsigned int bits = mbits;
+        if constexpr (P::BF16) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc_fence(acc[t]);
+          for (int t = 0; t < NT; ++t) acc_fence(acc[t]);  // the packed path converts with inline asm
+        }
         if constexpr (lp.ext_grad != 0) {
           f32x16_t eg[NT];
           tile_from_raw<P>(raw, lane, eg);
@@ -1391,6 +1465,9 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int q = 0; q < 2; ++q) slab[(t * UW + 2 * j + q) * 64] = make_uint4(w[t][4 * q], w[t][4 * q + 1], w[t][4 * q + 2], w[t][4 * q + 3]);
+#if defined(LAB4D_TRSTORE) && !defined(LAB4D_ABL_NOSTORE)
+          tr_issue(tr_base + (unsigned)j * 2048u, trt);
+#endif
         } else {
           // fp32 tiles: ReLU mask and the zero of the padded tail samples in one AND per value (v_bfe_i32 + v_and)
           unsigned int keep = lp.relu != 0 ? bits : 0xffffffffu;
@@ -1415,7 +1492,12 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
       auto flush_act = [&](int j, const unsigned int (&w)[2][8]) {
         if constexpr (P::BF16) {
 #ifndef LAB4D_ABL_NOSTORE
+#ifndef LAB4D_TRSTORE
           store_tile_packed(dzp, pad32(lp.mout), s0, j, lane, w);
+#else
+          tr_wait(trt);
+          tr_store(dzp, pad32(lp.mout), s0, j, lane, trt);
+#endif
 #endif
         }
       };
