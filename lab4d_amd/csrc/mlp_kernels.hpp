@@ -22,6 +22,7 @@
 // Weights stream from L2 as pre-packed, lane-linear 1-KiB A-groups (global_load_dwordx4).
 #pragma once
 #include <cstddef>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -1570,6 +1571,18 @@ inline int mlp_grid(int ntiles) {
     hipLaunchKernelGGL(kfn, dim3(mlp_grid<kfn>((k).ntiles)), dim3(256), 0, st, k);                   \
   } while (0)
 
+}  // namespace lab4d
+#include "mlp_kernels_h.hpp"
+namespace lab4d {
+// LAB4D_BWD_H=1 routes the 256-wide posenc nets to the 8-wave / 32-sample backward chain (mlp_kernels_h.hpp): parity-green but
+// measured SLOWER than the 4-wave kernel (9.12 vs 7.93 ms per 4.2 M samples), so it is off by default
+template <class Net>
+constexpr bool use_bwd_h() { return Net::EMB == 0 && net_wmax<Net>() == 256; }
+inline bool bwd_h_enabled() {
+  static const int on = getenv("LAB4D_BWD_H") ? atoi(getenv("LAB4D_BWD_H")) : 0;
+  return on != 0;
+}
+
 #define LAB4D_MLP_INSTANTIATE(Net)                                                                                        \
   namespace lab4d {                                                                                                       \
   template <>                                                                                                             \
@@ -1594,6 +1607,12 @@ inline int mlp_grid(int ntiles) {
     BwdK k = k0;                                                                                                          \
     if (precision == LAB4D_PREC_BF16) {                                                                                   \
       k.ntiles = k.S_pad / PBF16::TILE; /* padded tail tiles are processed too: they zero-fill dz */                                                                                  \
+      if constexpr (use_bwd_h<Net>()) {                                                                                   \
+        if (bwd_h_enabled()) {                                                                                            \
+          hipLaunchKernelGGL((k_mlp_bwd_h<Net>), dim3(mlp_grid_h(k.S_pad / 32)), dim3(512), 0, st, k);                    \
+          return check_launch("mlp_backward");                                                                            \
+        }                                                                                                                 \
+      }                                                                                                                   \
       LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16>), k, st);                         \
     } else if (precision == LAB4D_PREC_F32) {                                                                             \
       k.ntiles = k.S_pad / PF32::TILE;                                                                                   \
