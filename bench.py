@@ -134,7 +134,7 @@ def train_chunk_comp(DF, P, fr, Pb, frb, hxy, batch, rng, spp, res, prec):
     f["feature"] = batch["feature"]
     r = dict(rng, eik_inds_bg=rng["eik_inds"])
     out = DF.render_train_comp(P, f, Pb, frb, hxy, r, flow_thresh=float(res), n_depth=spp // 2, prec=prec)
-    total = sum(DF.losses_comp(out, batch, res, DF.DEFAULT_LOSS_WT).values())
+    total = DF.losses_comp(out, batch, res, DF.DEFAULT_LOSS_WT).total  # formed by the loss kernel
     total.backward()
     return total.detach()
 

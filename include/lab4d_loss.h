@@ -35,9 +35,15 @@ typedef struct {
   const float *t_mask, *t_feature, *t_hxy, *t_rgb, *t_depth, *t_flow, *t_flow_uct, *t_vis2d, *t_detected, *balance_wt;
   int hxy_ld;            /* row stride of t_hxy (3 for homogeneous pixel coordinates) */
   int dense_uses_mask;   /* 1: terms 3-6 are masked by t_mask * vis2d (field_type fg); 0: by vis2d only (comp) */
+  /* field_type "comp" (model.py:455-461, 486-493), both optional: `mask` is then the rendered FOREGROUND mask (mask_fg),
+   * mask_all the composite's mask -- term 0 becomes ((mask - t_mask)^2 * balance_wt + (mask_all - 1)^2) * vis2d * detected (the
+   * composite must be opaque) -- and vis_bg the background field's visibility loss: term 6 becomes (vis + vis_bg_wt * vis_bg) * m. */
+  const float *mask_all, *vis_bg;
+  float vis_bg_wt;
 } lab4d_loss_inputs;
 typedef struct {
   float *mask, *feature, *xy_reproj, *rgb, *depth, *flow, *vis, *gauss_mask, *eikonal, *cyc_dist, *delta_skin, *skin_entropy;
+  float *mask_all, *vis_bg; /* comp only (may be NULL) */
 } lab4d_loss_grads;
 
 /* acc: (2 * LAB4D_LOSS_TERMS) fp32 scratch, zeroed by the call; weights: (LAB4D_LOSS_TERMS) host array (term weight x scale);

@@ -20,7 +20,7 @@ __device__ __forceinline__ float l2n(const float* a, const float* b, int n) {
 
 // per-ray factors shared by forward and backward
 struct RayMask {
-  float m_mask, m_feat, m_dense;
+  float m_mask, m_feat, m_dense, m_vd;  // m_vd = vis2d * detected (the comp opacity term carries no balance weight)
 };
 __device__ __forceinline__ RayMask ray_mask(const lab4d_loss_inputs& in, long r, int N) {
   const float det = in.t_detected ? in.t_detected[r / N] : 1.f;
@@ -28,6 +28,7 @@ __device__ __forceinline__ RayMask ray_mask(const lab4d_loss_inputs& in, long r,
   const float tm = in.t_mask ? in.t_mask[r] : 1.f;
   RayMask k;
   k.m_mask = (in.balance_wt ? in.balance_wt[r] : 1.f) * vis2d * det;
+  k.m_vd = vis2d * det;
   k.m_feat = tm * det;
   k.m_dense = (in.dense_uses_mask ? tm : 1.f) * vis2d;
   return k;
@@ -42,14 +43,18 @@ __global__ void __launch_bounds__(256) k_ray_losses_fwd(lab4d_loss_inputs in, in
   };
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (long)gridDim.x * blockDim.x) {
     const RayMask m = ray_mask(in, r, N);
-    if (in.mask && in.t_mask) { const float d = in.mask[r] - in.t_mask[r]; add(0, d * d * m.m_mask); }
+    if (in.mask && in.t_mask) {
+      const float d = in.mask[r] - in.t_mask[r];
+      const float o = in.mask_all ? in.mask_all[r] - 1.f : 0.f;
+      add(0, d * d * m.m_mask + o * o * m.m_vd);
+    }
     if (in.feature) add(1, l2n(in.feature + r * 16, in.t_feature + r * 16, 16) * m.m_feat);
     if (in.xy_reproj) add(2, l2n(in.xy_reproj + r * 2, in.t_hxy + r * in.hxy_ld, 2) * m.m_feat);
     if (in.rgb)
       for (int j = 0; j < 3; ++j) { const float d = in.rgb[r * 3 + j] - in.t_rgb[r * 3 + j]; add(3, d * d * m.m_dense); }
     if (in.depth) add(4, fabsf(in.depth[r] - in.t_depth[r]) * m.m_dense);
     if (in.flow) add(5, l2n(in.flow + r * 2, in.t_flow + r * 2, 2) * (in.t_flow_uct[r] > 0.f ? 1.f : 0.f) * m.m_dense);
-    if (in.vis) add(6, in.vis[r] * m.m_dense);
+    if (in.vis) add(6, (in.vis[r] + (in.vis_bg ? in.vis_bg_wt * in.vis_bg[r] : 0.f)) * m.m_dense);
     if (in.gauss_mask && in.mask) { const float d = in.gauss_mask[r] - in.mask[r]; add(7, d * d); }
     if (in.eikonal) add(8, in.eikonal[r]);
     if (in.cyc_dist) add(9, in.cyc_dist[r]);
@@ -92,12 +97,17 @@ __global__ void __launch_bounds__(256) k_ray_losses_bwd(lab4d_loss_inputs in, in
   __syncthreads();
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (long)gridDim.x * blockDim.x) {
     const RayMask m = ray_mask(in, r, N);
-    float g_mask = 0.f;
+    float g_mask = 0.f, g_mask_all = 0.f;
     if (in.mask && in.t_mask) {
       const float d = in.mask[r] - in.t_mask[r];
-      if (d * d * m.m_mask > 0.f) g_mask = 2.f * d * m.m_mask * coef[0];
+      const float o = in.mask_all ? in.mask_all[r] - 1.f : 0.f;
+      if (d * d * m.m_mask + o * o * m.m_vd > 0.f) {
+        g_mask = 2.f * d * m.m_mask * coef[0];
+        g_mask_all = 2.f * o * m.m_vd * coef[0];
+      }
     }
     if (g.mask) g.mask[r] = g_mask;  // reg_gauss_mask sees the rendered mask detached (model.py:521)
+    if (g.mask_all) g.mask_all[r] = g_mask_all;
     if (g.feature) {
       const float nrm = l2n(in.feature + r * 16, in.t_feature + r * 16, 16);
       const float f = (nrm * m.m_feat > 0.f) ? coef[1] * m.m_feat / nrm : 0.f;
@@ -123,7 +133,12 @@ __global__ void __launch_bounds__(256) k_ray_losses_bwd(lab4d_loss_inputs in, in
       const float f = (nrm * u > 0.f) ? coef[5] * u / nrm : 0.f;
       for (int j = 0; j < 2; ++j) g.flow[r * 2 + j] = f * (in.flow[r * 2 + j] - in.t_flow[r * 2 + j]);
     }
-    if (g.vis) g.vis[r] = (in.vis[r] * m.m_dense > 0.f) ? m.m_dense * coef[6] : 0.f;
+    {
+      const float v = (in.vis ? in.vis[r] : 0.f) + (in.vis_bg ? in.vis_bg_wt * in.vis_bg[r] : 0.f);
+      const float gv = (in.vis && v * m.m_dense > 0.f) ? m.m_dense * coef[6] : 0.f;
+      if (g.vis) g.vis[r] = gv;
+      if (g.vis_bg) g.vis_bg[r] = gv * in.vis_bg_wt;
+    }
     if (g.gauss_mask) {
       const float d = in.gauss_mask[r] - in.mask[r];
       g.gauss_mask[r] = (d * d > 0.f) ? 2.f * d * coef[7] : 0.f;

@@ -69,7 +69,11 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_h(BwdK a) {
   static_assert(Net::EMB == 0, "posenc nets only");
   using P = PBF16;
   constexpr int NL = Net::NL, UW = Slab<Net, P>::UW, WAVES = 8, TILE = 32;
+#ifdef LAB4D_H_ACG16
+  constexpr int ACG = 16;  // experiment: every weight group through LDS (all 160 KiB used)
+#else
   constexpr int ACG = ACACHE_G;
+#endif
   constexpr int UNITS = UW * 64;  // uint4 slots per wave: one 32-sample n-tile
   __shared__ uint4 slab_all[WAVES * UNITS];
   __shared__ uint4 abuf[2 * ACG * 64];

@@ -518,12 +518,12 @@ LOSS_TERMS = ["mask", "feature", "feat_reproj", "rgb", "depth", "flow", "vis", "
 class _LossInputs(ctypes.Structure):
     _fields_ = [(n, vp) for n in ("mask", "feature", "xy_reproj", "rgb", "depth", "flow", "vis", "gauss_mask", "eikonal", "cyc_dist", "delta_skin",
                                   "skin_entropy", "t_mask", "t_feature", "t_hxy", "t_rgb", "t_depth", "t_flow", "t_flow_uct", "t_vis2d", "t_detected",
-                                  "balance_wt")] + [("hxy_ld", ci), ("dense_uses_mask", ci)]
+                                  "balance_wt")] + [("hxy_ld", ci), ("dense_uses_mask", ci), ("mask_all", vp), ("vis_bg", vp), ("vis_bg_wt", cf)]
 
 
 class _LossGrads(ctypes.Structure):
     _fields_ = [(n, vp) for n in ("mask", "feature", "xy_reproj", "rgb", "depth", "flow", "vis", "gauss_mask", "eikonal", "cyc_dist", "delta_skin",
-                                  "skin_entropy")]
+                                  "skin_entropy", "mask_all", "vis_bg")]
 
 
 _lib.register("lab4d_ray_losses_forward", [ctypes.POINTER(_LossInputs), ci, ci, ctypes.POINTER(cf * 12), vp, vp, vp])
@@ -534,37 +534,45 @@ _TARGETS = ("t_mask", "t_feature", "t_hxy", "t_rgb", "t_depth", "t_flow", "t_flo
 
 class RayLosses(Function):
     """All per-ray loss terms in one pass each way (include/lab4d_loss.h).  apply(N, weights (12 floats), *rendered (12), *targets
-    (10)) -> (13,): the weighted terms in LOSS_TERMS order, then their total."""
+    (10), mask_all, vis_bg) -> (13,): the weighted terms in LOSS_TERMS order, then their total.  mask_all / vis_bg (None for field_type
+    "fg") select the comp variant: opaque-composite term, background visibility at 1 %, dense terms masked by vis2d only."""
+
+    @staticmethod
+    def _inputs(rendered, targets, extras, hxy_ld):
+        a = _LossInputs()
+        for n, t in zip(_RENDERED + _TARGETS, rendered + targets):
+            setattr(a, n, None if t is None else t.data_ptr())
+        comp = extras[0] is not None or extras[1] is not None
+        a.hxy_ld, a.dense_uses_mask = hxy_ld, 0 if comp else 1
+        a.mask_all = None if extras[0] is None else extras[0].data_ptr()
+        a.vis_bg = None if extras[1] is None else extras[1].data_ptr()
+        a.vis_bg_wt = 0.01  # model.py:489
+        return a
 
     @staticmethod
     def forward(ctx, N, weights, *tensors):
         rendered = [None if t is None else t.contiguous().float() for t in tensors[:12]]
-        targets = [None if t is None else t.contiguous().float() for t in tensors[12:]]
-        _lib.require_device(*[t for t in rendered + targets if t is not None])
+        targets = [None if t is None else t.contiguous().float() for t in tensors[12:22]]
+        extras = [None if t is None else t.contiguous().float() for t in tensors[22:24]]
+        _lib.require_device(*[t for t in rendered + targets + extras if t is not None])
         ref = next(t for t in rendered if t is not None)
         R = targets[_TARGETS.index("t_vis2d")].numel()
-        a = _LossInputs()
-        for n, t in zip(_RENDERED + _TARGETS, rendered + targets):
-            setattr(a, n, None if t is None else t.data_ptr())
-        a.hxy_ld = targets[2].shape[-1] if targets[2] is not None else 0
-        a.dense_uses_mask = 1
+        hxy_ld = targets[2].shape[-1] if targets[2] is not None else 0
+        a = RayLosses._inputs(rendered, targets, extras, hxy_ld)
         w = (cf * 12)(*[float(x) for x in weights])
         acc = torch.empty(24, device=ref.device)
         loss = torch.empty(13, device=ref.device)
         _lib.check(_lib.lib().lab4d_ray_losses_forward(ctypes.byref(a), R, int(N), ctypes.byref(w), _lib.ptr(acc), _lib.ptr(loss), _lib.stream()),
                    "ray_losses_forward")
-        ctx.keep = (rendered, targets, acc, [float(x) for x in weights], R, int(N), a.hxy_ld)
-        ctx.shapes = [None if t is None else t.shape for t in tensors[:12]]
+        ctx.keep = (rendered, targets, extras, acc, [float(x) for x in weights], R, int(N), hxy_ld)
+        ctx.shapes = [None if t is None else t.shape for t in tensors[:12]] + [None if t is None else t.shape for t in tensors[22:24]]
         return loss
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        rendered, targets, acc, weights, R, N, hxy_ld = ctx.keep
-        a = _LossInputs()
-        for n, t in zip(_RENDERED + _TARGETS, rendered + targets):
-            setattr(a, n, None if t is None else t.data_ptr())
-        a.hxy_ld, a.dense_uses_mask = hxy_ld, 1
+        rendered, targets, extras, acc, weights, R, N, hxy_ld = ctx.keep
+        a = RayLosses._inputs(rendered, targets, extras, hxy_ld)
         g_loss = (g[:12] + g[12]).contiguous()
         gr = _LossGrads()
         outs = []
@@ -572,10 +580,15 @@ class RayLosses(Function):
             o = torch.empty_like(t) if (t is not None and ctx.needs_input_grad[2 + i]) else None
             outs.append(o)
             setattr(gr, n, None if o is None else o.data_ptr())
+        for i, (n, t) in enumerate(zip(("mask_all", "vis_bg"), extras)):
+            o = torch.empty_like(t) if (t is not None and ctx.needs_input_grad[24 + i]) else None
+            outs.append(o)
+            setattr(gr, n, None if o is None else o.data_ptr())
         w = (cf * 12)(*weights)
         _lib.check(_lib.lib().lab4d_ray_losses_backward(ctypes.byref(a), R, N, ctypes.byref(w), _lib.ptr(acc), _lib.ptr(g_loss), ctypes.byref(gr),
                                                         _lib.stream()), "ray_losses_backward")
-        return (None, None) + tuple(None if o is None else o.view(s) for o, s in zip(outs, ctx.shapes)) + (None,) * 10
+        gs = [None if o is None else o.view(sh) for o, sh in zip(outs, ctx.shapes)]
+        return (None, None) + tuple(gs[:12]) + (None,) * 10 + tuple(gs[12:])
 
 
 class LossDict(dict):
@@ -600,7 +613,7 @@ def losses_fg(results, batch, train_res, weights):
                 a["delta_skin"], a["skin_entropy"]]
     targets = [batch["mask"], batch["feature"], batch["hxy"], batch["rgb"], batch["depth"], batch["flow"], batch["flow_uct"], batch["vis2d"],
                batch["is_detected"], bal]
-    vec = RayLosses.apply(r["mask"].shape[1], wt, *rendered, *targets)
+    vec = RayLosses.apply(r["mask"].shape[1], wt, *rendered, *targets, None, None)
     out = LossDict((k, vec[i]) for i, k in enumerate(LOSS_TERMS))
     out.total = vec[12]
     return out
@@ -845,9 +858,30 @@ def render_train_comp(P_fg, fr_fg, P_bg, fr_bg, hxy, rng, flow_thresh=None, n_de
 
 
 def losses_comp(results, batch, train_res, weights):
-    """compute_recon_loss + mask_losses + rendered regularisers + apply_loss_weights for field_type "comp" (model.py:426-611):
-    fg mask = rendered mask_fg, the composite must be opaque, visibility supervised per field (bg at 1 %), dense terms
-    masked by vis2d only."""
+    """compute_recon_loss + mask_losses + rendered regularisers + apply_loss_weights for field_type "comp" (model.py:426-611) through
+    the same two kernel passes as `losses_fg` (csrc/losses.hip, comp inputs): fg mask = rendered mask_fg, the composite must be
+    opaque, visibility supervised per field (bg at 1 %), dense terms masked by vis2d only."""
+    r, a, b = results["rendered"], results["aux_dict"]["fg"], results["aux_dict"]["bg"]
+    bal = batch.get("mask_balance_wt")
+    if bal is None:
+        bal = mask_balance_wt(batch["mask"], batch["vis2d"], batch["is_detected"])
+    wt = []
+    for k in LOSS_TERMS:
+        w = 1.0 if weights is None or k + "_wt" not in weights else float(weights[k + "_wt"])
+        wt.append(w / train_res if k in ("flow", "feat_reproj") else w)
+    rendered = [r["mask_fg"], a["feature"], a["xy_reproj"], r["rgb"], r["depth"], r["flow"], a["vis"], a["gauss_mask"], r["eikonal"], a["cyc_dist"],
+                a["delta_skin"], a["skin_entropy"]]
+    targets = [batch["mask"], batch["feature"], batch["hxy"], batch["rgb"], batch["depth"], batch["flow"], batch["flow_uct"], batch["vis2d"],
+               batch["is_detected"], bal]
+    vec = RayLosses.apply(r["mask"].shape[1], wt, *rendered, *targets, r["mask"], b["vis"])
+    out = LossDict((k, vec[i]) for i, k in enumerate(LOSS_TERMS))
+    out.total = vec[12]
+    return out
+
+
+def losses_comp_reference_ops(results, batch, train_res, weights):
+    """The comp terms written with element-wise tensor operations, one term at a time like the reference -- the readable statement of
+    what the kernel computes (tests compare the two); not used by the renderer."""
     r, a, b = results["rendered"], results["aux_dict"]["fg"], results["aux_dict"]["bg"]
     L = {}
     L["mask"] = (r["mask_fg"] - batch["mask"].float()).pow(2) * mask_balance_wt(batch["mask"], batch["vis2d"], batch["is_detected"]) \

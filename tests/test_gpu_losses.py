@@ -78,3 +78,36 @@ def test_precomputed_balance_weights_are_used():
     assert torch.equal(L0["mask"], L1["mask"])
     bd3 = dict(bd, mask_balance_wt=2 * bd2["mask_balance_wt"])
     assert torch.allclose(DF.losses_fg(res, bd3, 64, None)["mask"], 2 * L0["mask"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,seed", [(2, 37, 11), (2, 16384, 12)])
+def test_fused_comp_losses_match_the_op_by_op_form(M, N, seed):
+    """field_type "comp" (engine/model.py:455-461, 486-493, 566-571) through the same kernels: foreground mask + opaque composite,
+    background visibility at 1 %, dense terms masked by vis2d only -- values and every input gradient against the op-by-op form."""
+    from lab4d_amd import deformable as DF
+    r, a, b = _case(seed, M, N)
+    g = torch.Generator().manual_seed(seed + 100)
+    r["mask_fg"] = torch.rand(M, N, 1, generator=g)
+    bg = {"vis": torch.rand(M, N, 1, generator=g)}
+    bd = {k: v.to(DEV) for k, v in b.items()}
+
+    def run(fn):
+        rd = {k: v.to(DEV).clone().requires_grad_(True) for k, v in r.items()}
+        ad = {k: v.to(DEV).clone().requires_grad_(True) for k, v in a.items()}
+        gd = {k: v.to(DEV).clone().requires_grad_(True) for k, v in bg.items()}
+        L = fn({"rendered": rd, "aux_dict": {"fg": ad, "bg": gd}}, bd, 64, DF.DEFAULT_LOSS_WT)
+        tot = L.total if getattr(L, "total", None) is not None else sum(L.values())
+        names = ["r." + k for k in rd] + ["a." + k for k in ad] + ["b." + k for k in gd]
+        grads = torch.autograd.grad(tot, list(rd.values()) + list(ad.values()) + list(gd.values()), allow_unused=True)
+        return L, tot, dict(zip(names, grads))
+
+    Lf, tf, gf = run(DF.losses_comp)
+    Lr, tr, gr = run(DF.losses_comp_reference_ops)
+    assert set(Lf.keys()) == set(Lr.keys())
+    for k in Lr:
+        assert torch.allclose(Lf[k], Lr[k], rtol=2e-5, atol=1e-9), (k, float(Lf[k]), float(Lr[k]))
+    assert torch.allclose(tf, tr, rtol=2e-5)
+    for k, g_ref in gr.items():
+        assert (g_ref is None) == (gf[k] is None), k
+        if g_ref is not None:
+            assert torch.allclose(gf[k], g_ref, rtol=1e-4, atol=1e-6 * float(g_ref.abs().max()) + 1e-12), (k, float((gf[k] - g_ref).abs().max()))

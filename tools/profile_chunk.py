@@ -16,7 +16,12 @@ res, spp = 512, 128
 dev = torch.device("cuda", 0)
 _lib.lib()
 P, fr = bench.make_problem(res, dev)
-hxy, batch = bench.chunk_inputs(res, 0, rows, dev, seed=100)
+from lab4d_amd.optim import FlatAdamW
+opt = FlatAdamW([v for v in P.values() if v.dtype.is_floating_point and v.requires_grad], lr=5e-4)
+mlp.FUSED_GRAD_ACCUM = True
+_pro = DF.FramePrologue(P, fr)
+fr = _pro.refresh()
+hxy, batch = bench.chunk_inputs(res, None, list(range(0, res, res // rows)), dev, seed=100)
 batch["hxy"] = hxy
 gen = torch.Generator(device=dev).manual_seed(1)
 M, N = hxy.shape[:2]
