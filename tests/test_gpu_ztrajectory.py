@@ -22,8 +22,8 @@ def problem(seed, res, rows, D):
     return P, fr, hxy, batch, rng
 
 
-@pytest.mark.parametrize("steps", [4])
-def test_training_trajectory_matches_the_oracle(steps):
+@pytest.mark.parametrize("steps,prec_name", [(4, "f32"), (12, "bf16")])
+def test_training_trajectory_matches_the_oracle(steps, prec_name):
     from lab4d_amd import deformable as DF, mlp
     from lab4d_amd.optim import FlatAdamW
     from oracle import lab4d_oracle as O
@@ -65,7 +65,7 @@ def test_training_trajectory_matches_the_oracle(steps):
             opt_d.zero_grad()
             f = synthetic.add_codes(dict(frd), Pd)
             f["feature"] = bd["feature"]
-            out = DF.render_train(Pd, f, hxy.to(DEV), rd, flow_thresh=float(res), n_depth=D, prec=mlp.PREC_F32)
+            out = DF.render_train(Pd, f, hxy.to(DEV), rd, flow_thresh=float(res), n_depth=D, prec=mlp.PREC_F32 if prec_name == "f32" else mlp.PREC_BF16)
             L = DF.losses_fg(out, bd, res, DF.DEFAULT_LOSS_WT)
             L.total.backward()
             opt_d.step(max_norm=5.0)
@@ -77,8 +77,19 @@ def test_training_trajectory_matches_the_oracle(steps):
         mlp.FUSED_GRAD_ACCUM = old
     assert all(torch.isfinite(torch.tensor(loss_d))) and all(bool(torch.isfinite(Pd[k]).all()) for k in names)
     assert loss_c[-1] < loss_c[0], "the oracle's own steps must reduce the loss for this test to mean anything: %s" % loss_c
+    # fp32 chains follow the oracle step by step.  The bf16 chains (the benched dtype) must TRAIN the same way: two trajectories that
+    # start 1e-3 apart drift apart slowly at this learning rate (measured: 0.1 % after 4 steps, 2.9 % after 12, the bf16 run slightly
+    # ahead), so every loss is held within 5 % of the fp32 reference trajectory and the overall reduction must be the same.
+    if prec_name != "f32":
+        import json, os
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump({"steps": steps, "loss_device_bf16": loss_d, "loss_oracle_fp32": loss_c}, open("gpurun_out/parity_trajectory_bf16.json", "w"), indent=1)
+    ltol = 2e-3 if prec_name == "f32" else 5e-2
     for i, (a, b) in enumerate(zip(loss_d, loss_c)):
-        assert abs(a - b) <= 2e-3 * abs(b), "loss after %d steps: device %.6f oracle %.6f" % (i, a, b)
+        assert abs(a - b) <= ltol * abs(b), "loss after %d steps: device %.6f oracle %.6f" % (i, a, b)
+    if prec_name != "f32":
+        assert loss_d[-1] < 0.75 * loss_d[0] and loss_c[-1] < 0.75 * loss_c[0]
+        return
     # Parameters after the FIRST step.  Adam divides by sqrt(v): an entry whose gradient is rounding noise moves by +-lr in a direction the
     # noise decides, so only entries with a well-defined gradient (>= 5 % of their tensor's largest) are comparable; those moved by ~lr,
     # and device and oracle must agree to 3 % of that (measured: see the assertion message / gpurun_out/parity_trajectory.json).  (Later steps are held through the loss trajectory above: by then the gradient
