@@ -51,9 +51,10 @@ def parse():
     ap.add_argument("--chunk-rows", type=int, default=None, help="image rows per frame per chunk (64 rows x 512 = 32768 rays/frame = 8.4 M samples per chunk; ~126 GiB of the 288 GB: "
                                                                 "fewer, larger launches -- 32-row chunks measured 5.8 %% slower, 128 rows do not fit)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--config", default="fg", choices=["fg", "comp"],
+    ap.add_argument("--config", default="fg", choices=["fg", "comp", "hash"],
                     help="fg: BASELINE configs[1] (the headline metric).  comp: BASELINE configs[2]'s per-GPU shape -- fg field with the 18-joint human skeleton and "
-                         "composed motion (comp_skel-human_dense) + background field, compose_fields, comp losses; spp/2 samples per field")
+                         "composed motion (comp_skel-human_dense) + background field, compose_fields, comp losses; spp/2 samples per field.  hash: BASELINE configs[4]'s "
+                         "per-GPU shape -- a field on the multiresolution hash encoding (no reference counterpart), 1024x1024, 256 samples/ray (--res / --spp default to those)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays per frame of one CPU-baseline pass (1 warm-up + 3 timed passes)")
@@ -64,6 +65,7 @@ def parse():
                          "time an N-GPU run cannot beat; reported under 'emulated', the headline fields stay those of the work actually done")
     ap.add_argument("--dry-ranks", type=int, default=0, help="no GPU work: print every rank's row band, chunk list and memory estimate for --gpus N")
     a = ap.parse_args()
+    a.res_given, a.spp_given, a.chunk_rows_given = "--res" in sys.argv, "--spp" in sys.argv, a.chunk_rows is not None
     if a.chunk_rows is None:
         a.chunk_rows = 64 if a.dtype == "bf16" else 32  # fp32 activations are twice the size
     return a
@@ -302,10 +304,117 @@ def dry_ranks(a):
     print(json.dumps({"world": world, "collective": "1 x all_reduce of the flat fp32 gradient per step", "plans": plans}))
 
 
+def hash_main(a):
+    """BASELINE configs[4]'s per-GPU shape: rays -> samples -> hash-grid field (lab4d_amd/hashfield.py) -> compositing -> colour + mask loss ->
+    backward -> AdamW, one 1024^2 frame pair x 256 samples/ray per step in row-interleaved chunks.  No reference counterpart (the reference
+    has no hash grid): an absolute number for the encoding variant north_star names, not a parity claim."""
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from lab4d_amd import _lib, hashfield, mlp, synthetic
+    from lab4d_amd import quat_utils as Q, render_utils as RU
+    from lab4d_amd.optim import FlatAdamW
+    _lib.lib()
+    res = a.res if a.res_given else 1024
+    spp = a.spp if a.spp_given else 256
+    rows = a.chunk_rows if a.chunk_rows_given else 16
+    prec = mlp.PREC_BF16 if a.dtype == "bf16" else mlp.PREC_F32
+    P, cfg = hashfield.make_weights(0, sdf_bias=0.02)
+    P = synthetic.to_device(P, dev)
+    params = [v for k, v in P.items() if k != "aabb"]
+    for v in params:
+        v.requires_grad_(True)
+    fr = synthetic.to_device(synthetic.make_frames(1, 2, res), dev)
+    cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
+    hres = hashfield.resolutions(cfg, dev)
+    opt = FlatAdamW(params, lr=1e-3)
+    mlp.FUSED_GRAD_ACCUM = True
+    n_chunks = res // rows
+    chunks = chunk_rows_of(list(range(res)), n_chunks)
+    inputs = []
+    for i, rr in enumerate(chunks):
+        hxy = synthetic.make_rays(res, 2, rows=rr).to(dev)
+        g = torch.Generator().manual_seed(100 + i)
+        tgt = {"rgb": torch.rand(2, hxy.shape[1], 3, generator=g).to(dev), "mask": ((hxy[..., :2] - res / 2).norm(dim=-1, keepdim=True) < res / 4).float()}
+        inputs.append((hxy, tgt))
+    M, N0 = inputs[0][0].shape[:2]
+
+    def chunk(hxy, tgt):
+        _, _, deltas, _, xyz, dirs = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=spp)
+        rgb, dens = hashfield.forward(P, cfg, xyz.reshape(-1, 3), dirs.reshape(-1, 3), spf=N0 * spp, prec=prec, res=hres)
+        r = RU.render_pixel({"rgb": rgb.view(M, N0, spp, 3), "density": dens.view(M, N0, spp, 1)}, deltas)
+        loss = (r["rgb"] - tgt["rgb"]).pow(2).mean() + 0.1 * (r["mask"] - tgt["mask"]).pow(2).mean()
+        loss.backward()
+        return loss.detach()
+
+    st_hxy, st_tgt = inputs[0][0].clone(), {k: v.clone() for k, v in inputs[0][1].items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            chunk(st_hxy, st_tgt)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = None
+    if not a.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            st_loss = chunk(st_hxy, st_tgt)
+    opt.zero_grad()
+
+    def step():
+        opt.zero_grad()
+        last = None
+        for hxy, tgt in inputs:
+            if graph is not None:
+                st_hxy.copy_(hxy)
+                for k in tgt:
+                    st_tgt[k].copy_(tgt[k])
+                graph.replay()
+                last = st_loss
+            else:
+                last = chunk(hxy, tgt)
+        opt.step(max_norm=5.0)
+        mlp.repack_all()
+        return last
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.PROF = {}
+    for hxy, tgt in inputs[:4]:
+        chunk(hxy, tgt)
+    torch.cuda.synchronize()
+    prof = _lib.prof_summary()
+    _lib.PROF = None
+    rays = 2 * res * res
+    value = rays * a.steps / dt
+    kern = {k: {"ms_per_step": round(v[1] / 4 * len(inputs), 2), "GBps": round(v[3] / v[1] / 1e6, 1) if v[3] else None} for k, v in sorted(prof.items())}
+    out = {"metric": "rendered rays/sec (fwd+bwd), hash-grid field at %dx%d x %d samples (BASELINE configs[4] per-GPU shape; no reference counterpart, not the headline metric)" % (res, res, spp),
+           "value": round(value, 1), "unit": "rays/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": "hash-grid field (L=16, F=2, T=2^19, 16..2048; geometry net 32-64-16, colour net 19-64-64-3), %dx%d frame pair, %d samples/ray, "
+                                  "rays -> samples -> field -> compositing -> rgb + mask loss -> backward -> AdamW" % (res, res, spp),
+                      "rays_per_step": rays, "chunk_rays": 2 * rows * res, "launch": "hipGraph replay per chunk" if graph is not None else "eager"},
+           "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1), "kernels": kern,
+           "loss_last_chunk": float(last), "params_finite": bool(all(bool(torch.isfinite(p).all()) for p in params))}
+    sys.stdout.flush()
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
+
+
 def main():
     a = parse()
     if a.dry_ranks:
         return dry_ranks(a)
+    if a.config == "hash":
+        return hash_main(a)
     rank_main(a)
 
 

@@ -27,15 +27,21 @@ __global__ void __launch_bounds__(256) k_hashgrid_bwd(const float* __restrict__ 
                                                       const float* __restrict__ g_out, int S, int L, int log2_T, int F, float* __restrict__ g_table,
                                                       float* __restrict__ g_x) {
   const size_t slab = ((size_t)1 << log2_T) * F;
-  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
-    const float p[3] = {x[3 * s], x[3 * s + 1], x[3 * s + 2]};
+  const int lane = threadIdx.x & 63;
+  // wave-uniform trip count: the table updates are combined across the lanes of a wave (wave_run_add), so every lane takes part;
+  // lanes past the end carry a zero gradient
+  for (long s0 = (long)blockIdx.x * blockDim.x; s0 < S; s0 += (long)gridDim.x * blockDim.x) {
+    const long s = s0 + threadIdx.x;
+    const bool live = s < S;
+    const long sc = live ? s : S - 1;
+    const float p[3] = {x[3 * sc], x[3 * sc + 1], x[3 * sc + 2]};
     float gx[3] = {0.f, 0.f, 0.f};
     for (int l = 0; l < L; ++l) {
       float g[MAXF];
-      for (int k = 0; k < F; ++k) g[k] = g_out[(size_t)s * L * F + l * F + k];
-      encode_level_bwd(p, table + l * slab, res[l], log2_T, F, g, g_table ? g_table + l * slab : nullptr, g_x ? gx : nullptr);
+      for (int k = 0; k < F; ++k) g[k] = live ? g_out[(size_t)s * L * F + l * F + k] : 0.f;
+      encode_level_bwd<true>(p, table + l * slab, res[l], log2_T, F, g, g_table ? g_table + l * slab : nullptr, g_x ? gx : nullptr, lane);
     }
-    if (g_x) { g_x[3 * s] = gx[0]; g_x[3 * s + 1] = gx[1]; g_x[3 * s + 2] = gx[2]; }
+    if (g_x && live) { g_x[3 * s] = gx[0]; g_x[3 * s + 1] = gx[1]; g_x[3 * s + 2] = gx[2]; }
   }
 }
 

@@ -68,8 +68,37 @@ LAB4D_HD void encode_level(const float* x, const float* tab, int res, int log2_T
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// g_tab[v + f] += val[f] for every lane of the wave, with the lanes of a RUN of equal consecutive vertices combined first (segmented
+// inclusive scan over the 64 lanes, one atomic per run and feature from its last lane).  Lanes are consecutive samples of a ray, and a
+// ray crosses a coarse cell in ~10 consecutive samples: at 8.4 M samples x 16 levels x 8 vertices x F the fp32 atomics of the first
+// version ran into the L2's atomic rate (12 G atomics/s; the table gradient took 11.8 s of a 13 s step).  EVERY lane of the wave must
+// call this (lanes without a sample pass val = 0 and any vertex).
+__device__ __forceinline__ void wave_run_add(float* g_tab, uint32_t v, const float* val, int F, int lane) {
+    const uint32_t prev = (uint32_t)__shfl_up((int)v, 1, 64);
+    int flag = (lane == 0) || (prev != v);
+    float a[MAXF];
+    for (int f = 0; f < F; ++f) a[f] = val[f];
+    for (int off = 1; off < 64; off <<= 1) {
+        const int of = __shfl_up(flag, off, 64);
+        float o[MAXF];
+        for (int f = 0; f < F; ++f) o[f] = __shfl_up(a[f], off, 64);
+        if (lane >= off && !flag) {
+            for (int f = 0; f < F; ++f) a[f] += o[f];
+            flag |= of;
+        }
+    }
+    const uint32_t next = (uint32_t)__shfl_down((int)v, 1, 64);
+    if (lane == 63 || next != v)
+        for (int f = 0; f < F; ++f)
+            if (a[f] != 0.f) atomicAdd(g_tab + (size_t)v + f, a[f]);
+}
+#endif
+
 // adjoint: g_tab[vertex][f] += weight * g[f] (atomic on the device); gx[a] += d out / d x_a . g  (gx may be null)
-LAB4D_HD void encode_level_bwd(const float* x, const float* tab, int res, int log2_T, int F, const float* g, float* g_tab, float* gx) {
+// WAVE = true (device only): the whole wave calls this together and the table updates go through wave_run_add
+template <bool WAVE = false>
+LAB4D_HD void encode_level_bwd(const float* x, const float* tab, int res, int log2_T, int F, const float* g, float* g_tab, float* gx, int lane = 0) {
     uint32_t i0[3];
     float w[3];
     cell_of(x, res, i0, w);
@@ -79,6 +108,16 @@ LAB4D_HD void encode_level_bwd(const float* x, const float* tab, int res, int lo
         const float wx = dx ? w[0] : 1.f - w[0], wy = dy ? w[1] : 1.f - w[1], wz = dz ? w[2] : 1.f - w[2];
         const size_t v = (size_t)vertex_index(i0[0] + dx, i0[1] + dy, i0[2] + dz, res, log2_T) * F;
         float dot = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (WAVE) {
+            if (g_tab) {
+                float val[MAXF];
+                for (int f = 0; f < F; ++f) val[f] = wx * wy * wz * g[f];
+                wave_run_add(g_tab, (uint32_t)v, val, F, lane);
+            }
+            for (int f = 0; f < F; ++f) dot += tab[v + f] * g[f];
+        } else
+#endif
         for (int f = 0; f < F; ++f) {
             if (g_tab) LAB4D_ATOMIC_ADD(g_tab + v + f, wx * wy * wz * g[f]);
             dot += tab[v + f] * g[f];

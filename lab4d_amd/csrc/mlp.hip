@@ -584,6 +584,8 @@ int with_net(int net, F&& f) {
     case LAB4D_NET_DENSE: return f(NetDense{});
     case LAB4D_NET_BG_BASE: return f(NetBgBase{});
     case LAB4D_NET_BG_COLOR: return f(NetBgColor{});
+    case LAB4D_NET_HASH_GEO: return f(NetHashGeo{});
+    case LAB4D_NET_HASH_COLOR: return f(NetHashColor{});
     default: set_error("unknown net id %d", net); return LAB4D_EINVAL;
   }
 }

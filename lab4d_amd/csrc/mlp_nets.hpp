@@ -72,6 +72,18 @@ struct NetBgColor {
                                {0, 64, 3, 0, 0, 0, 0}};
 };
 
+// Hash-grid field (BASELINE config 5; the reference has no such field: nerf.py:98 is a TODO).  Shapes follow Mueller et al. 2022, section 5.4
+// (NeRF): a density / geometry net with one hidden layer of 64 on the L*F = 32 hash features, 16 outputs (here: sdf + 15 geometry
+// features), and a colour net with two hidden layers of 64 on [16 geometry outputs | view direction].
+struct NetHashGeo {
+  static constexpr int ID = LAB4D_NET_HASH_GEO, NL = 2, EMB = 1, NFREQ = 0, CIN = 32, SLOTS = 32, KE = 32, COUT = 16, AUX3 = 0;
+  static constexpr LS L[NL] = {{32, 0, 64, 1, 0, 0, 0}, {0, 64, 16, 0, 0, 0, 0}};
+};
+struct NetHashColor {
+  static constexpr int ID = LAB4D_NET_HASH_COLOR, NL = 3, EMB = 1, NFREQ = 0, CIN = 19, SLOTS = 19, KE = 32, COUT = 3, AUX3 = 0;
+  static constexpr LS L[NL] = {{32, 0, 64, 1, 0, 0, 0}, {0, 64, 64, 1, 0, 0, 0}, {0, 64, 3, 0, 0, 0, 0}};
+};
+
 template <class Net>
 constexpr int net_wmax() {
   int w = 32;

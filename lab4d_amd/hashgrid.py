@@ -31,8 +31,10 @@ class _HashEncode(Function):
         if T != 1 << log2_T or res.numel() != L:
             raise RuntimeError("hash_encode: table must be (L, 2^log2_T, F) with one resolution per level")
         out = torch.empty(S, L * F, device=x.device)
-        _lib.check(_lib.lib().lab4d_hashgrid_forward(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), S, L, log2_T, F, _lib.ptr(out), _lib.stream()),
-                   "hashgrid_forward")
+        # algorithmic bytes: 8 vertices x F floats gathered per level, the point read, L*F floats written
+        with _lib.timed("k_hashgrid_fwd", (0.0, 4.0 * S * (8 * L * F + 3 + L * F))):
+            _lib.check(_lib.lib().lab4d_hashgrid_forward(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), S, L, log2_T, F, _lib.ptr(out), _lib.stream()),
+                       "hashgrid_forward")
         ctx.save_for_backward(x, table, res)
         ctx.log2_T = log2_T
         return out
@@ -47,8 +49,9 @@ class _HashEncode(Function):
         g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         if g_table is None and g_x is None:
             return None, None, None, None
-        _lib.check(_lib.lib().lab4d_hashgrid_backward(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), _lib.ptr(g), S, L, ctx.log2_T, F, _lib.ptr(g_table),
-                                                      _lib.ptr(g_x), _lib.stream()), "hashgrid_backward")
+        with _lib.timed("k_hashgrid_bwd", (0.0, 4.0 * S * (2 * 8 * L * F + 6 + L * F))):  # vertices read (d/dx) and atomically added to
+            _lib.check(_lib.lib().lab4d_hashgrid_backward(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), _lib.ptr(g), S, L, ctx.log2_T, F, _lib.ptr(g_table),
+                                                          _lib.ptr(g_x), _lib.stream()), "hashgrid_backward")
         return g_x, g_table, None, None
 
 

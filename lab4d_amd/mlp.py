@@ -21,7 +21,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 MAXL = 12
-NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE, NET_BG_BASE, NET_BG_COLOR, NET_SKIN18 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE, NET_BG_BASE, NET_BG_COLOR, NET_SKIN18, NET_HASH_GEO, NET_HASH_COLOR = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 PREC_F32, PREC_BF16 = 0, 1
 vp, ci = ctypes.c_void_p, ctypes.c_int
 
@@ -55,14 +55,14 @@ _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp
 _lib.register("lab4d_mlp_wgrad_mapped", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
 
-NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color", 8: "skin18"}
+NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color", 8: "skin18", 9: "hash_geo", 10: "hash_color"}
 # algorithmic MACs per sample (real layer shapes incl. conditioning columns)
 NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736, 5: 39 * 256 + 256 * 256 + 256 * 3,
-            6: 100096 + 128, 7: 43392 + 8576, 8: (54 + 160) * 64 + 64 * 64 + 64 * 18}
+            6: 100096 + 128, 7: 43392 + 8576, 8: (54 + 160) * 64 + 64 * 64 + 64 * 18, 9: 32 * 64 + 64 * 16, 10: 19 * 64 + 64 * 64 + 64 * 3}
 
 
 
-KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor", 8: "Skin18"}  # template argument names in csrc/mlp_nets.hpp
+KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor", 8: "Skin18", 9: "HashGeo", 10: "HashColor"}  # template argument names in csrc/mlp_nets.hpp
 
 
 def wgrad_kernel_name(L, prec):
@@ -180,6 +180,13 @@ def bindings(net, prefix=""):
                 LayerBinding(p + "colorfield.linear_final.0.weight", p + "colorfield.linear_final.0.bias", prev0=0),
                 LayerBinding(p + "rgb.0.weight", p + "rgb.0.bias", prev0=0, aux0=128),
                 LayerBinding(p + "rgb.2.weight", p + "rgb.2.bias", prev0=0)]
+    if net == NET_HASH_GEO:  # hashfield.py: raw 32 hash features -> 64 -> 16
+        q = p + "hash.geo."
+        return [LayerBinding(q + "0.weight", q + "0.bias", emb0=0), LayerBinding(q + "2.weight", q + "2.bias", prev0=0)]
+    if net == NET_HASH_COLOR:  # hashfield.py: raw [16 geometry features | 3 view direction] -> 64 -> 64 -> 3
+        q = p + "hash.color."
+        return [LayerBinding(q + "0.weight", q + "0.bias", emb0=0), LayerBinding(q + "2.weight", q + "2.bias", prev0=0),
+                LayerBinding(q + "4.weight", q + "4.bias", prev0=0)]
     raise ValueError(net)
 
 

@@ -45,3 +45,24 @@ def hash_encode(x, table, res_list, log2_T):
         wc = torch.where(corners[None].bool(), w[:, None, :], 1 - w[:, None, :]).prod(-1)   # (S,8)
         outs.append((wc[..., None] * table[l][idx]).sum(1))
     return torch.cat(outs, -1)
+
+
+def hash_field_forward(P, cfg, xyz, dirs, get_density=True):
+    """Torch-CPU restatement of lab4d_amd/hashfield.forward (parity unpinned like the encoding itself): hash encoding -> geometry net
+    32 -> 64 -> 16 (sdf = out[0]) -> VolSDF density (nerf.py:199-206's Laplace CDF) ; colour net [16 | dir] -> 64 -> 64 -> 3, sigmoid."""
+    import torch.nn.functional as F
+    lo, hi = P["aabb"][0], P["aabb"][1]
+    x01 = (xyz - lo) / (hi - lo)
+    enc = hash_encode(x01, P["hash.table"], level_resolutions(cfg["L"], cfg["n_min"], cfg["n_max"]), cfg["log2_T"])
+    h = F.relu(F.linear(enc, P["hash.geo.0.weight"], P["hash.geo.0.bias"]))
+    geo = F.linear(h, P["hash.geo.2.weight"], P["hash.geo.2.bias"])
+    sdf = geo[:, :1]
+    c = torch.cat([geo, dirs], -1)
+    c = F.relu(F.linear(c, P["hash.color.0.weight"], P["hash.color.0.bias"]))
+    c = F.relu(F.linear(c, P["hash.color.2.weight"], P["hash.color.2.bias"]))
+    rgb = torch.sigmoid(F.linear(c, P["hash.color.4.weight"], P["hash.color.4.bias"]))
+    if not get_density:
+        return rgb, sdf
+    ibeta = P["logibeta"].exp()
+    density = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta  # nerf.py:203-205
+    return rgb, density

@@ -44,3 +44,41 @@ def test_hash_encode_matches_the_oracle(L, F, log2_T, n_min, n_max, S):
     b = hashgrid.hash_encode(xd.detach(), t2, rd, log2_T)
     ab = hashgrid.hash_encode(xd.detach(), td.detach() * 2 - t2 * 0.5, rd, log2_T)
     assert torch.allclose(ab, 2 * a - 0.5 * b, atol=1e-5)
+
+
+@pytest.mark.parametrize("prec_name,tol,gtol", [("f32", 2e-4, 2e-3), ("bf16", 3e-2, 5e-2)])
+def test_hash_field_matches_the_oracle(prec_name, tol, gtol):
+    """The hash-grid FIELD (hash encoding -> fused geometry / colour chains -> VolSDF density; lab4d_amd/hashfield.py) against its
+    torch-CPU restatement: outputs and the gradients of the table, every Linear and the points.  Parity unpinned against the
+    reference (it has no hash grid); fp32 chains to 2e-4, bf16 chains to their rounding."""
+    from lab4d_amd import hashfield, mlp
+    from oracle import hashgrid_oracle as HO
+    cfg = {"L": 16, "F": 2, "log2_T": 14, "n_min": 16, "n_max": 512}
+    P, cfg = hashfield.make_weights(3, cfg, sdf_bias=0.01)
+    P["hash.table"] = P["hash.table"] * 3e3  # features of order 0.3 so that the nets see a signal
+    g = torch.Generator().manual_seed(5)
+    S = 1000
+    xyz = (torch.rand(S, 3, generator=g) * 2 - 1) * 0.11
+    dirs = torch.nn.functional.normalize(torch.randn(S, 3, generator=g), dim=-1)
+    names = [k for k in P if k != "aabb"]
+    cw = [torch.randn(S, 3, generator=g), torch.randn(S, 1, generator=g)]
+
+    def run(fwd, dev):
+        Pl = {k: (v.to(dev).clone().requires_grad_(True) if k in names else v.to(dev)) for k, v in P.items()}
+        x = xyz.to(dev).clone().requires_grad_(True)
+        rgb, dens = fwd(Pl, x, dirs.to(dev))
+        loss = (rgb * cw[0].to(dev)).sum() + (dens * cw[1].to(dev)).sum() * 1e-2
+        gs = torch.autograd.grad(loss, [Pl[k] for k in names] + [x])
+        return rgb, dens, dict(zip(names + ["xyz"], gs))
+
+    prec = mlp.PREC_F32 if prec_name == "f32" else mlp.PREC_BF16
+    rr, rd, rg = run(lambda Pl, x, d: HO.hash_field_forward(Pl, cfg, x, d), "cpu")
+    dr, dd, dg = run(lambda Pl, x, d: hashfield.forward(Pl, cfg, x, d, spf=S, prec=prec), DEV)
+    rel = lambda a, b: float((a.detach().cpu() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-12))
+    assert rel(dr, rr) < tol and rel(dd, rd) < tol, (rel(dr, rr), rel(dd, rd))
+    # fp32: max-norm; bf16: relative L2 per tensor, like the bf16 bounds of the training-graph tests (a table entry sees a handful of
+    # samples, its bf16 rounding noise does not average out entry by entry)
+    rl2 = lambda a, b: float((a.detach().cpu() - b.detach()).norm() / b.detach().norm().clamp_min(1e-20))
+    for k in names + ["xyz"]:
+        e = rel(dg[k], rg[k]) if prec_name == "f32" else rl2(dg[k], rg[k])
+        assert e < gtol, (k, e)
