@@ -1,0 +1,108 @@
+// Probe (measurement only): how fast can ONE wave per SIMD run the chain kernels' core loop -- per "step" 16 weight groups read from
+// LDS (ds_read_b128, shared by the 4 waves of the workgroup) feeding 32 v_mfma_f32_32x32x16_bf16 (2 n-tiles) -- with nothing else?
+// Variants: V0 reads + MFMAs; V1 + one s_barrier per step; V2 + 4 ds_write_b128 per wave and step (the weight stash);
+// V3 = V2 + a 180-instruction VALU epilogue on the previous accumulators (independent of the MFMAs in flight);
+// V5 = no LDS reads at all (A held in registers): the MFMA rate of ONE wave per SIMD with the kernel's two dependent accumulation chains;
+// V6 = V5 with FOUR independent chains (the same 32 MFMAs per step spread over 4 accumulators).
+// V4 = V1 with PROGRESSIVE reads: each group's register is re-read for the next step right behind the MFMAs that consumed it.
+// Ideal: 32 MFMAs x 32 cycles = 1024 cycles per step.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_core tools/probes/mfma_core.hip && /tmp/mfma_core
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int V>
+__global__ void __launch_bounds__(256) k_core(float* out, int steps) {
+  __shared__ uint4 abuf[2 * 16 * 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 2 * 16 * 64; i += 256) abuf[i] = make_uint4(0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  __syncthreads();
+  uint4 B[2][16];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) B[t][g] = make_uint4(0x3c003c00u + lane + g, 0x3c003c00u, 0x3c003c00u + t, 0x3c003c00u);
+  f32x16_t acc[2], prev[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; prev[t][r] = (float)(lane + r); }
+  float sink = 0.f;
+  uint4 A[16];
+  f32x16_t acc4[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc4[t][r] = 0.f;
+  for (int s = 0; s < steps; ++s) {
+    if (V >= 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int buf = s & 1;
+    if ((V != 4 && V < 5) || s == 0) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) A[g] = abuf[(buf * 16 + g) * 64 + lane];
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8_t av, bv;
+        __builtin_memcpy(&av, &A[g], 16);
+        __builtin_memcpy(&bv, &B[t][g], 16);
+        if (V == 6) acc4[2 * t + (g & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc4[2 * t + (g & 1)], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+      }
+      if (V == 4) A[g] = abuf[((buf ^ 1) * 16 + g) * 64 + lane];
+    }
+    if (V >= 3) {  // stand-in epilogue on the PREVIOUS tile: ~180 dependent-free VALU ops
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float x = prev[t][r];
+          x = x * 1.0001f + 0.5f; x = fmaxf(x, 0.f); x = x * 0.999f - 0.25f; x = fminf(x, 1e6f); x = x + (float)r;
+          prev[t][r] = x;
+        }
+      sink += prev[0][0] + prev[1][15];
+    }
+    if (V >= 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) abuf[((buf ^ 1) * 16 + wid + 4 * i) * 64 + lane] = make_uint4(0x3f803f80u + s, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + i);
+    }
+    if (V >= 3) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) prev[t] = acc[t];
+    }
+  }
+  float v = sink;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v += acc[t][r] + acc4[t][r] + acc4[t + 2][r];
+  out[blockIdx.x * 256 + threadIdx.x] = v;
+}
+
+template <int V>
+void run(float* out, int steps) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((k_core<V>), dim3(256), dim3(256), 0, 0, out, 64);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL((k_core<V>), dim3(256), dim3(256), 0, 0, out, steps);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us_per_step = ms * 1e3 / steps;
+  printf("  \"V%d\": {\"us_per_step\": %.4f, \"cycles_at_2.4GHz\": %.0f, \"mfma_duty\": %.3f},\n", V, us_per_step, us_per_step * 2400.0, 1024.0 / (us_per_step * 2400.0));
+}
+
+int main() {
+  float* out; CK(hipMalloc(&out, 256 * 256 * 4));
+  const int steps = 20000;
+  printf("{\n");
+  run<0>(out, steps); run<1>(out, steps); run<2>(out, steps); run<3>(out, steps); run<4>(out, steps); run<5>(out, steps); run<6>(out, steps);
+  printf("  \"ideal_cycles\": 1024\n}\n");
+  return 0;
+}
