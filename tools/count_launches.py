@@ -6,7 +6,7 @@ import bench
 from lab4d_amd import deformable as DF, mlp
 dev = torch.device("cuda")
 P, fr = bench.make_problem(512, dev)
-hxy, batch = bench.chunk_inputs(512, 0, 16, dev, 1)
+hxy, batch = bench.chunk_inputs(512, None, list(range(0, 512, 8)), dev, 1)  # one of the bench's 64-row chunks (rows spread over the frame)
 from lab4d_amd.optim import FlatAdamW
 opt = FlatAdamW([v for v in P.values() if v.dtype.is_floating_point and v.requires_grad], lr=5e-4)  # the bench's configuration:
 mlp.FUSED_GRAD_ACCUM = True                                                                       # gradients accumulate in the flat buffer
