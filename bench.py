@@ -433,7 +433,8 @@ def rank_main(a):
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL on ROCm, bound to this rank's GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
