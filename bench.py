@@ -36,9 +36,9 @@ PEAK_BF16 = 2.5e15  # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
 # algorithmic GEMM FLOPs of the fg training graph per sample, fwd+bwd: 3 x 2 x 918,912 MAC
 FLOP_PER_SAMPLE = 5513472.0
-# device memory per sample of a training chunk (stored activations, dZ, masks, per-sample fields): measured 126.1 GiB peak for an
-# 8.39 M-sample chunk (64 rows x 2 frames, profiles/r02_bench.json) -- used by --dry-ranks to check that a rank's chunk fits
-BYTES_PER_SAMPLE = 126.1 * 2**30 / (2 * 64 * 512 * 128)
+# device memory per sample of a training chunk (stored activations, the largest dZ set, masks, per-sample fields): measured 194.9 GiB peak
+# for a 16.8 M-sample chunk (128 rows x 2 frames, profiles/r02_bench.json) -- used by --dry-ranks to check that a rank's chunk fits
+BYTES_PER_SAMPLE = 194.9 * 2**30 / (2 * 128 * 512 * 128)
 
 
 def parse():
@@ -48,8 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=128)
-    ap.add_argument("--chunk-rows", type=int, default=None, help="image rows per frame per chunk (64 rows x 512 = 32768 rays/frame = 8.4 M samples per chunk; ~126 GiB of the 288 GB: "
-                                                                "fewer, larger launches -- 32-row chunks measured 5.8 %% slower, 128 rows do not fit)")
+    ap.add_argument("--chunk-rows", type=int, default=None, help="image rows per frame per chunk (default 128 rows x 512 = 65536 rays/frame = 16.8 M samples per chunk, 195 GiB of the 288 GB: "
+                                                                "fewer, larger launches -- 64-row chunks measured 2.4 %% slower, 32-row chunks 8 %%)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--config", default="fg", choices=["fg", "comp", "hash"],
                     help="fg: BASELINE configs[1] (the headline metric).  comp: BASELINE configs[2]'s per-GPU shape -- fg field with the 18-joint human skeleton and "
@@ -67,7 +67,7 @@ def parse():
     a = ap.parse_args()
     a.res_given, a.spp_given, a.chunk_rows_given = "--res" in sys.argv, "--spp" in sys.argv, a.chunk_rows is not None
     if a.chunk_rows is None:
-        a.chunk_rows = 64 if a.dtype == "bf16" else 32  # fp32 activations are twice the size
+        a.chunk_rows = 128 if a.dtype == "bf16" else 64  # fp32 activations are twice the size
     return a
 
 
@@ -511,6 +511,8 @@ def rank_main(a):
             for _ in range(2):  # eager warm-up on the capture stream: allocator pools, rocBLAS workspaces, column maps, packed weights
                 train_chunk_(DF, P, fr, st_hxy, st_batch, st_rng, spp, res, prec)
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()  # the eager warm-up's blocks go back to the device: the graph's private pool needs the same amount again
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             st_loss = train_chunk_(DF, P, fr, st_hxy, st_batch, st_rng, spp, res, prec)
@@ -570,7 +572,18 @@ def rank_main(a):
     dt = time.perf_counter() - t0
     prof_src = "HIP events around every launch of the family during the timed steps"
     n_prof_chunks = len(inputs) * a.steps
+    loss_last = float(last)
+    peak_hbm = torch.cuda.max_memory_allocated()
+    launch_mode = "hipGraph replay per chunk" if graph is not None else "eager"
     if graph is not None:
+        # the eager re-run below needs the memory the graph's private pool holds
+        last = st_loss = None
+        graph = None
+        torch.cuda.empty_cache()
+        graph_was = True
+    else:
+        graph_was = False
+    if graph_was:
         # a replayed hipGraph cannot host HIP events between its launches: the per-family durations come from an eager
         # re-run of 4 chunks right after the timed region (same kernels, same sizes, same stream)
         _lib.PROF = {}
@@ -638,19 +651,19 @@ def rank_main(a):
                                    "cat-pikachu fg NeRF (Deformable skel-quad, 25 bones), %dx%d frame pair, %d samples/ray, training graph fwd+bwd+AdamW"
                                    % (res, res, spp), "rays_per_step": rays_per_step, "chunk_rays": 2 * a.chunk_rows * res,
                        "parallelism": "rows dealt round-robin to %d rank(s) and to each rank's chunks, one RCCL all-reduce of the flat fp32 gradient (%d elements) per step" % (world, opt.n),
-                       "launch": "hipGraph replay per chunk" if graph is not None else "eager",
+                       "launch": launch_mode,
                        "optimizer": "lab4d_amd.optim.FlatAdamW: clip_grad_norm_(5.0) + AdamW in 3 launches over one flat buffer; "
                                     "weight gradients accumulated into it by the wgrad kernels"},
             "rank_ms_per_step": [round(x, 2) for x in rank_ms], "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
             "rank_plan": {k: plan[k] for k in ("rows", "chunk_sizes", "rays_per_step", "est_peak_hbm_gib")},
-            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+            "peak_hbm_gib": round(peak_hbm / 2**30, 1),
             "whole_graph_tflops": round(value * (comp_flop_per_ray(spp // 2) if comp else spp * FLOP_PER_SAMPLE) / 1e12, 2),
             "whole_graph_frac_of_peak": round(value * (comp_flop_per_ray(spp // 2) if comp else spp * FLOP_PER_SAMPLE) / peak, 4),
             "roofline": roofline,
             # sanity of the timed work: the loss of the last chunk and whether every parameter is still finite after the timed optimizer steps
             "emulated": None if not a.emulate_rank_of else {"rank_0_of": a.emulate_rank_of, "note": "rank 0's share of the strong-scaling job on one GPU, no collective: "
                          "ms_per_step is the per-rank time an %d-GPU run is bounded by (plus its all-reduce of %.1f MB)" % (a.emulate_rank_of, opt.n * 4 / 1e6)},
-            "loss_last_chunk": float(last), "params_finite": bool(all(bool(torch.isfinite(p).all()) for p in params)),
+            "loss_last_chunk": loss_last, "params_finite": bool(all(bool(torch.isfinite(p).all()) for p in params)),
         }
         if eval_result is not None:
             out["eval_forward_only"] = eval_result
