@@ -113,6 +113,10 @@ typedef struct {
                                        processed (stream-compacted valid samples, nnutils/nerf.py:782-819, whose count stays on the
                                        device); NULL: all S                                                                       */
   const int32_t* frame_idx;         /* (S) int32 frame of every sample, or NULL: frame of sample s = s / spf                       */
+  const float* aff;                 /* raw-input nets (LAB4D_NET_SKIN / _SKIN18) only, or NULL.  Non-NULL: x is the (S,3) POINTS and the net's
+                                       c_in raw inputs are formed in the kernel as aff[frame][c][0..2] . x + aff[frame][c][3], aff = (M, c_in, 4)
+                                       fp32 -- the gaussian-scaled bone coordinates of SkinningField.forward (skinning.py:126-140) in
+                                       their per-frame affine form (lab4d_bone_affine), so the (S, 3B) tensor never exists in HBM     */
 } lab4d_mlp_fwd_args;
 int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream);
 

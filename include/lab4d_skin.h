@@ -67,4 +67,10 @@ int lab4d_gauss_density_backward(const float* xyz, const float* centres, int B, 
  * (bone transforms are affine in the point, the blended dual quaternion is linear in the skin weights). */
 int lab4d_gram_per_frame(const float* A, int CA, const float* Bm, int CB, int S, int spf, int M, float* out, void* stream);
 
+/* The gaussian-scaled bone coordinates of a point are affine in the point: c[b][k] = aff[m][b][k][0..2] . x + aff[m][b][k][3] with
+ * aff = (M, B, 3, 4) fp32 built from the bone-to-object dual quaternions and the gaussian scales (transforms.py:9-25,
+ * skinning.py:126-140).  The blend kernels build the table internally; this entry hands it to the delta-skin chain
+ * (lab4d_mlp_fwd_args.aff), which then forms its 3B inputs in the kernel instead of reading an (S,3B) tensor. */
+int lab4d_bone_affine(const float* art_r, const float* art_d, const float* gauss, int M, int B, float* aff, void* stream);
+
 #endif /* LAB4D_SKIN_H */

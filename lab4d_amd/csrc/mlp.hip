@@ -635,7 +635,8 @@ extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
     FwdK k;
     memset(&k, 0, sizeof(k));
     k.S = a->S; k.S_pad = a->S_pad; k.ld = a->ld; k.spf = a->spf; k.x = a->x; k.freq_w = a->freq_w; k.emb = a->emb; k.ext = a->ext; k.out = a->out; k.x2 = a->x2;
-    k.S_dev = a->S_dev; k.frame_idx = a->frame_idx;
+    k.S_dev = a->S_dev; k.frame_idx = a->frame_idx; k.aff = a->aff;
+    LAB4D_REQUIRE(!a->aff || Net::EMB != 0, "mlp_forward: aff is for the raw-input nets only");
     LAB4D_REQUIRE(!Net::AUX3 || a->x2, "mlp_forward: this network needs the second input x2");
     LAB4D_REQUIRE(!(a->S_dev && a->emb), "mlp_forward: a device-side sample count is for the evaluation path (no stored activations)");
     for (int l = 0; l < Net::NL; ++l) {

@@ -471,6 +471,7 @@ struct FwdK {
   const float* x2;  // nets with AUX3: second per-sample 3-vector (view direction), raw embedding slots 6L+3..6L+5
   const int* S_dev;      // device-side sample count (compacted evaluation: the count never visits the host), or NULL
   const int* frame_idx;  // (S) frame of every sample (compacted samples are not frame-contiguous), or NULL: frame = s / spf
+  const float* aff;      // raw-input nets: (M, CIN, 4) per-frame affine rows -- x is then the (S,3) points and the inputs are formed here
 };
 struct BwdK {
   int S, S_pad, ld, spf, ntiles;
@@ -676,6 +677,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
   constexpr int ACG = acache_g<Net, P>();
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
   __shared__ uint4 abuf[2 * ACG * 64];  // workgroup-shared A groups of the current / next M-tile step
+  __shared__ float4 afftab[(Net::EMB != 0 && !TAN) ? 4 * 96 : 1];  // raw-input nets: the current frame's affine rows, one copy per wave
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
   // the wave index is the same in all lanes, but the compiler only knows that after a readfirstlane: with it the tile
   // index and every tile base address are scalar (SGPR) values instead of 64-bit per-lane VGPR pairs
@@ -711,7 +713,50 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
     constexpr bool RAW = (Net::EMB != 0) || TAN;
     constexpr int CINR = TAN ? KE : Net::CIN;
     float* stagef = reinterpret_cast<float*>(slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE);
-    if constexpr (RAW) stage_in<TILE * CINR>(stagef, a.x, (long)s0 * CINR, (long)S_eff * CINR - 1, lane);
+    if constexpr (RAW) {
+      bool staged = false;
+      if constexpr (Net::EMB != 0 && !TAN) {
+        if (a.aff != nullptr) {
+          // Fused bone coordinates: the tile's (TILE, CIN) input rows are FORMED here, c = aff[frame][c][0..2] . x + aff[frame][c][3],
+          // and dropped into the staging area the copy below would have filled -- the (S, 3B) tensor (300 B per sample written by a
+          // kernel of its own and read back here) never exists.  The two lane halves of a sample split its CIN columns.
+          static_assert(Net::CIN <= 96, "affine table");
+          constexpr int HALF = (Net::CIN + 1) / 2;
+          const GLOBAL_AS float4* tabg = (const GLOBAL_AS float4*)a.aff;
+          float4* ltab = afftab + wid * 96;
+          const bool uni = (a.spf % TILE) == 0 && a.frame_idx == nullptr;  // the tile lies in one frame: stage its rows in LDS once
+          if (uni) {
+            const int m = __builtin_amdgcn_readfirstlane(frame[0]);
+            for (int e = lane; e < Net::CIN; e += 64) {
+              const f32x4_t r = *(const GLOBAL_AS f32x4_t*)(tabg + (size_t)m * Net::CIN + e);
+              ltab[e] = make_float4(r.x, r.y, r.z, r.w);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int s = sidx[t] < S_eff ? sidx[t] : S_eff - 1;
+            const float x0 = a.x[(size_t)s * 3], x1 = a.x[(size_t)s * 3 + 1], x2_ = a.x[(size_t)s * 3 + 2];
+            float* row = stagef + (NT * n + t) * Net::CIN;
+            for (int i = 0; i < HALF; ++i) {
+              const int c = i + h * HALF;
+              if (c < Net::CIN) {
+                float4 r;
+                if (uni) r = ltab[c];
+                else {
+                  const f32x4_t g = *(const GLOBAL_AS f32x4_t*)(tabg + (size_t)frame[t] * Net::CIN + c);
+                  r = make_float4(g.x, g.y, g.z, g.w);
+                }
+                row[c] = r.x * x0 + r.y * x1 + r.z * x2_ + r.w;
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          staged = true;
+        }
+      }
+      if (!staged) stage_in<TILE * CINR>(stagef, a.x, (long)s0 * CINR, (long)S_eff * CINR - 1, lane);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int s = sidx[t] < S_eff ? sidx[t] : S_eff - 1;

@@ -675,6 +675,13 @@ extern "C" int lab4d_bone_params_from_gram(const float* art_r, const float* art_
   return check_launch("bone_params_from_gram");
 }
 
+extern "C" int lab4d_bone_affine(const float* art_r, const float* art_d, const float* gauss, int M, int B, float* aff, void* stream) {
+  LAB4D_REQUIRE(art_r && art_d && gauss && aff, "bone_affine: null pointer");
+  if (M * B == 0) return LAB4D_OK;
+  hipLaunchKernelGGL(k_bone_affine, dim3(div_up(M * B, 64)), dim3(64), 0, (hipStream_t)stream, art_r, art_d, gauss, M, B, aff);
+  return check_launch("bone_affine");
+}
+
 extern "C" int lab4d_skin_blend_forward(const float* xyz, const float* art_r, const float* art_d, const float* gauss, const float* raw,
                                         const float* sr, const float* sd, int S, int spf, int M, int B, float* out, float* ent, float* dskin,
                                         float* work, void* stream) {

@@ -37,7 +37,7 @@ class NetDesc(ctypes.Structure):
 class FwdArgs(ctypes.Structure):
     _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("S_pad", ci), ("ld", ci), ("spf", ci), ("x", vp), ("freq_w", vp),
                 ("W", vp * MAXL), ("bias", vp * MAXL), ("pf_bias", vp * MAXL), ("act", vp * MAXL), ("mask", vp * MAXL), ("emb", vp),
-                ("ext", vp), ("out", vp), ("x2", vp), ("S_dev", vp), ("frame_idx", vp)]
+                ("ext", vp), ("out", vp), ("x2", vp), ("S_dev", vp), ("frame_idx", vp), ("aff", vp)]
 
 
 class BwdArgs(ctypes.Structure):
@@ -352,7 +352,9 @@ class MlpChain(Function):
     """out (S, c_out) [, export] = net(x; weights), differentiable wrt x, ext, per-frame biases, weights."""
 
     @staticmethod
-    def forward(ctx, net, prec, spf, x, ext, freq_w, export_layer, n_pf, x2, *rest):
+    def forward(ctx, net, prec, spf, x, ext, freq_w, export_layer, n_pf, x2, *rest, aff=None):
+        # aff (never passed through apply(); warping.SkinChain calls this body directly): the raw-input nets form their inputs in
+        # the kernel from the (S,3) points x and the per-frame affine rows aff (M, c_in, 4) -- lab4d_mlp_fwd_args.aff
         d = describe(net)
         NL = d.n_layers
         pfs = list(rest[:n_pf])
@@ -372,6 +374,11 @@ class MlpChain(Function):
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, ld, int(spf)
         a.x = x.data_ptr()
+        if aff is not None:
+            if tuple(aff.shape[1:]) != (d.c_in, 4) or x.shape[1] != 3 or aff.dtype != torch.float32 or not aff.is_contiguous():
+                raise RuntimeError("MlpChain: aff must be a contiguous fp32 (M, %d, 4) table and x the (S,3) points" % d.c_in)
+            _lib.require_device(aff)
+            a.aff = aff.data_ptr()
         if x2 is not None:
             x2 = x2.contiguous().float()
             _lib.require_device(x2)
@@ -427,7 +434,7 @@ class MlpChain(Function):
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
         ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
         ctx.params = params
-        ctx.x_shape = x.shape
+        ctx.x_shape = x.shape if aff is None else (S, d.c_in)  # what d_x is the gradient of: the net's own inputs
         ctx.has_x2 = x2 is not None
         if export_layer is not None and export_layer >= 0:
             # a separate tensor object over the same storage: returning ctx.acts[export_layer] itself would make the node own a

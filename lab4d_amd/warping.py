@@ -1,6 +1,9 @@
 """Host-side mirror of lab4d/nnutils/warping.py SkinningWarp.forward (+ skinning.py SkinningField,
 transforms.get_bone_coords, geom_utils.dual_quaternion_skinning, loss_utils.cross_entropy_skin_loss)
 on the gfx950 kernels of csrc/skinning.hip and the fused delta-skin MLP (LAB4D_NET_SKIN)."""
+import os
+import types
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -15,6 +18,10 @@ _lib.register("lab4d_skin_blend_forward", [vp] * 7 + [ci] * 4 + [vp] * 4 + [vp])
 _lib.register("lab4d_skin_blend_backward", [vp] * 10 + [ci] * 4 + [vp] * 7 + [vp])
 _lib.register("lab4d_gram_per_frame", [vp, ci, vp, ci, ci, ci, ci, vp, vp])
 _lib.register("lab4d_bone_params_from_gram", [vp] * 4 + [ci] * 2 + [vp] * 3 + [vp])
+_lib.register("lab4d_bone_affine", [vp] * 3 + [ci] * 2 + [vp, vp])
+
+# The delta-skin chain forms the bone coordinates in its own kernel (SkinChain); 0 restores the two-kernel form (A/B measurements).
+FUSE_BONE_COORDS = os.environ.get("LAB4D_FUSE_BONE", "1") != "0"
 
 
 class BoneCoords(Function):
@@ -60,6 +67,41 @@ class BoneCoords(Function):
             _lib.check(_lib.lib().lab4d_bone_params_from_gram(_lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(G), M, B, _lib.ptr(gar),
                                                               _lib.ptr(gad), _lib.ptr(gg), _lib.stream()), "bone_params_from_gram")
         return gx, gar, gad, gg, None
+
+
+def bone_affine(art_r, art_d, gauss):
+    """(M, 3B, 4) fp32: row 3b+k holds the affine map point -> k-th gaussian-scaled coordinate in bone b (lab4d_bone_affine)."""
+    art_r, art_d, gauss = art_r.contiguous(), art_d.contiguous(), gauss.contiguous()
+    _lib.require_device(art_r, art_d, gauss)
+    M, B = art_r.shape[:2]
+    aff = torch.empty(M, 3 * B, 4, device=art_r.device)
+    _lib.check(_lib.lib().lab4d_bone_affine(_lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), M, B, _lib.ptr(aff), _lib.stream()), "bone_affine")
+    return aff
+
+
+class SkinChain(Function):
+    """BoneCoords followed by the delta-skin MLP (skinning.py:89-124) with the (S,3B) bone coordinates never written: the chain
+    kernel forms them from the points and the per-frame affine table while it stages its input tile (lab4d_mlp_fwd_args.aff).
+    The backward pass is the two existing ones back to back: the chain's input gradient (S,3B) feeds k_bone_bwd_x and the
+    per-frame Gram reduction of BoneCoords.backward.  Arguments after gauss are those of mlp.MlpChain after x2."""
+
+    @staticmethod
+    def forward(ctx, net, prec, spf, xyz, art_r, art_d, gauss, n_pf, *rest):
+        xyz = xyz.contiguous()
+        inner = types.SimpleNamespace(needs_input_grad=(False, False, False, True, False, False, False, False, False) + tuple(ctx.needs_input_grad[8:]))
+        out = mlp.MlpChain.forward(inner, net, prec, spf, xyz, None, None, -1, n_pf, None, *rest, aff=bone_affine(art_r, art_d, gauss))
+        ctx.inner, ctx.spf = inner, spf
+        ctx.save_for_backward(xyz, art_r.contiguous(), art_d.contiguous(), gauss.contiguous())
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out):
+        res = mlp.MlpChain.backward(ctx.inner, d_out)
+        bone_ctx = types.SimpleNamespace(saved_tensors=ctx.saved_tensors, spf=ctx.spf, needs_input_grad=(True,) + tuple(ctx.needs_input_grad[4:7]) + (False,))
+        gx, gar, gad, gg, _ = BoneCoords.backward(bone_ctx, res[3])
+        ctx.inner = None
+        return (None, None, None, gx, gar, gad, gg, None) + tuple(res[9:])
 
 
 class SkinBlend(Function):
@@ -135,11 +177,16 @@ def skin_logits(P, x, art, t_embed, code, M, spf, prec, pre=None):
     coordinates -> delta-skin MLP.  x (S,3).  Returns the raw (S,B) MLP output and gauss (B,3).
     pre = {"gauss", "pf"}: the per-frame terms already evaluated by the step's prologue (deformable.frame_terms)."""
     gauss = pre["gauss"] if pre is not None else get_gauss(P)
-    bone = BoneCoords.apply(x, art[0], art[1], gauss, spf)  # (S,3B): input of the delta-skin MLP only
     net = mlp.skin_net_for(art[0].shape[1])
-    if pre is not None:
-        return mlp.run_chain(net, prec, P, bone, spf, pfs_pre={0: pre["pf"]}), gauss
-    return mlp.run_chain(net, prec, P, bone, spf, conds={0: skin_cond(t_embed, code, M)}), gauss
+    d, bd = mlp.describe(net), mlp.bindings(net, "")
+    pf = pre["pf"] if pre is not None else mlp.pf_bias_of(net, 0, P[bd[0].wname], skin_cond(t_embed, code, M))
+    params = []
+    for l in range(d.n_layers):
+        params += [P[bd[l].wname], P[bd[l].bname]]
+    if not FUSE_BONE_COORDS:
+        bone = BoneCoords.apply(x, art[0], art[1], gauss, spf)  # (S,3B): input of the delta-skin MLP only
+        return mlp.MlpChain.apply(net, prec, spf, bone, None, None, -1, 1, None, pf, *params), gauss
+    return SkinChain.apply(net, prec, spf, x, art[0], art[1], gauss, 1, pf, *params), gauss
 
 
 def skinning_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, prec=mlp.PREC_F32, pre=None):

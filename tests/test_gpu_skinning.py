@@ -102,3 +102,36 @@ def test_dense_warp_bf16_close_to_fp32():
     a = warping.dense_warp(P, xyz, fr["dense"]["t_embed"], fr["dense"]["code_bw"], True, mlp.PREC_F32)
     b = warping.dense_warp(P, xyz, fr["dense"]["t_embed"], fr["dense"]["code_bw"], True, mlp.PREC_BF16)
     assert float((a - b).abs().max()) < 2e-3  # motion is 0.1 * O(0.3): bf16 operand rounding
+
+
+@pytest.mark.parametrize("prec_name", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 8, 64), (3, 5, 13)])
+def test_fused_bone_coordinates_match_the_two_kernel_form(prec_name, shape, monkeypatch):
+    """warping.SkinChain (bone coordinates formed inside the delta-skin chain kernel, lab4d_mlp_fwd_args.aff) against BoneCoords ->
+    MlpChain on the same inputs: the (S,B) logits and every gradient.  (2,8,64): every 64-sample tile lies in one frame (affine rows
+    staged in LDS); (3,5,13): tiles straddle frames (rows read per sample)."""
+    from lab4d_amd import warping, mlp
+    prec = mlp.PREC_F32 if prec_name == "f32" else mlp.PREC_BF16
+    M, N, D = shape
+    P0 = synthetic.make_weights(4)
+    fr = synthetic.add_codes(synthetic.make_frames(5, M, 64), P0)
+    g = torch.Generator().manual_seed(16)
+    xyz = (torch.randn(M * N * D, 3, generator=g) * 0.08).to(DEV)
+    w = torch.randn(M * N * D, 25, generator=g).to(DEV)
+    pkeys = ["warp.skinning_model.log_gauss", "warp.skinning_model.delta_field.linear_1.0.weight", "warp.skinning_model.delta_field.linear_final.weight"]
+
+    def run(fused):
+        monkeypatch.setattr(warping, "FUSE_BONE_COORDS", fused)
+        P = {k: (v.to(DEV).clone().requires_grad_(True) if v.dtype.is_floating_point else v.to(DEV)) for k, v in P0.items()}
+        art = tuple(t.to(DEV).clone().requires_grad_(True) for t in fr["t_articulation"])
+        x = xyz.clone().requires_grad_(True)
+        raw, _ = warping.skin_logits(P, x, art, fr["t_embed"].to(DEV), fr["code_skin"].to(DEV), M, N * D, prec)
+        gs = torch.autograd.grad((raw * w).sum(), [x, art[0], art[1]] + [P[k] for k in pkeys])
+        return raw, gs
+
+    r1, g1 = run(True)
+    r0, g0 = run(False)
+    tol = 1e-5 if prec_name == "f32" else 2e-2
+    assert rel(r1, r0.cpu()) < tol
+    for a, b, n in zip(g1, g0, ["x", "art_r", "art_d"] + pkeys):
+        assert rel(a, b.cpu()) < tol, (n, rel(a, b.cpu()))
