@@ -518,7 +518,10 @@ __device__ __forceinline__ void emb_pair(int pair, const float* x /* [6]: point,
 // the end of the step, and after ONE barrier per step all waves read the groups they need back (lane-linear
 // ds_read_b128, conflict-free).  Up to ACACHE_G groups go through LDS (2 buffers x 16 KiB: with the four 32 KiB slabs
 // that is the CU's whole 160 KiB); the few groups beyond (skip-layer embedding columns) keep the direct path.
-constexpr int ACACHE_G = 14;  // 2 x 14 KiB: leaves 4 KiB of the 160 KiB unallocated (a kernel that needs ALL of the LDS cannot be co-scheduled with anything, e.g. a profiler's helper)
+#ifndef LAB4D_ACACHE_G
+#define LAB4D_ACACHE_G 14
+#endif
+constexpr int ACACHE_G = LAB4D_ACACHE_G;  // 2 x 14 KiB: leaves 4 KiB of the 160 KiB unallocated (a kernel that needs ALL of the LDS cannot be co-scheduled with anything, e.g. a profiler's helper)
 // The narrow fg nets (feature 128 wide, visibility 64 wide; bf16) are built for TWO workgroups per CU (two waves per SIMD from independent, not lock-stepped
 // workgroups: while one waits at its barrier / on a store the other issues MFMAs): <= 256 registers per lane
 // (__launch_bounds__(256, 2)) and <= 78 KiB of LDS (4 x 16 KiB slabs + 2 x 7 KiB of shared A groups).
@@ -547,6 +550,32 @@ __device__ __forceinline__ void wg_step_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// One wave per SIMD issues in order: an MFMA that is followed in the instruction stream by a long run of VALU work leaves the matrix pipe
+// idle for the whole run, and a run of back-to-back MFMAs leaves the VALU idle.  The machine scheduler interleaves the two only
+// partly (tools/isa_blocks.py: runs of 40-100 vector instructions without an MFMA at the end of every pipeline step), so the step
+// regions ask for the pattern explicitly: NM times {1 MFMA, NV VALU}.  Scheduling only -- results are unaffected.
+#ifndef LAB4D_SCHED_NV
+#define LAB4D_SCHED_NV 5
+#endif
+#ifndef LAB4D_SCHED_NV_FWD
+#define LAB4D_SCHED_NV_FWD 5
+#endif
+#ifndef LAB4D_SCHED_FWD_ON  // forward chains: every pattern tried (3..7 VALU per MFMA) made the static schedule WORSE than the scheduler's own; off
+#define LAB4D_SCHED_FWD_ON false
+#endif
+template <class Net>
+constexpr bool sched_il_bwd() { return Net::ID != LAB4D_NET_FG_COLOR; }  // the colour net's backward spills 10 registers with the pattern
+template <int NM, int NV, bool ON = true>
+__device__ __forceinline__ void sched_interleave() {
+#ifdef LAB4D_SCHED_IL
+#pragma unroll
+  for (int i = 0; i < (ON ? NM : 0); ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);  // VALU
+  }
 #endif
 }
 
@@ -1172,6 +1201,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
           a_stash(0, stg);
           a_fetch(k + 3 < MT ? k + 3 : MT - 1, stg);
           flush(k, pw, pbits);
+          if constexpr (PACKED) sched_interleave<NT * G, LAB4D_SCHED_NV_FWD, LAB4D_SCHED_FWD_ON>();
           // step k+1
           wg_step_barrier();
           a_grab(0, A);
@@ -1181,6 +1211,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
           a_stash(1, stg);
           a_fetch(k + 4 < MT ? k + 4 : MT - 1, stg);
           flush(k + 1, pw, pbits);
+          if constexpr (PACKED) sched_interleave<NT * G, LAB4D_SCHED_NV_FWD, LAB4D_SCHED_FWD_ON>();
         }
       }
       if constexpr (NSTEP % 2 == 1) {
@@ -1189,6 +1220,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
         mfma_tile(std::false_type{}, 0, -1, A, bv, acc1);  // tile MT-1
         epilogue(MT - 2, acc0, pw, pbits);
         flush(MT - 2, pw, pbits);
+        if constexpr (PACKED) sched_interleave<NT * G, LAB4D_SCHED_NV_FWD, LAB4D_SCHED_FWD_ON>();
         prefetch(MT - 1);
         epilogue(MT - 1, acc1, pw, pbits);
         flush(MT - 1, pw, pbits);
@@ -1321,7 +1353,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
       // Software pipeline over N row tiles starting at tile0 (same scheme as the forward chain): step k issues the MFMAs
       // of tile k+1 into the other accumulator set in the same basic block as the epilogue of tile k.
       // pre(j) requests the HBM inputs of epi(j) (mask bits, stored embedding / external gradient tile) one step ahead.
-      auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi, auto&& fl) {
+      auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi, auto&& fl, auto&& prem) {
         constexpr int N = decltype(n_c)::value;
         if constexpr (N > 0) {
           uint4 A[GK], stg[NQ];
@@ -1338,6 +1370,8 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
 #pragma unroll
           for (int g = GL; g < GK; ++g) A[g] = load_a(Wt, GK, tile0, g, lane);
           pre(0);
+          prem(std::integral_constant<int, 0>{}, 0);  // ReLU sign words: requested TWO steps ahead (see pre_mask)
+          prem(std::integral_constant<int, 1>{}, N > 1 ? 1 : 0);
           wg_step_barrier();
           a_grab(0, A);
           constexpr int NSTEP = N - 1, NPAIR = NSTEP / 2;
@@ -1355,16 +1389,20 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
               mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), 0, A, acc1);
               epi(k, acc0, pw);
               pre(k + 1);
+              prem(std::integral_constant<int, 0>{}, k + 2 < N ? k + 2 : N - 1);
               a_stash(1, stg);
               a_fetch(tile0 + (k + 4 < N ? k + 4 : N - 1), stg);
               fl(k, pw);
+              if constexpr (P::BF16) sched_interleave<NT * GK, LAB4D_SCHED_NV, sched_il_bwd<Net>()>();
               wg_step_barrier();
               mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), 1, A, acc0);
               epi(k + 1, acc1, pw);
               pre(k + 2 < N ? k + 2 : N - 1);
+              prem(std::integral_constant<int, 1>{}, k + 3 < N ? k + 3 : N - 1);
               a_stash(0, stg);
               a_fetch(tile0 + (k + 5 < N ? k + 5 : N - 1), stg);
               fl(k + 1, pw);
+              if constexpr (P::BF16) sched_interleave<NT * GK, LAB4D_SCHED_NV, sched_il_bwd<Net>()>();
             }
           }
           if constexpr (NSTEP % 2 == 1) {
@@ -1372,6 +1410,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
             mfma_tile(std::false_type{}, 0, -1, A, acc1);
             epi(N - 2, acc0, pw);
             fl(N - 2, pw);
+            if constexpr (P::BF16) sched_interleave<NT * GK, LAB4D_SCHED_NV, sched_il_bwd<Net>()>();
             pre(N - 1);
             epi(N - 1, acc1, pw);
             fl(N - 1, pw);
@@ -1420,11 +1459,33 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
       };
       uint4 raw[4];            // prefetched tile: stored embedding (epi_emb) or external gradient (epi_act)
       unsigned int mbits = 0;  // prefetched ReLU sign bits
+      // The sign words come from HBM (written by the forward pass a whole chunk earlier).  Requested one step ahead (~0.4 us of
+      // matrix work) they arrived later than the epilogue that needs them; they are requested TWO steps ahead into a two-deep ring
+      // (even / odd tile, one more register): basefield backward -3.5 %, colour -5 %, feature -6 %, skin -7 % (a build with the
+      // mask work removed altogether bounds the gain at -9 .. -19 %).  -DLAB4D_ABL_MASK1 restores the one-step form.
+      unsigned int mb0 = 0, mb1 = 0;
+#if !defined(LAB4D_ABL_MASK1) && !defined(LAB4D_ABL_NOPROG)
+#define LAB4D_MASK_RING 1
+#endif
+#if defined(LAB4D_MASK_RING) && defined(LAB4D_ABL_NOPROG)
+#error "LAB4D_MASK_RING is wired into the progressive-reload pipeline only"
+#endif
+      auto no_prem = [&](auto, int) {};
+      auto pre_mask = [&](auto par_c, int j) {
+#ifdef LAB4D_MASK_RING
+        if constexpr (lp.relu != 0) {
+          const unsigned int v = maskp[((size_t)tile * (pad32(lp.mout) / 32) + j) * 64 + lane];
+          if constexpr (decltype(par_c)::value == 0) mb0 = v; else mb1 = v;
+        }
+#endif
+      };
       auto pre_emb = [&](int mt) {
         if constexpr (Net::EMB == 0) load_tile_raw<P>((const GLOBAL_AS void*)a.emb, Net::KE, s0, mt, lane, raw);
       };
       auto pre_act = [&](int j) {
+#ifndef LAB4D_MASK_RING
         if constexpr (lp.relu != 0) mbits = maskp[((size_t)tile * (pad32(lp.mout) / 32) + j) * 64 + lane];
+#endif
         if constexpr (lp.ext_grad != 0) load_tile_raw<P>((const GLOBAL_AS void*)a.ext_gin, pad32(lp.mout), s0, j, lane, raw);
       };
       // (a) gradient wrt the embedding slots -> input gradient
@@ -1472,7 +1533,11 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
       };
       // (b) gradient wrt the previous layer's output -> masked dZ_{l-1}
       auto epi_act = [&](int j, f32x16_t (&acc)[NT], unsigned int (&w)[2][8]) {
+#ifdef LAB4D_MASK_RING
+        const unsigned int bits = (j & 1) ? mb1 : mb0;
+#else
         const unsigned int bits = mbits;
+#endif
         if constexpr (P::BF16) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc_fence(acc[t]);  // the packed path converts with inline asm
@@ -1550,13 +1615,13 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
       // embedding row tiles come first in W^T; they are skipped when no input gradient is wanted
       if constexpr (MTE > 0) {
         if (a.d_x != nullptr) {
-          pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb, no_flush);
+          pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb, no_flush, no_prem);
           // raw-input nets: the (TILE, CIN) input-gradient tile sits in the wave's staging area (the slab is idle while the
           // last layer's embedding tiles are processed); one contiguous coalesced copy, rows >= S dropped
           if constexpr (Net::EMB != 0) stage_out(stagef, a.d_x, (long)s0 * Net::CIN, TILE * Net::CIN, (long)a.S * Net::CIN - 1, lane);
         }
       }
-      if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act, flush_act);
+      if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act, flush_act, pre_mask);
     });
 
     if constexpr (Net::EMB == 0) {
