@@ -34,8 +34,10 @@ def test_library_loaded_is_the_in_tree_hip_library():
 def test_mfma_layout_probe():
     from lab4d_amd import _lib
     import ctypes
-    lib = _lib.lib()
-    lib.lab4d_debug_mfma_probe.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_harness", "_build", "libmfma_layout.so")
+    assert os.path.exists(so), "build the probe first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(so)
+    lib.mfma_layout_probe.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]
     g = gen(0)
     for use_bf16, K in [(1, 16), (0, 2)]:
         A = torch.randn(32, K, generator=g)
@@ -44,7 +46,7 @@ def test_mfma_layout_probe():
             A, B = A.bfloat16().float(), B.bfloat16().float()
         D = torch.zeros(32, 32, device=DEV)
         Ad, Bd = A.to(DEV), B.to(DEV)
-        _lib.check(lib.lab4d_debug_mfma_probe(_lib.ptr(Ad), _lib.ptr(Bd), _lib.ptr(D), use_bf16, _lib.stream()), "probe")
+        assert lib.mfma_layout_probe(_lib.ptr(Ad), _lib.ptr(Bd), _lib.ptr(D), use_bf16, _lib.stream()) == 0
         close(D, A @ B, f"mfma bf16={use_bf16}", rtol=1e-5)
 
 

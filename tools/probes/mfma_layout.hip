@@ -1,7 +1,7 @@
-// Debug entry point: one-wave MFMA tiles with the operand/accumulator lane layouts that
-// csrc/mlp.hip assumes.  tests/test_gpu_mfma_layout.py multiplies asymmetric matrices through it
-// so a wrong layout assumption is caught in isolation.
-#include "common.hpp"
+// Test probe (NOT part of liblab4d_hip.so): one-wave MFMA tiles with the operand / accumulator lane layouts that csrc/mlp_kernels.hpp
+// assumes.  tests/test_gpu_ops.py::test_mfma_layout_probe multiplies asymmetric matrices through it so a wrong layout assumption
+// is caught in isolation.  Built by __graft_entry__.build() into tests/host_harness/_build/libmfma_layout.so.
+#include <hip/hip_runtime.h>
 
 namespace lab4d {
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
@@ -35,8 +35,8 @@ __global__ void k_probe_f32(const float* A, const float* B, float* Dm) {
 }
 }  // namespace lab4d
 
-extern "C" int lab4d_debug_mfma_probe(const float* A, const float* B, float* D, int use_bf16, void* stream) {
+extern "C" int mfma_layout_probe(const float* A, const float* B, float* D, int use_bf16, void* stream) {
   if (use_bf16) hipLaunchKernelGGL(lab4d::k_probe_bf16, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, D);
   else hipLaunchKernelGGL(lab4d::k_probe_f32, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, D);
-  return lab4d::check_launch("mfma_probe");
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
