@@ -404,6 +404,31 @@ __device__ __forceinline__ void tr_store(GLOBAL_AS void* buf, int F, int s0, int
   }
 }
 
+// The same tile IO in four independent pieces (qa = 2q + a: rows 16q + 8a + ..): two transposing reads, one 16-byte store each.
+// -DLAB4D_TRSPREAD issues the pieces BETWEEN the MFMAs of the second half of the step the tile was finished in, instead of four
+// back-to-back stores per wave at the end of every step (the counters say the vector L1 stalls the store data path for a quarter
+// of the kernel: profiles/r02_stall_counters.txt).  The data waits in the wave's slab, not in registers.
+struct TrPiece {
+  unsigned long long a, b;
+};
+template <int QA>
+__device__ __forceinline__ void trp_issue(unsigned addr /* tr_lane_base + mt * 2048 */, TrPiece& r) {
+  constexpr int OFF = 1024 * (QA >> 1) + 8 * (QA & 1);
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\t"
+               "ds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(r.a), "=&v"(r.b)
+               : "v"(addr), "n"(OFF), "n"(OFF + 32)
+               : "memory");
+}
+template <int QA>
+__device__ __forceinline__ void trp_store(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, TrPiece& r) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b));
+  const int i = lane & 15, G = lane >> 4, h = G & 1, S = G >> 1;
+  GLOBAL_AS char* base = (GLOBAL_AS char*)buf + tile_base_offset<PBF16>(F, s0, 32 * mt);
+  const unsigned lo = (unsigned)((4 * h + (i & 3)) * 128 + (32 * S + 8 * (i >> 2)) * 2);
+  gst16(base + (lo + (unsigned)((16 * (QA >> 1) + 8 * (QA & 1)) * 128)), (unsigned)r.a, (unsigned)(r.a >> 32), (unsigned)r.b, (unsigned)(r.b >> 32));
+}
+
 template <class P>
 __device__ __forceinline__ void store_tile(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, const f32x16_t* c /*[NT]*/) {
   const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
@@ -1312,21 +1337,23 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
         for (int u = 0; u < GK; ++u) bin[t][u] = slab[(t * UW + u) * 64];
 
       // MFMA phase of one row tile of W^T: acc = W^T[mt] dz.  pre = row tile whose A groups are requested behind it.
-      auto mfma_tile = [&](auto has_pre, int pre, int rbuf, uint4 (&A)[GK], f32x16_t (&acc)[NT]) {
+      auto no_hook = [&](auto) {};
+      auto mfma_tile = [&](auto has_pre, int pre, int rbuf, uint4 (&A)[GK], f32x16_t (&acc)[NT], auto&& hook) {
         constexpr bool PRE = decltype(has_pre)::value;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < GK; ++g) {
+        sfor<0, GK>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
 #pragma unroll
           for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], bin[t][g]);
           if constexpr (PRE) {
-            if (g >= GL) A[g] = load_a(Wt, GK, pre, g, lane);  // groups beyond the LDS-shared ones (g is unrolled)
+            if (g >= GL) A[g] = load_a(Wt, GK, pre, g, lane);  // groups beyond the LDS-shared ones
             else if (rbuf >= 0) A[g] = abuf[(rbuf * ACG + g) * 64 + lane];  // progressive reload (see the forward kernel)
           }
-        }
+          hook(gc);
+        });
       };
       auto a_fetch = [&](int mt, uint4 (&stg)[NQ]) {
 #ifndef LAB4D_ABL_NOAFETCH
@@ -1353,7 +1380,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
       // Software pipeline over N row tiles starting at tile0 (same scheme as the forward chain): step k issues the MFMAs
       // of tile k+1 into the other accumulator set in the same basic block as the epilogue of tile k.
       // pre(j) requests the HBM inputs of epi(j) (mask bits, stored embedding / external gradient tile) one step ahead.
-      auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi, auto&& fl, auto&& prem) {
+      auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi, auto&& fl, auto&& prem, auto&& sp, auto&& sp_all) {
         constexpr int N = decltype(n_c)::value;
         if constexpr (N > 0) {
           uint4 A[GK], stg[NQ];
@@ -1376,7 +1403,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
           a_grab(0, A);
           constexpr int NSTEP = N - 1, NPAIR = NSTEP / 2;
 #ifndef LAB4D_ABL_NOPROG
-          mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, 1, A, acc0);  // tile 0, reloading tile 1 from buffer 1
+          mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, 1, A, acc0, no_hook);  // tile 0, reloading tile 1 from buffer 1
           if constexpr (N > 1) {
             wg_step_barrier();  // every wave has grabbed tile 0 out of buffer 0
             a_stash(0, stg);    // tile 2
@@ -1386,8 +1413,13 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
 #pragma nounroll
             for (int k = 0; k < 2 * NPAIR; k += 2) {
               wg_step_barrier();
-              mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), 0, A, acc1);
+#ifdef LAB4D_TRSPREAD  // the epilogue first in program order: its slab writes precede the transposing reads of the hook
               epi(k, acc0, pw);
+              mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), 0, A, acc1, [&](auto gc) { sp(k, gc); });
+#else
+              mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), 0, A, acc1, no_hook);
+              epi(k, acc0, pw);
+#endif
               pre(k + 1);
               prem(std::integral_constant<int, 0>{}, k + 2 < N ? k + 2 : N - 1);
               a_stash(1, stg);
@@ -1395,8 +1427,13 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
               fl(k, pw);
               if constexpr (P::BF16) sched_interleave<NT * GK, LAB4D_SCHED_NV, sched_il_bwd<Net>()>();
               wg_step_barrier();
-              mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), 1, A, acc0);
+#ifdef LAB4D_TRSPREAD
               epi(k + 1, acc1, pw);
+              mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), 1, A, acc0, [&](auto gc) { sp(k + 1, gc); });
+#else
+              mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), 1, A, acc0, no_hook);
+              epi(k + 1, acc1, pw);
+#endif
               pre(k + 2 < N ? k + 2 : N - 1);
               prem(std::integral_constant<int, 1>{}, k + 3 < N ? k + 3 : N - 1);
               a_stash(0, stg);
@@ -1407,25 +1444,32 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
           }
           if constexpr (NSTEP % 2 == 1) {
             wg_step_barrier();
-            mfma_tile(std::false_type{}, 0, -1, A, acc1);
+#ifdef LAB4D_TRSPREAD
             epi(N - 2, acc0, pw);
+            mfma_tile(std::false_type{}, 0, -1, A, acc1, [&](auto gc) { sp(N - 2, gc); });
+#else
+            mfma_tile(std::false_type{}, 0, -1, A, acc1, no_hook);
+            epi(N - 2, acc0, pw);
+#endif
             fl(N - 2, pw);
             if constexpr (P::BF16) sched_interleave<NT * GK, LAB4D_SCHED_NV, sched_il_bwd<Net>()>();
             pre(N - 1);
             epi(N - 1, acc1, pw);
             fl(N - 1, pw);
+            sp_all(N - 1);  // no matrix work left in this layer to hide the last tile's pieces behind
           } else {
             epi(N - 1, acc0, pw);
             fl(N - 1, pw);
+            sp_all(N - 1);
           }
 #else
-          mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, -1, A, acc0);
+          mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, -1, A, acc0, no_hook);
           if constexpr (NPAIR > 0) {
 #pragma nounroll
             for (int k = 0; k < 2 * NPAIR; k += 2) {
               wg_step_barrier();
               a_grab(1, A);
-              mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), -1, A, acc1);
+              mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), -1, A, acc1, no_hook);
               epi(k, acc0, pw);
               pre(k + 1);
               a_stash(0, stg);
@@ -1433,7 +1477,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
               fl(k, pw);
               wg_step_barrier();
               a_grab(0, A);
-              mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), -1, A, acc0);
+              mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), -1, A, acc0, no_hook);
               epi(k + 1, acc1, pw);
               pre(k + 2 < N ? k + 2 : N - 1);
               a_stash(1, stg);
@@ -1444,7 +1488,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
           if constexpr (NSTEP % 2 == 1) {
             wg_step_barrier();
             a_grab(1, A);
-            mfma_tile(std::false_type{}, 0, -1, A, acc1);
+            mfma_tile(std::false_type{}, 0, -1, A, acc1, no_hook);
             epi(N - 2, acc0, pw);
             fl(N - 2, pw);
             pre(N - 1);
@@ -1467,8 +1511,8 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
 #if !defined(LAB4D_ABL_MASK1) && !defined(LAB4D_ABL_NOPROG)
 #define LAB4D_MASK_RING 1
 #endif
-#if defined(LAB4D_MASK_RING) && defined(LAB4D_ABL_NOPROG)
-#error "LAB4D_MASK_RING is wired into the progressive-reload pipeline only"
+#if (defined(LAB4D_MASK_RING) || defined(LAB4D_TRSPREAD)) && defined(LAB4D_ABL_NOPROG)
+#error "LAB4D_MASK_RING / LAB4D_TRSPREAD are wired into the progressive-reload pipeline only"
 #endif
       auto no_prem = [&](auto, int) {};
       auto pre_mask = [&](auto par_c, int j) {
@@ -1576,7 +1620,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int q = 0; q < 2; ++q) slab[(t * UW + 2 * j + q) * 64] = make_uint4(w[t][4 * q], w[t][4 * q + 1], w[t][4 * q + 2], w[t][4 * q + 3]);
-#if defined(LAB4D_TRSTORE) && !defined(LAB4D_ABL_NOSTORE)
+#if defined(LAB4D_TRSTORE) && !defined(LAB4D_TRSPREAD) && !defined(LAB4D_ABL_NOSTORE)
           tr_issue(tr_base + (unsigned)j * 2048u, trt);
 #endif
         } else {
@@ -1602,7 +1646,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
       };
       auto flush_act = [&](int j, const unsigned int (&w)[2][8]) {
         if constexpr (P::BF16) {
-#ifndef LAB4D_ABL_NOSTORE
+#if !defined(LAB4D_ABL_NOSTORE) && !defined(LAB4D_TRSPREAD)
 #ifndef LAB4D_TRSTORE
           store_tile_packed(dzp, pad32(lp.mout), s0, j, lane, w);
 #else
@@ -1612,16 +1656,52 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
 #endif
         }
       };
+      // LAB4D_TRSPREAD: the dZ tile j (packed, in the slab since epi_act) leaves in four pieces between the MFMAs of the second half
+      // of the step: piece qa is read at group I(qa) and stored at St(qa) = I(qa) + D; two piece buffers alternate
+      TrPiece tp0, tp1;
+      auto sp_none = [&](int, auto) {};
+      auto sp_all_none = [&](int) {};
+      auto sp_act = [&](int j, auto gc) {
+#if defined(LAB4D_TRSPREAD) && !defined(LAB4D_ABL_NOSTORE)
+        if constexpr (P::BF16) {
+          constexpr int g = decltype(gc)::value;
+          constexpr int D = GK >= 16 ? GK / 8 : 1;
+          if constexpr (GK >= 8) {
+            sfor<0, 4>([&](auto qc) {
+              constexpr int qa = decltype(qc)::value;
+              if constexpr (g == GK - 1 - D * (3 - qa)) trp_store<qa>(dzp, pad32(lp.mout), s0, j, lane, (qa & 1) ? tp1 : tp0);
+            });
+            sfor<0, 4>([&](auto qc) {
+              constexpr int qa = decltype(qc)::value;
+              if constexpr (g == GK - 1 - D * (3 - qa) - D) trp_issue<qa>(tr_base + (unsigned)j * 2048u, (qa & 1) ? tp1 : tp0);
+            });
+          } else if constexpr (g == GK - 1) {  // narrow layers: too few groups to spread over
+            tr_issue(tr_base + (unsigned)j * 2048u, trt);
+            tr_wait(trt);
+            tr_store(dzp, pad32(lp.mout), s0, j, lane, trt);
+          }
+        }
+#endif
+      };
+      auto sp_all_act = [&](int j) {
+#if defined(LAB4D_TRSPREAD) && !defined(LAB4D_ABL_NOSTORE)
+        if constexpr (P::BF16) {
+          tr_issue(tr_base + (unsigned)j * 2048u, trt);
+          tr_wait(trt);
+          tr_store(dzp, pad32(lp.mout), s0, j, lane, trt);
+        }
+#endif
+      };
       // embedding row tiles come first in W^T; they are skipped when no input gradient is wanted
       if constexpr (MTE > 0) {
         if (a.d_x != nullptr) {
-          pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb, no_flush, no_prem);
+          pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb, no_flush, no_prem, sp_none, sp_all_none);
           // raw-input nets: the (TILE, CIN) input-gradient tile sits in the wave's staging area (the slab is idle while the
           // last layer's embedding tiles are processed); one contiguous coalesced copy, rows >= S dropped
           if constexpr (Net::EMB != 0) stage_out(stagef, a.d_x, (long)s0 * Net::CIN, TILE * Net::CIN, (long)a.S * Net::CIN - 1, lane);
         }
       }
-      if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act, flush_act, pre_mask);
+      if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act, flush_act, pre_mask, sp_act, sp_all_act);
     });
 
     if constexpr (Net::EMB == 0) {
