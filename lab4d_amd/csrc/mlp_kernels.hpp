@@ -115,9 +115,19 @@ __device__ __forceinline__ void gst16(GLOBAL_AS void* p, unsigned int x, unsigne
 // `base`, G and mt are wave-uniform: the tile base stays in SGPRs and the load uses the saddr + 32-bit lane offset +
 // immediate form (64-bit per-lane addresses cost two VGPRs per group and, under the register pressure of this kernel,
 // were being spilled to scratch and reloaded one by one).
+// Kernel experiments for the next round: the weight stream never hits in the 32-KiB vector L1 (a layer is
+// 128 KiB), so it can be told not to allocate there -- -DLAB4D_A_NT: nt bit (streaming); -DLAB4D_A_SC: sc0 sc1 (system-coherent, L1 bypass).
 __device__ __forceinline__ uint4 load_a(const GLOBAL_AS void* base, int G, int mt, int g, int lane) {
   const GLOBAL_AS char* tile = (const GLOBAL_AS char*)base + (size_t)(unsigned)(mt * G) * 1024u;
+#if defined(LAB4D_A_NT)
+  const u32x4_t v = __builtin_nontemporal_load((const GLOBAL_AS u32x4_t*)(tile + (unsigned)(g * 1024 + lane * 16)));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#elif defined(LAB4D_A_SC)
+  const u32x4_t v = *(const volatile GLOBAL_AS u32x4_t*)(tile + (unsigned)(g * 1024 + lane * 16));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
   return gld16(tile + (unsigned)(g * 1024 + lane * 16));
+#endif
 }
 
 // Kernel arguments are read from the kernarg segment at the point of use.  Left to itself the compiler hoists the ~60
