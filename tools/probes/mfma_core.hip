@@ -5,6 +5,9 @@
 // V5 = no LDS reads at all (A held in registers): the MFMA rate of ONE wave per SIMD with the kernel's two dependent accumulation chains;
 // V6 = V5 with FOUR independent chains (the same 32 MFMAs per step spread over 4 accumulators).
 // V4 = V1 with PROGRESSIVE reads: each group's register is re-read for the next step right behind the MFMAs that consumed it.
+// V7 = V3 + the tile store of a step (4 x 1 KiB streaming stores per wave, the chain kernels' address pattern, 16 KiB per CU and step);
+// V8 = V5 + the same stores; V9 = V7 + 4 L2-resident 16-byte loads per wave and step (weight-fetch stand-in)
+// consumed one step later.  profiles/r02_store_ack.json: the same stores cost 45 ns per step next to a SLEEPING wave.
 // Ideal: 32 MFMAs x 32 cycles = 1024 cycles per step.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_core tools/probes/mfma_core.hip && /tmp/mfma_core
 #include <hip/hip_runtime.h>
@@ -15,7 +18,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int V>
-__global__ void __launch_bounds__(256) k_core(float* out, int steps) {
+__global__ void __launch_bounds__(256) k_core(float* out, int steps, char* sbuf, const uint4* table) {
+  constexpr bool REGS = (V == 5 || V == 6 || V == 8 || V >= 10);  // V12 = V11 with the store data in one of FOUR dedicated register sets (reused four steps later): is the cost a write-after-read interlock on the store's data registers?          // A operand held in registers (no LDS reads)
+  constexpr bool EPI = (V >= 3);    // VALU epilogue stand-in (as recorded in profiles/r02_mfma_core_probe.json: V3..V6 all carry it)
+  constexpr bool STASH = (V >= 2);
+  constexpr bool BAR = (V >= 1 && V < 10);  // V10 = V8 without the step barrier (waves drift apart); V11 = V8, no barrier, ONE store per step
+  constexpr bool STORES = (V >= 7), LOADS = (V == 9);
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  u32x4_t wl[4] = {};
+  u32x4_t sd[4] = {};
   __shared__ uint4 abuf[2 * 16 * 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 2 * 16 * 64; i += 256) abuf[i] = make_uint4(0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
@@ -37,10 +49,13 @@ __global__ void __launch_bounds__(256) k_core(float* out, int steps) {
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc4[t][r] = 0.f;
-  for (int s = 0; s < steps; ++s) {
-    if (V >= 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int s0 = 0; s0 < steps; s0 += 4)
+#pragma unroll
+  for (int sj = 0; sj < 4; ++sj) {
+    const int s = s0 + sj;
+    if (BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int buf = s & 1;
-    if ((V != 4 && V < 5) || s == 0) {
+    if ((V != 4 && !REGS) || s == 0) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) A[g] = abuf[(buf * 16 + g) * 64 + lane];
     }
@@ -56,7 +71,12 @@ __global__ void __launch_bounds__(256) k_core(float* out, int steps) {
       }
       if (V == 4) A[g] = abuf[((buf ^ 1) * 16 + g) * 64 + lane];
     }
-    if (V >= 3) {  // stand-in epilogue on the PREVIOUS tile: ~180 dependent-free VALU ops
+    if (LOADS) {
+      sink += __uint_as_float(wl[0].x ^ wl[1].y ^ wl[2].z ^ wl[3].w);  // consume last step's loads, request this step's
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wl[i] = ((const __attribute__((address_space(1))) u32x4_t*)table)[(((s * 4 + i) * 61 + wave) & 1023) * 64 + lane];
+    }
+    if (EPI) {  // stand-in epilogue on the PREVIOUS tile: ~180 dependent-free VALU ops
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -67,11 +87,25 @@ __global__ void __launch_bounds__(256) k_core(float* out, int steps) {
         }
       sink += prev[0][0] + prev[1][15];
     }
-    if (V >= 2) {
+    if (STORES) {
+      const int n = lane & 31, h = lane >> 5, q = n & 3, k = n >> 2;
+      __attribute__((address_space(1))) char* base = (__attribute__((address_space(1))) char*)sbuf + ((size_t)wave * 4096 + (size_t)(s & 4095)) * 4096;
+#pragma unroll
+      for (int i = 0; i < (V >= 11 ? 1 : 4); ++i) {
+        u32x4_t v = {__float_as_uint(prev[0][4 * i]), __float_as_uint(prev[0][4 * i + 1]), __float_as_uint(prev[1][4 * i + 2]), __float_as_uint(prev[1][4 * i + 3])};
+        if (V == 12) {
+          sd[sj] = v;
+          asm volatile("" : "+v"(sd[sj]));  // keep the set in its own registers
+          v = sd[sj];
+        }
+        __builtin_nontemporal_store(v, (__attribute__((address_space(1))) u32x4_t*)(base + (8 * i + 4 * h + q) * 128 + 16 * k));
+      }
+    }
+    if (STASH) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) abuf[((buf ^ 1) * 16 + wid + 4 * i) * 64 + lane] = make_uint4(0x3f803f80u + s, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + i);
     }
-    if (V >= 3) {
+    if (EPI) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) prev[t] = acc[t];
     }
@@ -85,13 +119,13 @@ __global__ void __launch_bounds__(256) k_core(float* out, int steps) {
 }
 
 template <int V>
-void run(float* out, int steps) {
+void run(float* out, int steps, char* sbuf, const uint4* table) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((k_core<V>), dim3(256), dim3(256), 0, 0, out, 64);
+  hipLaunchKernelGGL((k_core<V>), dim3(256), dim3(256), 0, 0, out, 64, sbuf, table);  // steps: multiples of 4
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL((k_core<V>), dim3(256), dim3(256), 0, 0, out, steps);
+  hipLaunchKernelGGL((k_core<V>), dim3(256), dim3(256), 0, 0, out, steps, sbuf, table);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us_per_step = ms * 1e3 / steps;
@@ -102,7 +136,10 @@ int main() {
   float* out; CK(hipMalloc(&out, 256 * 256 * 4));
   const int steps = 20000;
   printf("{\n");
-  run<0>(out, steps); run<1>(out, steps); run<2>(out, steps); run<3>(out, steps); run<4>(out, steps); run<5>(out, steps); run<6>(out, steps);
+  char* sbuf; CK(hipMalloc(&sbuf, (size_t)1024 * 4096 * 4096));  // 16 MiB per wave, 16 GiB: the stores stream to HBM
+  uint4* table; CK(hipMalloc(&table, 1 << 20)); CK(hipMemset(table, 1, 1 << 20));
+  run<0>(out, steps, sbuf, table); run<1>(out, steps, sbuf, table); run<2>(out, steps, sbuf, table); run<3>(out, steps, sbuf, table); run<4>(out, steps, sbuf, table);
+  run<5>(out, steps, sbuf, table); run<6>(out, steps, sbuf, table); run<7>(out, steps, sbuf, table); run<8>(out, steps, sbuf, table); run<9>(out, steps, sbuf, table); run<10>(out, steps, sbuf, table); run<11>(out, steps, sbuf, table); run<12>(out, steps, sbuf, table);
   printf("  \"ideal_cycles\": 1024\n}\n");
   return 0;
 }
