@@ -106,8 +106,21 @@ __device__ __forceinline__ void gst16(GLOBAL_AS void* p, unsigned int x, unsigne
   // kernels -- measured -6.5 % on the training-mode forward and -6.3 % on the backward chain against plain stores
 #ifdef LAB4D_ABL_PLAINSTORE
   *(GLOBAL_AS u32x4_t*)p = v;
+#elif defined(LAB4D_ST_AGPR)  // kernel experiment: the store takes its data from accumulation registers
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "a"(v) : "memory");
 #else
   __builtin_nontemporal_store(v, (GLOBAL_AS u32x4_t*)p);
+#endif
+}
+// the same store as (wave-uniform tile base, per-lane byte offset): -DLAB4D_ST_BUF issues it as buffer_store_dwordx4 with the base in an
+// SGPR resource descriptor (kernel experiment); otherwise identical to gst16(base + off, ..)
+__device__ __forceinline__ void gst16o(GLOBAL_AS char* base, unsigned off, unsigned int x, unsigned int y, unsigned int z, unsigned int w) {
+#ifdef LAB4D_ST_BUF
+  u32x4_t v = {x, y, z, w};
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)off, 0, 2);
+#else
+  gst16(base + off, x, y, z, w);
 #endif
 }
 
@@ -357,7 +370,7 @@ __device__ __forceinline__ void store_tile_packed(GLOBAL_AS void* buf, int F, in
     }
   quad_transpose4(d, c);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) gst16(base + (lo + tile_lane_offset<PBF16>(8 * i, 0)), c[i][0], c[i][1], c[i][2], c[i][3]);
+  for (int i = 0; i < 4; ++i) gst16o(base, lo + tile_lane_offset<PBF16>(8 * i, 0), c[i][0], c[i][1], c[i][2], c[i][3]);
 }
 
 

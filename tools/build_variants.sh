@@ -5,7 +5,8 @@
 #   then on the GPU box:   for v in gpurun_abl/lib_*.so; do LAB4D_SO_PATH=$v python tools/bench_chain.py; done
 # Timing-only ablations (results wrong): NOSTORE NOMASK NOAFETCH NOBAR.  Correct builds: MASK1 (one-step sign-word prefetch), NOPROG,
 # OCC1, ACG14/ACG7, WGRAD4, PLAINSTORE, =A_NT / =A_SC (weight loads nt / sc0 sc1), =TRSPREAD (backward dZ tiles leave the slab in pieces),
-# =SCHED_IL (MFMA / VALU interleave pattern), =TRSTORE (transposing-read tile stores), =ACACHE_G=16 (all of the LDS for shared weights).
+# =SCHED_IL (MFMA / VALU interleave pattern), =TRSTORE (transposing-read tile stores), =ACACHE_G=16 (all of the LDS for shared weights),
+# =ST_AGPR / =ST_BUF (tile stores with AGPR data / as buffer_store with an SGPR base: the store-form experiments of DESIGN.md section 8).
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_abl
 for v in "$@"; do
