@@ -328,23 +328,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 #else
 #define LAB4D_WGRAD_NB5 1
 #endif
-template <int MT, int NBW, int NW = 4>
+// WC = columns of the wave grid (2: the layers; 4: the <= 32-row heads, MT = 1 -- every wave owns the one row tile and a quarter of
+// the 64 NBW columns, LAB4D_WGRAD_HEAD_DMA=1, an experiment for the next round: the heads still use the pre-DMA kernel by default).
+template <int MT, int NBW, int NW = 4, int WC = 2>
 __global__ void __launch_bounds__(64 * NW) k_mlp_wgrad_dma(const unsigned short* __restrict__ dz, const unsigned short* __restrict__ emb,
                                                         const unsigned short* __restrict__ actp, int ke, int kin, int S_pad, int chunk,
                                                         int spf, int cpf, float* __restrict__ dW, float* __restrict__ db, DwMap wm) {
   using P = PBF16;
   static_assert(NW == 4 || NW == 8, "wave grid");
-  constexpr int TM = 2 * MT / NW, TN = NBW, MO = 32 * MT, KB = 64 * NBW;
-  static_assert(TM >= 1 && TM * (NW / 2) == MT, "row tiles per wave");
+  constexpr int WR = NW / WC;
+  static_assert(WR * WC == NW && (2 * NBW) % WC == 0, "wave grid");
+  constexpr int TM = MT / WR, TN = 2 * NBW / WC, MO = 32 * MT, KB = 64 * NBW;
+  static_assert(TM >= 1 && TM * WR == MT, "row tiles per wave");
   constexpr int A_BYTES = MT * 2048, STAGE = A_BYTES + NBW * 4096;  // 32 samples x (MO + KB) rows x 2 B
   constexpr int NS0 = 65536 / STAGE, NSTAGE = NS0 < 4 ? 4 : (NS0 > 8 ? 8 : NS0);  // ring depth: >= 64 KiB in flight per CU
-  constexpr int PA = 2 * MT / NW, PB = (4 * NBW + NW - 1) / NW, PW = PA + PB;  // transfers per wave per stage (exact: the counted waits rely on it)
-  static_assert(PA * NW == 2 * MT, "A pieces per wave");
+  constexpr int PA = (2 * MT + NW - 1) / NW, PB = (4 * NBW + NW - 1) / NW, PW = PA + PB;  // transfers per wave per stage (exact: the counted waits rely on it)
+  static_assert(PA * NW == 2 * MT || MT == 1, "A pieces per wave (MT = 1: two pieces, the other waves re-fetch the last one)");
   static_assert(PW * (NSTAGE - 2) <= 63, "vmcnt range");
   static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), row = lane & 31, h = lane >> 5;
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wr = wid / WC, wc = wid % WC;
   const int K = ke + kin;
   const int kb_n = (K + KB - 1) / KB;
   const int job = blockIdx.x;
@@ -392,7 +396,8 @@ __global__ void __launch_bounds__(64 * NW) k_mlp_wgrad_dma(const unsigned short*
     const unsigned char* ga = reinterpret_cast<const unsigned char*>(dz + (size_t)blk * block_stride(MO)) + half * 64 + lane_src;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const int piece = wid + NW * p;
+      int piece = wid + NW * p;
+      if constexpr (PA * NW != 2 * MT) piece = piece < 2 * MT ? piece : 2 * MT - 1;
       dma_1k(ga + piece * 2048, st + piece * 1024);
     }
     unsigned char* sb = st + A_BYTES;
@@ -699,10 +704,12 @@ extern "C" int lab4d_mlp_wgrad_mapped(int net, int layer, int precision, int S, 
   const int mo_tiles = L.mout_pad / 32, nk_tiles = (L.ke + L.kin) / 32;
   const bool big = mo_tiles >= 8;  // 256-wide layers: 8x8-tile workgroup blocks (k_mlp_wgrad_big / k_mlp_wgrad_dma)
   // bf16 layers of 64 / 128 / 256 output features run the LDS-DMA ring; NBW = 64-row blocks of X per workgroup
-  const bool dma = precision == LAB4D_PREC_BF16 && (mo_tiles == 8 || mo_tiles == 4 || mo_tiles == 2);
   const int Kt = L.ke + L.kin;
+  static const int head_dma = getenv("LAB4D_WGRAD_HEAD_DMA") ? atoi(getenv("LAB4D_WGRAD_HEAD_DMA")) : 0;  // kernel experiment (next round)
+  const bool dma = precision == LAB4D_PREC_BF16 && (mo_tiles == 8 || mo_tiles == 4 || mo_tiles == 2 || (mo_tiles == 1 && head_dma && Kt <= 256));
   // K = 320 (skip layer): one 320-column job with the 8-wave kernel of the 256-row layers, 192 + 128 otherwise
-  const int nbw = Kt <= 64 ? 1 : (Kt <= 128 ? 2 : (Kt <= 192 ? 3 : (Kt <= 256 ? 4 : (LAB4D_WGRAD_NB5 && mo_tiles == 8 && Kt <= 320 ? 5 : 3))));
+  const int nbw = (dma && mo_tiles == 1) ? (Kt <= 128 ? 2 : 4)  // heads: 1 x 4 wave grid, 128 or 256 columns per workgroup
+                  : Kt <= 64 ? 1 : (Kt <= 128 ? 2 : (Kt <= 192 ? 3 : (Kt <= 256 ? 4 : (LAB4D_WGRAD_NB5 && mo_tiles == 8 && Kt <= 320 ? 5 : 3))));
   const int TM = mo_tiles >= 4 ? 4 : (mo_tiles >= 2 ? 2 : 1);
   const int ob_n = dma ? 1 : (big ? div_up(mo_tiles, 8) : div_up(mo_tiles, TM));
   const int kb_n = dma ? div_up(Kt, 64 * nbw) : (big ? div_up(nk_tiles, 8) : div_up(nk_tiles, 4));
@@ -747,7 +754,11 @@ extern "C" int lab4d_mlp_wgrad_mapped(int net, int layer, int precision, int S, 
 #else
       if (nbw == 1) WGD8(1); else if (nbw == 2) WGD8(2); else if (nbw == 3) WGD8(3); else if (nbw == 4) WGD8(4); else WGD8(5);
 #endif
-    } else if (mo_tiles == 4) WGD_NB(4); else WGD_NB(2);
+    } else if (mo_tiles == 4) WGD_NB(4); else if (mo_tiles == 2) WGD_NB(2);
+    else if (nbw == 2) hipLaunchKernelGGL((k_mlp_wgrad_dma<1, 2, 4, 4>), grid, block, 0, st, (const unsigned short*)dz, (const unsigned short*)emb,
+                                          (const unsigned short*)act_prev, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg, wm);
+    else hipLaunchKernelGGL((k_mlp_wgrad_dma<1, 4, 4, 4>), grid, block, 0, st, (const unsigned short*)dz, (const unsigned short*)emb,
+                            (const unsigned short*)act_prev, L.ke, L.kin, S_pad, chunk, spf, cpf, dW, db_arg, wm);
   }
 #undef WGD_NB
 #undef WGD8
