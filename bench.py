@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16 = 2.5e15  # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
+GRAD_SKIP = 5.0 * 1.0  # Trainer.check_grad (engine/trainer.py:581-604): thresh = 5.0 * params_ref["grad_clip"] (1.0 for the parameter group here): a step whose
+#                        pre-clip norm exceeds it (or is not finite) is discarded
 # algorithmic GEMM FLOPs of the fg training graph per sample, fwd+bwd: 3 x 2 x 918,912 MAC
 FLOP_PER_SAMPLE = 5513472.0
 # device memory per sample of a training chunk (stored activations, the largest dZ set, masks, per-sample fields): measured 194.9 GiB peak
@@ -44,8 +46,8 @@ BYTES_PER_SAMPLE = 194.9 * 2**30 / (2 * 128 * 512 * 128)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=128)
     ap.add_argument("--chunk-rows", type=int, default=None, help="image rows per frame per chunk (default 128 rows x 512 = 65536 rays/frame = 16.8 M samples per chunk, 195 GiB of the 288 GB: "
@@ -63,6 +65,10 @@ def parse():
     ap.add_argument("--emulate-rank-of", type=int, default=0,
                     help="single process, no collective: run rank 0's share of an N-rank job (its rows, chunks, prologue, optimizer step) -- the per-rank step "
                          "time an N-GPU run cannot beat; reported under 'emulated', the headline fields stay those of the work actually done")
+    ap.add_argument("--trace", action="store_true", help="diagnostic, not a measurement: synchronise after every chunk and optimizer step and print (stderr) the 12 loss "
+                                                         "terms of every chunk, the gradient norm, the clip / skip decision and the first parameters that hold a non-finite value")
+    ap.add_argument("--poison", action="store_true", help="diagnostic: torch.empty returns NaN-filled memory (torch.utils.deterministic.fill_uninitialized_memory), "
+                                                          "so a read of an uninitialised buffer shows up in the first step")
     ap.add_argument("--dry-ranks", type=int, default=0, help="no GPU work: print every rank's row band, chunk list and memory estimate for --gpus N")
     a = ap.parse_args()
     a.res_given, a.spp_given, a.chunk_rows_given = "--res" in sys.argv, "--spp" in sys.argv, a.chunk_rows is not None
@@ -120,9 +126,8 @@ def train_chunk(DF, P, fr, hxy, batch, rng, spp, res, prec):
     f["feature"] = batch["feature"]
     res_d = DF.render_train(P, f, hxy, rng, flow_thresh=float(res), n_depth=spp, prec=prec)
     losses = DF.losses_fg(res_d, batch, res, DF.DEFAULT_LOSS_WT)
-    total = losses.total  # the sum of the weighted terms, formed by the loss kernel
-    total.backward()
-    return total.detach()
+    losses.total.backward()  # the sum of the weighted terms, formed by the loss kernel
+    return losses.vec.detach()  # the 12 weighted terms + their total
 
 
 # algorithmic GEMM FLOPs of the comp training graph per RAY at D samples per field, fwd+bwd: fg 918,912 MAC/sample + three
@@ -136,9 +141,9 @@ def train_chunk_comp(DF, P, fr, Pb, frb, hxy, batch, rng, spp, res, prec):
     f["feature"] = batch["feature"]
     r = dict(rng, eik_inds_bg=rng["eik_inds"])
     out = DF.render_train_comp(P, f, Pb, frb, hxy, r, flow_thresh=float(res), n_depth=spp // 2, prec=prec)
-    total = DF.losses_comp(out, batch, res, DF.DEFAULT_LOSS_WT).total  # formed by the loss kernel
-    total.backward()
-    return total.detach()
+    losses = DF.losses_comp(out, batch, res, DF.DEFAULT_LOSS_WT)
+    losses.total.backward()  # formed by the loss kernel
+    return losses.vec.detach()
 
 
 def eval_rate(DF, P, fr, inputs, spp, prec, use_graph):
@@ -418,6 +423,139 @@ def main():
     rank_main(a)
 
 
+class TrainLoop:
+    """The benchmark's training step as an object: problem + resident inputs + per-frame prologue + (optionally) the captured chunk graph +
+    FlatAdamW.  `step()` = zero_grad -> prologue -> every chunk (hipGraph replay or eager) -> prologue backward -> [all-reduce] ->
+    check_grad + AdamW -> repack.  bench.py times it; tests/test_gpu_ztrajectory.py runs it for 30+ steps."""
+
+    def __init__(self, dev, res, spp, chunks, prec, comp=False, use_graph=True, use_dist=False, world=1, rank=0, trace=False, lr=5e-4):
+        from lab4d_amd import mlp
+        from lab4d_amd import deformable as DF
+        from lab4d_amd.optim import FlatAdamW
+        self.DF, self.mlp = DF, mlp
+        self.dev, self.res, self.spp, self.prec, self.comp, self.use_dist, self.world, self.trace_on = dev, res, spp, prec, comp, use_dist, world, trace
+        Pb = frb = None
+        if comp:
+            P, fr, Pb, frb = make_problem(res, dev, comp=True)
+        else:
+            P, fr = make_problem(res, dev)
+        self.P, self.Pb = P, Pb
+        self.params = [v for k, v in P.items() if v.dtype.is_floating_point and v.requires_grad] + (list(Pb.values()) if comp else [])
+        self.param_names = [k for k, v in P.items() if v.dtype.is_floating_point and v.requires_grad] + (["bg." + k for k in Pb] if comp else [])
+        # the reference's optimizer step (trainer.py:164-190,349-350,581-604): check_grad (clip_grad_norm_(params, 5.0), discard above it) + AdamW,
+        # one learning rate per parameter -- here three launches over one flat buffer; p.grad are views of opt.flat_grad, which is also the
+        # all-reduce bucket
+        self.opt = FlatAdamW(self.params, lr=lr)
+        mlp.FUSED_GRAD_ACCUM = True  # weight-gradient kernels add straight into those views (no scatter / AccumulateGrad per layer)
+        self.gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        # pre-build the inputs (resident in HBM before the timed region)
+        self.inputs = [chunk_inputs(res, None, rows, dev, seed=100 + i) for i, rows in enumerate(chunks)]
+        self.fr0 = fr
+        # per-frame prologue: camera inverses, bone transforms, per-frame bias tables -- functions of (weights, frames) only, evaluated
+        # once per step; the chunks read them from static leaves and the summed leaf gradients go back through it after the last chunk
+        self.prologue = DF.FramePrologue(P, fr)
+        self.fr = self.prologue.refresh()
+        self.prologue.outs = None  # no autograd graph of the prologue (and none of its AccumulateGrad nodes) alive while the chunk is captured
+        self.prologue_bg = None
+        self.frb = None
+        if comp:
+            self.prologue_bg = DF.BgPrologue(Pb, frb)
+            self.frb = self.prologue_bg.refresh()
+            self.prologue_bg.outs = None
+        self.M, self.N0 = self.inputs[0][0].shape[:2]
+        self.S0 = self.M * self.N0 * (spp // 2 if comp else spp)
+        self.uniform = all(h.shape == self.inputs[0][0].shape for h, _ in self.inputs)
+        self.graph = None
+        self.ar_events = []
+        if use_graph and self.uniform:
+            self.capture()
+        self.opt.zero_grad()
+        self.prologue.zero_grad()  # the eager warm-up / capture passes accumulated into the leaves
+        if comp:
+            self.prologue_bg.zero_grad()
+
+    def chunk(self, hxy, batch, rng):
+        if self.comp:
+            return train_chunk_comp(self.DF, self.P, self.fr, self.Pb, self.frb, hxy, batch, rng, self.spp, self.res, self.prec)
+        return train_chunk(self.DF, self.P, self.fr, hxy, batch, rng, self.spp, self.res, self.prec)
+
+    def capture(self):
+        # One chunk (forward + losses + backward, ~4000 launches) is captured once as a hipGraph and replayed for every
+        # chunk: inputs are copied into static buffers, gradients accumulate in place in opt.flat_grad.  The packed bf16
+        # copies of the weights live in persistent buffers the graph reads; they are refreshed in place once per step, after
+        # the optimizer (mlp.repack_all) -- not once per chunk inside the graph.
+        self.st_hxy = self.inputs[0][0].clone()
+        self.st_batch = {k: v.clone() for k, v in self.inputs[0][1].items()}
+        self.st_batch["hxy"] = self.st_hxy
+        self.st_rng = draw_rng(self.M, self.N0, self.S0, self.dev, self.gen)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):  # eager warm-up on the capture stream: allocator pools, rocBLAS workspaces, column maps, packed weights
+                self.chunk(self.st_hxy, self.st_batch, self.st_rng)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()  # the eager warm-up's blocks go back to the device: the graph's private pool needs the same amount again
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.st_loss = self.chunk(self.st_hxy, self.st_batch, self.st_rng)
+
+    def release_graph(self):
+        self.st_loss = None
+        self.graph = None
+        torch.cuda.empty_cache()
+
+    def trace(self, what, t=None):
+        """--trace: synchronise and report (stderr).  t: a loss vector, or None for the state of the gradient / parameter buffers."""
+        torch.cuda.synchronize()
+        if t is not None:
+            print("[trace] %s " % what + " ".join("%s=%.4g" % (k, float(x)) for k, x in zip(self.DF.LOSS_TERMS + ["total"], t)), file=sys.stderr)
+            return
+        opt, params, param_names = self.opt, self.params, self.param_names
+        bad_g = [n for n, q in zip(param_names, params) if not bool(torch.isfinite(q.grad).all())]
+        bad_p = [n for n, q in zip(param_names, params) if not bool(torch.isfinite(q).all())]
+        top = sorted(((float(q.grad.abs().max()), n) for n, q in zip(param_names, params)), reverse=True)[:4]
+        print("[trace] %s grad_norm=%.6g coef=%.4g skipped=%d |p|max=%.4g largest |grad|: %s non-finite grads: %s params: %s"
+              % (what, float(opt.norm), float(opt.coef), int(opt.skipped), float(opt.flat.abs().max()), ["%s=%.3g" % (n, v) for v, n in top], bad_g[:6],
+                 bad_p[:6]), file=sys.stderr)
+
+    def step(self):
+        opt, comp = self.opt, self.comp
+        opt.zero_grad()
+        last = None
+        self.prologue.refresh()
+        if comp:
+            self.prologue_bg.refresh()
+        for ci_, (hxy, batch) in enumerate(self.inputs):
+            if self.graph is not None:
+                self.st_hxy.copy_(hxy)
+                for k, v in batch.items():
+                    if k != "hxy":
+                        self.st_batch[k].copy_(v)
+                draw_rng(self.M, self.N0, self.S0, self.dev, self.gen, out=self.st_rng)
+                self.graph.replay()
+                last = self.st_loss
+            else:
+                S = hxy.shape[0] * hxy.shape[1] * (self.spp // 2 if comp else self.spp)
+                last = self.chunk(hxy, batch, draw_rng(hxy.shape[0], hxy.shape[1], S, self.dev, self.gen))
+            if self.trace_on:
+                self.trace("step %d chunk %d" % (opt.steps, ci_), last)
+        self.prologue.backward()
+        if comp:
+            self.prologue_bg.backward()
+        if self.use_dist:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            allreduce_flat(opt.flat_grad, self.world)
+            e1.record()
+            self.ar_events.append((e0, e1))
+        opt.step(max_norm=5.0, skip_above=GRAD_SKIP)
+        self.mlp.repack_all()
+        if self.trace_on:
+            self.trace("step %d" % (opt.steps - 1))
+        return last
+
+
 def rank_main(a):
     # stdout carries exactly ONE line, the JSON.  Native libraries write banners to file descriptor 1 (RCCL prints its version block there
     # on first use): fd 1 is pointed at stderr for the run, the JSON goes to a private duplicate of the original stdout at the very end.
@@ -427,6 +565,9 @@ def rank_main(a):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.poison:
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
     use_dist = world > 1 or a.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -444,114 +585,31 @@ def rank_main(a):
     prec = mlp.PREC_BF16 if a.dtype == "bf16" else mlp.PREC_F32
     res, spp = a.res, a.spp
     comp = a.config == "comp"
-    Pb = frb = None
-    if comp:
-        P, fr, Pb, frb = make_problem(res, dev, comp=True)
-    else:
-        P, fr = make_problem(res, dev)
-    params = [v for k, v in P.items() if v.dtype.is_floating_point and v.requires_grad] + (list(Pb.values()) if comp else [])
-    # the reference's optimizer step (trainer.py:164-190,349-350,581-604): clip_grad_norm_(params, 5.0) + AdamW, one learning rate
-    # per parameter -- here three launches over one flat buffer; p.grad are views of opt.flat_grad, which is also the all-reduce bucket
-    from lab4d_amd.optim import FlatAdamW
-    opt = FlatAdamW(params, lr=5e-4)
-    mlp.FUSED_GRAD_ACCUM = True  # weight-gradient kernels add straight into those views (no scatter / AccumulateGrad per layer)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
     # strong scaling: this rank renders rows rank::world of both frames, its chunks interleave those rows again
     plan = rank_plan(rank, world, res, a.chunk_rows, spp) if not a.emulate_rank_of else rank_plan(0, a.emulate_rank_of, res, a.chunk_rows, spp)
-    chunks = plan["chunks"]
-    # pre-build the inputs (resident in HBM before the timed region)
-    inputs = [chunk_inputs(res, None, rows, dev, seed=100 + i) for i, rows in enumerate(chunks)]
     rays_per_step = 2 * res * res if not a.emulate_rank_of else plan["rays_per_step"]
 
     # SURVEY 8d also asks for the forward-only rate: eval-mode render (importance sampling -> 128 samples, field, normals
     # through one first-order backward, compositing) of the same rays.  Measured before the training graph is captured
-    # (its 150 GiB private pool would leave the allocator thrashing), eager launches, half a training chunk per call.
+    # (its 150 GiB private pool would leave the allocator thrashing), half a training chunk per call.
     eval_result = None
-    if world == 1 and rank == 0 and not comp:
+    if world == 1 and rank == 0 and not comp and not a.trace:
         try:
-            eval_result = eval_rate(DF, P, fr, inputs, spp, prec, not a.no_graph)
+            P_e, fr_e = make_problem(res, dev)
+            inputs_e = [chunk_inputs(res, None, rows, dev, seed=100 + i) for i, rows in enumerate(plan["chunks"])]
+            eval_result = eval_rate(DF, P_e, fr_e, inputs_e, spp, prec, not a.no_graph)
         except Exception as e:  # an extra, never the headline: report the failure instead of losing the bench line
             eval_result = {"value": None, "error": repr(e)[:300]}
+        P_e = fr_e = inputs_e = None
+        mlp.clear_caches()
         torch.cuda.empty_cache()
 
-    # per-frame prologue: camera inverses, bone transforms, per-frame bias tables -- functions of (weights, frames) only, evaluated
-    # once per step; the chunks read them from static leaves and the summed leaf gradients go back through it after the last chunk
-    prologue = DF.FramePrologue(P, fr)
-    fr = prologue.refresh()
-    prologue.outs = None  # no autograd graph of the prologue (and none of its AccumulateGrad nodes) alive while the chunk is captured
-    prologue_bg = None
-    if comp:
-        prologue_bg = DF.BgPrologue(Pb, frb)
-        frb = prologue_bg.refresh()
-        prologue_bg.outs = None
-
-    if comp:
-        def train_chunk_(DF_, P_, fr_, hxy_, batch_, rng_, spp_, res_, prec_):
-            return train_chunk_comp(DF_, P_, fr_, Pb, frb, hxy_, batch_, rng_, spp_, res_, prec_)
-    else:
-        train_chunk_ = train_chunk
-    M, N0 = inputs[0][0].shape[:2]
-    S0 = M * N0 * (spp // 2 if comp else spp)
-    uniform = all(h.shape == inputs[0][0].shape for h, _ in inputs)
-    use_graph = (not a.no_graph) and uniform
-    graph = None
-    if use_graph:
-        # One chunk (forward + losses + backward, ~4000 launches) is captured once as a hipGraph and replayed for every
-        # chunk: inputs are copied into static buffers, gradients accumulate in place in opt.flat_grad.  The packed bf16
-        # copies of the weights live in persistent buffers the graph reads; they are refreshed in place once per step, after
-        # the optimizer (mlp.repack_all) -- not once per chunk inside the graph.
-        st_hxy = inputs[0][0].clone()
-        st_batch = {k: v.clone() for k, v in inputs[0][1].items()}
-        st_batch["hxy"] = st_hxy
-        st_rng = draw_rng(M, N0, S0, dev, gen)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):  # eager warm-up on the capture stream: allocator pools, rocBLAS workspaces, column maps, packed weights
-                train_chunk_(DF, P, fr, st_hxy, st_batch, st_rng, spp, res, prec)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()  # the eager warm-up's blocks go back to the device: the graph's private pool needs the same amount again
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            st_loss = train_chunk_(DF, P, fr, st_hxy, st_batch, st_rng, spp, res, prec)
-    opt.zero_grad()
-    prologue.zero_grad()  # the eager warm-up / capture passes accumulated into the leaves
-    if comp:
-        prologue_bg.zero_grad()
-    ar_events = []
-
-    def step():
-        opt.zero_grad()
-        last = None
-        prologue.refresh()
-        if comp:
-            prologue_bg.refresh()
-        for hxy, batch in inputs:
-            if graph is not None:
-                st_hxy.copy_(hxy)
-                for k, v in batch.items():
-                    if k != "hxy":
-                        st_batch[k].copy_(v)
-                draw_rng(M, N0, S0, dev, gen, out=st_rng)
-                graph.replay()
-                last = st_loss
-            else:
-                last = train_chunk_(DF, P, fr, hxy, batch, draw_rng(hxy.shape[0], hxy.shape[1], hxy.shape[0] * hxy.shape[1] * (spp // 2 if comp else spp), dev, gen),
-                                   spp, res, prec)
-        prologue.backward()
-        if comp:
-            prologue_bg.backward()
-        if use_dist:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            allreduce_flat(opt.flat_grad, world)
-            e1.record()
-            ar_events.append((e0, e1))
-        opt.step(max_norm=5.0)
-        mlp.repack_all()
-        return last
+    loop = TrainLoop(dev, res, spp, plan["chunks"], prec, comp=comp, use_graph=not a.no_graph, use_dist=use_dist, world=world, rank=rank, trace=a.trace)
+    opt, params, inputs, step = loop.opt, loop.params, loop.inputs, loop.step
+    M, N0, S0, gen = loop.M, loop.N0, loop.S0, loop.gen
+    graph = loop.graph
+    ar_events = loop.ar_events
 
     for _ in range(a.warmup):
         step()
@@ -572,14 +630,14 @@ def rank_main(a):
     dt = time.perf_counter() - t0
     prof_src = "HIP events around every launch of the family during the timed steps"
     n_prof_chunks = len(inputs) * a.steps
-    loss_last = float(last)
+    loss_last = float(last[12])
     peak_hbm = torch.cuda.max_memory_allocated()
     launch_mode = "hipGraph replay per chunk" if graph is not None else "eager"
+    n_skipped = int(opt.steps - int(opt.dev_step))  # steps check_grad discarded (0 on a healthy run)
     if graph is not None:
         # the eager re-run below needs the memory the graph's private pool holds
-        last = st_loss = None
-        graph = None
-        torch.cuda.empty_cache()
+        last = graph = None
+        loop.release_graph()
         graph_was = True
     else:
         graph_was = False
@@ -589,7 +647,7 @@ def rank_main(a):
         _lib.PROF = {}
         n_prof_chunks = min(4, len(inputs))
         for hxy, batch in inputs[:n_prof_chunks]:
-            train_chunk_(DF, P, fr, hxy, batch, draw_rng(M, N0, S0, dev, gen), spp, res, prec)
+            loop.chunk(hxy, batch, draw_rng(M, N0, S0, dev, gen))
         torch.cuda.synchronize()
         prof_src = "HIP events around every launch of the family in an eager re-run of %d chunks right after the timed region " \
                    "(the timed region replays a captured hipGraph, which cannot host events)" % n_prof_chunks
@@ -653,7 +711,8 @@ def rank_main(a):
                        "parallelism": "rows dealt round-robin to %d rank(s) and to each rank's chunks, one RCCL all-reduce of the flat fp32 gradient (%d elements) per step" % (world, opt.n),
                        "launch": launch_mode,
                        "optimizer": "lab4d_amd.optim.FlatAdamW: clip_grad_norm_(5.0) + AdamW in 3 launches over one flat buffer; "
-                                    "weight gradients accumulated into it by the wgrad kernels"},
+                                    "weight gradients accumulated into it by the wgrad kernels; a step whose pre-clip norm exceeds 5 (or is not finite) is "
+                                    "discarded on the device like Trainer.check_grad does (steps_discarded below)"},
             "rank_ms_per_step": [round(x, 2) for x in rank_ms], "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
             "rank_plan": {k: plan[k] for k in ("rows", "chunk_sizes", "rays_per_step", "est_peak_hbm_gib")},
             "peak_hbm_gib": round(peak_hbm / 2**30, 1),
@@ -663,6 +722,7 @@ def rank_main(a):
             # sanity of the timed work: the loss of the last chunk and whether every parameter is still finite after the timed optimizer steps
             "emulated": None if not a.emulate_rank_of else {"rank_0_of": a.emulate_rank_of, "note": "rank 0's share of the strong-scaling job on one GPU, no collective: "
                          "ms_per_step is the per-rank time an %d-GPU run is bounded by (plus its all-reduce of %.1f MB)" % (a.emulate_rank_of, opt.n * 4 / 1e6)},
+            "steps_discarded_by_check_grad": n_skipped,
             "loss_last_chunk": loss_last, "params_finite": bool(all(bool(torch.isfinite(p).all()) for p in params)),
         }
         if eval_result is not None:

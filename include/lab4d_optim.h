@@ -23,4 +23,19 @@ int lab4d_grad_norm_clip(const float* g, int64_t n, float max_norm, float* work,
 int lab4d_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
                      float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_scale, void* stream);
 
+/* Trainer.check_grad (engine/trainer.py:581-604) without a host round trip: norm / coef as lab4d_grad_norm_clip, plus the reference's
+ * discard rule.  skipped[0] = 1 when the pre-clip norm exceeds skip_above (the reference's `if grad_norm > thresh: optimizer.zero_grad()`,
+ * after which torch's optimizer skips every parameter: weights, moments and step counts stay as they were) or is not finite (the
+ * reference would write NaN into every weight there), else 0.  step[0] (device int32, 0 before the first step) is incremented only
+ * when the step is NOT discarded -- it is the 1-based step count lab4d_adamw_step_guarded's bias corrections use.  The caller reads
+ * `skipped` whenever it likes (e.g. once per round) to do the reference's cached-weights reload (trainer.py:598-604). */
+int lab4d_check_grad(const float* g, int64_t n, float max_norm, float skip_above, float* work, float* norm, float* coef, int32_t* skipped,
+                     int32_t* step, void* stream);
+
+/* lab4d_adamw_step with the step count and the discard flag read on the device: a no-op (p, m, v untouched) when skipped[0] != 0,
+ * otherwise the AdamW step number step[0] (as left by lab4d_check_grad on the same stream). */
+int lab4d_adamw_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
+                             float beta1, float beta2, float eps, float weight_decay, const float* grad_scale, const int32_t* skipped,
+                             const int32_t* step, void* stream);
+
 #endif /* LAB4D_OPTIM_H */

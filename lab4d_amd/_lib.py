@@ -132,16 +132,57 @@ def lib():
     return _LIB
 
 
+# LAB4D_NANCHECK=1 (diagnostic): every tensor whose pointer is handed to the library is remembered, and after each entry point returns
+# the device is synchronised and the floating-point ones are scanned for non-finite values -- the first report names the kernel that
+# produced (or was fed) them.  Together with torch.utils.deterministic.fill_uninitialized_memory (torch.empty -> NaN) this finds reads
+# of uninitialised buffers.  Off by default: one attribute test per pointer.
+NANCHECK = os.environ.get("LAB4D_NANCHECK", "0") == "1"
+NANCHECK_IGNORE = set(os.environ.get("LAB4D_NANCHECK_IGNORE", "").split(","))
+_SEEN = []
+_REPORTED = set()
+
+
+def _nancheck(what):
+    torch.cuda.synchronize()
+    for i, t in enumerate(_SEEN):
+        if t.dtype.is_floating_point and t.numel() and what not in NANCHECK_IGNORE:
+            flat = t.reshape(-1)
+            n, first = 0, -1
+            for o in range(0, flat.numel(), 1 << 28):  # pieces: index arithmetic of nonzero() overflows on > 2^31 elements
+                piece = flat[o:o + (1 << 28)]
+                bad = ~(piece.abs() < 1e15)  # non-finite, or a magnitude no quantity of this renderer reaches (uninitialised memory)
+                k = int(bad.sum())
+                if k and first < 0:
+                    first = o + int(bad.to(torch.uint8).argmax())
+                n += k
+            if n and n < t.numel() and (what, i) not in _REPORTED:  # a buffer that is ALL poison has simply not been written yet
+                _REPORTED.add((what, i))
+                print("[nancheck] %s: tensor #%d %s %s has %d non-finite / huge values of %d (first at flat index %d: %s)"
+                      % (what, i, tuple(t.shape), str(t.dtype).replace("torch.", ""), n, t.numel(), first, float(flat[first])), file=sys.stderr)
+    _SEEN.clear()
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().lab4d_last_error().decode()))
+    if NANCHECK:
+        _nancheck(what)
 
 
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     if t is None:
         return None
+    if NANCHECK:
+        _SEEN.append(t)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def dp(t):
+    """Raw device address of a tensor, for pointer fields of the argument structs."""
+    if NANCHECK:
+        _SEEN.append(t)
+    return t.data_ptr()
 
 
 def ptr_at(t):

@@ -29,6 +29,12 @@ inline int check_launch(const char* what) {
   return LAB4D_OK;
 }
 
+// Zero `bytes` (a multiple of 4) at p, ordered on the stream like any kernel.  A fill KERNEL, not hipMemsetAsync: a memset node captured
+// into a hipGraph is not ordered against the kernel nodes around it on this runtime (ROCm 7.2) -- on the first replay the accumulator it
+// should clear is fresh (zero) memory and everything looks right, from the second replay on the atomics land on the previous replay's
+// sums (found in round 3: the loss vector and the per-frame gradient accumulators of a replayed training chunk were garbage).
+int zero_async(void* p, size_t bytes, hipStream_t stream);
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -143,7 +143,7 @@ extern "C" int lab4d_compact(const unsigned char* mask, long S, int* idx, int* c
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)((S + kCompactBlock - 1) / kCompactBlock);
   if (nb == 0) {
-    if (hipMemsetAsync(count, 0, sizeof(int), st) != hipSuccess) { set_error("compact: memset failed"); return LAB4D_ELAUNCH; }
+    if (int e = zero_async(count, sizeof(int), st)) return e;
     return LAB4D_OK;
   }
   hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(256), 0, st, mask, S, work);

@@ -151,9 +151,10 @@ extern "C" int lab4d_flow_cyc_backward(const float* xyz_next, const float* q, co
   LAB4D_REQUIRE(xyz_next && q && t && K && g_flow && g_xyz_next && g_per_frame, "flow_cyc_backward: null pointer");
   LAB4D_REQUIRE((g_xyz_cyc == nullptr) == (g_xyz_t == nullptr) && (g_xyz_cyc == nullptr || (xyz_cyc && xyz_t && g_cyc)), "flow_cyc_backward: cycle arguments go together");
   LAB4D_REQUIRE(spf > 0 && M > 0 && (long)M * spf >= S, "flow_cyc_backward: M * spf < S");
-  if (S == 0) return LAB4D_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(g_per_frame, 0, (size_t)M * 16 * sizeof(float), st) != hipSuccess) { set_error("flow_cyc_backward: memset failed"); return LAB4D_ELAUNCH; }
+  // before the early return: an empty chunk still hands g_per_frame back as the (zero) gradients of q / t / K
+  if (int e = zero_async(g_per_frame, (size_t)M * 16 * sizeof(float), st)) return e;
+  if (S == 0) return LAB4D_OK;
   int bx = (int)((spf + 16383) / 16384);
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(k_flow_cyc_bwd, dim3(bx, M), dim3(256), 0, st, xyz_next, q, t, K, xyz_cyc, xyz_t, g_flow, g_cyc, S, spf, g_xyz_next, g_per_frame, g_xyz_cyc,
@@ -170,9 +171,10 @@ extern "C" int lab4d_volsdf_forward(const float* sdf, const float* ibeta, long S
 
 extern "C" int lab4d_volsdf_backward(const float* sdf, const float* ibeta, const float* g_density, long S, float* g_sdf, float* g_ibeta, void* stream) {
   LAB4D_REQUIRE(sdf && ibeta && g_density && g_sdf, "volsdf_backward: null pointer");
-  if (S == 0) return LAB4D_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (g_ibeta && hipMemsetAsync(g_ibeta, 0, sizeof(float), st) != hipSuccess) { set_error("volsdf_backward: memset failed"); return LAB4D_ELAUNCH; }
+  if (g_ibeta)
+    if (int e = zero_async(g_ibeta, sizeof(float), st)) return e;
+  if (S == 0) return LAB4D_OK;
   hipLaunchKernelGGL(k_volsdf_bwd, dim3(grid1(S) > 1024 ? 1024 : grid1(S)), dim3(256), 0, st, sdf, ibeta, g_density, S, g_sdf, g_ibeta);
   return check_launch("volsdf_backward");
 }

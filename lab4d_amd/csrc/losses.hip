@@ -176,7 +176,7 @@ extern "C" int lab4d_ray_losses_forward(const lab4d_loss_inputs* in, int R, int 
   if (int e = check_inputs(in, "ray_losses_forward")) return e;
   LAB4D_REQUIRE(R > 0 && N > 0 && weights && acc && loss, "ray_losses_forward: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(acc, 0, 2 * LAB4D_LOSS_TERMS * sizeof(float), st) != hipSuccess) { set_error("ray_losses_forward: memset failed"); return LAB4D_ELAUNCH; }
+  if (int e = zero_async(acc, 2 * LAB4D_LOSS_TERMS * sizeof(float), st)) return e;
   int grid = div_up(R, 256); if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(k_ray_losses_fwd, dim3(grid), dim3(256), 0, st, *in, R, N, acc);
   LossW w;

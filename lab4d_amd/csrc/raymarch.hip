@@ -4,6 +4,7 @@
 // per ray with lanes over samples for the adjoint (coalesced reads, wave reductions, per-frame
 // accumulation through LDS then a handful of atomics per block).
 #include "common.hpp"
+#include "sample_pdf_math.hpp"
 
 namespace lab4d {
 
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256) k_ray_samples_bwd(const float* __restrict
   }
 }
 
-// sample_pdf(det=True): one thread per ray, two-pointer sweep over the (monotone) cdf and u.
+// sample_pdf: one thread per ray (csrc/sample_pdf_math.hpp holds the per-ray arithmetic).
 // u_in: caller-drawn uniforms (R, n_imp), sorted ascending per ray (det=False: the host draws torch.rand, sorts, and un-sorts
 // the result -- searchsorted is a per-element operation, so the order of the queries is immaterial), or NULL for linspace.
 __global__ void __launch_bounds__(256) k_sample_pdf(const float* __restrict__ bins, const float* __restrict__ weights, int R,
@@ -175,50 +176,8 @@ __global__ void __launch_bounds__(256) k_sample_pdf(const float* __restrict__ bi
                                                      float* __restrict__ samples, int64_t* __restrict__ inds) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
-  const float* w = weights + (long)r * n_w;
-  const float* b = bins + (long)r * (n_w + 1);
-  // normaliser: sum of (w + eps) (render_utils.py:203-204); accumulated in f64 (torch's own CPU /
-  // CUDA reductions differ from each other in the last ulp, see DESIGN.md "sample_pdf")
-  double tot = 0.0;
-  for (int i = 0; i < n_w; ++i) tot += (double)(w[i] + eps);
-  const float totf = (float)tot;
-  const float step = 1.0f / (float)(n_imp - 1);
-  // cdf[j], j = 0..n_w; cdf[0] = 0; cumsum accumulates in f64 and rounds each entry to f32 like
-  // torch.cumsum on CPU
-  int j = 0;              // number of cdf entries consumed that are <= u  (searchsorted right=True)
-  double run = 0.0;       // f64 running sum of pdf[0..j-1]
-  float c_lo = 0.f;       // cdf[j-1] (for j >= 1)
-  float c_hi = 0.f;       // cdf[j]
-  // cdf[0] = 0 is entry 0
-  c_hi = 0.f;
-  bool have_hi = true;    // c_hi holds cdf[j] for current j
-  for (int k = 0; k < n_imp; ++k) {
-    // torch.linspace (CPU): start + step*k for the first half, end - step*(n-1-k) for the second, the latter evaluated with a
-    // FUSED multiply-add by its vectorised kernel -- fmaf reproduces it bit for bit for every n (checked for n = 16..128 in
-    // tests/test_oracle_properties.py::test_linspace_arithmetic); an unfused product does not (n = 16, 64, 128 differ)
-    const float u = u_in ? u_in[(long)r * n_imp + k]
-                         : ((k < n_imp / 2) ? mul_rn(step, (float)k) : fmaf(-step, (float)(n_imp - 1 - k), 1.0f));
-    // advance while cdf[j] <= u
-    while (j <= n_w && c_hi <= u) {
-      c_lo = c_hi;
-      ++j;
-      if (j <= n_w) {
-        run += (double)((w[j - 1] + eps) / totf);
-        c_hi = (float)run;
-      }
-    }
-    // inds = j (count of entries <= u); below = max(j-1,0); above = min(j, n_w)
-    const int below = j - 1 < 0 ? 0 : j - 1;
-    const int above = j > n_w ? n_w : j;
-    const float cb = (j == 0) ? c_hi : c_lo;              // cdf[below]
-    const float ca = (j > n_w) ? c_lo : c_hi;              // cdf[above]
-    float denom = ca - cb;
-    if (denom < eps) denom = 1.0f;
-    const float b0 = b[below], b1 = b[above];
-    samples[(long)r * n_imp + k] = add_rn(b0, mul_rn(__fdiv_rn(u - cb, denom), b1 - b0));  // separate tensor ops in the reference: unfused
-    inds[(long)r * n_imp + k] = (int64_t)j;
-  }
-  (void)have_hi;
+  lab4d_pdf::sample_pdf_ray(bins + (long)r * (n_w + 1), weights + (long)r * n_w, n_w, n_imp, eps, u_in ? u_in + (long)r * n_imp : nullptr,
+                            samples + (long)r * n_imp, inds + (long)r * n_imp);
 }
 
 // sorted(cat(a, b)) per ray: merge two (nearly) sorted runs, then one insertion pass to repair the

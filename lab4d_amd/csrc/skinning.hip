@@ -719,7 +719,7 @@ extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* art_r, c
     // bone-coordinate path: per-frame moments -> Gram matrix -> (M,B)-sized chain rule
     float* Q = ws + (size_t)S * (2 * B + 18);   // (M,B,10), zero-filled here
     float* G = Q + (size_t)M * B * 10;            // (M,B,3,4)
-    if (hipMemsetAsync(Q, 0, (size_t)M * B * 10 * sizeof(float), st) != hipSuccess) { set_error("skin_blend_backward: memset failed"); return LAB4D_ELAUNCH; }
+    if (int e = zero_async(Q, (size_t)M * B * 10 * sizeof(float), st)) return e;
     if (int e = lab4d_gram_per_frame(ws + (size_t)S * (B + 8), B, ws + (size_t)S * (2 * B + 8), 10, S, spf, M, Q, stream)) return e;
     hipLaunchKernelGGL(k_bone_gram_from_moments, dim3(div_up(M * B, 64)), dim3(64), 0, st, art_r, art_d, gauss, Q, M, B, G);
     if (int e = check_launch("bone_gram_from_moments")) return e;

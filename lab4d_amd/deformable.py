@@ -445,6 +445,8 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     fd["rgb"], fd["density"], fd["density_fg"], fd["vis"] = rgb, density, density, vis
     # flow: canonical points into the pair partner's camera (nerf.py:948-997)
     nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam", "t_articulation", "rest_articulation"]})
+    # pair partners are frames of one video, so the rest articulation (a per-instance quantity from get_vals_and_mean) equals its
+    # flip_pair; a caller that supplies its own states it (patch._frames checks it), anything else takes the general path
     shared = skinning and fr.get("rest_shared_in_pair", True)
     fw_pre = {"gauss": ft["gauss"], "pf": ft["pf.skin_fw"]} if skinning else None
     if shared:
@@ -469,6 +471,9 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     fd["depth"] = depth / ft["scale"]
     fd["feature"] = compute_feat(P, xyz, prec)
     aux = {}
+    if fr.get("feature") is None:  # FeatureNeRF.query_field (feature.py:104-107): the matching terms need the pixel features of the batch
+        fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"], ft)
+        return fd, deltas, aux
     xyz_matches = global_match(P, fr["feature"], fd["feature"], xyz, rng["match_perm"])
     if skinning:
         xm_next, _ = skinning_warp(P, xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], fr["code_skin"], False,
@@ -541,11 +546,11 @@ class RayLosses(Function):
     def _inputs(rendered, targets, extras, hxy_ld):
         a = _LossInputs()
         for n, t in zip(_RENDERED + _TARGETS, rendered + targets):
-            setattr(a, n, None if t is None else t.data_ptr())
+            setattr(a, n, None if t is None else _lib.dp(t))
         comp = extras[0] is not None or extras[1] is not None
         a.hxy_ld, a.dense_uses_mask = hxy_ld, 0 if comp else 1
-        a.mask_all = None if extras[0] is None else extras[0].data_ptr()
-        a.vis_bg = None if extras[1] is None else extras[1].data_ptr()
+        a.mask_all = None if extras[0] is None else _lib.dp(extras[0])
+        a.vis_bg = None if extras[1] is None else _lib.dp(extras[1])
         a.vis_bg_wt = 0.01  # model.py:489
         return a
 
@@ -579,11 +584,11 @@ class RayLosses(Function):
         for i, (n, t) in enumerate(zip(_RENDERED, rendered)):
             o = torch.empty_like(t) if (t is not None and ctx.needs_input_grad[2 + i]) else None
             outs.append(o)
-            setattr(gr, n, None if o is None else o.data_ptr())
+            setattr(gr, n, None if o is None else _lib.dp(o))
         for i, (n, t) in enumerate(zip(("mask_all", "vis_bg"), extras)):
             o = torch.empty_like(t) if (t is not None and ctx.needs_input_grad[24 + i]) else None
             outs.append(o)
-            setattr(gr, n, None if o is None else o.data_ptr())
+            setattr(gr, n, None if o is None else _lib.dp(o))
         w = (cf * 12)(*weights)
         _lib.check(_lib.lib().lab4d_ray_losses_backward(ctypes.byref(a), R, N, ctypes.byref(w), _lib.ptr(acc), _lib.ptr(g_loss), ctypes.byref(gr),
                                                         _lib.stream()), "ray_losses_backward")
@@ -594,6 +599,7 @@ class RayLosses(Function):
 class LossDict(dict):
     """{term: scalar}; `.total` is their sum, formed by the kernel (summing the dict's values costs one launch per term)."""
     total = None
+    vec = None  # the kernel's output: the 12 weighted terms in LOSS_TERMS order, then their total
 
 
 def losses_fg(results, batch, train_res, weights):
@@ -615,7 +621,7 @@ def losses_fg(results, batch, train_res, weights):
                batch["is_detected"], bal]
     vec = RayLosses.apply(r["mask"].shape[1], wt, *rendered, *targets, None, None)
     out = LossDict((k, vec[i]) for i, k in enumerate(LOSS_TERMS))
-    out.total = vec[12]
+    out.total, out.vec = vec[12], vec
     return out
 
 
@@ -875,7 +881,7 @@ def losses_comp(results, batch, train_res, weights):
                batch["is_detected"], bal]
     vec = RayLosses.apply(r["mask"].shape[1], wt, *rendered, *targets, r["mask"], b["vis"])
     out = LossDict((k, vec[i]) for i, k in enumerate(LOSS_TERMS))
-    out.total = vec[12]
+    out.total, out.vec = vec[12], vec
     return out
 
 

@@ -376,19 +376,19 @@ class MlpChain(Function):
         need_grad = any(ctx.needs_input_grad)
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, ld, int(spf)
-        a.x = x.data_ptr()
+        a.x = _lib.dp(x)
         if aff is not None:
             if tuple(aff.shape[1:]) != (d.c_in, 4) or x.shape[1] != 3 or aff.dtype != torch.float32 or not aff.is_contiguous():
                 raise RuntimeError("MlpChain: aff must be a contiguous fp32 (M, %d, 4) table and x the (S,3) points" % d.c_in)
             _lib.require_device(aff)
-            a.aff = aff.data_ptr()
+            a.aff = _lib.dp(aff)
         if x2 is not None:
             x2 = x2.contiguous().float()
             _lib.require_device(x2)
-            a.x2 = x2.data_ptr()
+            a.x2 = _lib.dp(x2)
         if freq_w is not None:
             freq_w = freq_w.contiguous().float()
-            a.freq_w = freq_w.data_ptr()
+            a.freq_w = _lib.dp(freq_w)
         keep = [x2]
         acts = [None] * NL
         masks = [None] * NL
@@ -397,39 +397,39 @@ class MlpChain(Function):
         for l in range(NL):
             L = d.layers[l]
             pw = packed_weights(net, l, prec, Ws[l], False)
-            a.W[l] = pw.data_ptr()
+            a.W[l] = _lib.dp(pw)
             b = bs[l].detach().float()
             if b.numel() != L.mout_pad:
                 b = torch.nn.functional.pad(b, (0, L.mout_pad - b.numel()))
             b = b.contiguous()
-            a.bias[l] = b.data_ptr()
+            a.bias[l] = _lib.dp(b)
             keep += [pw, b]
             if L.pf_bias:
                 pf = (pfs[pf_i].detach().float() + b[None]).contiguous()  # kernel contract: the per-frame table includes the bias
                 pf_i += 1
                 if pf.shape[1] != L.mout_pad:
                     raise RuntimeError("per-frame bias of layer %d must have %d columns" % (l, L.mout_pad))
-                a.pf_bias[l] = pf.data_ptr()
+                a.pf_bias[l] = _lib.dp(pf)
                 pf_used[l] = pf
                 keep.append(pf)
             if (need_grad and l + 1 < NL) or l == export_layer:
                 acts[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
-                a.act[l] = acts[l].data_ptr()
+                a.act[l] = _lib.dp(acts[l])
             if need_grad and L.relu and l + 1 < NL:
                 tile = 64 if prec == PREC_BF16 else 32
                 masks[l] = torch.empty((S_pad // tile) * (L.mout_pad // 32) * 64, dtype=torch.int32, device=dev)
-                a.mask[l] = masks[l].data_ptr()
+                a.mask[l] = _lib.dp(masks[l])
         emb = None
         if need_grad:
             emb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
-            a.emb = emb.data_ptr()
+            a.emb = _lib.dp(emb)
         if ext is not None:
             ext = ext.contiguous()
             if ext.dtype != sdt:
                 raise RuntimeError("ext must be stored as %s" % sdt)
-            a.ext = ext.data_ptr()
+            a.ext = _lib.dp(ext)
         out = torch.empty(S, d.c_out, device=dev)
-        a.out = out.data_ptr()
+        a.out = _lib.dp(out)
         # algorithmic HBM bytes of this launch: every stored tensor written once, inputs read once
         nbytes = sum(t.numel() * t.element_size() for t in acts + masks + [emb, ext, out, x] if t is not None)
         with _lib.timed("k_mlp_fwd<%s>%s" % (KERNEL_NET[net], "" if need_grad else " inference"), (2.0 * S * NET_MACS[net], float(nbytes))):
@@ -463,36 +463,36 @@ class MlpChain(Function):
         for l in range(NL):
             L = d.layers[l]
             pw = packed_weights(net, l, prec, Ws[l], True)
-            a.WT[l] = pw.data_ptr()
+            a.WT[l] = _lib.dp(pw)
             keep.append(pw)
             if ctx.acts[l] is not None:
-                a.act[l] = ctx.acts[l].data_ptr()
+                a.act[l] = _lib.dp(ctx.acts[l])
             if ctx.masks[l] is not None:
-                a.mask[l] = ctx.masks[l].data_ptr()
+                a.mask[l] = _lib.dp(ctx.masks[l])
             dz[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
-            a.dz[l] = dz[l].data_ptr()
+            a.dz[l] = _lib.dp(dz[l])
             if L.ext_grad:
                 if d_export is None:
                     d_export = torch.zeros(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
                 d_export = d_export.contiguous()
-                a.ext_gin = d_export.data_ptr()
+                a.ext_gin = _lib.dp(d_export)
         if ctx.emb is not None:
-            a.emb = ctx.emb.data_ptr()
+            a.emb = _lib.dp(ctx.emb)
         ext_g = None
         if ctx.ext is not None:
-            a.ext = ctx.ext.data_ptr()
+            a.ext = _lib.dp(ctx.ext)
             ext_g = torch.empty_like(ctx.ext)  # always written by the kernel (no stores in runtime branches)
-            a.ext_gout = ext_g.data_ptr()
+            a.ext_gout = _lib.dp(ext_g)
         d_out = d_out.contiguous().float()
-        a.d_out = d_out.data_ptr()
+        a.d_out = _lib.dp(d_out)
         d_x = None
         d_x2 = None
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[8]:
             d_x = torch.empty(ctx.x_shape, device=dev)
-            a.d_x = d_x.data_ptr()
+            a.d_x = _lib.dp(d_x)
             if ctx.has_x2:  # written together with d_x by the kernel
                 d_x2 = torch.empty(ctx.x_shape, device=dev)
-                a.d_x2 = d_x2.data_ptr()
+                a.d_x2 = _lib.dp(d_x2)
         # algorithmic HBM bytes: every dZ written once; masks, head gradient, stored embedding / external tensors read once
         nbytes = sum(t.numel() * t.element_size() for t in list(dz) + list(ctx.masks) + [d_out, d_x, ext_g, ctx.emb if d_x is not None else None]
                      if t is not None)
@@ -594,35 +594,35 @@ def run_chain_compacted(net, prec, P, x, frame_idx, count, conds=None, ext=None,
     dev, sdt = x.device, store_dtype(prec)
     a = FwdArgs()
     a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, S_pad, 1
-    a.x, a.S_dev, a.frame_idx = x.data_ptr(), count.data_ptr(), frame_idx.data_ptr()
+    a.x, a.S_dev, a.frame_idx = _lib.dp(x), _lib.dp(count), _lib.dp(frame_idx)
     keep = []
     if freq_w is not None:
         freq_w = freq_w.contiguous().float()
-        a.freq_w = freq_w.data_ptr()
+        a.freq_w = _lib.dp(freq_w)
     exported = None
     for l in range(d.n_layers):
         L = d.layers[l]
         W, b = P[bd[l].wname], P[bd[l].bname].detach().float()
         pw = packed_weights(net, l, prec, W, False)
-        a.W[l] = pw.data_ptr()
+        a.W[l] = _lib.dp(pw)
         if b.numel() != L.mout_pad:
             b = torch.nn.functional.pad(b, (0, L.mout_pad - b.numel()))
         b = b.contiguous()
-        a.bias[l] = b.data_ptr()
+        a.bias[l] = _lib.dp(b)
         keep += [pw, b]
         if L.pf_bias:
             pf = (pf_bias_of(net, l, W, conds[l]).float() + b[None]).contiguous()
-            a.pf_bias[l] = pf.data_ptr()
+            a.pf_bias[l] = _lib.dp(pf)
             keep.append(pf)
         if l == export_layer:
             exported = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
-            a.act[l] = exported.data_ptr()
+            a.act[l] = _lib.dp(exported)
     if ext is not None:
         if ext.dtype != sdt:
             raise RuntimeError("ext must be stored as %s" % sdt)
-        a.ext = ext.data_ptr()
+        a.ext = _lib.dp(ext)
     out = torch.empty(S, d.c_out, device=dev)
-    a.out = out.data_ptr()
+    a.out = _lib.dp(out)
     with _lib.timed("k_mlp_fwd<%s> inference" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], 0.0)):
         _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(compacted)")
     return (out, exported) if exported is not None else out
@@ -650,41 +650,41 @@ class EikonalSdf(Function):
         tile = 64 if prec == PREC_BF16 else 32
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, S_pad, int(spf)
-        a.x = x.data_ptr()
+        a.x = _lib.dp(x)
         fw = None
         if freq_w is not None:
             fw = freq_w.detach().contiguous().float()
-            a.freq_w = fw.data_ptr()
+            a.freq_w = _lib.dp(fw)
         keep, masks, packed = [], [None] * NL, []
         pfs = {0: pf0.detach().contiguous().float(), 4: pf4.detach().contiguous().float()}
         for l in range(NL):
             L = d.layers[l]
             pw = packed_weights(net, l, prec, Ws[l], False)
             packed.append(pw)
-            a.W[l] = pw.data_ptr()
+            a.W[l] = _lib.dp(pw)
             b = bs[l].detach().float()
             if b.numel() != L.mout_pad:
                 b = torch.nn.functional.pad(b, (0, L.mout_pad - b.numel()))
             b = b.contiguous()
             keep.append(b)
-            a.bias[l] = b.data_ptr()
+            a.bias[l] = _lib.dp(b)
             if L.pf_bias:
                 pfb = (pfs[l].detach().float() + b[None]).contiguous()
                 keep.append(pfb)
-                a.pf_bias[l] = pfb.data_ptr()
+                a.pf_bias[l] = _lib.dp(pfb)
             if L.relu and l + 1 < NL:
                 masks[l] = torch.empty((S_pad // tile) * (L.mout_pad // 32) * 64, dtype=torch.int32, device=dev)
-                a.mask[l] = masks[l].data_ptr()
+                a.mask[l] = _lib.dp(masks[l])
         emb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
-        a.emb = emb.data_ptr()
+        a.emb = _lib.dp(emb)
         # training-mode forward stores every hidden activation; the primal ones are not needed here, so the buffers are
         # the ones the tangent pass of backward() overwrites with the tangent activations
         tact = [None] * NL
         for l in range(NL - 1):
             tact[l] = torch.empty(buf_numel(d.layers[l].mout_pad, S_pad), dtype=sdt, device=dev)
-            a.act[l] = tact[l].data_ptr()
+            a.act[l] = _lib.dp(tact[l])
         sdf = torch.empty(S, 1, device=dev)
-        a.out = sdf.data_ptr()
+        a.out = _lib.dp(sdf)
         _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(eikonal primal)")
         bk = BwdArgs()
         bk.net, bk.precision, bk.S, bk.S_pad, bk.ld, bk.spf = net, prec, S, S_pad, S_pad, int(spf)
@@ -693,20 +693,20 @@ class EikonalSdf(Function):
             L = d.layers[l]
             pt = packed_weights(net, l, prec, Ws[l], True)
             keep.append(pt)
-            bk.WT[l] = pt.data_ptr()
+            bk.WT[l] = _lib.dp(pt)
             if masks[l] is not None:
-                bk.mask[l] = masks[l].data_ptr()
+                bk.mask[l] = _lib.dp(masks[l])
             dz[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
-            bk.dz[l] = dz[l].data_ptr()
+            bk.dz[l] = _lib.dp(dz[l])
             if L.ext_grad:
                 zg = torch.zeros(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
                 keep.append(zg)
-                bk.ext_gin = zg.data_ptr()
-        bk.emb = emb.data_ptr()
+                bk.ext_gin = _lib.dp(zg)
+        bk.emb = _lib.dp(emb)
         ones = torch.ones(S, 1, device=dev)
-        bk.d_out = ones.data_ptr()
+        bk.d_out = _lib.dp(ones)
         g = torch.empty(S, 3, device=dev)
-        bk.d_x = g.data_ptr()
+        bk.d_x = _lib.dp(g)
         _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(bk), _lib.stream()), "mlp_backward(eikonal primal)")
         gn = g.norm(2, dim=-1, keepdim=True)
         ctx.meta = (net, prec, int(spf), S, S_pad)
@@ -733,16 +733,16 @@ class EikonalSdf(Function):
         u = torch.cat([u.reshape(S, 6 * L0), dLdg, torch.zeros(S, d.ke - 6 * L0 - 3, device=dev)], -1).contiguous()
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, S_pad, spf
-        a.x = u.data_ptr()
+        a.x = _lib.dp(u)
         for l in range(NL):
             L = d.layers[l]
-            a.W[l] = packed[l].data_ptr()
+            a.W[l] = _lib.dp(packed[l])
             if masks[l] is not None:
-                a.mask[l] = masks[l].data_ptr()
+                a.mask[l] = _lib.dp(masks[l])
             if l + 1 < NL:
-                a.act[l] = tact[l].data_ptr()
+                a.act[l] = _lib.dp(tact[l])
         temb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
-        a.emb = temb.data_ptr()
+        a.emb = _lib.dp(temb)
         _lib.check(_lib.lib().lab4d_mlp_forward_tangent(ctypes.byref(a), _lib.stream()), "mlp_forward_tangent")
         sinks = [(_grad_sink(Ws[l]) if ctx.needs_input_grad[7 + 2 * l] else None) for l in range(NL)]
         sizes = [0 if sinks[l] is not None else d.layers[l].mout_pad * (d.layers[l].ke + d.layers[l].kin) for l in range(NL)]

@@ -13,6 +13,8 @@ from . import _lib
 vp, ci, cf, i64 = _lib.vp, _lib.ci, _lib.cf, __import__("ctypes").c_int64
 _lib.register("lab4d_grad_norm_clip", [vp, i64, cf, vp, vp, vp, vp])
 _lib.register("lab4d_adamw_step", [vp, vp, vp, vp, i64, vp, vp, ci, cf, cf, cf, cf, ci, vp, vp])
+_lib.register("lab4d_check_grad", [vp, i64, cf, cf, vp, vp, vp, vp, vp, vp])
+_lib.register("lab4d_adamw_step_guarded", [vp, vp, vp, vp, i64, vp, vp, ci, cf, cf, cf, cf, vp, vp, vp, vp])
 
 
 class FlatAdamW:
@@ -54,7 +56,10 @@ class FlatAdamW:
         self.work = torch.empty(512, device=dev)
         self.norm = torch.zeros(1, device=dev)
         self.coef = torch.ones(1, device=dev)
-        self.steps = 0
+        self.steps = 0  # host-side count of step() calls
+        # check_grad state on the device: 1 when the last step was discarded; the number of steps actually taken; how many were discarded
+        self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dev_step = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def set_lr(self, lr):
         lrs = [float(lr)] * len(self.params) if not hasattr(lr, "__len__") else [float(x) for x in lr]
@@ -72,15 +77,40 @@ class FlatAdamW:
                                                    _lib.ptr(self.coef), _lib.stream()), "grad_norm_clip")
         return self.norm
 
-    def step(self, max_norm=None):
-        """One AdamW step; with max_norm the gradients are scaled by min(1, max_norm / (norm + 1e-6)) inside the update."""
+    def step(self, max_norm=None, skip_above=None):
+        """One AdamW step; with max_norm the gradients are scaled by min(1, max_norm / (norm + 1e-6)) inside the update.
+
+        skip_above (with max_norm) = Trainer.check_grad's discard rule (engine/trainer.py:581-604): when the pre-clip norm exceeds it,
+        or is not finite, the step is a no-op on the device -- parameters, moments and the step count of the bias corrections stay
+        untouched -- and `self.skipped` (device int32) is 1; no host synchronisation.  The reference then reloads the weights cached two
+        rounds ago when it has any (trainer.py:598-604): a caller does that from `self.skipped` at a point where it synchronises anyway."""
         _lib.require_device(self.flat, self.flat_grad)
+        self.steps += 1
+        if skip_above is not None:
+            if max_norm is None:
+                raise RuntimeError("FlatAdamW.step: skip_above needs max_norm (check_grad clips and checks in one pass)")
+            _lib.check(_lib.lib().lab4d_check_grad(_lib.ptr(self.flat_grad), self.n, float(max_norm), float(skip_above), _lib.ptr(self.work),
+                                                   _lib.ptr(self.norm), _lib.ptr(self.coef), _lib.ptr(self.skipped), _lib.ptr(self.dev_step),
+                                                   _lib.stream()), "check_grad")
+            _lib.check(_lib.lib().lab4d_adamw_step_guarded(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.m), _lib.ptr(self.v), self.n,
+                                                           _lib.ptr(self.seg_end), _lib.ptr(self.seg_lr), len(self.params), self.betas[0],
+                                                           self.betas[1], self.eps, self.weight_decay, _lib.ptr(self.coef), _lib.ptr(self.skipped),
+                                                           _lib.ptr(self.dev_step), _lib.stream()), "adamw_step_guarded")
+            torch.autograd.graph.increment_version(self.params)
+            self._guarded_used = True
+            return
         if max_norm is not None:
             self.grad_norm_clip(max_norm)
-        self.steps += 1
         _lib.check(_lib.lib().lab4d_adamw_step(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.m), _lib.ptr(self.v), self.n,
                                                _lib.ptr(self.seg_end), _lib.ptr(self.seg_lr), len(self.params), self.betas[0], self.betas[1], self.eps,
-                                               self.weight_decay, self.steps, _lib.ptr(self.coef) if max_norm is not None else None, _lib.stream()),
+                                               self.weight_decay, self._taken(), _lib.ptr(self.coef) if max_norm is not None else None, _lib.stream()),
                    "adamw_step")
         # the kernel wrote through raw pointers: tell autograd (and the packed-weight caches keyed on it) that the data changed
         torch.autograd.graph.increment_version(self.params)
+
+    def _taken(self):
+        """Step number of the unguarded path (host-side): steps taken so far.  Mixing guarded and unguarded steps on one optimizer would
+        need the device count on the host -- refused."""
+        if getattr(self, "_guarded_used", False):
+            raise RuntimeError("FlatAdamW: step() without skip_above after guarded steps (the step count lives on the device)")
+        return self.steps

@@ -246,6 +246,11 @@ def _frames(self, samples_dict, need_color=True):
     if kind != "rigid":
         warp = self.warp
         fr["t_articulation"], fr["rest_articulation"] = _articulations(warp, frame_id, samples_dict)
+        if "rest_articulation" in samples_dict and M % 2 == 0:
+            # a caller-supplied rest articulation may differ between pair partners (the reference then warps into the partner's frame with
+            # the PARTNER's rest, nerf.py:966-973): the shared-skinning-field shortcut holds only when it equals its flip_pair
+            rest = fr["rest_articulation"]
+            fr["rest_shared_in_pair"] = all(bool(torch.equal(r, r.view(M // 2, 2, *r.shape[1:]).flip(1).reshape(r.shape))) for r in rest)
         sk = warp.skinning_model
         fr["t_embed"] = sk.time_embedding(frame_id)
         fr["t_embed_mean"] = sk.time_embedding.get_mean_embedding(dev)

@@ -114,7 +114,7 @@ class _Composite(Function):
         fl.n_fields = len(fields)
         sumC = 0
         for i, (f, m) in enumerate(zip(fields, modes)):
-            fl.fields[i] = f.data_ptr()
+            fl.fields[i] = _lib.dp(f)
             fl.channels[i] = f.shape[-1]
             fl.modes[i] = m
             sumC += 1 if m == 2 else f.shape[-1]
@@ -159,13 +159,13 @@ class _Composite(Function):
         fl.n_fields = gf.n_fields = len(fields)
         gfields = []
         for i, (f, m) in enumerate(zip(fields, ctx.modes)):
-            fl.fields[i] = f.data_ptr()
+            fl.fields[i] = _lib.dp(f)
             fl.channels[i] = f.shape[-1]
             fl.modes[i] = m
             need = ctx.needs_input_grad[6 + i]
             g = torch.empty_like(f) if need else None
             gfields.append(g)
-            gf.fields[i] = g.data_ptr() if g is not None else None
+            gf.fields[i] = _lib.dp(g) if g is not None else None
         g_density = torch.empty_like(density)
         g_deltas = torch.empty_like(deltas)
         g_flow = torch.empty_like(flow) if (flow is not None and ctx.needs_input_grad[2]) else None

@@ -218,15 +218,16 @@ def skinning_warp_forward_multi(P, xyz, t_articulations, rest_articulation, t_em
     frame_id = None) -- not on the target -- so the bone coordinates and the delta-skin MLP are evaluated ONCE and only the
     dual-quaternion blend runs per target.  The training graph warps every canonical sample forward twice (compute_flow into
     the pair partner's frame, nerf.py:966-973; cycle_loss into its own, deformable.py:173-198): the reference evaluates the
-    skinning field twice with identical inputs, this evaluates it once.  Returns [(warped xyz, aux), ...]."""
+    skinning field twice with identical inputs, this evaluates it once.  Returns [(warped xyz, aux), ...].
+    pre = {"gauss", "pf", "se3s": [(r, d) per target]}: the per-frame terms evaluated by the step's prologue (deformable.frame_terms)."""
     shape = xyz.shape
     M, spf = shape[0], _spf(shape)
     x = xyz.reshape(-1, 3)
-    raw, gauss = skin_logits(P, x, rest_articulation, t_embed_mean, code, M, spf, prec)
-    rest_inv = Q.dual_quaternion_inverse(rest_articulation)
+    raw, gauss = skin_logits(P, x, rest_articulation, t_embed_mean, code, M, spf, prec, pre)
+    rest_inv = None if pre is not None else Q.dual_quaternion_inverse(rest_articulation)
     outs = []
-    for t_art in t_articulations:
-        se3 = Q.dual_quaternion_mul(t_art, rest_inv)
+    for i, t_art in enumerate(t_articulations):
+        se3 = pre["se3s"][i] if pre is not None else Q.dual_quaternion_mul(t_art, rest_inv)
         out, ent, dsk = SkinBlend.apply(x, raw, rest_articulation[0], rest_articulation[1], gauss, se3[0], se3[1], spf)
         outs.append((out.view(shape), {"skin_entropy": ent.view(shape[:-1] + (1,)), "delta_skin": dsk.view(shape[:-1] + (1,))}))
     return outs

@@ -31,6 +31,14 @@ def main():
         vis = ns.geom_utils.eval_func_chunk(lambda xyz: f.vis_mlp(xyz, inst_id=None) > 0, grid, chunk_size=500)
         out.update({"aabb": f.aabb.clone(), "box": box.clone(), "grid": grid.clone(), "sdf": sdf.reshape(G, G, G).clone(), "vis": vis.reshape(G, G, G).clone(),
                     "sdf_min_max": (float(sdf.min()), float(sdf.max()))})
+        # the same grid with the annealing window live (MultiFields.set_alpha ramps pos_embedding.alpha over the first steps;
+        # extract_canonical_mesh calls self.forward, which applies it): alpha = 0.7 of 10 octaves
+        f.pos_embedding.set_alpha(0.7)
+        f.pos_embedding_color.set_alpha(0.7)
+        sdf_a = ns.geom_utils.eval_func_chunk(lambda xyz: f.forward(xyz, inst_id=None, get_density=False), grid, chunk_size=500)
+        f.pos_embedding.set_alpha(None)
+        f.pos_embedding_color.set_alpha(None)
+        out.update({"alpha": 0.7, "sdf_alpha": sdf_a.reshape(G, G, G).clone()})
         # a stand-in proxy mesh (marching cubes itself needs skimage, absent here): a jittered sphere's vertices and bounds
         g = torch.Generator().manual_seed(seed)
         verts = torch.nn.functional.normalize(torch.randn(200, 3, generator=g), dim=-1) * (0.1 + 0.02 * torch.rand(200, 1, generator=g))

@@ -28,6 +28,10 @@ def test_grid_query_and_bound_updates_match_the_reference(golden_dir):
     sdf, vis, box = proxy.grid_query(P, P["aabb"], G, prec=mlp.PREC_F32)
     assert torch.allclose(box.cpu(), g["box"], atol=1e-7)
     assert rel(sdf, g["sdf"]) < 1e-4, rel(sdf, g["sdf"])
+    # annealing window live (pos_embedding.alpha = 0.7): the volume the reference meshes during the first steps of training
+    sdf_a, _, _ = proxy.grid_query(P, P["aabb"], G, prec=mlp.PREC_F32, alpha=g["alpha"], use_visibility=False)
+    assert rel(sdf_a, g["sdf_alpha"]) < 1e-4, rel(sdf_a, g["sdf_alpha"])
+    assert rel(sdf_a, g["sdf"]) > 1e-3  # the window does change the field
     # visibility > 0 is a sign test: it may differ only where the logit is within fp32 noise of zero
     dis = vis.cpu() != g["vis"]
     assert int(dis.sum()) <= 2, int(dis.sum())

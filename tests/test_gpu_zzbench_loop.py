@@ -1,0 +1,113 @@
+"""The benchmark's own step (bench.TrainLoop: captured chunk hipGraph replayed per chunk + FramePrologue + check_grad + FlatAdamW + in-place
+repack, bf16) driven for 30+ optimizer steps on a 4-row slice per chunk of the 512^2 frame pair: the loss and every parameter must stay
+finite, no step may be discarded by check_grad, and replaying the captured chunk must be idempotent (round 2's bench went non-finite
+because memset nodes inside the captured graph were not ordered against the kernels around them: the first replay was right, every
+later one accumulated onto the previous replay's sums -- a 2-step eager test cannot see that)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+CHUNKS = [[0, 128, 256, 384], [64, 192, 320, 448]]  # rows through the frame: object and background in every chunk
+
+
+def make_loop(use_graph=True, comp=False, spp=128):
+    import bench
+    from lab4d_amd import _lib, mlp
+    _lib.lib()
+    mlp.clear_caches()
+    return bench.TrainLoop(torch.device("cuda", 0), 512, spp, CHUNKS, mlp.PREC_BF16, comp=comp, use_graph=use_graph)
+
+
+def teardown_function(_):
+    from lab4d_amd import mlp
+    mlp.FUSED_GRAD_ACCUM = False
+    mlp.clear_caches()
+
+
+def test_replaying_the_captured_chunk_is_idempotent():
+    loop = make_loop()
+    assert loop.graph is not None
+    outs = []
+    for rep in range(4):
+        loop.opt.zero_grad()
+        loop.prologue.zero_grad()
+        loop.graph.replay()
+        torch.cuda.synchronize()
+        leaves = torch.cat([v.grad.reshape(-1) for v in loop.prologue.leaves.values() if v.grad is not None])
+        outs.append((loop.st_loss.clone(), loop.opt.flat_grad.clone(), leaves.clone()))
+    loss0, g0, l0 = outs[0]
+    assert bool(torch.isfinite(loss0).all()) and float(loss0[12]) > 0
+    for loss, g, l in outs[1:]:
+        assert torch.allclose(loss, loss0, rtol=1e-5, atol=0), (loss, loss0)  # same inputs, same kernels: equal up to the order of the loss sums' atomics
+        # gradients are sums of fp32 atomics: equal up to the order of the additions
+        assert float((g - g0).abs().max()) <= 1e-3 * float(g0.abs().max())
+        assert float((l - l0).abs().max()) <= 1e-3 * float(l0.abs().max())
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_thirty_two_steps_stay_finite(use_graph):
+    loop = make_loop(use_graph=use_graph)
+    losses = []
+    for _ in range(32):
+        last = loop.step()
+        losses.append(last[12].clone())
+    torch.cuda.synchronize()
+    losses = torch.stack(losses).cpu()
+    assert bool(torch.isfinite(losses).all()), losses
+    assert int(loop.opt.dev_step) == 32, "check_grad discarded %d of 32 steps" % (32 - int(loop.opt.dev_step))
+    assert all(bool(torch.isfinite(p).all()) for p in loop.params)
+    assert float(losses[-1]) < float(losses[0]), (float(losses[0]), float(losses[-1]))  # and the optimizer does optimise
+
+
+def test_graph_and_eager_steps_agree():
+    """Eight steps replayed from the graph against the same eight steps launched eagerly: same parameters up to bf16 / atomic-order noise."""
+    a = make_loop(use_graph=True)
+    for _ in range(8):
+        a.step()
+    torch.cuda.synchronize()
+    pa = a.opt.flat.clone()
+    a = None
+    b = make_loop(use_graph=False)
+    for _ in range(8):
+        b.step()
+    torch.cuda.synchronize()
+    pb = b.opt.flat
+    # 8 Adam steps of lr 5e-4 move a weight by at most 4e-3; a divergent trajectory differs at that scale
+    assert float((pa - pb).abs().max()) < 1e-3, float((pa - pb).abs().max())
+
+
+def test_check_grad_discards_a_blown_up_step():
+    """Trainer.check_grad (engine/trainer.py:581-604): a step whose pre-clip gradient norm exceeds the threshold leaves weights, moments and
+    the step count untouched; so does a non-finite one.  Decided on the device: no host round trip in step()."""
+    from lab4d_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in [(7, 5), (33,), (3,)]]
+    opt = FlatAdamW(ps, 1e-3)
+    ref = [p.detach().clone().requires_grad_(True) for p in ps]
+    ropt = torch.optim.AdamW([{"params": [p], "lr": 1e-3} for p in ref], betas=(0.9, 0.999), weight_decay=1e-4)
+    scales = [1.0, 1e6, 1.0, float("nan"), 0.5, float("inf"), 2.0]
+    for i, sc in enumerate(scales):
+        for params, o in ((ps, opt), (ref, ropt)):
+            o.zero_grad()
+            (sum((p * p).sum() for p in params) * 0.01 * sc).backward()
+        before = opt.flat.clone(), opt.m.clone(), opt.v.clone()
+        opt.step(max_norm=5.0, skip_above=5.0)
+        # the reference: clip, then discard when the pre-clip norm exceeds the threshold (zero_grad -> torch's optimizer skips every parameter)
+        tn = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        if bool(tn > 5.0) or not bool(torch.isfinite(tn)):
+            ropt.zero_grad()
+        ropt.step()
+        torch.cuda.synchronize()
+        blown = not (sc == sc and abs(sc) < 1e3)
+        assert int(opt.skipped) == int(blown), (i, sc, int(opt.skipped), float(opt.norm))
+        if blown:
+            assert torch.equal(opt.flat, before[0]) and torch.equal(opt.m, before[1]) and torch.equal(opt.v, before[2])
+        for a, b in zip(ps, ref):
+            assert torch.allclose(a, b, rtol=5e-6, atol=2e-7), (i, sc)
+    assert int(opt.dev_step) == 4
