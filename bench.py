@@ -25,6 +25,9 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL needs it (no-op when already exported)
+# replayed hipGraphs: memset nodes (PyTorch's multi-block reductions clear their semaphores with one) are only ordered against the kernel
+# nodes around them with the runtime's AQL packet capture off; read at HIP initialisation, costs nothing measurable (lab4d_amd/__init__.py)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -255,7 +255,7 @@ def test_sample_pdf_indices_and_samples(golden_dir):
 # torch's GPU reduction and a sequential sum give normalisers that differ in the last ulp, so the reference does not agree
 # with ITSELF across its own platforms there; both choices interpolate to the same sample (bins[n_w]).  Interior queries can
 # differ only where a cdf entry is within 3 ulp of u; none does on these cases: the interior indices are bit-exact.
-SAMPLE_PDF_MISMATCH_MAX = {"reference_golden": (0, 0), "random_positive_weights": (0, 0.2), "random_zero_weight_runs": (0, 0.2)}  # measured: interior 0 of 315,040; end point 593 of 5,000 rows
+SAMPLE_PDF_MISMATCH_MAX = {"reference_golden": (0, 0), "random_positive_weights": (0, 0), "random_zero_weight_runs": (0, 0)}  # round 3: the normaliser is summed in ATen's own order (csrc/sample_pdf_math.hpp) -- every index incl. the end point is bit-exact
 
 
 def _check_inds(inds, samples, bins, wts, n_imp, tag):
