@@ -329,7 +329,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define LAB4D_WGRAD_NB5 1
 #endif
 // WC = columns of the wave grid (2: the layers; 4: the <= 32-row heads, MT = 1 -- every wave owns the one row tile and a quarter of
-// the 64 NBW columns, LAB4D_WGRAD_HEAD_DMA=1, an experiment for the next round: the heads still use the pre-DMA kernel by default).
+// the 64 NBW columns, the default since round 3; LAB4D_WGRAD_HEAD_DMA=0 selects the pre-DMA kernel).
 template <int MT, int NBW, int NW = 4, int WC = 2>
 __global__ void __launch_bounds__(64 * NW) k_mlp_wgrad_dma(const unsigned short* __restrict__ dz, const unsigned short* __restrict__ emb,
                                                         const unsigned short* __restrict__ actp, int ke, int kin, int S_pad, int chunk,
@@ -705,7 +705,7 @@ extern "C" int lab4d_mlp_wgrad_mapped(int net, int layer, int precision, int S, 
   const bool big = mo_tiles >= 8;  // 256-wide layers: 8x8-tile workgroup blocks (k_mlp_wgrad_big / k_mlp_wgrad_dma)
   // bf16 layers of 64 / 128 / 256 output features run the LDS-DMA ring; NBW = 64-row blocks of X per workgroup
   const int Kt = L.ke + L.kin;
-  static const int head_dma = getenv("LAB4D_WGRAD_HEAD_DMA") ? atoi(getenv("LAB4D_WGRAD_HEAD_DMA")) : 0;  // kernel experiment (next round)
+  static const int head_dma = getenv("LAB4D_WGRAD_HEAD_DMA") ? atoi(getenv("LAB4D_WGRAD_HEAD_DMA")) : 1;  // round 3: on (heads 23.8 -> 19.7 ms per step); 0 = the pre-DMA kernel
   const bool dma = precision == LAB4D_PREC_BF16 && (mo_tiles == 8 || mo_tiles == 4 || mo_tiles == 2 || (mo_tiles == 1 && head_dma && Kt <= 256));
   // K = 320 (skip layer): one 320-column job with the 8-wave kernel of the 256-row layers, 192 + 128 otherwise
   const int nbw = (dma && mo_tiles == 1) ? (Kt <= 128 ? 2 : 4)  // heads: 1 x 4 wave grid, 128 or 256 columns per workgroup

@@ -68,8 +68,8 @@ KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Den
 
 def wgrad_kernel_name(L, prec):
     """Which kernel lab4d_mlp_wgrad dispatches to for this layer (mirrors the dispatch in csrc/mlp.hip)."""
-    if prec == PREC_BF16 and L.mout_pad == 32 and os.environ.get("LAB4D_WGRAD_HEAD_DMA", "0") not in ("", "0") and L.ke + L.kin <= 256:
-        return "k_mlp_wgrad_dma<1,%d>" % (2 if L.ke + L.kin <= 128 else 4)  # kernel experiment: the heads on the DMA ring (csrc/mlp.hip)
+    if prec == PREC_BF16 and L.mout_pad == 32 and os.environ.get("LAB4D_WGRAD_HEAD_DMA", "1") not in ("", "0") and L.ke + L.kin <= 256:
+        return "k_mlp_wgrad_dma<1,%d>" % (2 if L.ke + L.kin <= 128 else 4)  # the <= 32-row heads on the DMA ring (csrc/mlp.hip; LAB4D_WGRAD_HEAD_DMA=0: the pre-DMA kernel)
     if prec == PREC_BF16 and L.mout_pad in (64, 128, 256):
         K = L.ke + L.kin
         nbw = 1 if K <= 64 else (2 if K <= 128 else (3 if K <= 192 else (4 if K <= 256 else (5 if (L.mout_pad == 256 and K <= 320) else 3))))
