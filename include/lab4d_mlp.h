@@ -43,7 +43,8 @@
 #define LAB4D_NET_SKIN18 8    /* the delta-skin net of the 18-joint skel-human skeleton: raw 54 bone coords -> 64 -> 64 -> 18 */
 #define LAB4D_NET_HASH_GEO 9  /* hash-grid field (BASELINE config 5; no reference counterpart): raw 32 hash features -> 64 -> 16 (sdf + 15 geometry features) */
 #define LAB4D_NET_HASH_COLOR 10 /* hash-grid field: raw [16 geometry features | 3 view direction] -> 64 -> 64 -> 3                                       */
-#define LAB4D_NET_COUNT 11
+#define LAB4D_NET_DENSE6 11   /* fg_motion "dense" (nnutils/warping.py:37-38,94-141): a bare DenseWarp with its class defaults, posenc6 -> CondMLP(D=6, W=256, skip at 4) -> 3 */
+#define LAB4D_NET_COUNT 12
 
 #define LAB4D_PREC_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32, parity path                       */
 #define LAB4D_PREC_BF16 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate: throughput path            */

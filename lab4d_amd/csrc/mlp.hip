@@ -587,6 +587,7 @@ int with_net(int net, F&& f) {
     case LAB4D_NET_SKIN: return f(NetSkin{});
     case LAB4D_NET_SKIN18: return f(NetSkin18{});
     case LAB4D_NET_DENSE: return f(NetDense{});
+    case LAB4D_NET_DENSE6: return f(NetDense6{});
     case LAB4D_NET_BG_BASE: return f(NetBgBase{});
     case LAB4D_NET_BG_COLOR: return f(NetBgColor{});
     case LAB4D_NET_HASH_GEO: return f(NetHashGeo{});

@@ -55,6 +55,14 @@ struct NetDense {
   static constexpr LS L[NL] = {{64, 0, 256, 1, 1, 0, 0}, {0, 256, 256, 1, 0, 0, 0}, {0, 256, 3, 0, 0, 0, 0}};
 };
 
+// warping.py:37-38,94-141 : fg_motion "dense" -- a bare DenseWarp with the class defaults D=6, W=256 (BaseMLP skips=[4], base.py:30-59):
+// PosEmbedding(3,6)=39 (+128 time embedding +32 instance code as per-frame bias) -> 256 x 4 -> [input | 256] -> 256 -> 256 -> 3
+struct NetDense6 {
+  static constexpr int ID = LAB4D_NET_DENSE6, NL = 7, EMB = 0, NFREQ = 6, CIN = 3, SLOTS = 39, KE = 64, COUT = 3, AUX3 = 0;
+  static constexpr LS L[NL] = {{64, 0, 256, 1, 1, 0, 0},  {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 0, 0}, {0, 256, 256, 1, 0, 0, 0},
+                               {64, 256, 256, 1, 1, 0, 0}, {0, 256, 256, 1, 0, 0, 0}, {0, 256, 3, 0, 0, 0, 0}};
+};
+
 // multifields.py:86-93 + nerf.py:60-140 : the background field NeRF(num_freq_xyz=6, num_freq_dir=0, appr_channels=0, D=5, W=128):
 // PosEmbedding(3,6) -> CondMLP(D=5,W=128,skips=[4],final_act) -> sdf Linear(128,1)
 struct NetBgBase {

@@ -20,7 +20,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib, mlp
 from . import quat_utils as Q
 from . import render_utils as RU
-from .warping import composed_warp, skinning_warp, skinning_warp_forward_multi
+from .warping import composed_warp, dense_warp, skinning_warp, skinning_warp_forward_multi
 
 vp, ci, cf = _lib.vp, _lib.ci, _lib.cf
 _lib.register("lab4d_gauss_density_forward", [vp, vp, ci, vp, ci, vp, vp, vp])
@@ -316,19 +316,21 @@ def frame_terms(P, fr):
     ft = {}
     M = fr["field2cam"][0].shape[0]
     ft["cam2field.q"], ft["cam2field.t"] = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
-    nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam", "t_articulation"]})
+    nxt = flip_pair({k: fr.get(k) for k in ["Kinv", "field2cam", "t_articulation"]})
     ft["Kmat"], ft["Kmat_next"] = Q.kmatinv(fr["Kinv"]), Q.kmatinv(nxt["Kinv"])
     ft["field2cam_next.q"], ft["field2cam_next.t"] = nxt["field2cam"][0].contiguous(), nxt["field2cam"][1].contiguous()
     ft["scale"] = P["logscale"].exp()
-    _, centre = Q.dual_quaternion_to_quaternion_translation((fr["rest_articulation"][0][:1], fr["rest_articulation"][1][:1]))
-    ft["gauss_centre"], ft["gauss_ibeta"] = centre, P["warp.logibeta"].exp()
+    motion = fr.get("motion", "skinning")
+    if motion not in ("rigid", "dense"):  # gaussian-bone density: SkinningWarp fields only (deformable.py:344)
+        _, centre = Q.dual_quaternion_to_quaternion_translation((fr["rest_articulation"][0][:1], fr["rest_articulation"][1][:1]))
+        ft["gauss_centre"], ft["gauss_ibeta"] = centre, P["warp.logibeta"].exp()
     W = lambda net, l: P[mlp.bindings(net)[l].wname]
     ft["pf.base0"] = mlp.pf_bias_of(mlp.NET_FG_BASE, 0, W(mlp.NET_FG_BASE, 0), fr["code_base"])
     ft["pf.base4"] = mlp.pf_bias_of(mlp.NET_FG_BASE, 4, W(mlp.NET_FG_BASE, 4), fr["code_base"])
     ft["pf.color0"] = mlp.pf_bias_of(mlp.NET_FG_COLOR, 0, W(mlp.NET_FG_COLOR, 0), fr["code_color"])
     ft["pf.color3"] = mlp.pf_bias_of(mlp.NET_FG_COLOR, 3, W(mlp.NET_FG_COLOR, 3), fr["appr_code"])
     ft["pf.vis0"] = mlp.pf_bias_of(mlp.NET_VIS, 0, W(mlp.NET_VIS, 0), fr["code_vis"])
-    if fr.get("dense") is None:
+    if fr.get("dense") is None and motion == "skinning":
         t_art, rest = fr["t_articulation"], fr["rest_articulation"]
         skin = mlp.skin_net_for(t_art[0].shape[1])
         ft["gauss"] = get_gauss(P)
@@ -413,8 +415,14 @@ def _warp_fn(P, fr, prec):
     post-warp's inputs.  partner=True: the warp into the pair partner's frame (compute_flow, nerf.py:966-973) -- the
     post-warp then sees the partner's time embedding."""
     dense = fr.get("dense")
+    motion = fr.get("motion", "skinning")
 
     def warp(x, t_art, rest_art, t_embed, backward, partner=False):
+        if motion == "rigid":  # IdentityWarp (warping.py:59-91)
+            return x, {}
+        if motion == "dense":  # a bare DenseWarp(D=6) (warping.py:94-170): parameters under "warp.", its own time embedding
+            te = flip_pair(fr["t_embed_dense"]) if partner else fr["t_embed_dense"]
+            return dense_warp(P, x, te, fr["code_dense_bw" if backward else "code_dense_fw"], backward, prec, prefix="warp.", net=mlp.NET_DENSE6), {}
         if dense is None:
             return skinning_warp(P, x, t_art, rest_art, t_embed, fr["code_skin"], backward, prec)
         d = dict(dense, t_embed=flip_pair(dense["t_embed"])) if partner else dense
@@ -424,27 +432,30 @@ def _warp_fn(P, fr, prec):
 
 
 def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None, prec=mlp.PREC_F32):
-    """Training-mode Deformable.query_field for a SkinningWarp foreground (same contract as
-    oracle.lab4d_oracle.query_field_train).  With fr["dense"] = {"t_embed", "code_fw", "code_bw"} every warp is the
-    ComposedWarp of fg_motion "comp_skel-*_dense" (skinning composed with the dense post-warp, warping.py:445-483)."""
+    """Training-mode Deformable.query_field (same contract as oracle.lab4d_oracle.query_field_train) for every fg_motion create_warp builds
+    on kernels (warping.py:35-48): SkinningWarp ("bob", "skel-*": the default here); with fr["dense"] = {"t_embed", "code_fw", "code_bw"} the
+    ComposedWarp of "comp_skel-*_dense" (skinning composed with the dense post-warp, warping.py:445-483); fr["motion"] = "rigid": IdentityWarp
+    (the reference's default fg_motion); fr["motion"] = "dense": a bare DenseWarp (fr["t_embed_dense"], fr["code_dense_fw" / "_bw"])."""
     warp = _warp_fn(P, fr, prec)
     ft = fr.get("frame_terms")  # the step's prologue (FramePrologue.refresh), or evaluated here: same arithmetic either way
     if ft is None:
         ft = frame_terms(P, fr)
-    skinning = fr.get("dense") is None
+    motion = fr.get("motion", "skinning")  # "rigid" / "dense": fg_motion rigid (IdentityWarp, the reference's default) / dense (bare DenseWarp)
+    skinning = fr.get("dense") is None and motion == "skinning"
     cam2field = (ft["cam2field.q"], ft["cam2field.t"])
     xyz_cam, dir_cam, deltas, depth, xyz_t, _ = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=n_depth)
+    t_art, rest_art = fr.get("t_articulation"), fr.get("rest_articulation")  # absent for fg_motion "rigid" / "dense"
     if skinning:
-        xyz, bw_aux = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, prec,
+        xyz, bw_aux = skinning_warp(P, xyz_t, t_art, rest_art, fr["t_embed"], fr["code_skin"], True, prec,
                                     pre={"se3": (ft["se3_bw.r"], ft["se3_bw.d"]), "gauss": ft["gauss"], "pf": ft["pf.skin_bw"]})
     else:
-        xyz, bw_aux = warp(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
+        xyz, bw_aux = warp(xyz_t, t_art, rest_art, fr.get("t_embed"), True)
     fd = {}
     vis = vis_field(P, xyz, fr, prec, ft)
     rgb, density = nerf_forward(P, xyz, fr, prec, alpha=alpha, ft=ft)
     fd["rgb"], fd["density"], fd["density_fg"], fd["vis"] = rgb, density, density, vis
     # flow: canonical points into the pair partner's camera (nerf.py:948-997)
-    nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam", "t_articulation", "rest_articulation"]})
+    nxt = flip_pair({k: fr.get(k) for k in ["Kinv", "field2cam", "t_articulation", "rest_articulation"]})
     # pair partners are frames of one video, so the rest articulation (a per-instance quantity from get_vals_and_mean) equals its
     # flip_pair; a caller that supplies its own states it (patch._frames checks it), anything else takes the general path
     shared = skinning and fr.get("rest_shared_in_pair", True)
@@ -453,38 +464,42 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
         # both forward warps of the canonical samples (into the partner's frame here, into the own frame for the cycle term
         # below) see the same skinning field: the rest articulation is a per-instance quantity and pair partners are frames
         # of one video (rest_articulation == its flip_pair), so it is evaluated once (warping.skinning_warp_forward_multi)
-        (xyz_next, _), (xyz_cyc, cyc_aux) = skinning_warp_forward_multi(P, xyz, [nxt["t_articulation"], fr["t_articulation"]], fr["rest_articulation"],
+        (xyz_next, _), (xyz_cyc, cyc_aux) = skinning_warp_forward_multi(P, xyz, [nxt["t_articulation"], t_art], rest_art,
                                                                         fr["t_embed_mean"], fr["code_skin"], prec,
                                                                         pre=dict(fw_pre, se3s=[(ft["se3_next.r"], ft["se3_next.d"]), (ft["se3_own.r"], ft["se3_own.d"])]))
     else:
-        xyz_next, _ = warp(xyz, nxt["t_articulation"], nxt["rest_articulation"], fr["t_embed_mean"], False, partner=True)
+        xyz_next, _ = warp(xyz, nxt["t_articulation"], nxt["rest_articulation"], fr.get("t_embed_mean"), False, partner=True)
     # cycle consistency (deformable.py:173-198)
     if not shared:
-        xyz_cyc, cyc_aux = warp(xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
+        xyz_cyc, cyc_aux = warp(xyz, t_art, rest_art, fr.get("t_embed_mean"), False)
     # projection into the partner's camera, flow, validity and the cycle distance: one kernel each way (csrc/flow.hip)
     fd["flow"], fd["cyc_dist"] = FlowCyc.apply(xyz_next, ft["field2cam_next.q"], ft["field2cam_next.t"], ft["Kmat_next"], hxy, xyz_cyc, xyz_t, flow_thresh)
     for k in ["skin_entropy", "delta_skin"]:
-        fd[k] = (cyc_aux[k] + bw_aux[k]) / 2
+        # NeRF.cycle_loss's zeros (nerf.py:905-927) unless the warp reports the term (nerf.py:658-664)
+        fd[k] = (cyc_aux[k] + bw_aux[k]) / 2 if k in cyc_aux else torch.zeros_like(fd["cyc_dist"])
     fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha, prec, pf_tables=(ft["pf.base0"], ft["pf.base4"]))
     fd["xyz"] = xyz
     fd["xyz_cam"] = xyz_cam
     fd["depth"] = depth / ft["scale"]
     fd["feature"] = compute_feat(P, xyz, prec)
     aux = {}
+    has_gauss = motion not in ("rigid", "dense")
     if fr.get("feature") is None:  # FeatureNeRF.query_field (feature.py:104-107): the matching terms need the pixel features of the batch
-        fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"], ft)
+        if has_gauss:
+            fd["gauss_density"] = gauss_density(P, xyz, rest_art, ft)
         return fd, deltas, aux
     xyz_matches = global_match(P, fr["feature"], fd["feature"], xyz, rng["match_perm"])
     if skinning:
-        xm_next, _ = skinning_warp(P, xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], fr["code_skin"], False,
+        xm_next, _ = skinning_warp(P, xyz_matches[:, :, None], t_art, rest_art, fr["t_embed_mean"], fr["code_skin"], False,
                                    prec, pre=dict(fw_pre, se3=(ft["se3_own.r"], ft["se3_own.d"])))
     else:
-        xm_next, _ = warp(xyz_matches[:, :, None], fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
+        xm_next, _ = warp(xyz_matches[:, :, None], t_art, rest_art, fr.get("t_embed_mean"), False)
     xyz_reproj = rigid_apply(fr["field2cam"][0], fr["field2cam"][1], xm_next)[:, :, 0]
     aux["xyz_matches"] = xyz_matches
     aux["xyz_reproj"] = xyz_reproj
     aux["xy_reproj"] = pinhole_projection(ft["Kmat"], xyz_reproj)[..., :2]
-    fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"], ft)
+    if has_gauss:
+        fd["gauss_density"] = gauss_density(P, xyz, rest_art, ft)
     return fd, deltas, aux
 
 
@@ -615,12 +630,14 @@ def losses_fg(results, batch, train_res, weights):
     for k in LOSS_TERMS:
         w = 1.0 if weights is None or k + "_wt" not in weights else float(weights[k + "_wt"])
         wt.append(w / train_res if k in ("flow", "feat_reproj") else w)
-    rendered = [r["mask"], a["feature"], a["xy_reproj"], r["rgb"], r["depth"], r["flow"], a["vis"], a["gauss_mask"], r["eikonal"], a["cyc_dist"],
+    rendered = [r["mask"], a.get("feature"), a.get("xy_reproj"), r["rgb"], r["depth"], r["flow"], a["vis"], a.get("gauss_mask"), r["eikonal"], a["cyc_dist"],
                 a["delta_skin"], a["skin_entropy"]]
-    targets = [batch["mask"], batch["feature"], batch["hxy"], batch["rgb"], batch["depth"], batch["flow"], batch["flow_uct"], batch["vis2d"],
+    targets = [batch["mask"], batch.get("feature"), batch["hxy"], batch["rgb"], batch["depth"], batch["flow"], batch["flow_uct"], batch["vis2d"],
                batch["is_detected"], bal]
     vec = RayLosses.apply(r["mask"].shape[1], wt, *rendered, *targets, None, None)
-    out = LossDict((k, vec[i]) for i, k in enumerate(LOSS_TERMS))
+    # a term whose rendered input does not exist is not in the reference's loss_dict either (reg_gauss_mask without a SkinningWarp,
+    # model.py:497-501; the matching terms without pixel features); the kernel reports it as 0 in `vec` / `total`
+    out = LossDict((k, vec[i]) for i, k in enumerate(LOSS_TERMS) if rendered[i] is not None)
     out.total, out.vec = vec[12], vec
     return out
 
@@ -706,7 +723,7 @@ def importance_sampling(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
     nc = n_depth // 2
     cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
     xyz_cam, _, deltas, depth, xyz_t, _ = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=nc)
-    xyz, _ = _warp_fn(P, fr, prec)(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
+    xyz, _ = _warp_fn(P, fr, prec)(xyz_t, fr.get("t_articulation"), fr.get("rest_articulation"), fr.get("t_embed"), True)
     density = nerf_forward(P, xyz, fr, prec, with_color=False, alpha=alpha)
     weights, _ = RU.compute_weights(density, deltas)
     depth_mid = (0.5 * (depth[:, :, :-1] + depth[:, :, 1:])).reshape(-1, nc - 1)
@@ -744,7 +761,7 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
         xc = xyz_cam.detach().requires_grad_(True)
         qi, ti = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
         xyz_t = rigid_apply(qi, ti, xc)
-        xyz, _ = _warp_fn(P, fr, prec)(xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], True)
+        xyz, _ = _warp_fn(P, fr, prec)(xyz_t, fr.get("t_articulation"), fr.get("rest_articulation"), fr.get("t_embed"), True)
         sdf = nerf_forward(P, xyz, fr, prec, with_color=False, get_density=False, alpha=alpha)
         (g,) = torch.autograd.grad(sdf, xc, torch.ones_like(sdf))
     with torch.no_grad():
@@ -752,9 +769,13 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
         shape = xyz.shape[:-1]
         S, spf = xyz.numel() // 3, _spf(xyz)
         vis = vis_field(P, xyz, fr, prec)
-        # get_valid_idx (nerf.py:495-528): inside the field's aabb (+10 %) and, in time-t space, inside the box of frame 0's bones (x2)
-        _, tb = Q.dual_quaternion_to_quaternion_translation(fr["t_articulation"])
-        t_aabb = extend_aabb(torch.stack([tb[0].min(0)[0], tb[0].max(0)[0]], 0), factor=1.0)
+        # get_valid_idx (nerf.py:495-528): inside the field's aabb (+10 %) and -- when the samples carry articulations, i.e. for SkinningWarp
+        # fields (deformable.py:254-289) -- in time-t space, inside the box of frame 0's bones (x2)
+        has_bones = fr.get("motion", "skinning") not in ("rigid", "dense")
+        t_aabb = None
+        if has_bones:
+            _, tb = Q.dual_quaternion_to_quaternion_translation(fr["t_articulation"])
+            t_aabb = extend_aabb(torch.stack([tb[0].min(0)[0], tb[0].max(0)[0]], 0), factor=1.0)
         mask = RU.valid_mask(xyz, xyz_t, extend_aabb(P["aabb"]), t_aabb)
         # query_nerf (nerf.py:782-819): the field on the valid samples only, scattered into zeros
         idx, count = RU.compact(mask)
@@ -768,7 +789,8 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
         fd["xyz"] = xyz
         fd["xyz_cam"] = xyz_cam
         fd["depth"] = depth / P["logscale"].exp()
-        fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
+        if has_bones:
+            fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
     return fd, deltas, {"valid": mask.view(shape).bool(), "inds": inds, "valid_count": count}
 
 

@@ -22,7 +22,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 MAXL = 12
-NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE, NET_BG_BASE, NET_BG_COLOR, NET_SKIN18, NET_HASH_GEO, NET_HASH_COLOR = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE, NET_BG_BASE, NET_BG_COLOR, NET_SKIN18, NET_HASH_GEO, NET_HASH_COLOR, NET_DENSE6 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 PREC_F32, PREC_BF16 = 0, 1
 vp, ci = ctypes.c_void_p, ctypes.c_int
 
@@ -56,14 +56,15 @@ _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp
 _lib.register("lab4d_mlp_wgrad_mapped", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
 
-NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color", 8: "skin18", 9: "hash_geo", 10: "hash_color"}
+NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color", 8: "skin18", 9: "hash_geo", 10: "hash_color", 11: "dense6"}
 # algorithmic MACs per sample (real layer shapes incl. conditioning columns)
 NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736, 5: 39 * 256 + 256 * 256 + 256 * 3,
-            6: 100096 + 128, 7: 43392 + 8576, 8: (54 + 160) * 64 + 64 * 64 + 64 * 18, 9: 32 * 64 + 64 * 16, 10: 19 * 64 + 64 * 64 + 64 * 3}
+            6: 100096 + 128, 7: 43392 + 8576, 8: (54 + 160) * 64 + 64 * 64 + 64 * 18, 9: 32 * 64 + 64 * 16, 10: 19 * 64 + 64 * 64 + 64 * 3,
+            11: 199 * 256 + 3 * 256 * 256 + 455 * 256 + 256 * 256 + 256 * 3}
 
 
 
-KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor", 8: "Skin18", 9: "HashGeo", 10: "HashColor"}  # template argument names in csrc/mlp_nets.hpp
+KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor", 8: "Skin18", 9: "HashGeo", 10: "HashColor", 11: "Dense6"}  # template argument names in csrc/mlp_nets.hpp
 
 
 def wgrad_kernel_name(L, prec):
@@ -169,6 +170,15 @@ def bindings(net, prefix=""):
         return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(39, 160)),
                 LayerBinding(q + "linear_2.0.weight", q + "linear_2.0.bias", prev0=0),
                 LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0)]
+    if net == NET_DENSE6:  # fg_motion "dense" (warping.py:94-141, class defaults D=6, skips=[4]): skip layer = [39 posenc | 128 time | 32 code | 256 previous]
+        q = p
+        b = [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(39, 160))]
+        for i in (2, 3, 4):
+            b.append(LayerBinding(q + f"linear_{i}.0.weight", q + f"linear_{i}.0.bias", prev0=0))
+        b.append(LayerBinding(q + "linear_5.0.weight", q + "linear_5.0.bias", emb0=0, cond=(39, 160), prev0=199))
+        b.append(LayerBinding(q + "linear_6.0.weight", q + "linear_6.0.bias", prev0=0))
+        b.append(LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0))
+        return b
     if net == NET_BG_BASE:  # multifields.py:86-93, nerf.py:95-109: [39 posenc | 32 instance code], D=5, skip at 4
         b = [LayerBinding(p + "basefield.linear_1.0.weight", p + "basefield.linear_1.0.bias", emb0=0, cond=(39, 32))]
         for i in (2, 3, 4):

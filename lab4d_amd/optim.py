@@ -77,27 +77,39 @@ class FlatAdamW:
                                                    _lib.ptr(self.coef), _lib.stream()), "grad_norm_clip")
         return self.norm
 
+    def check_grad(self, max_norm, skip_above=None):
+        """Trainer.check_grad (engine/trainer.py:581-604) on the device: the global gradient norm, clip_grad_norm_'s coefficient and the
+        discard decision (pre-clip norm > skip_above, default max_norm like the reference, or not finite) -- `norm`, `coef`, `skipped` stay on
+        the device, the NEXT step() applies them; no host synchronisation.  Returns the norm tensor."""
+        _lib.require_device(self.flat_grad)
+        thresh = float(max_norm if skip_above is None else skip_above)
+        _lib.check(_lib.lib().lab4d_check_grad(_lib.ptr(self.flat_grad), self.n, float(max_norm), thresh, _lib.ptr(self.work), _lib.ptr(self.norm),
+                                               _lib.ptr(self.coef), _lib.ptr(self.skipped), _lib.ptr(self.dev_step), _lib.stream()), "check_grad")
+        self._checked = True
+        self._guarded_used = True
+        return self.norm
+
     def step(self, max_norm=None, skip_above=None):
         """One AdamW step; with max_norm the gradients are scaled by min(1, max_norm / (norm + 1e-6)) inside the update.
 
         skip_above (with max_norm) = Trainer.check_grad's discard rule (engine/trainer.py:581-604): when the pre-clip norm exceeds it,
         or is not finite, the step is a no-op on the device -- parameters, moments and the step count of the bias corrections stay
         untouched -- and `self.skipped` (device int32) is 1; no host synchronisation.  The reference then reloads the weights cached two
-        rounds ago when it has any (trainer.py:598-604): a caller does that from `self.skipped` at a point where it synchronises anyway."""
+        rounds ago when it has any (trainer.py:598-604): a caller does that from `self.skipped` at a point where it synchronises anyway.
+        After a separate check_grad() call (the reference's order: check_grad(), then optimizer.step()) step() takes no arguments."""
         _lib.require_device(self.flat, self.flat_grad)
         self.steps += 1
         if skip_above is not None:
             if max_norm is None:
                 raise RuntimeError("FlatAdamW.step: skip_above needs max_norm (check_grad clips and checks in one pass)")
-            _lib.check(_lib.lib().lab4d_check_grad(_lib.ptr(self.flat_grad), self.n, float(max_norm), float(skip_above), _lib.ptr(self.work),
-                                                   _lib.ptr(self.norm), _lib.ptr(self.coef), _lib.ptr(self.skipped), _lib.ptr(self.dev_step),
-                                                   _lib.stream()), "check_grad")
+            self.check_grad(max_norm, skip_above)
+        if getattr(self, "_checked", False):
+            self._checked = False
             _lib.check(_lib.lib().lab4d_adamw_step_guarded(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.m), _lib.ptr(self.v), self.n,
                                                            _lib.ptr(self.seg_end), _lib.ptr(self.seg_lr), len(self.params), self.betas[0],
                                                            self.betas[1], self.eps, self.weight_decay, _lib.ptr(self.coef), _lib.ptr(self.skipped),
                                                            _lib.ptr(self.dev_step), _lib.stream()), "adamw_step_guarded")
             torch.autograd.graph.increment_version(self.params)
-            self._guarded_used = True
             return
         if max_norm is not None:
             self.grad_norm_clip(max_norm)
@@ -114,3 +126,99 @@ class FlatAdamW:
         if getattr(self, "_guarded_used", False):
             raise RuntimeError("FlatAdamW: step() without skip_above after guarded steps (the step count lives on the device)")
         return self.steps
+
+
+class TorchFlatAdamW(torch.optim.Optimizer):
+    """FlatAdamW behind the torch.optim.Optimizer interface the reference's trainer programs against (engine/trainer.py:185-210,
+    255-270, 343-350, 581-604): `param_groups` with one group per parameter (OneCycleLR writes group["lr"] every step and stores
+    "initial_lr" / "max_lr" / "min_lr" there), step() / zero_grad(), state_dict() / load_state_dict() (the two-rounds-back cache of
+    check_grad's rollback and the checkpoints).  The update itself is FlatAdamW's three launches; the groups' learning rates are uploaded
+    when they changed.  Build it directly from a list of {"params": [p]} groups like torch.optim.AdamW, or adopt an existing AdamW (and
+    whatever scheduler already points at it) with TorchFlatAdamW.adopt(opt)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._build()
+
+    @classmethod
+    def adopt(cls, opt):
+        """Turn a freshly constructed torch.optim.AdamW (no step taken yet) into a TorchFlatAdamW IN PLACE: the object identity, its
+        param_groups list and the group dicts survive, so a learning-rate scheduler created on it keeps working."""
+        if not isinstance(opt, torch.optim.AdamW):
+            raise RuntimeError("TorchFlatAdamW.adopt: expected torch.optim.AdamW, got %s" % type(opt).__name__)
+        if any(len(st) for st in opt.state.values()):
+            raise RuntimeError("TorchFlatAdamW.adopt: the optimizer has already stepped")
+        opt.__class__ = cls
+        opt._build()
+        return opt
+
+    def _build(self):
+        ps, seen = [], set()
+        for g in self.param_groups:
+            if g.get("amsgrad") or g.get("maximize"):
+                raise NotImplementedError("TorchFlatAdamW: amsgrad / maximize are not implemented")
+            for p in g["params"]:
+                if id(p) in seen:
+                    raise RuntimeError("TorchFlatAdamW: a parameter appears in two groups")
+                seen.add(id(p))
+                ps.append(p)
+        g0 = self.param_groups[0]
+        for g in self.param_groups:
+            if (tuple(g["betas"]), g["eps"], g["weight_decay"]) != (tuple(g0["betas"]), g0["eps"], g0["weight_decay"]):
+                raise NotImplementedError("TorchFlatAdamW: betas / eps / weight_decay must be the same for every group (the reference's are)")
+        self.flat = FlatAdamW(ps, self._lrs(), betas=tuple(g0["betas"]), eps=g0["eps"], weight_decay=g0["weight_decay"])
+        self._lr_sent = self._lrs()
+        for p, o in zip(self.flat.params, self.flat.offsets):  # torch's per-parameter state, as views of the flat moment buffers
+            self.state[p] = {"step": torch.zeros((), dtype=torch.float32), "exp_avg": self.flat.m[o:o + p.numel()].view_as(p),
+                             "exp_avg_sq": self.flat.v[o:o + p.numel()].view_as(p)}
+
+    def _lrs(self):
+        return [float(g["lr"]) for g in self.param_groups for _ in g["params"]]
+
+    @property
+    def skipped(self):
+        return self.flat.skipped
+
+    def check_grad(self, thresh):
+        return self.flat.check_grad(thresh)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None if closure is None else closure()
+        lrs = self._lrs()
+        if lrs != self._lr_sent:
+            self.flat.set_lr(lrs)
+            self._lr_sent = lrs
+        self.flat.step()
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        """Zeroes the flat gradient buffer; the parameters keep their .grad VIEWS of it whatever set_to_none says (the weight-gradient
+        kernels and the data-parallel all-reduce work on that buffer)."""
+        self.flat.zero_grad()
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat.flat_grad[o:o + p.numel()].view_as(p)
+
+    def state_dict(self):
+        step = float(int(self.flat.dev_step)) if getattr(self.flat, "_guarded_used", False) else float(self.flat.steps)
+        for st in self.state.values():
+            st["step"] = torch.tensor(step)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        views = {p: (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items()}
+        super().load_state_dict(state_dict)
+        step = 0
+        with torch.no_grad():
+            for p, (m, v) in views.items():
+                st = self.state.get(p)
+                if st:  # loaded moments are copies: put them back into the flat buffers and re-point the state at the views
+                    m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                    step = int(st["step"])
+                else:
+                    m.zero_(); v.zero_()
+                self.state[p] = {"step": torch.tensor(float(step)), "exp_avg": m, "exp_avg_sq": v}
+        self.flat.steps = step
+        self.flat.dev_step.fill_(step)
+        self._lr_sent = None

@@ -19,6 +19,8 @@
     AppearanceEmbedding.get_vals              nnutils/appearance.py:8-56, time.py:107      -> appearance_get_vals
     dvr_model.render / evaluate / render_samples / render_samples_chunk
                                               engine/model.py:162,217,259,328              -> dvr_*
+    dvr_model.compute_loss                    engine/model.py:375-399 (+ 401-611)          -> dvr_compute_loss (fused per-ray loss kernels)
+    Trainer.optimizer_init / check_grad       engine/trainer.py:150-210,581-604            -> trainer_* (TorchFlatAdamW, device-side discard rule)
 
 Every function below takes the reference module as `self` and reads only attributes the reference defines (parameter
 names = the reference's state_dict names: a checkpoint loads unchanged); per-frame quantities (instance / time /
@@ -42,11 +44,33 @@ from . import mlp, multifields
 from . import render_utils as RU
 from . import warping as W
 
+# Process-wide DEFAULTS, set by patch(precision=..., n_depth=...); a model overrides them for itself with configure(model, ...), which
+# stores the setting on the module objects -- two models with different settings can live in one process.
 # precision of the MLP chains the adapters launch (mlp.PREC_BF16 = BASELINE configs[1]; mlp.PREC_F32 = 1e-4 parity path)
 PRECISION = mlp.PREC_BF16
 # samples per ray: the reference hard-codes the defaults of sample_cam_rays (render_utils.py:8) and importance_sampling
-# (nerf.py:686-696), n_depth=64; BASELINE configs[1] / [4] ask for 128 / 256 -- set through patch(n_depth=...)
+# (nerf.py:686-696), n_depth=64; BASELINE configs[1] / [4] ask for 128 / 256
 N_DEPTH = 64
+_PREC_NAMES = {"bf16": mlp.PREC_BF16, "f32": mlp.PREC_F32}
+
+
+def configure(module, precision=None, n_depth=None):
+    """Per-model settings: every sub-module of `module` (a dvr_model, a MultiFields, one field, one warp ...) runs its kernels at this
+    precision ("bf16" / "f32") / with this many samples per ray, whatever the process-wide defaults of patch() are."""
+    for m in module.modules():
+        if precision is not None:
+            m._lab4d_amd_precision = _PREC_NAMES[precision] if isinstance(precision, str) else int(precision)
+        if n_depth is not None:
+            m._lab4d_amd_n_depth = int(n_depth)
+    return module
+
+
+def _prec(self):
+    return getattr(self, "_lab4d_amd_precision", PRECISION)
+
+
+def _ndepth(self):
+    return getattr(self, "_lab4d_amd_n_depth", N_DEPTH)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -101,15 +125,36 @@ def field_kind(field):
 
 
 def warp_kind(field):
+    """The fg_motion create_warp built (nnutils/warping.py:35-48): "rigid" (IdentityWarp, the reference's default, or a field without a
+    warp), "dense" (a bare DenseWarp), "skinning" (bob / skel-*), "composed" (comp_skel-*_dense)."""
     warp = getattr(field, "warp", None)
     if warp is None:
         return "rigid"
     name = type(warp).__name__
+    if name == "IdentityWarp":
+        return "rigid"
+    if name == "DenseWarp":
+        return "dense"
     if name == "ComposedWarp":
         return "composed"
     if name == "SkinningWarp":
         return "skinning"
-    raise NotImplementedError("lab4d_amd: no kernel path for warp %s" % name)
+    raise NotImplementedError("lab4d_amd: no kernel path for warp %s (NVPWarp is outside the hot path, SURVEY.md section 2)" % name)
+
+
+def dense_net_of(cond_mlp):
+    """The chain-kernel instantiation of a DenseWarp map: D=2 (ComposedWarp's post-warp, warping.py:432-434) or the class default D=6 with the
+    skip connection at layer 4 (fg_motion "dense", warping.py:94-141); W = 256 either way."""
+    # read off the module's own layers (base.py:50-64: linear_1 .. linear_D, each a Sequential(Linear, ReLU), then linear_final)
+    hidden = [getattr(cond_mlp, "linear_%d" % (i + 1)) for i in range(64) if hasattr(cond_mlp, "linear_%d" % (i + 1))]
+    lin = [next(iter(h.parameters())) for h in hidden]  # the Linear's weight (out, in)
+    D, Wd = len(lin), (lin[0].shape[0] if lin else 0)
+    skips = [i for i in range(1, D) if lin[i].shape[1] != Wd]
+    if Wd == 256 and D == 2:
+        return mlp.NET_DENSE
+    if Wd == 256 and D == 6 and skips == [4]:
+        return mlp.NET_DENSE6
+    raise NotImplementedError("lab4d_amd: no kernel instantiation for DenseWarp(D=%d, W=%d, skips=%s)" % (D, Wd, skips))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -127,28 +172,28 @@ def nerf_forward(self, xyz, dir=None, frame_id=None, inst_id=None, get_density=T
     if field_kind(self) == "fg":
         fr = {"code_base": inst_code(self.basefield, inst_id, M, dev)}
         if dir is None:
-            return DF.nerf_forward(P, xyz, fr, PRECISION, with_color=False, get_density=get_density, alpha=alpha)
+            return DF.nerf_forward(P, xyz, fr, _prec(self), with_color=False, get_density=get_density, alpha=alpha)
         fr["code_color"] = inst_code(self.colorfield, inst_id, M, dev)
         fr["appr_code"] = self.appr_embedding.get_vals(frame_id)
-        return DF.nerf_forward(P, xyz, fr, PRECISION, with_color=True, get_density=get_density, alpha=alpha)
+        return DF.nerf_forward(P, xyz, fr, _prec(self), with_color=True, get_density=get_density, alpha=alpha)
     codes = {"basefield": inst_code(self.basefield, inst_id, M, dev)}
     if dir is not None:
         codes["colorfield"] = inst_code(self.colorfield, inst_id, M, dev)
-    return DF.nerf_forward_bg(P, xyz, dir, codes, PRECISION, get_density=get_density, alpha=alpha)
+    return DF.nerf_forward_bg(P, xyz, dir, codes, _prec(self), get_density=get_density, alpha=alpha)
 
 
 def vis_forward(self, xyz, inst_id=None):
     """VisField.forward (nnutils/visibility.py:53-63)."""
     P = params_of(self, "vis_mlp.")
     fr = {"code_vis": inst_code(self.basefield, inst_id, xyz.shape[0], xyz.device)}
-    return DF.vis_field(P, xyz, fr, PRECISION)
+    return DF.vis_field(P, xyz, fr, _prec(self))
 
 
 def compute_feat(self, xyz):
     """FeatureNeRF.compute_feat (nnutils/feature.py:136-150); train-only like the reference's decorator (decorator.py:4-17)."""
     if not self.training:
         return {}
-    return {"feature": DF.compute_feat(field_params(self), xyz, PRECISION)}
+    return {"feature": DF.compute_feat(field_params(self), xyz, _prec(self))}
 
 
 def _articulations(self, frame_id, samples_dict):
@@ -181,7 +226,7 @@ def skinning_forward(self, xyz, frame_id, inst_id, backward=False, samples_dict=
     """SkinningWarp.forward (nnutils/warping.py:277-336)."""
     t_art, rest_art = _articulations(self, frame_id, samples_dict)
     te, code = _skin_inputs(self, xyz, frame_id, inst_id, backward)
-    out, aux = W.skinning_warp(_warp_params(self), xyz, t_art, rest_art, te, code, backward, PRECISION)
+    out, aux = W.skinning_warp(_warp_params(self), xyz, t_art, rest_art, te, code, backward, _prec(self))
     return (out, aux) if return_aux else out
 
 
@@ -189,8 +234,8 @@ def dense_forward(self, xyz, frame_id, inst_id, backward=False, samples_dict={},
     """DenseWarp.forward (nnutils/warping.py:143-170)."""
     which = self.backward_map if backward else self.forward_map
     P = {"d." + k: v for k, v in params_of(self).items()}
-    out = W.dense_warp(P, xyz, self.time_embedding(frame_id), inst_code(which, inst_id, xyz.shape[0], xyz.device), backward, PRECISION,
-                       prefix="d.")
+    out = W.dense_warp(P, xyz, self.time_embedding(frame_id), inst_code(which, inst_id, xyz.shape[0], xyz.device), backward, _prec(self),
+                       prefix="d.", net=dense_net_of(which))
     return (out, {}) if return_aux else out
 
 
@@ -207,7 +252,7 @@ def composed_forward(self, xyz, frame_id, inst_id, backward=False, samples_dict=
     """ComposedWarp.forward (nnutils/warping.py:445-483): skeleton skinning composed with the dense post-warp."""
     t_art, rest_art = _articulations(self, frame_id, samples_dict)
     te, code = _skin_inputs(self, xyz, frame_id, inst_id, backward)
-    out, aux = W.composed_warp(_warp_params(self), xyz, t_art, rest_art, te, code, backward, PRECISION,
+    out, aux = W.composed_warp(_warp_params(self), xyz, t_art, rest_art, te, code, backward, _prec(self),
                                dense=_dense_inputs(self, xyz, frame_id, inst_id))
     return (out, aux) if return_aux else out
 
@@ -243,7 +288,16 @@ def _frames(self, samples_dict, need_color=True):
     if self.appr_channels > 0:
         fr["appr_code"] = self.appr_embedding.get_vals(frame_id)
     kind = warp_kind(self)
-    if kind != "rigid":
+    if kind == "rigid":
+        fr["motion"] = "rigid"
+    elif kind == "dense":
+        warp = self.warp
+        dense_net_of(warp.forward_map)  # D=6, W=256 or a loud refusal
+        fr["motion"] = "dense"
+        fr["t_embed_dense"] = warp.time_embedding(frame_id)
+        fr["code_dense_fw"] = inst_code(warp.forward_map, inst_id, M, dev)
+        fr["code_dense_bw"] = inst_code(warp.backward_map, inst_id, M, dev)
+    else:
         warp = self.warp
         fr["t_articulation"], fr["rest_articulation"] = _articulations(warp, frame_id, samples_dict)
         if "rest_articulation" in samples_dict and M % 2 == 0:
@@ -283,15 +337,13 @@ def query_field(self, samples_dict, flow_thresh=None):
     if kind == "bg":
         if self.training:
             M, N = hxy.shape[:2]
-            return DF.query_field_train_bg(P, fr, hxy, draw_rng(M, N, N_DEPTH, hxy.device), flow_thresh, N_DEPTH, alpha, PRECISION)
-        fd, deltas, _ = DF.query_field_eval_bg(P, fr, hxy, N_DEPTH, alpha, PRECISION)
+            return DF.query_field_train_bg(P, fr, hxy, draw_rng(M, N, _ndepth(self), hxy.device), flow_thresh, _ndepth(self), alpha, _prec(self))
+        fd, deltas, _ = DF.query_field_eval_bg(P, fr, hxy, _ndepth(self), alpha, _prec(self))
         return fd, deltas, {}
-    if warp_kind(self) == "rigid":
-        raise NotImplementedError("lab4d_amd: the fg kernel path needs a SkinningWarp / ComposedWarp (fg_motion bob, skel-*, comp_skel-*_dense)")
     if self.training:
         M, N = hxy.shape[:2]
-        return DF.query_field_train(P, fr, hxy, draw_rng(M, N, N_DEPTH, hxy.device), flow_thresh, N_DEPTH, alpha, PRECISION)
-    fd, deltas, _ = DF.query_field_eval(P, fr, hxy, N_DEPTH, alpha, PRECISION)
+        return DF.query_field_train(P, fr, hxy, draw_rng(M, N, _ndepth(self), hxy.device), flow_thresh, _ndepth(self), alpha, _prec(self))
+    fd, deltas, _ = DF.query_field_eval(P, fr, hxy, _ndepth(self), alpha, _prec(self))
     return fd, deltas, {}
 
 
@@ -394,6 +446,73 @@ def dvr_evaluate(self, batch, is_pair=True):
 
 
 # ---------------------------------------------------------------------------------------------------
+# loss epilogue and optimizer step
+# ---------------------------------------------------------------------------------------------------
+REG_FIELD_TERMS = ("reg_visibility", "reg_soft_deform", "reg_gauss_skin", "reg_cam_prior", "reg_skel_prior")
+LOSS_ORDER = ("mask", "feature", "feat_reproj", "rgb", "depth", "flow", "vis", "reg_gauss_mask", "reg_visibility", "reg_eikonal", "reg_deform_cyc",
+              "reg_delta_skin", "reg_skin_entropy", "reg_soft_deform", "reg_gauss_skin", "reg_cam_prior", "reg_skel_prior")
+
+
+def dvr_compute_loss(self, batch, results):
+    """dvr_model.compute_loss (engine/model.py:375-399) = compute_recon_loss + mask_losses + compute_reg_loss + apply_loss_weights.
+    Every per-ray term (the eight reconstruction terms and the four rendered regularisers) comes out of ONE kernel pass each way
+    (csrc/losses.hip through deformable.losses_fg / losses_comp: masked sums, positive counts, weights); the field-level regularisers
+    (visibility decay, soft deformation, gaussian-skin consistency, camera / skeleton priors) are the reference's own small queries --
+    their field evaluations already run on the kernels through the patched module forwards -- weighted by the reference's own
+    apply_loss_weights.  Same keys, same values, same order as the reference's loss_dict."""
+    config = self.config
+    field_type = config["field_type"]
+    if field_type == "fg":
+        per_ray = DF.losses_fg(results, batch, config["train_res"], config)
+    elif field_type == "comp":
+        per_ray = DF.losses_comp(results, batch, config["train_res"], config)
+    else:
+        raise NotImplementedError("lab4d_amd: the fused loss epilogue is instantiated for field_type fg and comp (got %r)" % (field_type,))
+    reg = {}
+    self.compute_reg_loss(reg, results)  # the reference's method; the rendered terms it also lists are dropped, the kernel formed them
+    reg = {k: v for k, v in reg.items() if k in REG_FIELD_TERMS}
+    self.apply_loss_weights(reg, config)
+    merged = dict(per_ray)
+    merged.update(reg)
+    return {k: merged[k] for k in LOSS_ORDER if k in merged}
+
+
+def _original(name):
+    for n, _, _, orig in _ORIGINALS:
+        if n == name:
+            return orig
+    raise RuntimeError("lab4d_amd.patch: %s is not bound (call patch() first)" % name)
+
+
+def trainer_optimizer_init(self, is_resumed=False):
+    """Trainer.optimizer_init (engine/trainer.py:150-210): the reference's own selection of parameters and learning rates and its
+    OneCycleLR stay as they are; the torch.optim.AdamW they were built around becomes a TorchFlatAdamW IN PLACE (one flat parameter /
+    gradient / moment buffer, three launches per step, gradients accumulated by the weight-gradient kernels), so the scheduler, the
+    two-rounds-back state cache and the checkpoints keep talking to the same object."""
+    from . import mlp as _mlp
+    from .optim import TorchFlatAdamW
+    _original("lab4d.engine.trainer.Trainer.optimizer_init")(self, is_resumed)
+    TorchFlatAdamW.adopt(self.optimizer)
+    _mlp.FUSED_GRAD_ACCUM = True
+
+
+def trainer_check_grad(self, thresh=5.0):
+    """Trainer.check_grad (engine/trainer.py:581-604): clip to `thresh`; a step whose pre-clip norm exceeds it is discarded (the
+    reference zeroes the gradients, after which torch's optimizer skips every parameter) and the state cached two rounds ago is loaded when
+    there is one.  Norm, clip coefficient and the discard decision are formed on the device and applied by the following
+    optimizer.step(); the host only looks at the decision when there is a cache to roll back to -- the one place the reference
+    synchronises as well (`if grad_norm > thresh`)."""
+    opt = self.optimizer
+    grad_norm = opt.check_grad(thresh)
+    if self.model_cache[0] is not None and int(opt.skipped):
+        opt.zero_grad()
+        print("large grad: %.2f, resume from cached weights" % float(grad_norm))
+        self.model.load_state_dict(self.model_cache[0])
+        self.optimizer.load_state_dict(self.optimizer_cache[0])
+        self.scheduler.load_state_dict(self.scheduler_cache[0])
+
+
+# ---------------------------------------------------------------------------------------------------
 # per-frame articulation (SURVEY 8f row 1): the kinematic tree behind every SkinningWarp call
 # ---------------------------------------------------------------------------------------------------
 def articulation_skel_forward(self, t_embed, inst_id, return_so3=False, override_so3=None, override_log_bone_len=None,
@@ -458,6 +577,9 @@ def bindings():
         ("lab4d.engine.model", "dvr_model", "evaluate", dvr_evaluate, False),
         ("lab4d.engine.model", "dvr_model", "render_samples", dvr_render_samples, False),
         ("lab4d.engine.model", "dvr_model", "render_samples_chunk", dvr_render_samples_chunk, False),
+        ("lab4d.engine.model", "dvr_model", "compute_loss", dvr_compute_loss, False),
+        ("lab4d.engine.trainer", "Trainer", "optimizer_init", trainer_optimizer_init, False),
+        ("lab4d.engine.trainer", "Trainer", "check_grad", trainer_check_grad, False),
     ]
 
 
@@ -482,7 +604,7 @@ def patch(precision="bf16", n_depth=64):
     restores the originals.  Returns the list of "module.Class.attr" names that were rebound."""
     import importlib
     global PRECISION, N_DEPTH
-    PRECISION = {"bf16": mlp.PREC_BF16, "f32": mlp.PREC_F32}[precision]
+    PRECISION = _PREC_NAMES[precision]
     N_DEPTH = int(n_depth)
     if _ORIGINALS:
         return [n for n, *_ in _ORIGINALS]

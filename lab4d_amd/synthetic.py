@@ -114,8 +114,17 @@ def add_bg_codes(fr, P):
     return fr
 
 
-def make_weights(seed=0, num_inst=1, sdf_bias=None, num_bones=NUM_BONES):
-    """Flat dict of fp32 CPU tensors keyed by the reference's state_dict names."""
+# fg_motion "dense" (warping.py:37-38,94-141): DenseWarp with its class defaults D=6, W=256, skips=[4]; 199 = 39 + 128 + 32 inputs
+DENSE6_LINEARS = [(f"warp.{m}.{l}", o, i) for m in ("forward_map", "backward_map")
+                  for l, o, i in (("linear_1.0", 256, 199), ("linear_2.0", 256, 256), ("linear_3.0", 256, 256), ("linear_4.0", 256, 256),
+                                  ("linear_5.0", 256, 455), ("linear_6.0", 256, 256), ("linear_final", 3, 256))]
+DENSE6_EMBEDDINGS = [(f"warp.{m}.inst_embedding.mapping.weight", 32) for m in ("forward_map", "backward_map")]
+
+
+def make_weights(seed=0, num_inst=1, sdf_bias=None, num_bones=NUM_BONES, motion="skinning"):
+    """Flat dict of fp32 CPU tensors keyed by the reference's state_dict names.  motion: "skinning" (bob / skel-*), "rigid" (fg_motion
+    "rigid", the reference's default: no warp parameters) or "dense" (fg_motion "dense": the two 6-layer maps of a bare DenseWarp); the
+    non-warp parameters are the same numbers for every motion."""
     g = torch.Generator().manual_seed(seed)
     P = {}
     for name, o, i in FG_LINEARS:
@@ -137,6 +146,16 @@ def make_weights(seed=0, num_inst=1, sdf_bias=None, num_bones=NUM_BONES):
     P["aabb"] = torch.tensor([[-0.12, -0.12, -0.12], [0.12, 0.12, 0.12]])  # proxy sphere r=0.12
     if sdf_bias is not None:
         P["sdf.bias"] = torch.tensor([float(sdf_bias)])
+    if motion in ("rigid", "dense"):
+        P = {k: v for k, v in P.items() if not k.startswith("warp.")}
+    if motion == "dense":
+        gd = torch.Generator().manual_seed(seed + 611953)
+        for name, o, i in DENSE6_LINEARS:
+            bound = 1.0 / math.sqrt(i)
+            P[name + ".weight"] = (torch.rand(o, i, generator=gd) * 2 - 1) * bound
+            P[name + ".bias"] = (torch.rand(o, generator=gd) * 2 - 1) * bound
+        for name, c in DENSE6_EMBEDDINGS:
+            P[name] = torch.randn(num_inst, c, generator=gd)
     return P
 
 
@@ -198,7 +217,13 @@ def add_codes(fr, P):
     fr["code_base"] = look("basefield.inst_embedding.mapping.weight")
     fr["code_color"] = look("colorfield.inst_embedding.mapping.weight")
     fr["code_vis"] = look("vis_mlp.basefield.inst_embedding.mapping.weight")
-    fr["code_skin"] = look("warp.skinning_model.delta_field.inst_embedding.mapping.weight")
+    if "warp.skinning_model.delta_field.inst_embedding.mapping.weight" in P:
+        fr["code_skin"] = look("warp.skinning_model.delta_field.inst_embedding.mapping.weight")
+    elif "warp.forward_map.inst_embedding.mapping.weight" in P:  # fg_motion "dense"
+        fr["motion"] = "dense"
+        fr["code_dense_fw"], fr["code_dense_bw"] = look("warp.forward_map.inst_embedding.mapping.weight"), look("warp.backward_map.inst_embedding.mapping.weight")
+    else:
+        fr["motion"] = "rigid"
     if "warp.post_warp.forward_map.inst_embedding.mapping.weight" in P:
         fr["dense"] = {"t_embed": fr["t_embed_dense"], "code_fw": look("warp.post_warp.forward_map.inst_embedding.mapping.weight"),
                        "code_bw": look("warp.post_warp.backward_map.inst_embedding.mapping.weight")}

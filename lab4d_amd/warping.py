@@ -233,16 +233,18 @@ def skinning_warp_forward_multi(P, xyz, t_articulations, rest_articulation, t_em
     return outs
 
 
-def dense_warp(P, xyz, t_embed, code, backward, prec=mlp.PREC_F32, prefix="warp.post_warp."):
+def dense_warp(P, xyz, t_embed, code, backward, prec=mlp.PREC_F32, prefix="warp.post_warp.", net=mlp.NET_DENSE):
     """DenseWarp.forward (warping.py:143-170): xyz + 0.1 * CondMLP([posenc6(xyz) | time embedding | instance code]) with the
-    backward_map / forward_map weights.  t_embed: (M,128) output of the warp's own TimeEmbedding, code: (M,32)."""
+    backward_map / forward_map weights.  t_embed: (M,128) output of the warp's own TimeEmbedding, code: (M,32).
+    net: NET_DENSE = the D=2 post-warp of ComposedWarp (prefix "warp.post_warp."), NET_DENSE6 = fg_motion "dense" (prefix "warp.")."""
     shape = xyz.shape
     spf = 1
     for d in shape[1:-1]:
         spf *= d
     which = "backward_map." if backward else "forward_map."
     cond = torch.cat([t_embed, code], -1)
-    motion = mlp.run_chain(mlp.NET_DENSE, prec, P, xyz.reshape(-1, 3), spf, conds={0: cond}, prefix=prefix + which)
+    conds = {0: cond, 4: cond} if net == mlp.NET_DENSE6 else {0: cond}  # the skip layer re-reads the whole input (base.py:74-75)
+    motion = mlp.run_chain(net, prec, P, xyz.reshape(-1, 3), spf, conds=conds, prefix=prefix + which)
     return xyz + 0.1 * motion.view(shape)
 
 

@@ -485,12 +485,13 @@ def vis_field(P, xyz, code):
     return cond_mlp(P, "vis_mlp.basefield", pos_embedding(xyz, 10), code, D=2, final_act=False)
 
 
-def dense_warp(P, xyz, t_embed, code, backward, prefix="warp.post_warp"):
-    """DenseWarp.forward (warping.py:143-170): xyz + 0.1 * CondMLP(D=2)([posenc6 | time embedding | instance code])."""
+def dense_warp(P, xyz, t_embed, code, backward, prefix="warp.post_warp", D=2):
+    """DenseWarp.forward (warping.py:143-170): xyz + 0.1 * CondMLP(D)([posenc6 | time embedding | instance code]); D = 2 for ComposedWarp's
+    post-warp (warping.py:432-434), 6 (the class default, skip connection at layer 4) for fg_motion "dense"."""
     m = f"{prefix}.backward_map" if backward else f"{prefix}.forward_map"
     te = t_embed.view(t_embed.shape[:1] + (1,) * (xyz.ndim - 2) + (-1,)).expand(xyz.shape[:-1] + (-1,))
     feat = torch.cat([pos_embedding(xyz, 6), te], -1)
-    return xyz + 0.1 * cond_mlp(P, m, feat, code, D=2, final_act=False)
+    return xyz + 0.1 * cond_mlp(P, m, feat, code, D=D, final_act=False)
 
 
 def composed_warp(P, xyz, t_articulation, rest_articulation, t_embed, code, backward, dense=None):
@@ -572,10 +573,19 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None)
         dense post-warp (fg_motion "comp_skel-*_dense", warping.py:445-483); every warp below then goes through
         composed_warp.  The flow branch warps into the pair partner's frame, so its post-warp sees the partner's time
         embedding (nerf.py:966-973: frame_id_next).
+    fr["motion"] (optional): "rigid" = fg_motion "rigid", the reference's default (warping.py:35-36,59-91: IdentityWarp -- every warp is the
+        identity, the skin terms stay the zeros of NeRF.cycle_loss, nerf.py:905-927, and there is no gaussian-bone density, deformable.py:344);
+        "dense" = fg_motion "dense" (warping.py:37-38,94-170: a bare DenseWarp(D=6, W=256) with parameters under "warp.").
     Returns feat_dict, deltas, aux_dict exactly as the reference does."""
     dense = fr.get("dense")
+    motion = fr.get("motion", "skinning")
 
     def warp(x, t_art, rest_art, t_embed, backward, partner=False):
+        if motion == "rigid":
+            return x, {}
+        if motion == "dense":
+            te = flip_pair(fr["t_embed_dense"]) if partner else fr["t_embed_dense"]
+            return dense_warp(P, x, te, fr["code_dense_bw" if backward else "code_dense_fw"], backward, prefix="warp", D=6), {}
         if dense is None:
             return skinning_warp(P, x, t_art, rest_art, t_embed, fr["code_skin"], backward=backward)
         d = dict(dense, t_embed=flip_pair(dense["t_embed"])) if partner else dense
@@ -605,7 +615,8 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None)
     xyz_cyc, cyc_aux = warp(xyz, fr["t_articulation"], fr["rest_articulation"], fr["t_embed_mean"], False)
     fd["cyc_dist"] = (xyz_cyc - xyz_t).norm(2, -1, keepdim=True)
     for k in ["skin_entropy", "delta_skin"]:
-        fd[k] = (cyc_aux[k] + bw_aux[k]) / 2
+        # NeRF.cycle_loss's zeros (nerf.py:905-927) unless the warp reports the term (nerf.py:658-664)
+        fd[k] = (cyc_aux[k] + bw_aux[k]) / 2 if k in cyc_aux else torch.zeros_like(fd["cyc_dist"])
     # eikonal on a ray subset (nerf.py:740-767)
     fd["eikonal"] = compute_eikonal(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha)
     fd["xyz"] = xyz
@@ -620,7 +631,8 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None)
     aux["xyz_matches"] = xyz_matches
     aux["xyz_reproj"] = xyz_reproj
     aux["xy_reproj"] = pinhole_projection(kmatinv(fr["Kinv"]), xyz_reproj)[..., :2]
-    fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
+    if motion not in ("rigid", "dense"):  # deformable.py:344: SkinningWarp (and its ComposedWarp subclass) only
+        fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
     return fd, deltas, aux
 
 
@@ -653,10 +665,24 @@ def check_inside_aabb(xyz, aabb):
     return ((xyz > aabb[:1]) & (xyz < aabb[1:])).all(-1)
 
 
+def backward_warp_of(P, fr, xyz_t):
+    """Deformable.backward_warp's warp step (deformable.py:139-146) for every fg_motion restated here (see query_field_train)."""
+    motion = fr.get("motion", "skinning")
+    if motion == "rigid":
+        return xyz_t
+    if motion == "dense":
+        return dense_warp(P, xyz_t, fr["t_embed_dense"], fr["code_dense_bw"], True, prefix="warp", D=6)
+    if fr.get("dense") is not None:
+        return composed_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], True, dense=fr["dense"])[0]
+    return skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"], fr["code_skin"], backward=True)[0]
+
+
 def get_valid_idx(P, xyz, xyz_t, t_articulation):
-    """NeRF.get_valid_idx (nerf.py:495-528): inside extend_aabb(aabb,0.1) AND inside the
-    frame-0 bone-centre aabb extended by 1.0.  bool (M,N,D); must be bit-exact."""
+    """NeRF.get_valid_idx (nerf.py:495-528): inside extend_aabb(aabb,0.1) AND (when the samples carry articulations: SkinningWarp
+    fields, deformable.py:254-289) inside the frame-0 bone-centre aabb extended by 1.0.  bool (M,N,D); must be bit-exact."""
     valid = check_inside_aabb(xyz, extend_aabb(P["aabb"]))
+    if t_articulation is None:
+        return valid
     _, tb = dual_quaternion_to_quaternion_translation(t_articulation)
     tb = tb[0]
     t_aabb = extend_aabb(torch.stack([tb.min(0)[0], tb.max(0)[0]], 0), factor=1.0)
@@ -668,8 +694,7 @@ def importance_sampling(P, fr, hxy, n_depth=64, alpha=None):
     nc = n_depth // 2
     xyz_cam, _, deltas, depth = sample_cam_rays(hxy, fr["Kinv"], fr["near_far"], n_depth=nc)
     xyz_t, _ = cam_to_field(xyz_cam, None, fr["field2cam"])
-    xyz, _ = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"],
-                           fr["code_skin"], backward=True)
+    xyz = backward_warp_of(P, fr, xyz_t)
     density = nerf_forward(P, xyz, {"basefield": fr["code_base"]}, with_color=False, alpha=alpha)
     weights, _ = compute_weights(density, deltas)
     depth_mid = (0.5 * (depth[:, :, :-1] + depth[:, :, 1:])).view(-1, nc - 1)
@@ -682,10 +707,10 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None):
     """Eval-mode Deformable.query_field (train-only fields return {}, decorator.py:4-17)."""
     (xyz_cam, dir_cam, deltas, depth), inds = importance_sampling(P, fr, hxy, n_depth, alpha)
     xyz_t, _ = cam_to_field(xyz_cam, None, fr["field2cam"])
-    xyz, _ = skinning_warp(P, xyz_t, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"],
-                           fr["code_skin"], backward=True)
+    xyz = backward_warp_of(P, fr, xyz_t)
     vis = vis_field(P, xyz, fr["code_vis"])
-    valid = get_valid_idx(P, xyz, xyz_t, fr["t_articulation"])
+    has_bones = fr.get("motion", "skinning") not in ("rigid", "dense")
+    valid = get_valid_idx(P, xyz, xyz_t, fr["t_articulation"] if has_bones else None)
     # query_nerf with compaction (nerf.py:782-819): invalid samples get rgb = density = 0
     rgb, density = nerf_forward(P, xyz, {"basefield": fr["code_base"], "colorfield": fr["code_color"]},
                                 appr_code=fr["appr_code"], alpha=alpha)
@@ -696,8 +721,7 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None):
     # normals in camera space through the whole warp (nerf.py:455-493)
     def fn_sdf(xc):
         xt, _ = cam_to_field(xc, None, fr["field2cam"])
-        xx, _ = skinning_warp(P, xt, fr["t_articulation"], fr["rest_articulation"], fr["t_embed"],
-                              fr["code_skin"], backward=True)
+        xx = backward_warp_of(P, fr, xt)
         return nerf_forward(P, xx, {"basefield": fr["code_base"]}, with_color=False, get_density=False, alpha=alpha)
 
     with torch.enable_grad():
@@ -709,7 +733,8 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None):
     fd["xyz"] = xyz
     fd["xyz_cam"] = xyz_cam
     fd["depth"] = depth / P["logscale"].exp()
-    fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
+    if has_bones:
+        fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
     return fd, deltas, {"valid": valid, "inds": inds}
 
 
@@ -891,7 +916,8 @@ def recon_losses_fg(results, batch, train_res, weights=None):
     L["depth"] = (r["depth"] - batch["depth"]).norm(2, -1, keepdim=True)
     L["flow"] = (r["flow"] - batch["flow"]).norm(2, -1, keepdim=True) * (batch["flow_uct"] > 0).float()
     L["vis"] = a["vis"]
-    L["reg_gauss_mask"] = (a["gauss_mask"] - r["mask"].detach()).pow(2)
+    if "gauss_mask" in r:  # model.py:497-501: SkinningWarp fields only
+        L["reg_gauss_mask"] = (a["gauss_mask"] - r["mask"].detach()).pow(2)
     vis2d, mfg = batch["vis2d"].float(), batch["mask"].float()
     det = batch["is_detected"].float()[:, None, None]
     for k in list(L.keys()):

@@ -81,7 +81,9 @@ def load():
         raise RuntimeError("reference tree not found at %s" % REF_ROOT)
 
     # 1. third-party stubs
-    for name in ["trimesh", "pysdf", "cv2", "skimage", "imageio", "absl", "absl.app", "absl.flags", "tqdm"]:
+    # (tensorboard / matplotlib: only lab4d.engine.trainer and its vis_utils want them -- imported by the binding tests of lab4d_amd.patch)
+    for name in ["trimesh", "pysdf", "cv2", "skimage", "imageio", "absl", "absl.app", "absl.flags", "tqdm", "tensorboard", "torch.utils.tensorboard",
+                 "matplotlib", "matplotlib.pyplot", "matplotlib.cm", "einops"]:
         if name in sys.modules:
             continue
         try:

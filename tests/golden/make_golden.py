@@ -50,7 +50,10 @@ def build_reference_field(ns, P, num_inst=1, fg_motion="skel-quad"):
     missing = [k for k in P if k not in f.state_dict() and k != "warp.skinning_model.symm_idx"]
     assert not missing, missing
     f.load_state_dict(sd, strict=False)
-    assert list(f.warp.skinning_model.symm_idx) == synthetic.SYMM_IDX[len(f.warp.skinning_model.symm_idx)]
+    if hasattr(f.warp, "skinning_model"):
+        assert list(f.warp.skinning_model.symm_idx) == synthetic.SYMM_IDX[len(f.warp.skinning_model.symm_idx)]
+    else:  # fg_motion "rigid" / "dense": every warp parameter of the module must have come from P
+        assert all(("warp." + k) in P for k in f.warp.state_dict() if "time_embedding" not in k), [k for k in f.warp.state_dict()]
     return f
 
 
@@ -58,9 +61,13 @@ def frames_from_reference(f, fr):
     """Per-frame codes the reference's own per-frame modules produce for these frame ids."""
     with torch.no_grad():
         fid = fr["frame_id"]
+        fr["appr_code"] = f.appr_embedding.get_vals(fid).clone()
+        if not hasattr(f.warp, "skinning_model"):
+            if hasattr(f.warp, "time_embedding"):  # fg_motion "dense": the DenseWarp's own TimeEmbedding (warping.py:119)
+                fr["t_embed_dense"] = f.warp.time_embedding(fid).clone()
+            return fr
         fr["t_embed"] = f.warp.skinning_model.time_embedding(fid).clone()
         fr["t_embed_mean"] = f.warp.skinning_model.time_embedding.get_mean_embedding("cpu").clone()
-        fr["appr_code"] = f.appr_embedding.get_vals(fid).clone()
         if hasattr(f.warp, "post_warp"):  # ComposedWarp: the dense post-warp has its own TimeEmbedding (warping.py:119)
             fr["t_embed_dense"] = f.warp.post_warp.time_embedding(fid).clone()
     return fr
@@ -95,7 +102,7 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
     """num_inst > 1 / inst_id: the multi-instance configuration (BASELINE config 4): per-instance codes in every CondMLP
     (base.py:123-150), frames of one pair share their video's instance id."""
     num_bones = 18 if "skel-human" in fg_motion else 25  # utils/skel_utils.py:348-351
-    P = synthetic.make_weights(seed, num_inst=num_inst, num_bones=num_bones)
+    P = synthetic.make_weights(seed, num_inst=num_inst, num_bones=num_bones, motion=fg_motion if fg_motion in ("rigid", "dense") else "skinning")
     if fg_motion.startswith("comp_"):  # fg_motion "comp_skel-quad_dense" (BASELINE configs 2-3): skinning + dense post-warp
         P = synthetic.add_dense_weights(P, seed, num_inst)
     f = build_reference_field(ns, P, num_inst, fg_motion)
@@ -141,6 +148,8 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
     loss_dict = {}
     model.compute_recon_loss(loss_dict, results, batch, config)
     model.mask_losses(loss_dict, batch, config)
+    if "gauss_mask" not in rendered:
+        assert fg_motion in ("rigid", "dense")  # deformable.py:344: the gaussian-bone density exists for SkinningWarp only
     loss_dict["reg_eikonal"] = rendered["eikonal"]
     loss_dict["reg_deform_cyc"] = aux_fg["cyc_dist"]
     loss_dict["reg_delta_skin"] = aux_fg["delta_skin"]
@@ -148,7 +157,10 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
     from oracle.lab4d_oracle import DEFAULT_LOSS_WT
     config.update(DEFAULT_LOSS_WT)
     model.apply_loss_weights(loss_dict, config)
-    total = sum(loss_dict.values())
+    # a term without a positive element is the mean of an empty selection = NaN in the reference (model.py:602; with fg_motion "rigid" that
+    # is reg_deform_cyc / reg_delta_skin / reg_skin_entropy, all identically zero): it contributes no gradient, and the sum the trainer
+    # backpropagates (trainer.py:343-345) is NaN only as a number -- the gradients below are those of the finite terms
+    total = sum(v for v in loss_dict.values() if bool(torch.isfinite(v)))
     params = dict(f.named_parameters())
     gnames = [k for k in P if k in params and params[k].requires_grad]
     grads = torch.autograd.grad(total, [params[k] for k in gnames] + list(leaves.values()), allow_unused=True)
@@ -179,9 +191,9 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
     print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", {k: float(v) for k, v in loss_dict.items()})
 
 
-def gen_eval(ns, tag, M, N, D, res, seed):
-    P = synthetic.make_weights(seed, sdf_bias=-0.02)
-    f = build_reference_field(ns, P)
+def gen_eval(ns, tag, M, N, D, res, seed, fg_motion="skel-quad"):
+    P = synthetic.make_weights(seed, sdf_bias=-0.02, motion=fg_motion if fg_motion in ("rigid", "dense") else "skinning")
+    f = build_reference_field(ns, P, fg_motion=fg_motion)
     f.eval()
     fr = synthetic.make_frames(seed + 1, M, res)
     fr = frames_from_reference(f, fr)
@@ -192,6 +204,8 @@ def gen_eval(ns, tag, M, N, D, res, seed):
     f.importance_sampling = lambda *a, **k: orig(*a, n_depth=D, **k)
     sd = samples_dict_of(fr, hxy, None)
     del sd["feature"]
+    if fg_motion in ("rigid", "dense"):  # only SkinningWarp fields put articulations into the samples (deformable.py:254-289)
+        del sd["t_articulation"], sd["rest_articulation"]
     captured = {}
     _sp = ns.render_utils.sample_pdf
     _ss = torch.searchsorted
@@ -216,7 +230,7 @@ def gen_eval(ns, tag, M, N, D, res, seed):
         ns.render_utils.torch.searchsorted = _ss
     rendered = ns.render_utils.render_pixel(feat_dict, deltas)
     out = {
-        "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "weight_checksum": weight_checksum(P), "sdf_bias": -0.02},
+        "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "weight_checksum": weight_checksum(P), "sdf_bias": -0.02, "fg_motion": fg_motion},
         "frames": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in fr.items()},
         "hxy": hxy, "feat_dict": {k: v.detach() for k, v in feat_dict.items()}, "deltas": deltas.detach(),
         "rendered": {k: v.detach() for k, v in rendered.items()},
@@ -464,6 +478,8 @@ def gen_comp_train(ns):
     loss_dict = {}
     model.compute_recon_loss(loss_dict, results, batch, config)  # (scales aux_dict["bg"]["vis"] by 0.01 in place)
     model.mask_losses(loss_dict, batch, config)
+    if "gauss_mask" not in rendered:
+        assert fg_motion in ("rigid", "dense")  # deformable.py:344: the gaussian-bone density exists for SkinningWarp only
     loss_dict["reg_eikonal"] = rendered["eikonal"]
     loss_dict["reg_deform_cyc"] = aux_fg["cyc_dist"]
     loss_dict["reg_delta_skin"] = aux_fg["delta_skin"]
@@ -506,6 +522,9 @@ def main(only=None):
         ("train_compmotion", lambda: gen_train(ns, "compmotion", M=2, N=6, D=8, res=64, seed=51, fg_motion="comp_skel-quad_dense", frame_id=[3, 4])),
         # BASELINE configs[2]'s fg field: the 18-joint human skeleton with the dense post-warp (fg_motion "comp_skel-human_dense")
         ("train_human", lambda: gen_train(ns, "human", M=2, N=6, D=8, res=64, seed=81, fg_motion="comp_skel-human_dense", frame_id=[10, 11])),
+        # fg_motion "rigid" (the reference's default, config.py:42; IdentityWarp) and "dense" (a bare DenseWarp, D=6)
+        ("train_rigid", lambda: gen_train(ns, "rigid", M=2, N=6, D=8, res=64, seed=91, fg_motion="rigid")),
+        ("train_dense", lambda: gen_train(ns, "dense", M=2, N=6, D=8, res=64, seed=101, fg_motion="dense", frame_id=[7, 8])),
         ("train_multi", lambda: gen_train(ns, "multi", M=4, N=5, D=6, res=64, seed=31, num_inst=3, inst_id=[1, 1, 2, 2], frame_id=[22, 23, 44, 45])),
         # BASELINE config 0: 64x64 crop x 64 samples
         ("train_c1", lambda: gen_train(ns, "c1", M=2, N=None, D=64, res=64, seed=41, full_grid_stride=16)),
@@ -513,6 +532,8 @@ def main(only=None):
         # disc) of a frame pair = 2 x 1,024 rays = 262,144 samples through the reference; every 16th ray is stored
         ("train_bench", lambda: gen_train(ns, "bench", M=2, N=None, D=128, res=512, seed=61, full_grid_stride=16, rows=(255, 257))),
         ("eval_small", lambda: gen_eval(ns, "small", M=2, N=8, D=16, res=64, seed=31)),
+        ("eval_rigid", lambda: gen_eval(ns, "rigid", M=2, N=8, D=16, res=64, seed=33, fg_motion="rigid")),
+        ("eval_dense", lambda: gen_eval(ns, "dense", M=2, N=8, D=16, res=64, seed=35, fg_motion="dense")),
         ("comp_warp", lambda: gen_comp_warp(ns)),
         ("bg_field", lambda: gen_bg_field(ns)),
         ("comp_eval", lambda: gen_comp_eval(ns)),

@@ -63,6 +63,14 @@ class ComposedWarp(Node):
     pass
 
 
+class IdentityWarp(Node):  # fg_motion "rigid" (warping.py:59-91)
+    pass
+
+
+class DenseWarp(Node):  # fg_motion "dense" (warping.py:94-170): forward_map / backward_map CondMLPs + its own time embedding
+    pass
+
+
 class PosEmb:
     def __init__(self, n_freqs, alpha=None):
         self.N_freqs, self.alpha = n_freqs, alpha
@@ -83,11 +91,11 @@ def _tree(root, P):
     return root
 
 
-def fg_field(P, frames, composed=False, alpha=None, training=True):
-    """Stand-in for Deformable("skel-quad" | "comp_skel-quad_dense") holding the device weights P (flat, reference names) and the
-    fixture's per-frame values `frames` (t_embed, t_embed_mean, appr_code, articulations, frame_id[, t_embed_dense])."""
+def fg_field(P, frames, composed=False, alpha=None, training=True, motion=None):
+    """Stand-in for Deformable("skel-quad" | "comp_skel-quad_dense" | "rigid" | "dense") holding the device weights P (flat, reference names)
+    and the fixture's per-frame values `frames` (t_embed, t_embed_mean, appr_code, articulations, frame_id[, t_embed_dense])."""
     f = Node()
-    warp = ComposedWarp() if composed else SkinningWarp()
+    warp = {"rigid": IdentityWarp, "dense": DenseWarp}[motion]() if motion in ("rigid", "dense") else (ComposedWarp() if composed else SkinningWarp())
     f.add_module("warp", warp)
     _tree(f, P)
     f.register_buffer("aabb", P["aabb"])
@@ -96,6 +104,11 @@ def fg_field(P, frames, composed=False, alpha=None, training=True):
     f.sdf.in_features = f.sdf.weight.shape[1]
     f.appr_channels = 32
     f.appr_embedding = FrameTable(fid, frames["appr_code"])
+    if motion in ("rigid", "dense"):
+        if motion == "dense":
+            warp.time_embedding = FrameTable(fid, frames["t_embed_dense"])
+        f.train(training)
+        return f
     sk = warp.skinning_model
     sk.symm_idx = [int(i) for i in P["warp.skinning_model.symm_idx"]]
     sk.time_embedding = FrameTable(fid, frames["t_embed"], frames["t_embed_mean"])

@@ -45,7 +45,7 @@ def _regen(script, args, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("names", [["ops", "train_small", "eval_small"], ["comp_train"]])
+@pytest.mark.parametrize("names", [["ops", "train_small", "eval_small"], ["comp_train"], ["train_rigid", "train_dense", "eval_rigid", "eval_dense"]])
 def test_make_golden_reproduces_the_committed_fixtures(tmp_path, golden_dir, names):
     _regen("make_golden.py", names, tmp_path)
     for n in names:

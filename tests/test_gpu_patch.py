@@ -35,8 +35,9 @@ def patch_f32():
 def _load(golden_dir, name):
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
     meta = g["meta"]
+    motion = meta.get("fg_motion", "skel-quad")
     P = synthetic.make_weights(meta["seed"], num_inst=meta.get("num_inst", 1), sdf_bias=meta.get("sdf_bias"),
-                               num_bones=18 if "skel-human" in meta.get("fg_motion", "") else 25)
+                               num_bones=18 if "skel-human" in motion else 25, motion=motion if motion in ("rigid", "dense") else "skinning")
     composed = meta.get("fg_motion", "skel-quad").startswith("comp_")
     if composed:
         P = synthetic.add_dense_weights(P, meta["seed"], meta.get("num_inst", 1))
@@ -46,6 +47,8 @@ def _load(golden_dir, name):
 def _samples_dict(g, with_feature=True):
     fr = synthetic.to_device(dict(g["frames"]), DEV)
     sd = {k: fr[k] for k in ("Kinv", "field2cam", "frame_id", "inst_id", "near_far", "t_articulation", "rest_articulation")}
+    if g["meta"].get("fg_motion") in ("rigid", "dense"):  # only SkinningWarp fields put articulations into the samples (deformable.py:254-289)
+        del sd["t_articulation"], sd["rest_articulation"]
     sd["hxy"] = g["hxy"].to(DEV)
     if with_feature:
         sd["feature"] = g["batch"]["feature"].to(DEV)
@@ -60,7 +63,7 @@ def _model(field):
     return m
 
 
-@pytest.mark.parametrize("case", ["train_small.pt", "train_compmotion.pt", "train_human.pt"])
+@pytest.mark.parametrize("case", ["train_small.pt", "train_compmotion.pt", "train_human.pt", "train_rigid.pt", "train_dense.pt"])
 def test_query_field_and_render_samples_match_the_reference(golden_dir, patch_f32, case):
     """Deformable.query_field -> dvr_model.render_samples_chunk through the adapters, training mode, vs the reference's own
     outputs for the same rays / weights / random draws; gradients reach the stand-in module's parameters."""
@@ -69,7 +72,7 @@ def test_query_field_and_render_samples_match_the_reference(golden_dir, patch_f3
     g, P, composed = _load(golden_dir, case)
     meta = g["meta"]
     fr, sd = _samples_dict(g)
-    field = standins.fg_field(P, fr, composed=composed, alpha=meta["alpha"], training=True)
+    field = standins.fg_field(P, fr, composed=composed, alpha=meta["alpha"], training=True, motion=meta.get("fg_motion"))
     patch.N_DEPTH = meta["D"]
     rng = synthetic.to_device(g["rng"], DEV)
     patch.draw_rng = lambda M, N, D, device: rng  # the fixture's draws instead of fresh ones
@@ -88,7 +91,7 @@ def test_query_field_and_render_samples_match_the_reference(golden_dir, patch_f3
     params = dict(field.named_parameters())
     names = [k for k in g["grads"] if not k.startswith("frame:") and k in params]
     assert len(names) > 40
-    grads = torch.autograd.grad(sum(losses.values()), [params[k] for k in names], allow_unused=True)
+    grads = torch.autograd.grad(sum(v for v in losses.values() if bool(torch.isfinite(v))), [params[k] for k in names], allow_unused=True)
     for k, gv in zip(names, grads):
         ref = g["grads"][k]
         assert gv is not None, k
@@ -96,13 +99,15 @@ def test_query_field_and_render_samples_match_the_reference(golden_dir, patch_f3
         assert e < 5e-3, (k, e)
 
 
-def test_eval_query_field_and_chunking(golden_dir, patch_f32):
+@pytest.mark.parametrize("case", ["eval_small.pt", "eval_rigid.pt", "eval_dense.pt"])
+def test_eval_query_field_and_chunking(golden_dir, patch_f32, case):
     """Eval mode (importance sampling, valid-sample compaction, normals) through the adapters vs the reference fixture; chunked
-    rendering concatenates to the unchunked result (per-ray quantities; "vis" is normalised per chunk by design)."""
+    rendering concatenates to the unchunked result (per-ray quantities; "vis" is normalised per chunk by design).
+    eval_rigid / eval_dense: fg_motion "rigid" / "dense" (no articulations in the samples: the valid mask is the aabb test alone)."""
     patch = patch_f32
-    g, P, _ = _load(golden_dir, "eval_small.pt")
+    g, P, _ = _load(golden_dir, case)
     fr, sd = _samples_dict(g, with_feature=False)
-    field = standins.fg_field(P, fr, training=False)
+    field = standins.fg_field(P, fr, training=False, motion=g["meta"].get("fg_motion"))
     patch.N_DEPTH = g["meta"]["D"]
     fd, deltas, aux = patch.query_field(field, sd)
     assert aux == {}
@@ -224,3 +229,71 @@ def test_evaluate_and_render_entry_points(golden_dir, patch_f32):
     assert torch.allclose(ev["mask"][0].reshape(-1, 1), raw["mask"][0], atol=1e-6)
     ev1 = patch.dvr_evaluate(m, batch, is_pair=False)
     assert ev1["rgb"].shape == (M, res, res, 3)
+
+
+def test_compute_loss_and_optimizer_bindings(golden_dir, patch_f32):
+    """dvr_model.compute_loss, Trainer.check_grad and the optimizer step through the adapters on stand-in objects: the loss_dict against the
+    reference's own values for the fixture (keys, order, numbers), then check_grad + optimizer.step() against torch's clip_grad_norm_ +
+    AdamW on a copy of the parameters, incl. a blown-up step that must be discarded without touching weights, moments or step count."""
+    from lab4d_amd import deformable as DF
+    from lab4d_amd.optim import TorchFlatAdamW
+    patch = patch_f32
+    g, P, composed = _load(golden_dir, "train_small.pt")
+    meta = g["meta"]
+    fr, sd = _samples_dict(g)
+    field = standins.fg_field(P, fr, composed=composed, alpha=meta["alpha"], training=True)
+    patch.N_DEPTH = meta["D"]
+    rng = synthetic.to_device(g["rng"], DEV)
+    patch.draw_rng = lambda M, N, D, device: rng
+    model = _model(field)
+    model.config = dict(DF.DEFAULT_LOSS_WT, field_type="fg", train_res=meta["res"])
+    reg_vals = {"reg_visibility": torch.tensor(0.3, device=DEV), "reg_soft_deform": torch.tensor(0.0, device=DEV),
+                "reg_gauss_skin": torch.tensor(0.2, device=DEV), "reg_cam_prior": torch.tensor(0.5, device=DEV), "reg_skel_prior": torch.tensor(0.1, device=DEV)}
+
+    def compute_reg_loss(loss_dict, results):  # what the reference's method adds (model.py:503-526): field-level terms + the rendered ones
+        loss_dict.update(reg_vals)
+        loss_dict["reg_eikonal"] = results["rendered"]["eikonal"]
+
+    def apply_loss_weights(loss_dict, config):  # model.py:587-611
+        for k, v in loss_dict.items():
+            loss_dict[k] = v[v > 0].mean() * config.get(k + "_wt", 1.0)
+
+    model.compute_reg_loss, model.apply_loss_weights = compute_reg_loss, apply_loss_weights
+    batch = synthetic.to_device(g["batch"], DEV)
+    params = [p for p in field.parameters()]
+    opt = TorchFlatAdamW([{"params": [p], "lr": 1e-3} for p in params], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+    ref_params = [p.detach().clone().requires_grad_(True) for p in params]
+    ref_opt = torch.optim.AdamW([{"params": [p], "lr": 1e-3} for p in ref_params], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+    trainer = types.SimpleNamespace(optimizer=opt, model_cache=[None, None], optimizer_cache=[None, None], scheduler_cache=[None, None])
+    for it, scale in enumerate([1.0, 1e5, 1.0]):
+        opt.zero_grad()
+        res = patch.dvr_render_samples_chunk(model, {"fg": sd}, flow_thresh=meta["flow_thresh"], chunk_size=8192)
+        loss_dict = patch.dvr_compute_loss(model, batch, res)
+        if it == 0:
+            want = [k for k in patch.LOSS_ORDER if k in g["loss"] or k in reg_vals]
+            assert list(loss_dict) == want, (list(loss_dict), want)
+            for k, v in g["loss"].items():
+                assert rel(loss_dict[k], v) < 5e-4, (k, rel(loss_dict[k], v))
+            for k, v in reg_vals.items():  # a zero term is the mean of an empty selection = NaN, like the reference
+                w = DF.DEFAULT_LOSS_WT[k + "_wt"]
+                assert (bool(torch.isnan(loss_dict[k])) if float(v) == 0 else abs(float(loss_dict[k]) - float(v) * w) < 1e-7), k
+        total = torch.sum(torch.stack([v for v in loss_dict.values() if bool(torch.isfinite(v))])) * scale
+        total.backward()
+        for p, q in zip(params, ref_params):
+            q.grad = p.grad.detach().clone()
+        before = opt.flat.flat.clone()
+        patch.trainer_check_grad(trainer, thresh=5.0)
+        opt.step()
+        tn = torch.nn.utils.clip_grad_norm_(ref_params, 5.0)
+        if float(tn) > 5.0:
+            ref_opt.zero_grad()
+        ref_opt.step()
+        torch.cuda.synchronize()
+        assert int(opt.skipped) == int(scale > 1), (it, float(tn))
+        if scale > 1:
+            assert torch.equal(opt.flat.flat, before)
+        for p, q in zip(params, ref_params):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), it
+    assert int(opt.flat.dev_step) == 2
+    sd_opt = opt.state_dict()
+    assert float(sd_opt["state"][0]["step"]) == 2.0

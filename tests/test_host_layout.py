@@ -12,12 +12,13 @@ from oracle import lab4d_oracle as O
 def all_weights():
     P = synthetic.add_dense_weights(synthetic.make_weights(0))
     P.update({"bg." + k: v for k, v in synthetic.make_bg_weights(0).items()})
+    P.update({"d6." + k: v for k, v in synthetic.make_weights(0, motion="dense").items() if k.startswith("warp.")})  # fg_motion "dense"
     return P
 
 
 CASES = [(mlp.NET_FG_BASE, ""), (mlp.NET_FG_COLOR, ""), (mlp.NET_VIS, ""), (mlp.NET_FEAT, ""), (mlp.NET_SKIN, ""),
          (mlp.NET_DENSE, "warp.post_warp.forward_map."), (mlp.NET_DENSE, "warp.post_warp.backward_map."),
-         (mlp.NET_BG_BASE, "bg."), (mlp.NET_BG_COLOR, "bg.")]
+         (mlp.NET_BG_BASE, "bg."), (mlp.NET_BG_COLOR, "bg."), (mlp.NET_DENSE6, "d6.warp.forward_map."), (mlp.NET_DENSE6, "d6.warp.backward_map.")]
 
 
 def test_every_reference_weight_column_is_consumed_exactly_once():

@@ -88,8 +88,9 @@ def test_compose_fields(ops):
 
 def _load_case(golden_dir, name):
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
+    motion = g["meta"].get("fg_motion", "skel-quad")
     P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"),
-                               num_bones=18 if "skel-human" in g["meta"].get("fg_motion", "") else 25)
+                               num_bones=18 if "skel-human" in motion else 25, motion=motion if motion in ("rigid", "dense") else "skinning")
     if g["meta"].get("fg_motion", "skel-quad").startswith("comp_"):
         P = synthetic.add_dense_weights(P, g["meta"]["seed"], g["meta"].get("num_inst", 1))
     chk = float(sum(v.double().abs().sum() for k, v in sorted(P.items()) if v.dtype.is_floating_point))
@@ -98,10 +99,13 @@ def _load_case(golden_dir, name):
     return g, P, fr
 
 
-@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_multi.pt", "train_compmotion.pt", "train_human.pt"])
+@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_multi.pt", "train_compmotion.pt", "train_human.pt", "train_rigid.pt",
+                                  "train_dense.pt"])
 def test_training_graph_against_reference(golden_dir, case):
     """train_multi: BASELINE config 4's shape -- 3 instances, two frame pairs from different videos, per-instance codes.
-    train_compmotion: fg_motion "comp_skel-quad_dense" (BASELINE configs 2-3): every warp of the graph is the ComposedWarp."""
+    train_compmotion: fg_motion "comp_skel-quad_dense" (BASELINE configs 2-3): every warp of the graph is the ComposedWarp.
+    train_rigid / train_dense: fg_motion "rigid" (the reference's default: IdentityWarp) and "dense" (a bare 6-layer DenseWarp); their
+    identically-zero skin terms (and, for rigid, the cycle distance) are NaN losses in the reference (mean of an empty selection)."""
     g, P, fr = _load_case(golden_dir, case)
     meta = g["meta"]
     P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v) for k, v in P.items()}
@@ -129,9 +133,13 @@ def test_training_graph_against_reference(golden_dir, case):
     for k, v in g["aux_fg"].items():
         close(res["aux_dict"]["fg"][k], v, "aux_fg." + k)
     losses = O.recon_losses_fg(res, g["batch"], meta["res"], O.DEFAULT_LOSS_WT)
+    assert set(losses) == set(g["loss"]), (sorted(losses), sorted(g["loss"]))
     for k, v in g["loss"].items():
-        close(losses[k], v, "loss." + k)
-    total = sum(losses.values())
+        if bool(torch.isnan(v)):
+            assert bool(torch.isnan(losses[k])), k
+        else:
+            close(losses[k], v, "loss." + k)
+    total = sum(v for v in losses.values() if bool(torch.isfinite(v)))
     names = [k for k in g["grads"] if not k.startswith("frame:")]
     fnames = [k[6:] for k in g["grads"] if k.startswith("frame:")]
     grads = torch.autograd.grad(total, [P[k] for k in names] + [leaves[k] for k in fnames], allow_unused=True)
@@ -148,8 +156,11 @@ def test_training_graph_against_reference(golden_dir, case):
             assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 1e-3 * float(ref["norm"]) + 1e-12, k
 
 
-def test_eval_graph_against_reference(golden_dir):
-    g, P, fr = _load_case(golden_dir, "eval_small.pt")
+@pytest.mark.parametrize("case", ["eval_small.pt", "eval_rigid.pt", "eval_dense.pt"])
+def test_eval_graph_against_reference(golden_dir, case):
+    """eval_rigid / eval_dense: fg_motion "rigid" / "dense" -- no articulations in the samples, so get_valid_idx is the field's aabb test alone
+    (nerf.py:515-523) and there is no gaussian-bone mask."""
+    g, P, fr = _load_case(golden_dir, case)
     meta = g["meta"]
     out = O.render_eval(P, fr, g["hxy"], n_depth=meta["D"])
     assert torch.equal(out["debug"]["inds"], g["inds"]), "importance-sampling indices must be bit-exact"

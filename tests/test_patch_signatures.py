@@ -192,3 +192,47 @@ def test_draw_rng_follows_the_reference_draw_order():
     torch.manual_seed(7)
     r = patch.draw_rng(M, N, D, torch.device("cpu"))
     assert torch.equal(r["eik_inds"], eik) and torch.equal(r["match_perm"], perm)
+
+
+def test_optimizer_init_adopts_the_reference_optimizer(ns, patched):
+    """Trainer.optimizer_init through the binding: the reference's own parameter / learning-rate selection and OneCycleLR run unchanged, the
+    AdamW they built becomes a TorchFlatAdamW IN PLACE (same object, same param_groups the scheduler writes to), every parameter's .data and
+    .grad are views of the flat buffers, and state_dict() / load_state_dict() round-trip (the two-rounds-back cache of check_grad)."""
+    import types
+    import importlib
+    from lab4d_amd import synthetic
+    from lab4d_amd.optim import TorchFlatAdamW
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden"))
+    import make_golden as MG
+    patch, _ = patched
+    trainer_mod = importlib.import_module("lab4d.engine.trainer")
+    field = MG.build_reference_field(ns, synthetic.make_weights(5))
+    model = torch.nn.Module()
+    model.module = torch.nn.Module()
+    model.module.fields = torch.nn.Module()
+    model.module.fields.field_params = torch.nn.ModuleDict({"fg": field})
+    t = types.SimpleNamespace(opts={"learning_rate": 5e-4, "freeze_bone_len": False, "num_rounds": 20}, model=model, total_steps=400)
+    t.get_lr_dict = types.MethodType(trainer_mod.Trainer.get_lr_dict, t)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    before = [p.detach().clone() for p in trainable]
+    trainer_mod.Trainer.optimizer_init(t)
+    assert isinstance(t.optimizer, TorchFlatAdamW) and t.scheduler.optimizer is t.optimizer
+    lrs = {id(g["params"][0]): g["lr"] for g in t.optimizer.param_groups}
+    named = dict(model.named_parameters())
+    # the reference's rule (trainer.py:122-148): 10x the base rate for the explicitly listed scalars, OneCycleLR starts at 1/25 of it
+    assert abs(lrs[id(named["module.fields.field_params.fg.logibeta"])] - 5e-3 / 25) < 1e-12
+    assert abs(lrs[id(named["module.fields.field_params.fg.basefield.linear_1.0.weight"])] - 5e-4 / 25) < 1e-12
+    flat = t.optimizer.flat
+    for p, b in zip(trainable, before):
+        assert torch.equal(p.detach(), b)
+    inside = [p for g in t.optimizer.param_groups for p in g["params"]]
+    lo, hi = flat.flat.data_ptr(), flat.flat.data_ptr() + 4 * flat.n
+    assert all(lo <= p.data_ptr() < hi for p in inside) and all(p.grad is not None for p in inside)
+    t.scheduler.step()
+    assert t.optimizer._lrs() != t.optimizer._lr_sent  # OneCycleLR wrote the groups; the next step() uploads the new rates
+    from copy import deepcopy
+    sd = deepcopy(t.optimizer.state_dict())  # what Trainer.save_checkpoint caches (trainer.py:262-269)
+    flat.m.fill_(3.0)
+    t.optimizer.load_state_dict(sd)
+    assert all(float(t.optimizer.state[p]["exp_avg"].abs().max()) == 0.0 for p in inside)
+    assert t.optimizer.state[inside[0]]["exp_avg"].data_ptr() == flat.m.data_ptr()  # still views of the flat moment buffer
