@@ -26,6 +26,13 @@ int lab4d_bone_coords_backward(const float* xyz, const float* art_r, const float
                                const float* g_bone, int S, int spf, int M, int B, float* g_xyz, float* g_art_r,
                                float* g_art_d, float* g_gauss, void* stream);
 
+/* lab4d_bone_coords_backward's point gradient AND the per-frame Gram matrix of the parameter path in one pass over the (S,3B) gradient:
+ * g_xyz (S,3) is written, G (M,3B,4) = sum over the frame's samples of g_bone[s,:]^T [x_s, 1] is zero-filled and accumulated (feed it to
+ * lab4d_bone_params_from_gram).  Needs spf % 256 == 0 (every 256-sample tile inside one frame); otherwise use lab4d_bone_coords_backward
+ * + lab4d_gram_per_frame. */
+int lab4d_bone_coords_backward_gram(const float* xyz, const float* art_r, const float* gauss, const float* g_bone, int S, int spf, int M, int B,
+                                    float* g_xyz, float* G, void* stream);
+
 /* Parameter gradients of lab4d_bone_coords_forward from the per-frame Gram matrix G (M,B,3,4) =
  * lab4d_gram_per_frame(g_bone (S,3B), [xyz,1] (S,4)): g_art_r, g_art_d (M,B,4) written, g_gauss (B,3) accumulated
  * (zero-fill first); any of the three may be NULL.  Replaces the reference's autograd through
@@ -46,7 +53,8 @@ int lab4d_skin_blend_forward(const float* xyz, const float* art_r, const float* 
  * g_raw (S,B); accumulates g_se3 (M,B,8) = [d/d se3_r (4) | d/d se3_d (4)] (zero-fill first); writes g_art_r, g_art_d
  * (M,B,4) and accumulates g_gauss (B,3) (zero-fill first) -- the three may be NULL together.  The bone-coordinate
  * gradient dL/dc_b = -2 dL/dskin_b * c_b is never materialised: it reaches the point analytically and the parameters
- * through per-frame second moments.  `work`: scratch of S*(2B+18) + M*B*34 floats. */
+ * through per-frame second moments.  `work`: scratch of M*B*34 floats when spf % 256 == 0 and g_se3 is given (every 256-sample
+ * tile then lies in one frame and the per-frame reductions are formed inside the kernel), else M*B*34 + S*(2B+18) floats. */
 int lab4d_skin_blend_backward(const float* xyz, const float* art_r, const float* art_d, const float* gauss,
                               const float* delta_raw, const float* se3_r, const float* se3_d, const float* g_out,
                               const float* g_ent, const float* g_dskin, int S, int spf, int M, int B, float* g_xyz,

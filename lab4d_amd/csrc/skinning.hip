@@ -140,16 +140,45 @@ __global__ void __launch_bounds__(256) k_bone_fwd(const float* __restrict__ xyz,
   }
 }
 
-// g_xyz[s] = sum_b R_b^T (g_bone[s,b] / gauss_b): one thread per sample
-template <int B, bool UNI>
+// g_xyz[s] = sum_b R_b^T (g_bone[s,b] / gauss_b): one thread per sample.
+// FUSE (needs UNI): the per-frame Gram matrix of the parameter path, G[m] += g_bone^T [x,1] (3B x 4), is formed from the LDS tile the
+// rows already sit in (thread (slice, column) walks every SLICES-th row; slices meet in LDS; block sums stay in LDS across tiles and
+// leave as one atomic per output when the frame changes and at the end) -- before round 3 a torch.cat built [x,1] in HBM and
+// k_gram_pf_rb read the (S,3B) gradient a second time.
+template <int B, bool UNI, bool FUSE>
 __global__ void __launch_bounds__(256) k_bone_bwd_x(const float* __restrict__ ar, const float* __restrict__ gauss,
-                                                     const float* __restrict__ g_bone, long S, int spf, float* __restrict__ g_xyz) {
+                                                     const float* __restrict__ g_bone, long S, int spf, float* __restrict__ g_xyz,
+                                                     const float* __restrict__ xyz, float* __restrict__ G) {
+  static_assert(!FUSE || UNI, "the fused Gram reduction needs frame-uniform tiles");
   using T = RowTile<3 * B>;
+  constexpr int C = 3 * B, SLICES = 256 / C;
   __shared__ float tile[T::FLOATS];
+  __shared__ float aux[FUSE ? 256 * 3 : 4];  // the points of the tile ([x,1]: the 1 is implicit -- a fourth float per row would push the block
+  __shared__ float lacc[FUSE ? C * 4 : 1];   // past 80 KiB of LDS, i.e. from two blocks per CU to one)
+  int cur_m = -1;
+  if (FUSE)
+    for (int e = threadIdx.x; e < C * 4; e += 256) lacc[e] = 0.f;
+  auto flush = [&](int m) {
+    for (int e = threadIdx.x; e < C * 4; e += 256) {
+      const float v = lacc[e];
+      if (v != 0.f) atomicAdd(G + (size_t)m * C * 4 + e, v);
+      lacc[e] = 0.f;
+    }
+  };
   for (long s0 = (long)blockIdx.x * 256; s0 < S; s0 += (long)gridDim.x * 256) {
     const long rem = S - s0;
     const int n = (int)(rem < 256 ? rem : 256);
+    if (FUSE) {
+      const int m_tile = __builtin_amdgcn_readfirstlane(frame_of(s0, spf));
+      if (m_tile != cur_m) {
+        if (cur_m >= 0) { __syncthreads(); flush(cur_m); }
+        cur_m = m_tile;
+      }
+    }
     T::load(g_bone, s0, n, tile);
+    if (FUSE && (int)threadIdx.x < n) {
+      stv3(aux + threadIdx.x * 3, ldv3(xyz + (s0 + threadIdx.x) * 3));
+    }
     __syncthreads();
     if ((int)threadIdx.x < n) {
       const long s = s0 + threadIdx.x;
@@ -165,8 +194,29 @@ __global__ void __launch_bounds__(256) k_bone_bwd_x(const float* __restrict__ ar
       }
       stv3(g_xyz + s * 3, acc);
     }
+    if (FUSE) {
+      const int t = threadIdx.x, sl = t / C, i = t - sl * C;
+      const bool act = sl < SLICES;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (act)
+        for (int k = sl; k < n; k += SLICES) {
+          const float a = tile[k * T::CP + i];
+          const V3 b = ldv3(aux + k * 3);
+          a0 += a * b.x; a1 += a * b.y; a2 += a * b.z; a3 += a;
+        }
+      __syncthreads();  // the tile's rows are consumed: it becomes the scratch of the slice reduction
+      if (act) { float* o = tile + (sl * C + i) * 4; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; }
+      __syncthreads();
+      for (int e = t; e < C * 4; e += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < SLICES; ++q) v += tile[q * C * 4 + e];
+        lacc[e] += v;
+      }
+    }
     __syncthreads();
   }
+  if (FUSE && cur_m >= 0) flush(cur_m);
 }
 
 // per-frame / per-bone parameter gradients: block = (frame m, chunk of samples), loop bones outermost
@@ -399,21 +449,82 @@ __global__ void __launch_bounds__(256) k_blend_fwd(const float* __restrict__ xyz
 // k_bone_gram_from_moments rebuilds the Gram matrix the parameter chain rule needs.
 // UNI: spf is a multiple of 256, so a block's 256 samples share ONE frame: the frame index is wave-uniform (readfirstlane) and the
 // per-frame tables (25 x (12 + 4 + 4) floats) are fetched with scalar loads instead of being held in ~200 vector registers.
-template <int B, bool UNI>
+// FUSE (needs UNI: a tile of 256 samples belongs to ONE frame): the two per-frame Gram reductions -- g_se3[m] += coef^T gw (B x 8) and
+// Q[m] += gsk^T xx (B x 10) -- are formed HERE from the LDS tiles, so coef / gw / gsk / xx never go to HBM (272 bytes per sample written and
+// read back by k_gram_pf_rb before round 3: 48 of the skinning adjoint's ms per step).  Thread (slice, b) walks every `slices`-th row of the
+// tile with the 8 (10) outputs of bone b in registers; the slices meet in LDS, the block keeps its sums in LDS across its tiles and
+// flushes them with one atomic per output when the frame changes and at the end.
+template <int B, bool UNI, bool FUSE>
 __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz, const float* __restrict__ aff, const float* __restrict__ raw,
                                                     const float* __restrict__ sr, const float* __restrict__ sd, const float* __restrict__ g_out,
                                                     const float* __restrict__ g_ent, const float* __restrict__ g_dskin, long S, int spf,
-                                                    float* __restrict__ g_xyz, float* __restrict__ g_raw, float* __restrict__ work) {
+                                                    float* __restrict__ g_xyz, float* __restrict__ g_raw, float* __restrict__ work,
+                                                    float* __restrict__ g_se3, float* __restrict__ Qm) {
+  static_assert(!FUSE || UNI, "the fused Gram reduction needs frame-uniform tiles");
   // The (S,B) operands -- raw in; coef, gsk, g_raw out -- go through ONE LDS tile of 256 rows, one after the other (RowTile): the
   // per-thread row accesses of the first version ran this kernel at 1.7 TB/s (a third of what its 516 bytes per sample allow).
   using T = RowTile<B>;
   __shared__ float tile[T::FLOATS];
+  constexpr int AUXW = 12;                 // floats per row of the second operand (gw: 8, xx: 10), 16-byte aligned rows
+  constexpr int SLICES = 256 / B;          // (slice, bone) threads of the Gram loops
+  static_assert(T::FLOATS >= SLICES * B * 10, "the tile doubles as the slice-reduction scratch");
+  __shared__ __attribute__((aligned(16))) float aux[FUSE ? 256 * AUXW : 4];
+  __shared__ float lacc[FUSE ? B * 18 : 1];  // block sums: [B x 8 | B x 10]
+  int cur_m = -1;
+  if (FUSE) {
+    for (int e = threadIdx.x; e < B * 18; e += 256) lacc[e] = 0.f;
+    // (the first __syncthreads of the loop orders this against the first use)
+  }
+  auto flush = [&](int m) {  // block sums -> the per-frame accumulators; callers sync before and after
+    for (int e = threadIdx.x; e < B * 18; e += 256) {
+      const float v = lacc[e];
+      if (v != 0.f) atomicAdd(e < B * 8 ? g_se3 + (size_t)m * B * 8 + e : Qm + (size_t)m * B * 10 + (e - B * 8), v);
+      lacc[e] = 0.f;
+    }
+  };
+  // acc[j] = sum over the rows k = sl, sl + SLICES, ... < n of tile[k][i] * aux[k][j]; then the slices are summed through the tile
+  auto gram = [&](int n, int ncol, int off) {
+    const int t = threadIdx.x, sl = t / B, i = t - sl * B;
+    const bool act = sl < SLICES;
+    float acc[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) acc[j] = 0.f;
+    if (act)
+      for (int k = sl; k < n; k += SLICES) {
+        const float a = tile[k * T::CP + i];
+        const float4 b0 = *reinterpret_cast<const float4*>(aux + k * AUXW), b1 = *reinterpret_cast<const float4*>(aux + k * AUXW + 4);
+        acc[0] += a * b0.x; acc[1] += a * b0.y; acc[2] += a * b0.z; acc[3] += a * b0.w;
+        acc[4] += a * b1.x; acc[5] += a * b1.y; acc[6] += a * b1.z; acc[7] += a * b1.w;
+        if (ncol == 10) {
+          const float2 b2 = *reinterpret_cast<const float2*>(aux + k * AUXW + 8);
+          acc[8] += a * b2.x; acc[9] += a * b2.y;
+        }
+      }
+    __syncthreads();  // every thread is done with the tile's rows: it becomes the scratch of the slice reduction
+    if (act)
+      for (int j = 0; j < ncol; ++j) tile[(sl * B + i) * ncol + j] = acc[j];
+    __syncthreads();
+    for (int e = t; e < B * ncol; e += 256) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < SLICES; ++q) v += tile[q * B * ncol + e];
+      lacc[off + e] += v;
+    }
+    __syncthreads();
+  };
   for (long s0 = (long)blockIdx.x * 256; s0 < S; s0 += (long)gridDim.x * 256) {
     const long rem = S - s0;
     const int n = (int)(rem < 256 ? rem : 256);
     const bool active = (int)threadIdx.x < n;
     const long s = s0 + threadIdx.x;
     float* row = tile + threadIdx.x * T::CP;
+    if (FUSE) {
+      const int m_tile = __builtin_amdgcn_readfirstlane(frame_of(s0, spf));
+      if (m_tile != cur_m) {  // block-uniform
+        if (cur_m >= 0) { __syncthreads(); flush(cur_m); }
+        cur_m = m_tile;
+      }
+    }
     T::load(raw, s0, n, tile);
     __syncthreads();
     Blend<B> bl;
@@ -452,7 +563,8 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz
       grw[2] = i * (gn_v.y - v.y * qg) - v.y * i * dg;
       grw[3] = i * (gn_v.z - v.z * qg) - v.z * i * dg;
       gdw[0] = i * gd_w; gdw[1] = i * gd_v.x; gdw[2] = i * gd_v.y; gdw[3] = i * gd_v.z;
-      float4* wg = reinterpret_cast<float4*>(work + S * B + s * 8);    // [g_rw (4) | g_dw (4)]: 32 contiguous bytes per sample
+      // [g_rw (4) | g_dw (4)]: 32 contiguous bytes per sample, in the work array -- or, fused, in the LDS operand tile of the Gram loop
+      float4* wg = FUSE ? reinterpret_cast<float4*>(aux + threadIdx.x * AUXW) : reinterpret_cast<float4*>(work + S * B + s * 8);
       wg[0] = make_float4(grw[0], grw[1], grw[2], grw[3]);
       wg[1] = make_float4(gdw[0], gdw[1], gdw[2], gdw[3]);
       // softmax / entropy / delta adjoint
@@ -476,10 +588,12 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz
         gx = gx + V3{A.r0.x * u0 + A.r1.x * u1 + A.r2.x * u2, A.r0.y * u0 + A.r1.y * u1 + A.r2.y * u2, A.r0.z * u0 + A.r1.z * u1 + A.r2.z * u2};
       }
       stv3(g_xyz + s * 3, gx);
-      float* xx = work + S * (2 * B + 8) + s * 10;  // upper triangle of [x,1][x,1]^T, row-major
-      xx[0] = x.x * x.x; xx[1] = x.x * x.y; xx[2] = x.x * x.z; xx[3] = x.x;
-      xx[4] = x.y * x.y; xx[5] = x.y * x.z; xx[6] = x.y;
-      xx[7] = x.z * x.z; xx[8] = x.z; xx[9] = 1.f;
+      if (!FUSE) {
+        float* xx = work + S * (2 * B + 8) + s * 10;  // upper triangle of [x,1][x,1]^T, row-major
+        xx[0] = x.x * x.x; xx[1] = x.x * x.y; xx[2] = x.x * x.z; xx[3] = x.x;
+        xx[4] = x.y * x.y; xx[5] = x.y * x.z; xx[6] = x.y;
+        xx[7] = x.z * x.z; xx[8] = x.z; xx[9] = 1.f;
+      }
     }
     // the three (S,B) outputs, one pass each through the tile (values re-derived from the registers of the pass above)
     // skin_b = -(dist2_b + delta_b);  entropy = lse(skin) - max(skin)
@@ -489,18 +603,24 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz
       for (int b_ = 0; b_ < B; ++b_) row[b_] = bl.p[b_] * bl.sg[b_];  // coef[s][b] = p_b * sign_b
     }
     __syncthreads();
-    T::store(work, s0, n, tile);
-    __syncthreads();
+    if (FUSE) gram(n, 8, 0);  // g_se3 += coef^T gw   (ends with a barrier)
+    else { T::store(work, s0, n, tile); __syncthreads(); }
     if (active) {
 #pragma unroll
       for (int b_ = 0; b_ < B; ++b_) {
         const float gskin = bl.p[b_] * (gp[b_] - pg) + ge * (bl.p[b_] - (b_ == bl.anchor ? 1.f : 0.f));
         row[b_] = -2.f * gskin;  // gsk[s][b]
       }
+      if (FUSE) {  // upper triangle of [x,1][x,1]^T, row-major: the second operand of Q += gsk^T xx
+        float* xx = aux + threadIdx.x * AUXW;
+        xx[0] = x.x * x.x; xx[1] = x.x * x.y; xx[2] = x.x * x.z; xx[3] = x.x;
+        xx[4] = x.y * x.y; xx[5] = x.y * x.z; xx[6] = x.y;
+        xx[7] = x.z * x.z; xx[8] = x.z; xx[9] = 1.f;
+      }
     }
     __syncthreads();
-    T::store(work + S * (B + 8), s0, n, tile);
-    __syncthreads();
+    if (FUSE) gram(n, 10, B * 8);
+    else { T::store(work + S * (B + 8), s0, n, tile); __syncthreads(); }
     if (active) {
 #pragma unroll
       for (int b_ = 0; b_ < B; ++b_) {
@@ -513,6 +633,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz
     T::store(g_raw, s0, n, tile);
     __syncthreads();
   }
+  if (FUSE && cur_m >= 0) flush(cur_m);
 }
 
 // Gram matrix of the blend's bone-coordinate path from its per-frame second moments (see k_blend_bwd):
@@ -654,8 +775,8 @@ extern "C" int lab4d_bone_coords_backward(const float* xyz, const float* ar, con
   if (S == 0) return LAB4D_OK;
   hipStream_t st = (hipStream_t)stream;
   if (g_xyz) {
-    if (spf % 256 == 0) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_x<NB, true>), dim3(sgrid(S)), dim3(256), 0, st, ar, gauss, g_bone, (long)S, spf, g_xyz)); }
-    else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_x<NB, false>), dim3(sgrid(S)), dim3(256), 0, st, ar, gauss, g_bone, (long)S, spf, g_xyz)); }
+    if (spf % 256 == 0) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_x<NB, true, false>), dim3(sgrid(S)), dim3(256), 0, st, ar, gauss, g_bone, (long)S, spf, g_xyz, nullptr, nullptr)); }
+    else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_x<NB, false, false>), dim3(sgrid(S)), dim3(256), 0, st, ar, gauss, g_bone, (long)S, spf, g_xyz, nullptr, nullptr)); }
   }
   if (g_ar || g_ad || g_gauss) {
     LAB4D_REQUIRE(g_ar && g_ad && g_gauss, "bone_coords_backward: parameter gradients must be requested together");
@@ -664,6 +785,18 @@ extern "C" int lab4d_bone_coords_backward(const float* xyz, const float* ar, con
     SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_p<NB>), grid, dim3(256), 0, st, xyz, ar, ad, gauss, g_bone, (long)S, spf, chunk, g_ar, g_ad, g_gauss));
   }
   return check_launch("bone_coords_backward");
+}
+
+extern "C" int lab4d_bone_coords_backward_gram(const float* xyz, const float* ar, const float* gauss, const float* g_bone, int S, int spf, int M, int B,
+                                               float* g_xyz, float* G, void* stream) {
+  LAB4D_REQUIRE(xyz && ar && gauss && g_bone && g_xyz && G, "bone_coords_backward_gram: null pointer");
+  LAB4D_REQUIRE(spf > 0 && spf % 256 == 0 && (long)M * spf >= S, "bone_coords_backward_gram: needs spf %% 256 == 0 and M*spf >= S (got spf=%d)", spf);
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = zero_async(G, (size_t)M * 3 * B * 4 * sizeof(float), st)) return e;
+  if (S == 0) return LAB4D_OK;
+  int grid = sgrid(S); if (grid > 2048) grid = 2048;  // resident blocks: every block ends with 3B x 4 atomics onto the same M x 3B x 4 words
+  SKIN_DISPATCH(B, hipLaunchKernelGGL((k_bone_bwd_x<NB, true, true>), dim3(grid), dim3(256), 0, st, ar, gauss, g_bone, (long)S, spf, g_xyz, xyz, G));
+  return check_launch("bone_coords_backward_gram");
 }
 
 extern "C" int lab4d_bone_params_from_gram(const float* art_r, const float* art_d, const float* gauss, const float* G, int M, int B,
@@ -703,24 +836,34 @@ extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* art_r, c
   LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "skin_blend_backward: M*spf < S");
   if (S == 0) return LAB4D_OK;
   hipStream_t st = (hipStream_t)stream;
-  // work = [aff (M,B,12) | coef (S,B) | gw (S,8) | gsk (S,B) | xx (S,10) | Q (M,B,10) | G (M,B,12)]; aff first: its rows are
-  // read as float4 and the caller's buffer is 16-byte aligned
+  // work = [aff (M,B,12) | Q (M,B,10) | G (M,B,12)] and, for the unfused path only, behind them [coef (S,B) | gw (S,8) | gsk (S,B) | xx (S,10)];
+  // aff first: its rows are read as float4 and the caller's buffer is 16-byte aligned
   float* aff = work;
-  float* ws = work + (size_t)M * B * 12;
+  float* Q = work + (size_t)M * B * 12;   // (M,B,10), zero-filled here
+  float* G = Q + (size_t)M * B * 10;      // (M,B,3,4)
+  float* ws = G + (size_t)M * B * 12;
+  static const int fuse_env = getenv("LAB4D_BLEND_FUSE") ? atoi(getenv("LAB4D_BLEND_FUSE")) : 1;  // 0: the round-2 path (A/B measurements)
+  const bool fused = fuse_env && spf % 256 == 0 && g_se3 != nullptr;
+  const bool params = g_art_r || g_art_d || g_gauss;
   hipLaunchKernelGGL(k_bone_affine, dim3(div_up(M * B, 64)), dim3(64), 0, st, art_r, art_d, gauss, M, B, aff);
-  if (spf % 256 == 0) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, true>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
-                                      (long)S, spf, g_xyz, g_raw, ws)); }
-  else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, false>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
-                                      (long)S, spf, g_xyz, g_raw, ws)); }
-  if (int e = check_launch("skin_blend_backward")) return e;
-  if (g_se3)
-    if (int e = lab4d_gram_per_frame(ws, B, ws + (size_t)S * B, 8, S, spf, M, g_se3, stream)) return e;
-  if (g_art_r || g_art_d || g_gauss) {
-    // bone-coordinate path: per-frame moments -> Gram matrix -> (M,B)-sized chain rule
-    float* Q = ws + (size_t)S * (2 * B + 18);   // (M,B,10), zero-filled here
-    float* G = Q + (size_t)M * B * 10;            // (M,B,3,4)
+  if (fused || params)
     if (int e = zero_async(Q, (size_t)M * B * 10 * sizeof(float), st)) return e;
-    if (int e = lab4d_gram_per_frame(ws + (size_t)S * (B + 8), B, ws + (size_t)S * (2 * B + 8), 10, S, spf, M, Q, stream)) return e;
+  if (fused) {
+    // one resident set of blocks walking the samples (every block ends with B x 18 atomics onto the same M x B x 18 words)
+    int grid = sgrid(S); if (grid > 2048) grid = 2048;
+    SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, true, true>), dim3(grid), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
+                                        (long)S, spf, g_xyz, g_raw, ws, g_se3, Q));
+  } else if (spf % 256 == 0) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, true, false>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
+                                      (long)S, spf, g_xyz, g_raw, ws, g_se3, Q)); }
+  else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, false, false>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
+                                      (long)S, spf, g_xyz, g_raw, ws, g_se3, Q)); }
+  if (int e = check_launch("skin_blend_backward")) return e;
+  if (g_se3 && !fused)
+    if (int e = lab4d_gram_per_frame(ws, B, ws + (size_t)S * B, 8, S, spf, M, g_se3, stream)) return e;
+  if (params) {
+    // bone-coordinate path: per-frame moments -> Gram matrix -> (M,B)-sized chain rule
+    if (!fused)
+      if (int e = lab4d_gram_per_frame(ws + (size_t)S * (B + 8), B, ws + (size_t)S * (2 * B + 8), 10, S, spf, M, Q, stream)) return e;
     hipLaunchKernelGGL(k_bone_gram_from_moments, dim3(div_up(M * B, 64)), dim3(64), 0, st, art_r, art_d, gauss, Q, M, B, G);
     if (int e = check_launch("bone_gram_from_moments")) return e;
     return lab4d_bone_params_from_gram(art_r, art_d, gauss, G, M, B, g_art_r, g_art_d, g_gauss, stream);

@@ -19,6 +19,7 @@ _lib.register("lab4d_skin_blend_backward", [vp] * 10 + [ci] * 4 + [vp] * 7 + [vp
 _lib.register("lab4d_gram_per_frame", [vp, ci, vp, ci, ci, ci, ci, vp, vp])
 _lib.register("lab4d_bone_params_from_gram", [vp] * 4 + [ci] * 2 + [vp] * 3 + [vp])
 _lib.register("lab4d_bone_affine", [vp] * 3 + [ci] * 2 + [vp, vp])
+_lib.register("lab4d_bone_coords_backward_gram", [vp] * 4 + [ci] * 4 + [vp, vp, vp])
 
 # The delta-skin chain forms the bone coordinates in its own kernel (SkinChain); 0 restores the two-kernel form (A/B measurements).
 FUSE_BONE_COORDS = os.environ.get("LAB4D_FUSE_BONE", "1") != "0"
@@ -47,6 +48,20 @@ class BoneCoords(Function):
         S, (M, B) = xyz.shape[0], art_r.shape[:2]
         g = g.contiguous()
         gx = torch.empty_like(xyz)
+        need_p = any(ctx.needs_input_grad[1:4])
+        if need_p and ctx.spf % 256 == 0 and os.environ.get("LAB4D_BONE_FUSE", "1") != "0":
+            # one pass over the (S,3B) gradient: the point gradient and the per-frame Gram matrix of the parameter path together
+            G = torch.empty(M, 3 * B, 4, device=xyz.device)
+            with _lib.timed("k_bone_bwd_x+gram", (2.0 * S * 3 * B * 4, 4.0 * S * (3 + 3 + 3 * B))):
+                _lib.check(_lib.lib().lab4d_bone_coords_backward_gram(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(gauss), _lib.ptr(g), S, ctx.spf, M, B,
+                                                                      _lib.ptr(gx), _lib.ptr(G), _lib.stream()), "bone_coords_backward_gram")
+            need_r, need_d, need_g = ctx.needs_input_grad[1:4]
+            gar = torch.empty_like(art_r) if need_r else None
+            gad = torch.empty_like(art_d) if need_d else None
+            gg = torch.zeros_like(gauss) if need_g else None
+            _lib.check(_lib.lib().lab4d_bone_params_from_gram(_lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(G), M, B, _lib.ptr(gar),
+                                                              _lib.ptr(gad), _lib.ptr(gg), _lib.stream()), "bone_params_from_gram")
+            return gx, gar, gad, gg, None
         with _lib.timed("k_bone_bwd_x", (0.0, 4.0 * S * (3 + 3 * B))):
             _lib.check(_lib.lib().lab4d_bone_coords_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(g), S, ctx.spf,
                                                              M, B, _lib.ptr(gx), None, None, None, _lib.stream()), "bone_coords_backward")
@@ -140,10 +155,11 @@ class SkinBlend(Function):
         gar = torch.empty_like(art_r) if need_p else None
         gad = torch.empty_like(art_d) if need_p else None
         gg = torch.zeros_like(gauss) if need_p else None
-        work = torch.empty(S * (2 * B + 18) + M * B * 34, device=xyz.device)
-        # one entry for the whole adjoint (k_blend_bwd + its two per-frame Gram reductions): reads xyz, raw, g_out, g_ent, g_dskin; writes
-        # g_xyz, g_raw and the (S, 2B+18) work arrays, which the Gram reductions read once more
-        with _lib.timed("k_blend_bwd+gram", (0.0, 4.0 * S * ((3 + B + 3 + 2) + (3 + B) + 2 * (2 * B + 18)))):
+        fused = ctx.spf % 256 == 0 and os.environ.get("LAB4D_BLEND_FUSE", "1") != "0"  # include/lab4d_skin.h: the per-frame reductions inside the kernel
+        work = torch.empty(M * B * 34 + (0 if fused else S * (2 * B + 18)), device=xyz.device)
+        # one entry for the whole adjoint (k_blend_bwd incl. its two per-frame Gram reductions): reads xyz, raw, g_out, g_ent, g_dskin; writes
+        # g_xyz, g_raw (unfused: also the (S, 2B+18) work arrays, which the Gram kernels read once more)
+        with _lib.timed("k_blend_bwd+gram", (0.0, 4.0 * S * ((3 + B + 3 + 2) + (3 + B) + (0 if fused else 2 * (2 * B + 18))))):
             _lib.check(_lib.lib().lab4d_skin_blend_backward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
                                                             _lib.ptr(se3_r), _lib.ptr(se3_d), _lib.ptr(g_out), _lib.ptr(g_ent), _lib.ptr(g_dsk), S,
                                                             ctx.spf, M, B, _lib.ptr(gx), _lib.ptr(gr), _lib.ptr(gse3), _lib.ptr(gar), _lib.ptr(gad),
