@@ -141,6 +141,25 @@ def main():
     (kv * ck).sum().backward()
     out["intr"] = {"vals": kv.detach().clone(), "cot": ck, "all_frames": intr.get_vals().detach().clone(),
                    "grads": {k: p.grad.clone() for k, p in intr.named_parameters() if p.grad is not None}}
+    # ---- appearance code: AppearanceEmbedding.get_vals = Fourier(t) -> TimeEmbedding -> TimeMLP(D=2, W=64) -> Linear(64, 32) ----
+    appearance = importlib.import_module("lab4d.nnutils.appearance")
+    torch.manual_seed(13)
+    ae = appearance.AppearanceEmbedding(frame_info, 32)
+    with torch.no_grad():
+        for p_ in ae.parameters():  # away from the init (zero biases) so that every term counts
+            p_.add_(0.05 * torch.randn_like(p_))
+    ta = ae.time_embedding
+    probe = ta.frame_to_tid(torch.zeros(1, dtype=torch.long))
+    max_ts = float(ta.raw_fid_to_vidlen.max())
+    out["appr_state"] = {k: v.clone() for k, v in ae.state_dict().items()}
+    out["appr_time"] = {"num_freq_t": int(ta.fourier_embedding.N_freqs), "max_ts": max_ts,
+                        "time_scale": float(probe[0]) / (-(float(ta.raw_fid_to_vidlen[0]) / 2) / max_ts * 2)}
+    ae.zero_grad()
+    av = ae.get_vals(fid)
+    ca = torch.randn(len(fid), 32, generator=g)
+    (av * ca).sum().backward()
+    out["appr"] = {"vals": av.detach().clone(), "cot": ca, "all_frames": ae.get_vals().detach().clone(),
+                   "grads": {k: p_.grad.clone() for k, p_ in ae.named_parameters() if p_.grad is not None}}
     path = os.path.join(OUT_DIR, "pose.pt")
     torch.save(out, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; matrix_to_quaternion branches:", out["fk"]["branch_hist"].tolist())

@@ -1,0 +1,120 @@
+"""fp32 noise floor of the REFERENCE arithmetic on every parity fixture: the oracle (oracle/lab4d_oracle.py, the CPU restatement pinned to the
+reference) evaluated in float32 and in float64 on the same inputs.  The difference is what ANY fp32 implementation with a different order of
+accumulation can differ from the reference by (discrete events included: a ReLU unit or an importance-sampling bin that flips between the
+two precisions); the device parity bounds of tests/test_gpu_field.py that exceed north_star's 1e-4 are held against it.
+
+    python tests/measure_fp32_noise_floor.py [case ...]      -> tests/golden/fp32_noise_floor.json (merged)
+
+TEST INFRASTRUCTURE ONLY.  Metrics: rendered / per-sample / loss entries = max |a - b| / max |b|; gradients = relative L2 (the metrics of the tests)."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from lab4d_amd import synthetic  # noqa: E402
+from oracle import lab4d_oracle as O  # noqa: E402
+
+OUT = os.path.join(HERE, "golden", "fp32_noise_floor.json")
+TRAIN = ["train_small", "train_alpha", "train_multi", "train_compmotion", "train_human", "train_rigid", "train_dense", "train_c1", "train_bench"]
+EVAL = ["eval_small", "eval_rigid", "eval_dense"]
+
+
+def to(x, dt):
+    if torch.is_tensor(x):
+        return x.to(dt) if x.dtype.is_floating_point else x
+    if isinstance(x, tuple):
+        return tuple(to(t, dt) for t in x)
+    if isinstance(x, dict):
+        return {k: to(v, dt) for k, v in x.items()}
+    return x
+
+
+def weights_of(meta):
+    motion = meta.get("fg_motion", "skel-quad")
+    P = synthetic.make_weights(meta["seed"], num_inst=meta.get("num_inst", 1), sdf_bias=meta.get("sdf_bias"), num_bones=18 if "skel-human" in motion else 25,
+                               motion=motion if motion in ("rigid", "dense") else "skinning")
+    if motion.startswith("comp_"):
+        P = synthetic.add_dense_weights(P, meta["seed"], meta.get("num_inst", 1))
+    return P
+
+
+def relmax(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-300))
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+def train_case(name):
+    g = torch.load(os.path.join(HERE, "golden", name + ".pt"), weights_only=False)
+    meta = g["meta"]
+    if "hxy" in g:
+        hxy0, batch0 = g["hxy"], g["batch"]
+    else:
+        hxy0 = synthetic.make_rays(meta["res"], meta["M"], rows=meta.get("rows"))
+        batch0 = synthetic.make_targets(meta["seed"] + 3, meta["M"], hxy0.shape[1], meta["res"], hxy0)
+
+    def run(dt):
+        P = {k: (to(v, dt).clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else to(v, dt)) for k, v in weights_of(meta).items()}
+        fr = synthetic.add_codes(to(dict(g["frames"]), dt), P)
+        batch = to(batch0, dt)
+        fr["feature"] = batch["feature"]
+        res = O.render_train(P, fr, to(hxy0, dt), g["rng"], flow_thresh=meta["flow_thresh"], n_depth=meta["D"], alpha=meta["alpha"])
+        losses = O.recon_losses_fg(res, batch, meta["res"], O.DEFAULT_LOSS_WT)
+        names = [k for k, v in P.items() if v.requires_grad]
+        total = sum(v for v in losses.values() if bool(torch.isfinite(v)))
+        gr = torch.autograd.grad(total, [P[k] for k in names], allow_unused=True)
+        return res, losses, {k: v for k, v in zip(names, gr) if v is not None}
+
+    (r32, l32, g32), (r64, l64, g64) = run(torch.float32), run(torch.float64)
+    out = {}
+    for k, v in r32["rendered"].items():
+        out["rendered." + k] = relmax(v, r64["rendered"][k])
+    for k, v in r32["aux_dict"]["fg"].items():
+        out["aux_fg." + k] = relmax(v, r64["aux_dict"]["fg"][k])
+    for k, v in l32.items():
+        if bool(torch.isfinite(v)):
+            out["loss." + k] = relmax(v, l64[k])
+    for k, v in g32.items():
+        out["grad." + k] = rel_l2(v, g64[k])
+        out["gradmax." + k] = relmax(v, g64[k])
+    return out
+
+
+def eval_case(name):
+    g = torch.load(os.path.join(HERE, "golden", name + ".pt"), weights_only=False)
+    meta = g["meta"]
+
+    def run(dt):
+        P = to(weights_of(meta), dt)
+        fr = synthetic.add_codes(to(dict(g["frames"]), dt), P)
+        out = O.render_eval(P, fr, to(g["hxy"], dt), n_depth=meta["D"])
+        fd, _, _ = O.query_field_eval(P, fr, to(g["hxy"], dt), n_depth=meta["D"])
+        return out, fd
+
+    (o32, f32), (o64, f64) = run(torch.float32), run(torch.float64)
+    out = {"index_mismatch_count": float((o32["debug"]["inds"] != o64["debug"]["inds"]).sum())}
+    for k, v in o32["rendered"].items():
+        out["rendered." + k] = relmax(v, o64["rendered"][k])
+    for k, v in f32.items():
+        out["feat_dict." + k] = relmax(v, f64[k])
+    return out
+
+
+def main(cases):
+    torch.set_num_threads(os.cpu_count() or 8)
+    res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    for c in cases:
+        t = time.time()
+        res[c] = {k: float("%.3e" % v) for k, v in (train_case(c) if c in TRAIN else eval_case(c)).items()}
+        print(c, "%.1f s" % (time.time() - t), "worst:", sorted(((v, k) for k, v in res[c].items() if not k.startswith("gradmax")), reverse=True)[:3])
+        json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or TRAIN + EVAL)

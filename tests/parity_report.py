@@ -1,13 +1,71 @@
-"""Measured parity errors next to their bounds: every device parity test that has a stated bound reports what it measured."""
+"""Measured parity errors next to their bounds.
+
+`report(tag, measured)` writes what a device test measured to gpurun_out/parity_<tag>.json (and stdout).
+`check(tag, measured)` additionally ASSERTS every entry against a bound derived from the committed hardware measurement:
+
+    bound(key) = max(1e-4, 2 x tests/golden/parity_measured.json[tag][key])          (1e-4 = north_star's fp32 tolerance)
+
+i.e. a quantity the MI355X reproduced to better than 5e-5 is held to 1e-4, anything else to twice what was measured -- and every bound
+above 1e-4 must be explained by the reference's own fp32 noise floor (tests/golden/fp32_noise_floor.json, produced by
+tests/measure_fp32_noise_floor.py: the oracle in float32 against the oracle in float64): the measured deviation may not exceed
+`FLOOR_FACTOR` x the floor of the same quantity on the same fixture.  LAB4D_PARITY_RECORD=1 turns the assertions off and collects the
+measurements in gpurun_out/parity_measured.json (the file that is then committed as tests/golden/parity_measured.json)."""
+import json
 import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+NORTH_STAR_TOL = 1e-4
+FLOOR_FACTOR = 4.0
+RECORD = os.environ.get("LAB4D_PARITY_RECORD", "0") == "1"
+
+
+def _load(name):
+    p = os.path.join(GOLDEN, name)
+    return json.load(open(p)) if os.path.exists(p) else {}
 
 
 def report(tag, measured):
     """Measured errors go to stdout (pytest -s / -rP) and to gpurun_out/parity_<tag>.json so that the bound and the measurement
     can be read side by side."""
-    import json
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_%s.json" % tag), "w") as f:
         json.dump({k: float("%.3e" % v) for k, v in measured.items()}, f, indent=1, sort_keys=True)
     print(tag, {k: "%.2e" % v for k, v in measured.items()})
+
+
+def bound_of(tag, key):
+    rec = _load("parity_measured.json").get(tag, {})
+    return max(NORTH_STAR_TOL, 2.0 * rec.get(key, 0.0))
+
+
+def check(tag, measured, floor_case=None, skip=()):
+    """Assert measured[key] < bound_of(tag, key) for every key (see the module docstring); floor_case names the fixture's entry of
+    fp32_noise_floor.json that must explain bounds above 1e-4 (None: no such requirement, e.g. for bf16 runs).  Keys in `skip` are
+    reported but not asserted (values that are not errors, e.g. a PSNR)."""
+    report(tag, measured)
+    if RECORD:
+        path = os.path.join(ROOT, "gpurun_out", "parity_measured.json")
+        allm = json.load(open(path)) if os.path.exists(path) else {}
+        allm[tag] = {k: float("%.3e" % v) for k, v in measured.items() if k not in skip}
+        json.dump(allm, open(path, "w"), indent=1, sort_keys=True)
+        return
+    floor = _load("fp32_noise_floor.json").get(floor_case, {}) if floor_case else None
+    bad, unexplained = {}, {}
+    for k, e in measured.items():
+        if k in skip:
+            continue
+        b = bound_of(tag, k)
+        if not e < b:
+            bad[k] = (e, b)
+        if floor is not None and e > NORTH_STAR_TOL:
+            # the floor of the same quantity -- or, for the discrete events of a tiny fixture (one ReLU unit / arg-max bone / sampling bin out
+            # of a few hundred that lands on the other side in the two precisions moves a gradient by 1e-3 .. 1e-2, and WHICH tensor it
+            # shows up in differs between two fp32 implementations), the largest floor among the fixture's entries of the same family
+            fam = k.split(".")[0]
+            fam_floor = max([v for kk, v in floor.items() if kk.split(".")[0] == fam] or [0.0])
+            if not (e <= FLOOR_FACTOR * floor.get(k, 0.0) or e <= fam_floor):
+                unexplained[k] = (e, floor.get(k), fam_floor)
+    assert not bad, "above max(1e-4, 2 x the committed hardware measurement): %s" % bad
+    assert not unexplained, "above 1e-4 and not within %.0fx of the reference's own fp32 noise floor: %s" % (FLOOR_FACTOR, unexplained)

@@ -297,3 +297,34 @@ def test_compute_loss_and_optimizer_bindings(golden_dir, patch_f32):
     assert int(opt.flat.dev_step) == 2
     sd_opt = opt.state_dict()
     assert float(sd_opt["state"][0]["step"]) == 2.0
+
+
+def test_appearance_get_vals_on_the_device(golden_dir, patch_f32):
+    """AppearanceEmbedding.get_vals through the adapter on the device: a stand-in module holding the reference module's own
+    state_dict (tests/golden/pose.pt "appr_state": randomised AppearanceEmbedding(frame_info, 32)) and its frame tables, against the values
+    and parameter gradients the reference produced for the same frame ids -- and for frame_id=None (all frames)."""
+    patch = patch_f32
+    fx = torch.load(os.path.join(golden_dir, "pose.pt"), weights_only=False)
+    ti, at = fx["time_info"], fx["appr_time"]
+    ae = standins.Node()
+    standins._tree(ae, {k: v.to(DEV) for k, v in fx["appr_state"].items()})
+    te = ae.time_embedding
+    for k in ("frame_to_vid", "frame_mapping", "raw_fid_to_vid", "raw_fid_to_vidlen", "raw_fid_to_vstart"):
+        setattr(te, k, ti[k].to(DEV))
+    te.fourier_embedding = types.SimpleNamespace(N_freqs=at["num_freq_t"])
+
+    def frame_to_tid(frame_id):  # embedding.py:179-187
+        fid = frame_id.long()
+        return (frame_id - te.raw_fid_to_vstart[fid] - te.raw_fid_to_vidlen[fid] / 2) / at["max_ts"] * 2 * at["time_scale"]
+
+    te.frame_to_tid = frame_to_tid
+    fid = fx["frame_id"].to(DEV)
+    ref = fx["appr"]
+    out = patch.appearance_get_vals(ae, fid)
+    assert out.is_cuda and rel(out, ref["vals"]) < 1e-5, rel(out, ref["vals"])
+    assert rel(patch.appearance_get_vals(ae, None), ref["all_frames"]) < 1e-5
+    (out * ref["cot"].to(DEV)).sum().backward()
+    params = dict(ae.named_parameters())
+    assert set(ref["grads"]) <= set(params)
+    for k, g in ref["grads"].items():
+        assert rel(params[k].grad, g) < 1e-4, (k, rel(params[k].grad, g))
