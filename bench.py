@@ -56,10 +56,12 @@ def parse():
     ap.add_argument("--chunk-rows", type=int, default=None, help="image rows per frame per chunk (default 128 rows x 512 = 65536 rays/frame = 16.8 M samples per chunk, 195 GiB of the 288 GB: "
                                                                 "fewer, larger launches -- 64-row chunks measured 2.4 %% slower, 32-row chunks 8 %%)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--config", default="fg", choices=["fg", "comp", "hash"],
+    ap.add_argument("--config", default="fg", choices=["fg", "comp", "multi", "hash"],
                     help="fg: BASELINE configs[1] (the headline metric).  comp: BASELINE configs[2]'s per-GPU shape -- fg field with the 18-joint human skeleton and "
                          "composed motion (comp_skel-human_dense) + background field, compose_fields, comp losses; spp/2 samples per field.  hash: BASELINE configs[4]'s "
-                         "per-GPU shape -- a field on the multiresolution hash encoding (no reference counterpart), 1024x1024, 256 samples/ray (--res / --spp default to those)")
+                         "per-GPU shape -- a field on the multiresolution hash encoding (no reference counterpart), 1024x1024, 256 samples/ray (--res / --spp default to those).  "
+                         "multi: BASELINE configs[3]'s per-GPU shape -- the fg field of a 10-video category model (num_inst=10: per-instance codes in every CondMLP, "
+                         "fg_motion comp_skel-quad_dense: shared quadruped skeleton + dense post-warp), a frame pair of one of the videos")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays per frame of one CPU-baseline pass (1 warm-up + 3 timed passes)")
@@ -77,11 +79,23 @@ def parse():
     a.res_given, a.spp_given, a.chunk_rows_given = "--res" in sys.argv, "--spp" in sys.argv, a.chunk_rows is not None
     if a.chunk_rows is None:
         a.chunk_rows = 128 if a.dtype == "bf16" else 64  # fp32 activations are twice the size
+        if a.config == "multi":
+            a.chunk_rows //= 2  # three dense post-warp chains more per sample: a 128-row chunk does not fit 288 GB
     return a
 
 
-def make_problem(res, device, comp=False):
+def make_problem(res, device, comp=False, multi=False):
     from lab4d_amd import synthetic
+    if multi:  # Deformable("comp_skel-quad_dense", num_inst=10): 25 bones + dense post-warp, 10 instance codes per CondMLP
+        w = synthetic.add_dense_weights(synthetic.make_weights(0, num_inst=10), 0, num_inst=10)
+        P = synthetic.to_device(w, device)
+        for k, v in P.items():
+            if v.dtype.is_floating_point and k != "aabb":
+                v.requires_grad_(True)
+        fr0 = synthetic.make_frames(1, 2, res, num_inst=10)
+        fr0["inst_id"] = torch.full((2,), 3, dtype=torch.long)  # both frames of the pair come from video 3
+        fr = synthetic.to_device(synthetic.add_codes(fr0, w), device)
+        return P, fr
     if comp:  # MultiFields(field_type="comp", fg_motion="comp_skel-human_dense"): 18 bones + dense post-warp
         w = synthetic.add_dense_weights(synthetic.make_weights(0, num_bones=18), 0)
         P = synthetic.to_device(w, device)
@@ -137,6 +151,10 @@ def train_chunk(DF, P, fr, hxy, batch, rng, spp, res, prec):
 # dense post-warps of 117,248 MAC (backward map once, forward map twice), bg 162,432 MAC/sample
 def comp_flop_per_ray(d_field):
     return 3 * 2 * d_field * (918912 + 3 * 117248 + 162432)
+
+
+def multi_flop_per_ray(d):
+    return 3 * 2 * d * (918912 + 3 * 117248)  # the fg field with the dense post-warp in all three warps
 
 
 def train_chunk_comp(DF, P, fr, Pb, frb, hxy, batch, rng, spp, res, prec):
@@ -229,27 +247,46 @@ def psnr_vs_reference(dev):
     return out
 
 
-def cpu_baseline(res, spp, n_rays):
-    """The oracle (CPU port of the reference algorithm) on a bounded sample of the same workload."""
+def cpu_baseline(res, spp, n_rays, config="fg"):
+    """The oracle (CPU port of the reference algorithm) on a bounded sample of the same workload (same field configuration)."""
     from lab4d_amd import synthetic
     from oracle import lab4d_oracle as O
     # PyTorch's intra-op pool stops scaling (and collapses from oversubscription) well below the 256
     # hardware threads of the GPU host on these small per-sample ops; 32 threads measured best.
     threads = min(os.cpu_count(), 32)
     torch.set_num_threads(threads)
-    P = synthetic.make_weights(0)
-    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v) for k, v in P.items()}
-    fr0 = synthetic.make_frames(1, 2, res)
+    leaf = lambda P: {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v) for k, v in P.items()}  # noqa: E731
+    Pb = frb0 = None
+    if config == "comp":
+        P = leaf(synthetic.add_dense_weights(synthetic.make_weights(0, num_bones=18), 0))
+        fr0 = synthetic.make_frames(1, 2, res, num_bones=18)
+        Pb = leaf(synthetic.make_bg_weights(0))
+        frb0 = synthetic.make_bg_frames(1, 2, res)
+    elif config == "multi":
+        P = leaf(synthetic.add_dense_weights(synthetic.make_weights(0, num_inst=10), 0, num_inst=10))
+        fr0 = synthetic.make_frames(1, 2, res, num_inst=10)
+        fr0["inst_id"] = torch.full((2,), 3, dtype=torch.long)
+    else:
+        P = leaf(synthetic.make_weights(0))
+        fr0 = synthetic.make_frames(1, 2, res)
     g = torch.Generator().manual_seed(0)
     hxy = torch.cat([torch.rand(2, n_rays, 2, generator=g) * res, torch.ones(2, n_rays, 1)], -1)
     batch = synthetic.make_targets(2, 2, n_rays, res, hxy)
-    S = 2 * n_rays * spp
-    rng = {"eik_inds": torch.randperm(2 * n_rays, generator=g)[: max(2 * n_rays // 16, 1)], "match_perm": torch.randperm(S, generator=g)[:1024]}
+    d_field = spp // 2 if config == "comp" else spp
+    S = 2 * n_rays * d_field
+    eik = torch.randperm(2 * n_rays, generator=g)[: max(2 * n_rays // 16, 1)]
+    rng = {"eik_inds": eik, "eik_inds_bg": eik, "match_perm": torch.randperm(S, generator=g)[:1024]}
+
     def one_pass(h, b, r):
         f = synthetic.add_codes(dict(fr0), P)
         f["feature"] = b["feature"]
-        out = O.render_train(P, f, h, r, flow_thresh=float(res), n_depth=spp)
-        sum(O.recon_losses_fg(out, b, res, O.DEFAULT_LOSS_WT).values()).backward()
+        if config == "comp":
+            frb = synthetic.add_bg_codes(dict(frb0), Pb)
+            out = O.render_train_comp(P, f, Pb, frb, h, r, flow_thresh=float(res), n_depth=d_field)
+            sum(O.recon_losses_comp(out, b, res, O.DEFAULT_LOSS_WT).values()).backward()
+        else:
+            out = O.render_train(P, f, h, r, flow_thresh=float(res), n_depth=spp)
+            sum(O.recon_losses_fg(out, b, res, O.DEFAULT_LOSS_WT).values()).backward()
 
     # SURVEY 8d protocol: 1 warm-up pass + median of 3 timed passes of the same sample
     one_pass(hxy, batch, rng)
@@ -260,10 +297,10 @@ def cpu_baseline(res, spp, n_rays):
         ts.append(time.perf_counter() - t0)
     dt = sorted(ts)[1]
     out = {"value": 2 * n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-           "sample": "oracle (torch-CPU fp32 port of the reference path) fwd+bwd, 2 frames x %d rays x %d samples, 1 warm-up + median of 3 "
-                     "passes (%.1f s each)" % (n_rays, spp, dt)}
+           "sample": "oracle (torch-CPU fp32 port of the reference path, configuration %r) fwd+bwd, 2 frames x %d rays x %d samples, 1 warm-up + median of 3 "
+                     "passes (%.1f s each)" % (config, n_rays, spp, dt)}
     ref = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
-    if os.path.exists(ref):  # the REFERENCE's own code timed in the build container (it cannot run on the GPU box): cited, not re-measured
+    if config == "fg" and os.path.exists(ref):  # the REFERENCE's own code timed in the build container (it cannot run on the GPU box): cited, not re-measured
         out["reference_in_build_container"] = json.load(open(ref))
     return out
 
@@ -431,7 +468,7 @@ class TrainLoop:
     FlatAdamW.  `step()` = zero_grad -> prologue -> every chunk (hipGraph replay or eager) -> prologue backward -> [all-reduce] ->
     check_grad + AdamW -> repack.  bench.py times it; tests/test_gpu_ztrajectory.py runs it for 30+ steps."""
 
-    def __init__(self, dev, res, spp, chunks, prec, comp=False, use_graph=True, use_dist=False, world=1, rank=0, trace=False, lr=5e-4):
+    def __init__(self, dev, res, spp, chunks, prec, comp=False, use_graph=True, use_dist=False, world=1, rank=0, trace=False, lr=5e-4, multi=False):
         from lab4d_amd import mlp
         from lab4d_amd import deformable as DF
         from lab4d_amd.optim import FlatAdamW
@@ -441,7 +478,7 @@ class TrainLoop:
         if comp:
             P, fr, Pb, frb = make_problem(res, dev, comp=True)
         else:
-            P, fr = make_problem(res, dev)
+            P, fr = make_problem(res, dev, multi=multi)
         self.P, self.Pb = P, Pb
         self.params = [v for k, v in P.items() if v.dtype.is_floating_point and v.requires_grad] + (list(Pb.values()) if comp else [])
         self.param_names = [k for k, v in P.items() if v.dtype.is_floating_point and v.requires_grad] + (["bg." + k for k in Pb] if comp else [])
@@ -587,7 +624,7 @@ def rank_main(a):
     _lib.lib()
     prec = mlp.PREC_BF16 if a.dtype == "bf16" else mlp.PREC_F32
     res, spp = a.res, a.spp
-    comp = a.config == "comp"
+    comp, multi = a.config == "comp", a.config == "multi"
 
     # strong scaling: this rank renders rows rank::world of both frames, its chunks interleave those rows again
     plan = rank_plan(rank, world, res, a.chunk_rows, spp) if not a.emulate_rank_of else rank_plan(0, a.emulate_rank_of, res, a.chunk_rows, spp)
@@ -597,7 +634,7 @@ def rank_main(a):
     # through one first-order backward, compositing) of the same rays.  Measured before the training graph is captured
     # (its 150 GiB private pool would leave the allocator thrashing), half a training chunk per call.
     eval_result = None
-    if world == 1 and rank == 0 and not comp and not a.trace:
+    if world == 1 and rank == 0 and not comp and not multi and not a.trace:
         try:
             P_e, fr_e = make_problem(res, dev)
             inputs_e = [chunk_inputs(res, None, rows, dev, seed=100 + i) for i, rows in enumerate(plan["chunks"])]
@@ -608,7 +645,8 @@ def rank_main(a):
         mlp.clear_caches()
         torch.cuda.empty_cache()
 
-    loop = TrainLoop(dev, res, spp, plan["chunks"], prec, comp=comp, use_graph=not a.no_graph, use_dist=use_dist, world=world, rank=rank, trace=a.trace)
+    loop = TrainLoop(dev, res, spp, plan["chunks"], prec, comp=comp, use_graph=not a.no_graph, use_dist=use_dist, world=world, rank=rank, trace=a.trace,
+                     multi=multi)
     opt, params, inputs, step = loop.opt, loop.params, loop.inputs, loop.step
     M, N0, S0, gen = loop.M, loop.N0, loop.S0, loop.gen
     graph = loop.graph
@@ -703,12 +741,15 @@ def rank_main(a):
             roofline.update({"traffic_source": pmc.get("_source") if roofline["traffic"] else None, "measured": prof_src,
                              "others": [roof(k, *v) for k, v in ranked[1:4]],
                              "kernels_ms_per_step": {k: round(v[1] / n_prof_chunks * len(inputs), 2) for k, v in sorted(prof.items())}})
+        flop_per_ray = comp_flop_per_ray(spp // 2) if comp else (multi_flop_per_ray(spp) if multi else spp * FLOP_PER_SAMPLE)
         out = {
             "metric": "rendered rays/sec (fwd+bwd) at 512\u00b2 \u00d7 128 samples; PSNR vs ref", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": ("human-48-shaped fg+bg composite (MultiFields comp: fg Deformable comp_skel-human_dense, 18 bones + dense post-warp; bg NeRF), "
                                     "%dx%d frame pair, %d + %d samples/ray composed, training graph fwd+bwd+AdamW" % (res, res, spp // 2, spp // 2)) if comp else
+                                   ("10-video category model (RAC): fg Deformable comp_skel-quad_dense with num_inst=10 (25 bones + dense post-warp, per-instance codes), "
+                                    "%dx%d frame pair of one video, %d samples/ray, training graph fwd+bwd+AdamW" % (res, res, spp)) if multi else
                                    "cat-pikachu fg NeRF (Deformable skel-quad, 25 bones), %dx%d frame pair, %d samples/ray, training graph fwd+bwd+AdamW"
                                    % (res, res, spp), "rays_per_step": rays_per_step, "chunk_rays": 2 * a.chunk_rows * res,
                        "parallelism": "rows dealt round-robin to %d rank(s) and to each rank's chunks, one RCCL all-reduce of the flat fp32 gradient (%d elements) per step" % (world, opt.n),
@@ -719,8 +760,8 @@ def rank_main(a):
             "rank_ms_per_step": [round(x, 2) for x in rank_ms], "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
             "rank_plan": {k: plan[k] for k in ("rows", "chunk_sizes", "rays_per_step", "est_peak_hbm_gib")},
             "peak_hbm_gib": round(peak_hbm / 2**30, 1),
-            "whole_graph_tflops": round(value * (comp_flop_per_ray(spp // 2) if comp else spp * FLOP_PER_SAMPLE) / 1e12, 2),
-            "whole_graph_frac_of_peak": round(value * (comp_flop_per_ray(spp // 2) if comp else spp * FLOP_PER_SAMPLE) / peak, 4),
+            "whole_graph_tflops": round(value * flop_per_ray / 1e12, 2),
+            "whole_graph_frac_of_peak": round(value * flop_per_ray / peak, 4),
             "roofline": roofline,
             # sanity of the timed work: the loss of the last chunk and whether every parameter is still finite after the timed optimizer steps
             "emulated": None if not a.emulate_rank_of else {"rank_0_of": a.emulate_rank_of, "note": "rank 0's share of the strong-scaling job on one GPU, no collective: "
@@ -732,13 +773,15 @@ def rank_main(a):
             out["eval_forward_only"] = eval_result
         if comp:
             out["metric"] = "rendered rays/sec (fwd+bwd), fg+bg composite at 512\u00b2 (BASELINE configs[2] per-GPU shape; not the headline metric)"
-        if world == 1 and not comp:
+        if multi:
+            out["metric"] = "rendered rays/sec (fwd+bwd), 10-instance category model at 512\u00b2 (BASELINE configs[3] per-GPU shape; not the headline metric)"
+        if world == 1 and not comp and not multi:
             try:
                 out["psnr_vs_ref_db"] = psnr_vs_reference(dev)
             except Exception as e:
                 out["psnr_vs_ref_db"] = {"error": repr(e)[:200]}
-        if world == 1 and not a.no_cpu_baseline and not comp:
-            out["cpu_baseline"] = cpu_baseline(res, spp, a.cpu_rays)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(res, spp, a.cpu_rays, a.config)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -107,7 +107,7 @@ LAB4D_HD void sample_pdf_ray(const float* __restrict__ b, const float* __restric
   for (int k = 0; k < n_imp; ++k) {
     // torch.linspace (CPU): start + step*k for the first half, end - step*(n-1-k) for the second, the latter evaluated with a
     // FUSED multiply-add by its vectorised kernel -- fmaf reproduces it bit for bit for every n (checked for n = 16..128 in
-    // tests/test_oracle_properties.py::test_linspace_arithmetic); an unfused product does not (n = 16, 64, 128 differ)
+    // tests/test_sample_pdf_host.py::test_linspace_arithmetic); an unfused product does not (n = 16, 64, 128 differ)
     const float u = u_in ? u_in[k] : ((k < n_imp / 2) ? mul_rn(step, (float)k) : fmaf(-step, (float)(n_imp - 1 - k), 1.0f));
     while (j <= n_w && c_hi <= u) {  // advance while cdf[j] <= u
       c_lo = c_hi;

@@ -526,6 +526,10 @@ def main(only=None):
         ("train_rigid", lambda: gen_train(ns, "rigid", M=2, N=6, D=8, res=64, seed=91, fg_motion="rigid")),
         ("train_dense", lambda: gen_train(ns, "dense", M=2, N=6, D=8, res=64, seed=101, fg_motion="dense", frame_id=[7, 8])),
         ("train_multi", lambda: gen_train(ns, "multi", M=4, N=5, D=6, res=64, seed=31, num_inst=3, inst_id=[1, 1, 2, 2], frame_id=[22, 23, 44, 45])),
+        # BASELINE configs[3]'s field: 10 videos (num_inst=10, per-instance codes in every CondMLP) with fg_motion comp_skel-quad_dense; a pair of video 3
+        # and a pair of video 7 (frames 21-22 / 46-47 of the 64-frame, 10-video synthetic set)
+        ("train_multi10", lambda: gen_train(ns, "multi10", M=4, N=5, D=6, res=64, seed=111, num_inst=10, inst_id=[3, 3, 7, 7], frame_id=[21, 22, 46, 47],
+                                            fg_motion="comp_skel-quad_dense")),
         # BASELINE config 0: 64x64 crop x 64 samples
         ("train_c1", lambda: gen_train(ns, "c1", M=2, N=None, D=64, res=64, seed=41, full_grid_stride=16)),
         # BASELINE config 1 = the bench shape: 512x512, 128 samples/ray; a 2-row band (rows 255-256: half inside the target mask's

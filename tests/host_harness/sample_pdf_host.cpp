@@ -13,3 +13,9 @@ extern "C" int sample_pdf_host(const float* bins, const float* weights, const fl
                               samples + (long)r * n_imp, (int64_t*)inds + (long)r * n_imp);
   return 0;
 }
+
+// the det=True queries of sample_pdf_ray, alone: u_k of torch.linspace(0, 1, n)
+extern "C" void linspace01_host(int n, float* out) {
+  const float step = 1.0f / (float)(n - 1);
+  for (int k = 0; k < n; ++k) out[k] = (k < n / 2) ? lab4d_pdf::mul_rn(step, (float)k) : fmaf(-step, (float)(n - 1 - k), 1.0f);
+}

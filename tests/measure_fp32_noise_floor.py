@@ -19,7 +19,7 @@ from lab4d_amd import synthetic  # noqa: E402
 from oracle import lab4d_oracle as O  # noqa: E402
 
 OUT = os.path.join(HERE, "golden", "fp32_noise_floor.json")
-TRAIN = ["train_small", "train_alpha", "train_multi", "train_compmotion", "train_human", "train_rigid", "train_dense", "train_c1", "train_bench"]
+TRAIN = ["train_small", "train_alpha", "train_multi", "train_multi10", "train_compmotion", "train_human", "train_rigid", "train_dense", "train_c1", "train_bench"]
 EVAL = ["eval_small", "eval_rigid", "eval_dense"]
 
 
@@ -65,6 +65,10 @@ def train_case(name):
         batch = to(batch0, dt)
         fr["feature"] = batch["feature"]
         res = O.render_train(P, fr, to(hxy0, dt), g["rng"], flow_thresh=meta["flow_thresh"], n_depth=meta["D"], alpha=meta["alpha"])
+        if "hxy" in g:  # the small fixtures also pin the per-sample fields
+            with torch.no_grad():
+                res["feat_dict"], res["deltas"], _ = O.query_field_train(P, fr, to(hxy0, dt), g["rng"], flow_thresh=meta["flow_thresh"], n_depth=meta["D"],
+                                                                        alpha=meta["alpha"])
         losses = O.recon_losses_fg(res, batch, meta["res"], O.DEFAULT_LOSS_WT)
         names = [k for k, v in P.items() if v.requires_grad]
         total = sum(v for v in losses.values() if bool(torch.isfinite(v)))
@@ -75,6 +79,8 @@ def train_case(name):
     out = {}
     for k, v in r32["rendered"].items():
         out["rendered." + k] = relmax(v, r64["rendered"][k])
+    for k, v in r32.get("feat_dict", {}).items():
+        out["feat_dict." + k] = relmax(v, r64["feat_dict"][k])
     for k, v in r32["aux_dict"]["fg"].items():
         out["aux_fg." + k] = relmax(v, r64["aux_dict"]["fg"][k])
     for k, v in l32.items():

@@ -100,7 +100,7 @@ def _load_case(golden_dir, name):
 
 
 @pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_multi.pt", "train_compmotion.pt", "train_human.pt", "train_rigid.pt",
-                                  "train_dense.pt"])
+                                  "train_dense.pt", "train_multi10.pt"])
 def test_training_graph_against_reference(golden_dir, case):
     """train_multi: BASELINE config 4's shape -- 3 instances, two frame pairs from different videos, per-instance codes.
     train_compmotion: fg_motion "comp_skel-quad_dense" (BASELINE configs 2-3): every warp of the graph is the ComposedWarp.

@@ -50,6 +50,17 @@ def test_row_normaliser_equals_torch_sum_bit_for_bit(host, n):
         assert np.float32(got) == ref[r].numpy(), (n, r, got, float(ref[r]))
 
 
+def test_linspace_arithmetic(host):
+    """The det=True queries: torch.linspace(0, 1, n) on the CPU is start + step * k for the first half and end - step * (n - 1 - k) -- evaluated with a
+    FUSED multiply-add by ATen's vectorised kernel -- for the second; the header's formula gives the same floats for every n the renderer can
+    use (n_depth // 2 for n_depth = 4 .. 512)."""
+    host.linspace01_host.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    for n in list(range(2, 260)) + [300, 512, 1000]:
+        out = np.empty(n, np.float32)
+        host.linspace01_host(n, out.ctypes.data)
+        assert np.array_equal(out, torch.linspace(0, 1, n).numpy()), n
+
+
 def run(host, bins, w, n_imp, u_sorted=None):
     R, n_w = w.shape
     s = np.empty((R, n_imp), np.float32)
