@@ -8,4 +8,4 @@ CMD="python $R/tools/bench_mlp.py 16777216 1"
 timeout -k 5 100 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch -- $CMD > /tmp/pmc_fetch.log 2>&1 || { echo "fetch pass failed"; tail -5 /tmp/pmc_fetch.log; exit 1; }
 timeout -k 5 100 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write -- $CMD > /tmp/pmc_write.log 2>&1 || { echo "write pass failed"; tail -5 /tmp/pmc_write.log; exit 1; }
 mkdir -p $R/gpurun_out
-python $R/tools/pmc_summary.py /tmp/pmc_fetch /tmp/pmc_write $R/gpurun_out/r02_pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over: tools/bench_mlp.py 16777216 1 (basefield + colourfield chains and their weight gradients at the bench's launch size)"
+python $R/tools/pmc_summary.py /tmp/pmc_fetch /tmp/pmc_write $R/gpurun_out/r03_pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over: tools/bench_mlp.py 16777216 1 (basefield + colourfield chains and their weight gradients at the bench's launch size)"
