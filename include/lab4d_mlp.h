@@ -44,7 +44,14 @@
 #define LAB4D_NET_HASH_GEO 9  /* hash-grid field (BASELINE config 5; no reference counterpart): raw 32 hash features -> 64 -> 16 (sdf + 15 geometry features) */
 #define LAB4D_NET_HASH_COLOR 10 /* hash-grid field: raw [16 geometry features | 3 view direction] -> 64 -> 64 -> 3                                       */
 #define LAB4D_NET_DENSE6 11   /* fg_motion "dense" (nnutils/warping.py:37-38,94-141): a bare DenseWarp with its class defaults, posenc6 -> CondMLP(D=6, W=256, skip at 4) -> 3 */
-#define LAB4D_NET_COUNT 12
+#define LAB4D_NET_SKIN_A 12   /* the delta-skin net with its FIRST LAYER IN PER-FRAME AFFINE FORM (emb_kind 2).  SkinningField.forward (nnutils/skinning.py:89-124)
+                                 feeds the MLP the gaussian-scaled bone coordinates with PosEmbedding(3B, 0) = identity, and those are an affine
+                                 function of the point per (frame, bone): linear_1 collapses to z0 = Wf[frame] [x; 1], Wf = W1[:, :3B] aff[frame]
+                                 (+ the per-frame bias in the last column), a (64 x 4) table per frame formed by the caller.  The kernels
+                                 evaluate relu(z0) as the net's "embedding" (fp32 FMAs, no 96-wide MFMA layer, no (S,3B) tensor in either
+                                 direction) and run linear_2 / linear_final as layers 0 / 1: points (S,3) -> [64] -> 64 -> 25                 */
+#define LAB4D_NET_SKIN18_A 13 /* the same for the 18-joint skeleton: points -> [64] -> 64 -> 18                                                  */
+#define LAB4D_NET_COUNT 14
 
 #define LAB4D_PREC_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32, parity path                       */
 #define LAB4D_PREC_BF16 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate: throughput path            */
@@ -62,7 +69,8 @@ typedef struct {
 
 typedef struct {
   int n_layers;
-  int emb_kind;   /* 0: posenc of a 3-vector with n_freq bands; 1: raw input with c_in channels             */
+  int emb_kind;   /* 0: posenc of a 3-vector with n_freq bands; 1: raw input with c_in channels;
+                     2: slot j = relu(aff[frame][j] . [x; 1]) of a 3-vector x (per-frame affine first layer)   */
   int n_freq;
   int c_in;       /* raw input channels (emb_kind 1) or 3                                                   */
   int emb_slots;  /* real embedding slots: 6*n_freq+3 or c_in                                               */
@@ -117,7 +125,9 @@ typedef struct {
   const float* aff;                 /* raw-input nets (LAB4D_NET_SKIN / _SKIN18) only, or NULL.  Non-NULL: x is the (S,3) POINTS and the net's
                                        c_in raw inputs are formed in the kernel as aff[frame][c][0..2] . x + aff[frame][c][3], aff = (M, c_in, 4)
                                        fp32 -- the gaussian-scaled bone coordinates of SkinningField.forward (skinning.py:126-140) in
-                                       their per-frame affine form (lab4d_bone_affine), so the (S, 3B) tensor never exists in HBM     */
+                                       their per-frame affine form (lab4d_bone_affine), so the (S, 3B) tensor never exists in HBM.
+                                       emb_kind 2 nets (LAB4D_NET_SKIN_A / _SKIN18_A): REQUIRED, (M, ke, 4) fp32 -- row j of frame m is
+                                       [Wf[m][j][0..2] | bias]; x is the (S,3) points                                                   */
 } lab4d_mlp_fwd_args;
 int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream);
 
@@ -143,6 +153,13 @@ typedef struct {
   void* dz[LAB4D_MLP_MAX_LAYERS];              /* [mout_pad][ld] dL/d(pre-activation) (written)         */
   float* d_x;                                  /* (S,3) or (S,c_in) gradient wrt the input, or NULL        */
   float* d_x2;                                 /* LAB4D_NET_BG_COLOR: (S,3) gradient wrt x2 (written with d_x), or NULL */
+  /* emb_kind 2 nets only (NULL otherwise): the adjoint of the per-frame affine first layer is taken inside the chain kernel */
+  const float* x;                              /* (S,3) the points the forward saw                                     */
+  const float* aff;                            /* (M, ke, 4) the table the forward saw                                  */
+  float* g_aff;                                /* (M, ke, 4) dL/d aff, ACCUMULATED (atomicAdd; zero-fill first): row j of frame m =
+                                                  sum over the frame's samples of dz0[s][j] * [x_s; 1] (reduced in registers per frame when
+                                                  spf % 64 == 0, i.e. every tile lies in one frame; element-wise atomics otherwise);
+                                                  d_x is then the (S,3) gradient wrt the points                                       */
 } lab4d_mlp_bwd_args;
 int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream);
 

@@ -586,6 +586,8 @@ int with_net(int net, F&& f) {
     case LAB4D_NET_FEAT: return f(NetFeat{});
     case LAB4D_NET_SKIN: return f(NetSkin{});
     case LAB4D_NET_SKIN18: return f(NetSkin18{});
+    case LAB4D_NET_SKIN_A: return f(NetSkinA{});
+    case LAB4D_NET_SKIN18_A: return f(NetSkin18A{});
     case LAB4D_NET_DENSE: return f(NetDense{});
     case LAB4D_NET_DENSE6: return f(NetDense6{});
     case LAB4D_NET_BG_BASE: return f(NetBgBase{});
@@ -643,6 +645,7 @@ extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
     k.S = a->S; k.S_pad = a->S_pad; k.ld = a->ld; k.spf = a->spf; k.x = a->x; k.freq_w = a->freq_w; k.emb = a->emb; k.ext = a->ext; k.out = a->out; k.x2 = a->x2;
     k.S_dev = a->S_dev; k.frame_idx = a->frame_idx; k.aff = a->aff;
     LAB4D_REQUIRE(!a->aff || Net::EMB != 0, "mlp_forward: aff is for the raw-input nets only");
+    LAB4D_REQUIRE(Net::EMB != 2 || a->aff, "mlp_forward: this network needs the per-frame affine table aff (M, ke, 4)");
     LAB4D_REQUIRE(!Net::AUX3 || a->x2, "mlp_forward: this network needs the second input x2");
     LAB4D_REQUIRE(!(a->S_dev && a->emb), "mlp_forward: a device-side sample count is for the evaluation path (no stored activations)");
     for (int l = 0; l < Net::NL; ++l) {
@@ -670,7 +673,12 @@ extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
     BwdK k;
     memset(&k, 0, sizeof(k));
     k.S = a->S; k.S_pad = a->S_pad; k.ld = a->ld; k.spf = a->spf; k.emb = a->emb; k.ext = a->ext; k.d_out = a->d_out; k.ext_gin = a->ext_gin;
-    k.ext_gout = a->ext_gout; k.d_x = a->d_x; k.d_x2 = a->d_x2;
+    k.ext_gout = a->ext_gout; k.d_x = a->d_x; k.d_x2 = a->d_x2; k.x = a->x; k.aff = a->aff; k.g_aff = a->g_aff;
+    if (Net::EMB == 2) {
+      LAB4D_REQUIRE(a->x && a->aff && a->emb, "mlp_backward: this network needs x, aff and the stored embedding");
+    } else {
+      LAB4D_REQUIRE(!a->g_aff, "mlp_backward: g_aff is for the affine-first-layer nets only");
+    }
     LAB4D_REQUIRE(!(a->d_x && Net::EMB == 0) || a->emb, "mlp_backward: d_x needs the stored embedding");
     for (int l = 0; l < Net::NL; ++l) {
       LAB4D_REQUIRE(a->WT[l], "mlp_backward: layer %d transposed weights missing", l);

@@ -534,6 +534,9 @@ struct BwdK {
   void* dz[LAB4D_MLP_MAX_LAYERS];
   float* d_x;
   float* d_x2;  // nets with AUX3: gradient wrt the second 3-vector, or NULL
+  const float* x;    // EMB == 2 nets: the (S,3) points, the (M, KE, 4) per-frame table of the affine first layer, and its gradient (accumulated)
+  const float* aff;
+  float* g_aff;
 };
 
 // values of embedding slots (2*pair, 2*pair+1) for a point x -- posenc nets
@@ -687,8 +690,8 @@ struct Slab {
   static constexpr int UW = W / P::FPG;                 // units per n-tile
   // raw-input nets (and the tangent forward) stage a tile of their (S, C) fp32 input / input gradient through the slab:
   // TILE x C floats, copied to / from global memory as one contiguous, coalesced region
-  static constexpr int STAGE_C = Net::EMB != 0 ? Net::CIN : Net::KE;
-  static constexpr bool STAGES = Net::EMB != 0 || Net::ID == LAB4D_NET_FG_BASE || Net::ID == LAB4D_NET_BG_BASE;  // raw input, or the tangent-mode forward
+  static constexpr int STAGE_C = Net::EMB == 1 ? Net::CIN : Net::KE;
+  static constexpr bool STAGES = Net::EMB == 1 || Net::ID == LAB4D_NET_FG_BASE || Net::ID == LAB4D_NET_BG_BASE;  // raw input, or the tangent-mode forward
   static constexpr int UNITS_STAGE = STAGES ? (P::TILE * STAGE_C * 4 + 15) / 16 : 0;
   static constexpr int UNITS_LAYER = P::NT * UW * 64;
   static constexpr int UNITS_PER_WAVE = UNITS_LAYER > UNITS_STAGE ? UNITS_LAYER : UNITS_STAGE;  // uint4 slots
@@ -787,12 +790,12 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
     }
     // ---- embedding as B units (identity slot order) ----
     uint4 emb[NT][UE];
-    constexpr bool RAW = (Net::EMB != 0) || TAN;
+    constexpr bool RAW = (Net::EMB == 1) || TAN;
     constexpr int CINR = TAN ? KE : Net::CIN;
     float* stagef = reinterpret_cast<float*>(slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE);
     if constexpr (RAW) {
       bool staged = false;
-      if constexpr (Net::EMB != 0 && !TAN) {
+      if constexpr (Net::EMB == 1 && !TAN) {
         if (a.aff != nullptr) {
           // Fused bone coordinates: the tile's (TILE, CIN) input rows are FORMED here, c = aff[frame][c][0..2] . x + aff[frame][c][3],
           // and dropped into the staging area the copy below would have filled -- the (S, 3B) tensor (300 B per sample written by a
@@ -834,8 +837,54 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
       }
       if (!staged) stage_in<TILE * CINR>(stagef, a.x, (long)s0 * CINR, (long)S_eff * CINR - 1, lane);
     }
+    if constexpr (Net::EMB == 2 && !TAN) {
+      // Per-frame affine first layer (lab4d_mlp.h, LAB4D_NET_SKIN_A): slot j = relu(aff[frame][j] . [x; 1]), fp32 FMAs straight into
+      // the B units of layer 0 (identity slot order).  The frame's KE rows are staged in LDS once per tile when the tile lies in one frame.
+      static_assert(KE <= 96, "affine table");
+      const GLOBAL_AS float4* tabg = (const GLOBAL_AS float4*)a.aff;
+      float4* ltab = afftab + wid * 96;
+      const bool uni = (a.spf % TILE) == 0 && a.frame_idx == nullptr;
+      if (uni) {
+        const int m = __builtin_amdgcn_readfirstlane(frame[0]);
+        for (int e = lane; e < KE; e += 64) {
+          const f32x4_t r = *(const GLOBAL_AS f32x4_t*)(tabg + (size_t)m * KE + e);
+          ltab[e] = make_float4(r.x, r.y, r.z, r.w);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int s = sidx[t] < S_eff ? sidx[t] : S_eff - 1;
+        const float x0 = a.x[(size_t)s * 3], x1 = a.x[(size_t)s * 3 + 1], x2_ = a.x[(size_t)s * 3 + 2];
+        auto slot_val = [&](int slot) {
+          float4 r;
+          if (uni) r = ltab[slot];
+          else {
+            const f32x4_t g4 = *(const GLOBAL_AS f32x4_t*)(tabg + (size_t)frame[t] * KE + slot);
+            r = make_float4(g4.x, g4.y, g4.z, g4.w);
+          }
+          return relu1(r.x * x0 + r.y * x1 + r.z * x2_ + r.w);
+        };
+#pragma unroll
+        for (int g = 0; g < UE; ++g) {
+          if constexpr (P::BF16) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = slot_val(16 * g + 8 * h + j);
+            emb[t][g] = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+          } else {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = slot_val(2 * (4 * g + e) + h);
+            emb[t][g] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      if constexpr (Net::EMB == 2 && !TAN) break;  // formed above
       const int s = sidx[t] < S_eff ? sidx[t] : S_eff - 1;
       if constexpr (Net::EMB == 0 && !TAN) {
         float x[6] = {a.x[(size_t)s * 3], a.x[(size_t)s * 3 + 1], a.x[(size_t)s * 3 + 2], 0.f, 0.f, 0.f};
@@ -1291,13 +1340,38 @@ constexpr int emb_layer_count() {
   return c;
 }
 
-template <class Net, class P>
+// AU (EMB == 2 nets only): every tile lies in one frame (spf % TILE == 0, the training shapes) -- the frame's table rows are staged in LDS and the
+// table gradient is reduced in registers; false: rows read per sample, element-wise atomics (tiny shapes whose tiles straddle frames)
+template <class Net, class P, bool AU = true>
 __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
   static_assert(Net::EMB == 0 || emb_layer_count<Net>() == 1, "raw-input nets may use the input in one layer only");
   constexpr int NT = P::NT, TILE = P::TILE, NL = Net::NL, UW = Slab<Net, P>::UW;
   constexpr int ACG = acache_g<Net, P>();
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
   __shared__ uint4 abuf[2 * ACG * 64];  // workgroup-shared A groups (see wg_step_barrier)
+  __shared__ float4 afftab[Net::EMB == 2 ? 4 * 96 : 1];  // EMB == 2: the current frame's rows of the affine first layer, one copy per wave
+  // EMB == 2: per-lane partial of the table gradient, g_aff[frame][32 mt + drow(r, h)][j] += dz0 * [x; 1]_j over this lane's samples; reduced over
+  // the 32 lanes of a half and added to g_aff when the wave's tiles move on to another frame (tiles come in increasing order) and at the end
+  constexpr int NGA = (Net::EMB == 2 && AU) ? (Net::KE / 32) * 16 * 4 : 1;
+  float gacc[NGA];
+#pragma unroll
+  for (int i = 0; i < NGA; ++i) gacc[i] = 0.f;
+  int gframe = -1;
+  auto gram_flush = [&]() {
+    if constexpr (Net::EMB == 2 && AU) {
+      if (gframe >= 0 && a.g_aff != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NGA; ++i) {
+          float v = gacc[i];
+#pragma unroll
+          for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, 64);
+          const int mt = i / 64, r = (i >> 2) & 15, j = i & 3;
+          if ((threadIdx.x & 31) == 0) atomicAdd(a.g_aff + ((size_t)gframe * Net::KE + 32 * mt + drow(r, (int)((threadIdx.x & 63) >> 5))) * 4 + j, v);
+          gacc[i] = 0.f;
+        }
+      }
+    }
+  };
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint4* slab = slab_all + wid * Slab<Net, P>::UNITS_PER_WAVE + lane;
@@ -1315,6 +1389,31 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
     float dx2[NT][3];  // ... and wrt the aux 3-vector (nets with AUX3)
 #pragma unroll
     for (int t = 0; t < NT; ++t) { dx[t][0] = dx[t][1] = dx[t][2] = 0.f; dx2[t][0] = dx2[t][1] = dx2[t][2] = 0.f; }
+    float xs[NT][3];  // EMB == 2: the tile's points
+    int frm[NT];      // ... and their frames
+    float4* ltab = afftab + wid * 96;
+    constexpr bool uni = AU;
+    if constexpr (Net::EMB == 2) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int sc = sidx[t] < a.S ? sidx[t] : a.S - 1;
+        frm[t] = sc / a.spf;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xs[t][k] = ((const GLOBAL_AS float*)a.x)[(size_t)sc * 3 + k];
+      }
+      if constexpr (uni) {
+        const int m = __builtin_amdgcn_readfirstlane(frm[0]);
+        if (m != gframe) {
+          gram_flush();
+          gframe = m;
+        }
+        for (int e = lane; e < Net::KE; e += 64) {
+          const f32x4_t r4 = *(const GLOBAL_AS f32x4_t*)((const GLOBAL_AS float4*)a.aff + (size_t)m * Net::KE + e);
+          ltab[e] = make_float4(r4.x, r4.y, r4.z, r4.w);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
 
     // ---- head gradient: (S, COUT) fp32 -> accumulator layout -> stored + B units in the slab ----
     {
@@ -1547,7 +1646,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
 #endif
       };
       auto pre_emb = [&](int mt) {
-        if constexpr (Net::EMB == 0) load_tile_raw<P>((const GLOBAL_AS void*)a.emb, Net::KE, s0, mt, lane, raw);
+        if constexpr (Net::EMB != 1) load_tile_raw<P>((const GLOBAL_AS void*)a.emb, Net::KE, s0, mt, lane, raw);
       };
       auto pre_act = [&](int j) {
 #ifndef LAB4D_MASK_RING
@@ -1588,6 +1687,50 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
                 dx2[t][2] += ax == 2 ? gv : 0.f;
               }
             }
+        } else if constexpr (Net::EMB == 2) {
+          // adjoint of slot = relu(aff[frame][slot] . [x; 1]): the stored slot value (> 0 or 0) is the ReLU mask; the point gradient and the
+          // table gradient are both fp32 FMAs on the accumulator tile -- no (S, KE) gradient tensor, no weight-gradient launch for this layer
+          f32x16_t e[NT];
+          tile_from_raw<P>(raw, lane, e);
+          auto body = [&](auto uni_c) {
+            constexpr bool U = decltype(uni_c)::value;
+            sfor<0, 16>([&](auto rc) {
+              constexpr int r = decltype(rc)::value;
+              const int slot = 32 * mt + drow(r, h);
+              float4 row;
+              if constexpr (U) row = ltab[slot];
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                if constexpr (!U) {
+                  const f32x4_t g4 = *(const GLOBAL_AS f32x4_t*)((const GLOBAL_AS float4*)a.aff + (size_t)frm[t] * Net::KE + slot);
+                  row = make_float4(g4.x, g4.y, g4.z, g4.w);
+                }
+                const float dz = e[t][r] > 0.f ? acc[t][r] : 0.f;
+                dx[t][0] += row.x * dz;
+                dx[t][1] += row.y * dz;
+                dx[t][2] += row.z * dz;
+                if constexpr (U) {
+                  // mt is a runtime value of the pipeline loop: the accumulator block is selected by compile-time comparison (registers, not scratch)
+                  sfor<0, Net::KE / 32>([&](auto mc) {
+                    constexpr int mm = decltype(mc)::value;
+                    if (mt == mm) {
+                      gacc[(mm * 16 + r) * 4 + 0] += dz * xs[t][0];
+                      gacc[(mm * 16 + r) * 4 + 1] += dz * xs[t][1];
+                      gacc[(mm * 16 + r) * 4 + 2] += dz * xs[t][2];
+                      gacc[(mm * 16 + r) * 4 + 3] += dz;
+                    }
+                  });
+                } else if (a.g_aff != nullptr && dz != 0.f && sidx[t] < a.S) {
+                  float* gp = a.g_aff + ((size_t)frm[t] * Net::KE + slot) * 4;
+                  atomicAdd(gp + 0, dz * xs[t][0]);
+                  atomicAdd(gp + 1, dz * xs[t][1]);
+                  atomicAdd(gp + 2, dz * xs[t][2]);
+                  atomicAdd(gp + 3, dz);
+                }
+              }
+            });
+          };
+          body(std::bool_constant<uni>{});
         } else {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -1721,13 +1864,13 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
           pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb, no_flush, no_prem, sp_none, sp_all_none);
           // raw-input nets: the (TILE, CIN) input-gradient tile sits in the wave's staging area (the slab is idle while the
           // last layer's embedding tiles are processed); one contiguous coalesced copy, rows >= S dropped
-          if constexpr (Net::EMB != 0) stage_out(stagef, a.d_x, (long)s0 * Net::CIN, TILE * Net::CIN, (long)a.S * Net::CIN - 1, lane);
+          if constexpr (Net::EMB == 1) stage_out(stagef, a.d_x, (long)s0 * Net::CIN, TILE * Net::CIN, (long)a.S * Net::CIN - 1, lane);
         }
       }
       if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act, flush_act, pre_mask, sp_act, sp_all_act);
     });
 
-    if constexpr (Net::EMB == 0) {
+    if constexpr (Net::EMB != 1) {
       if (a.d_x) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1751,6 +1894,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
       }
     }
   }
+  gram_flush();
 }
 
 // launchers implemented by each mlp_inst_<net>.hip
@@ -1826,10 +1970,16 @@ inline bool bwd_h_enabled() {
           return check_launch("mlp_backward");                                                                            \
         }                                                                                                                 \
       }                                                                                                                   \
-      LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16>), k, st);                         \
+      if constexpr (Net::EMB == 2) {                                                                                      \
+        if (k.spf % PBF16::TILE) LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16, false>), k, st);                                 \
+        else LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16, true>), k, st);                                                      \
+      } else LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16>), k, st);                         \
     } else if (precision == LAB4D_PREC_F32) {                                                                             \
       k.ntiles = k.S_pad / PF32::TILE;                                                                                   \
-      LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PF32>), k, st);                          \
+      if constexpr (Net::EMB == 2) {                                                                                      \
+        if (k.spf % PF32::TILE) LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PF32, false>), k, st);                                   \
+        else LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PF32, true>), k, st);                                                       \
+      } else LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PF32>), k, st);                          \
     } else {                                                                                                              \
       set_error("mlp_backward: bad precision %d", precision);                                                             \
       return LAB4D_EINVAL;                                                                                                \

@@ -48,6 +48,17 @@ struct NetSkin18 {
   static constexpr LS L[NL] = {{64, 0, 64, 1, 1, 0, 0}, {0, 64, 64, 1, 0, 0, 0}, {0, 64, 18, 0, 0, 0, 0}};
 };
 
+// skinning.py:70-124 with linear_1 in per-frame affine form (lab4d_mlp.h, LAB4D_NET_SKIN_A): the 64 "embedding" slots are
+// relu(aff[frame][j] . [x; 1]); layers 0 / 1 are linear_2 (64 -> 64) and linear_final (64 -> B)
+struct NetSkinA {
+  static constexpr int ID = LAB4D_NET_SKIN_A, NL = 2, EMB = 2, NFREQ = 0, CIN = 3, SLOTS = 64, KE = 64, COUT = 25, AUX3 = 0;
+  static constexpr LS L[NL] = {{64, 0, 64, 1, 0, 0, 0}, {0, 64, 25, 0, 0, 0, 0}};
+};
+struct NetSkin18A {
+  static constexpr int ID = LAB4D_NET_SKIN18_A, NL = 2, EMB = 2, NFREQ = 0, CIN = 3, SLOTS = 64, KE = 64, COUT = 18, AUX3 = 0;
+  static constexpr LS L[NL] = {{64, 0, 64, 1, 0, 0, 0}, {0, 64, 18, 0, 0, 0, 0}};
+};
+
 // warping.py:105-170,445-483 : DenseWarp(D=2,W=256) post-warp of ComposedWarp: PosEmbedding(3,6)=39 (+128 time embedding
 // +32 instance code as per-frame bias) -> 256 -> 256 -> 3 ; one table serves forward_map and backward_map
 struct NetDense {

@@ -312,7 +312,7 @@ def frame_terms(P, fr):
     every conditioned layer -- as a flat dict of tensors.  None of it depends on the rays, so a training step evaluates it ONCE
     (FramePrologue) instead of once per ray chunk; called inline (ft=None paths) it is the same arithmetic in the same order.
     SkinningWarp foreground only: with a dense post-warp (fr["dense"]) the warp terms stay inline."""
-    from .warping import get_gauss, skin_cond
+    from .warping import SKIN_AFFINE, get_gauss, skin_affine_table, skin_cond
     ft = {}
     M = fr["field2cam"][0].shape[0]
     ft["cam2field.q"], ft["cam2field.t"] = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
@@ -340,6 +340,10 @@ def frame_terms(P, fr):
         ft["se3_own.r"], ft["se3_own.d"] = Q.dual_quaternion_mul(t_art, rest_inv)
         ft["pf.skin_bw"] = mlp.pf_bias_of(skin, 0, W(skin, 0), skin_cond(fr["t_embed"], fr["code_skin"], M))
         ft["pf.skin_fw"] = mlp.pf_bias_of(skin, 0, W(skin, 0), skin_cond(fr["t_embed_mean"], fr["code_skin"], M))
+        if SKIN_AFFINE:  # the delta-skin MLP's first layer as a per-frame table of the point (warping.skin_affine_table)
+            B = t_art[0].shape[1]
+            ft["skinA.bw"] = skin_affine_table(P, t_art, ft["gauss"], ft["pf.skin_bw"], B)
+            ft["skinA.fw"] = skin_affine_table(P, rest, ft["gauss"], ft["pf.skin_fw"], B)
     return ft
 
 
@@ -447,7 +451,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     t_art, rest_art = fr.get("t_articulation"), fr.get("rest_articulation")  # absent for fg_motion "rigid" / "dense"
     if skinning:
         xyz, bw_aux = skinning_warp(P, xyz_t, t_art, rest_art, fr["t_embed"], fr["code_skin"], True, prec,
-                                    pre={"se3": (ft["se3_bw.r"], ft["se3_bw.d"]), "gauss": ft["gauss"], "pf": ft["pf.skin_bw"]})
+                                    pre={"se3": (ft["se3_bw.r"], ft["se3_bw.d"]), "gauss": ft["gauss"], "pf": ft["pf.skin_bw"], "tab": ft.get("skinA.bw")})
     else:
         xyz, bw_aux = warp(xyz_t, t_art, rest_art, fr.get("t_embed"), True)
     fd = {}
@@ -459,7 +463,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     # pair partners are frames of one video, so the rest articulation (a per-instance quantity from get_vals_and_mean) equals its
     # flip_pair; a caller that supplies its own states it (patch._frames checks it), anything else takes the general path
     shared = skinning and fr.get("rest_shared_in_pair", True)
-    fw_pre = {"gauss": ft["gauss"], "pf": ft["pf.skin_fw"]} if skinning else None
+    fw_pre = {"gauss": ft["gauss"], "pf": ft["pf.skin_fw"], "tab": ft.get("skinA.fw")} if skinning else None
     if shared:
         # both forward warps of the canonical samples (into the partner's frame here, into the own frame for the cycle term
         # below) see the same skinning field: the rest articulation is a per-instance quantity and pair partners are frames

@@ -23,6 +23,7 @@ from . import _lib
 
 MAXL = 12
 NET_FG_BASE, NET_FG_COLOR, NET_VIS, NET_FEAT, NET_SKIN, NET_DENSE, NET_BG_BASE, NET_BG_COLOR, NET_SKIN18, NET_HASH_GEO, NET_HASH_COLOR, NET_DENSE6 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+NET_SKIN_A, NET_SKIN18_A = 12, 13  # the delta-skin nets with linear_1 in per-frame affine form (include/lab4d_mlp.h)
 PREC_F32, PREC_BF16 = 0, 1
 vp, ci = ctypes.c_void_p, ctypes.c_int
 
@@ -44,7 +45,7 @@ class FwdArgs(ctypes.Structure):
 class BwdArgs(ctypes.Structure):
     _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("S_pad", ci), ("ld", ci), ("spf", ci), ("WT", vp * MAXL), ("act", vp * MAXL),
                 ("mask", vp * MAXL), ("emb", vp), ("ext", vp), ("d_out", vp), ("ext_gin", vp), ("ext_gout", vp), ("dz", vp * MAXL), ("d_x", vp),
-                ("d_x2", vp)]
+                ("d_x2", vp), ("x", vp), ("aff", vp), ("g_aff", vp)]
 
 
 _lib.register("lab4d_mlp_describe", [ci, ctypes.POINTER(NetDesc)])
@@ -56,15 +57,17 @@ _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp
 _lib.register("lab4d_mlp_wgrad_mapped", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
 
-NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color", 8: "skin18", 9: "hash_geo", 10: "hash_color", 11: "dense6"}
+NET_NAMES = {0: "fg_base", 1: "fg_color", 2: "vis", 3: "feat", 4: "skin", 5: "dense", 6: "bg_base", 7: "bg_color", 8: "skin18", 9: "hash_geo", 10: "hash_color", 11: "dense6",
+             12: "skin_a", 13: "skin18_a"}
 # algorithmic MACs per sample (real layer shapes incl. conditioning columns)
 NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736, 5: 39 * 256 + 256 * 256 + 256 * 3,
             6: 100096 + 128, 7: 43392 + 8576, 8: (54 + 160) * 64 + 64 * 64 + 64 * 18, 9: 32 * 64 + 64 * 16, 10: 19 * 64 + 64 * 64 + 64 * 3,
-            11: 199 * 256 + 3 * 256 * 256 + 455 * 256 + 256 * 256 + 256 * 3}
+            11: 199 * 256 + 3 * 256 * 256 + 455 * 256 + 256 * 256 + 256 * 3,
+            12: 4 * 64 + 64 * 64 + 64 * 25, 13: 4 * 64 + 64 * 64 + 64 * 18}  # affine form: what the kernels execute per sample
 
 
 
-KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor", 8: "Skin18", 9: "HashGeo", 10: "HashColor", 11: "Dense6"}  # template argument names in csrc/mlp_nets.hpp
+KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor", 8: "Skin18", 9: "HashGeo", 10: "HashColor", 11: "Dense6", 12: "SkinA", 13: "Skin18A"}  # template argument names in csrc/mlp_nets.hpp
 
 
 def wgrad_kernel_name(L, prec):
@@ -165,6 +168,10 @@ def bindings(net, prefix=""):
         return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(75 if net == NET_SKIN else 54, 160)),
                 LayerBinding(q + "linear_2.0.weight", q + "linear_2.0.bias", prev0=0),
                 LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0)]
+    if net in (NET_SKIN_A, NET_SKIN18_A):  # the same module with linear_1 folded into the per-frame table (warping.skin_affine_table): layers = linear_2, linear_final
+        q = p + "warp.skinning_model.delta_field."
+        return [LayerBinding(q + "linear_2.0.weight", q + "linear_2.0.bias", emb0=0),
+                LayerBinding(q + "linear_final.weight", q + "linear_final.bias", prev0=0)]
     if net == NET_DENSE:  # warping.py:123-141: [39 posenc | 128 time embedding | 32 instance code]; prefix selects the map,
         q = p  # "warp.post_warp.forward_map." / "warp.post_warp.backward_map." (the CondMLP itself, base.py:80-121)
         return [LayerBinding(q + "linear_1.0.weight", q + "linear_1.0.bias", emb0=0, cond=(39, 160)),
@@ -203,12 +210,13 @@ def bindings(net, prefix=""):
     raise ValueError(net)
 
 
-def skin_net_for(n_bones):
-    """The delta-skin network instantiation of a skeleton: 25 bones (bob, skel-quad) or 18 (skel-human)."""
+def skin_net_for(n_bones, affine=False):
+    """The delta-skin network instantiation of a skeleton: 25 bones (bob, skel-quad) or 18 (skel-human).  affine=True: the form with
+    linear_1 folded into a per-frame (64 x 4) table of the point (NET_SKIN_A / NET_SKIN18_A)."""
     if n_bones == 25:
-        return NET_SKIN
+        return NET_SKIN_A if affine else NET_SKIN
     if n_bones == 18:
-        return NET_SKIN18
+        return NET_SKIN18_A if affine else NET_SKIN18
     raise NotImplementedError("lab4d_amd: the delta-skin network is instantiated for 25 and 18 bones (got %d)" % n_bones)
 
 
@@ -237,6 +245,8 @@ def col_map(net, layer, device):
                         cm.append(bd.aux0 + slot - a0)
                     else:
                         cm.append(-1)
+            elif d.emb_kind == 2:  # slots = the hidden features of the folded first layer, in order
+                cm += [bd.emb0 + c for c in range(L.ke)]
             else:
                 cm += [(bd.emb0 + c if c < d.c_in else -1) for c in range(L.ke)]
         if L.kin:
@@ -387,9 +397,12 @@ class MlpChain(Function):
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, ld, int(spf)
         a.x = _lib.dp(x)
+        if d.emb_kind == 2 and aff is None:
+            raise RuntimeError("MlpChain: net %d needs the per-frame affine table aff" % net)
         if aff is not None:
-            if tuple(aff.shape[1:]) != (d.c_in, 4) or x.shape[1] != 3 or aff.dtype != torch.float32 or not aff.is_contiguous():
-                raise RuntimeError("MlpChain: aff must be a contiguous fp32 (M, %d, 4) table and x the (S,3) points" % d.c_in)
+            rows = d.ke if d.emb_kind == 2 else d.c_in
+            if tuple(aff.shape[1:]) != (rows, 4) or x.shape[1] != 3 or aff.dtype != torch.float32 or not aff.is_contiguous():
+                raise RuntimeError("MlpChain: aff must be a contiguous fp32 (M, %d, 4) table and x the (S,3) points" % rows)
             _lib.require_device(aff)
             a.aff = _lib.dp(aff)
         if x2 is not None:
@@ -449,6 +462,7 @@ class MlpChain(Function):
         ctx.params = params
         ctx.x_shape = x.shape if aff is None else (S, d.c_in)  # what d_x is the gradient of: the net's own inputs
         ctx.has_x2 = x2 is not None
+        ctx.aff_in = (x, aff) if (d.emb_kind == 2 and need_grad) else None  # the backward chain takes the adjoint of the affine first layer itself
         if export_layer is not None and export_layer >= 0:
             # a separate tensor object over the same storage: returning ctx.acts[export_layer] itself would make the node own a
             # tensor whose grad_fn is the node -- a reference cycle that keeps every stored activation of the chunk alive until
@@ -497,7 +511,13 @@ class MlpChain(Function):
         a.d_out = _lib.dp(d_out)
         d_x = None
         d_x2 = None
-        if ctx.needs_input_grad[3] or ctx.needs_input_grad[8]:
+        g_aff = None
+        if ctx.aff_in is not None:
+            xin, aff = ctx.aff_in
+            a.x, a.aff = _lib.dp(xin), _lib.dp(aff)
+            g_aff = torch.zeros_like(aff)
+            a.g_aff = _lib.dp(g_aff)
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[8] or g_aff is not None:
             d_x = torch.empty(ctx.x_shape, device=dev)
             a.d_x = _lib.dp(d_x)
             if ctx.has_x2:  # written together with d_x by the kernel
@@ -564,7 +584,8 @@ class MlpChain(Function):
         # so autograd would keep them until the whole graph dies at the end of backward(): every net's activations stayed alive
         # through every other net's backward (measured: backward peak = everything the forward saved + the largest dZ set, 15.7 KB
         # per sample).  Like freed saved tensors, this makes a second backward through the node an error.
-        ctx.acts = ctx.masks = ctx.emb = ctx.ext = ctx.params = None
+        ctx.acts = ctx.masks = ctx.emb = ctx.ext = ctx.params = ctx.aff_in = None
+        ctx.g_aff = g_aff  # read by the caller that passed aff (warping.SkinChainA)
         return (None, None, None, d_x, ext_g, None, None, None, d_x2, *grads_pf, *grads_params)
 
 

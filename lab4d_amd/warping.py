@@ -119,6 +119,74 @@ class SkinChain(Function):
         return (None, None, None, gx, gar, gad, gg, None) + tuple(res[9:])
 
 
+class BoneAffine(Function):
+    """bone_affine with its adjoint: dL/d aff (M, 3B, 4) IS the per-frame Gram matrix G[m, 3b+k, j] = sum_s g_coord[s, 3b+k] [x_s; 1]_j that
+    BoneCoords.backward reduces from the (S, 3B) coordinate gradient, so the (frame, bone)-sized chain rule to the articulation and the
+    gaussian scales is the same kernel (lab4d_bone_params_from_gram)."""
+
+    @staticmethod
+    def forward(ctx, art_r, art_d, gauss):
+        art_r, art_d, gauss = art_r.contiguous(), art_d.contiguous(), gauss.contiguous()
+        ctx.save_for_backward(art_r, art_d, gauss)
+        return bone_affine(art_r, art_d, gauss)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, G):
+        art_r, art_d, gauss = ctx.saved_tensors
+        M, B = art_r.shape[:2]
+        G = G.contiguous()
+        need_r, need_d, need_g = ctx.needs_input_grad
+        gar = torch.empty_like(art_r) if need_r else None
+        gad = torch.empty_like(art_d) if need_d else None
+        gg = torch.zeros_like(gauss) if need_g else None
+        if need_r or need_d or need_g:
+            _lib.check(_lib.lib().lab4d_bone_params_from_gram(_lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(G), M, B, _lib.ptr(gar),
+                                                              _lib.ptr(gad), _lib.ptr(gg), _lib.stream()), "bone_params_from_gram")
+        return gar, gad, gg
+
+
+def skin_affine_table(P, art, gauss, pf, n_bones):
+    """(M, 64, 4): the delta-skin MLP's first layer as a per-frame affine map of the POINT.  SkinningField.forward feeds linear_1 the
+    gaussian-scaled bone coordinates through PosEmbedding(3B, num_freq=0) = identity (skinning.py:69,107), and the coordinates are affine in
+    the point per (frame, bone) (transforms.py:9-25): z0 = W1[:, :3B] (aff[m] [x; 1]) + pf[m] + b1 = Wf[m] [x; 1].  Frame-sized torch algebra:
+    autograd carries dL/dWf (reduced per frame inside the backward chain kernel) back to linear_1, the articulation, the gaussian scales and
+    the conditioning codes.  pf (M, 64) = [time embedding | instance code] @ W1[:, 3B:]^T (mlp.pf_bias_of)."""
+    bd = mlp.bindings(mlp.skin_net_for(n_bones), "")[0]
+    W1, b1 = P[bd.wname], P[bd.bname]
+    aff = BoneAffine.apply(art[0], art[1], gauss)  # (M, 3B, 4)
+    tab = torch.einsum("fc,mcj->mfj", W1[:, :3 * n_bones], aff)
+    return torch.cat([tab[..., :3], tab[..., 3:] + (pf + b1)[..., None]], -1).contiguous()
+
+
+class SkinChainA(Function):
+    """The delta-skin MLP behind the per-frame table of skin_affine_table (LAB4D_NET_SKIN_A / _SKIN18_A, include/lab4d_mlp.h): points (S,3) ->
+    relu(Wf[frame] [x; 1]) -> linear_2 -> linear_final.  Against SkinChain: no 96-wide MFMA layer, no stored bf16 copy of the coordinates and no
+    weight-gradient launch for linear_1, no (S, 3B) coordinate gradient and no pass over it (k_bone_bwd_x + Gram): the backward chain kernel
+    returns the point gradient (S,3) and dL/dWf (M,64,4) directly."""
+
+    @staticmethod
+    def forward(ctx, net, prec, spf, xyz, tab, *params):
+        xyz = xyz.contiguous()
+        need = any(ctx.needs_input_grad)
+        inner = types.SimpleNamespace(needs_input_grad=(False, False, False, need, False, False, False, False, False) + tuple(ctx.needs_input_grad[5:]))
+        out = mlp.MlpChain.forward(inner, net, prec, spf, xyz, None, None, -1, 0, None, *params, aff=tab.detach().contiguous())
+        ctx.inner = inner
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out):
+        res = mlp.MlpChain.backward(ctx.inner, d_out)
+        g_tab = ctx.inner.g_aff
+        ctx.inner = None
+        return (None, None, None, res[3], g_tab) + tuple(res[9:])
+
+
+# The delta-skin MLP runs in its per-frame affine form (SkinChainA); 0 restores the bone-coordinate form (SkinChain) for A/B measurements.
+SKIN_AFFINE = os.environ.get("LAB4D_SKIN_AFFINE", "1") != "0"
+
+
 class SkinBlend(Function):
     """skin weights + hemisphere-consistent dual-quaternion blend + apply (warping.py:322-333, geom_utils.py:45-83).
     The gaussian-scaled bone coordinates the skin weights depend on are recomputed inside the kernels from
@@ -193,8 +261,20 @@ def skin_logits(P, x, art, t_embed, code, M, spf, prec, pre=None):
     coordinates -> delta-skin MLP.  x (S,3).  Returns the raw (S,B) MLP output and gauss (B,3).
     pre = {"gauss", "pf"}: the per-frame terms already evaluated by the step's prologue (deformable.frame_terms)."""
     gauss = pre["gauss"] if pre is not None else get_gauss(P)
-    net = mlp.skin_net_for(art[0].shape[1])
+    B = art[0].shape[1]
+    net = mlp.skin_net_for(B)
     d, bd = mlp.describe(net), mlp.bindings(net, "")
+    if SKIN_AFFINE and FUSE_BONE_COORDS:
+        tab = pre.get("tab") if pre is not None else None
+        if tab is None:
+            pf = pre["pf"] if pre is not None else mlp.pf_bias_of(net, 0, P[bd[0].wname], skin_cond(t_embed, code, M))
+            tab = skin_affine_table(P, art, gauss, pf, B)
+        net_a = mlp.skin_net_for(B, affine=True)
+        bda = mlp.bindings(net_a, "")
+        params = []
+        for l in range(mlp.describe(net_a).n_layers):
+            params += [P[bda[l].wname], P[bda[l].bname]]
+        return SkinChainA.apply(net_a, prec, spf, x, tab, *params), gauss
     pf = pre["pf"] if pre is not None else mlp.pf_bias_of(net, 0, P[bd[0].wname], skin_cond(t_embed, code, M))
     params = []
     for l in range(d.n_layers):
