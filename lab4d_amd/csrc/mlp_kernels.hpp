@@ -576,11 +576,12 @@ constexpr int ACACHE_G = LAB4D_ACACHE_G;  // 2 x 14 KiB: leaves 4 KiB of the 160
 // The narrow fg nets (feature 128 wide, visibility 64 wide; bf16) are built for TWO workgroups per CU (two waves per SIMD from independent, not lock-stepped
 // workgroups: while one waits at its barrier / on a store the other issues MFMAs): <= 256 registers per lane
 // (__launch_bounds__(256, 2)) and <= 78 KiB of LDS (4 x 16 KiB slabs + 2 x 7 KiB of shared A groups).
-template <class Net, class P>
+template <class Net, class P, bool BWD = false>
 constexpr int want_occ() {
 #ifdef LAB4D_ABL_OCC1
   return 1;
 #else
+  // (the affine-form skin nets were tried at 2: their forward spills 126-158 registers at 256, their backward carries 128 accumulators of the table gradient)
   return (P::BF16 && (Net::ID == LAB4D_NET_FEAT || Net::ID == LAB4D_NET_VIS)) ? 2 : 1;  // the bg nets (per-frame bias in two layers) spill 25-53 registers at 256
 #endif
 }
@@ -1343,7 +1344,7 @@ constexpr int emb_layer_count() {
 // AU (EMB == 2 nets only): every tile lies in one frame (spf % TILE == 0, the training shapes) -- the frame's table rows are staged in LDS and the
 // table gradient is reduced in registers; false: rows read per sample, element-wise atomics (tiny shapes whose tiles straddle frames)
 template <class Net, class P, bool AU = true>
-__global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_bwd(BwdK a) {
+__global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(BwdK a) {
   static_assert(Net::EMB == 0 || emb_layer_count<Net>() == 1, "raw-input nets may use the input in one layer only");
   constexpr int NT = P::NT, TILE = P::TILE, NL = Net::NL, UW = Slab<Net, P>::UW;
   constexpr int ACG = acache_g<Net, P>();
