@@ -192,6 +192,22 @@ int lab4d_l2_normalize_forward(const float* x, int S, int C, float* y, void* str
 int lab4d_l2_normalize_backward(const float* x, const float* g, int S, int C, float* g_x, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 3d. FeatureNeRF.global_match -- nnutils/feature.py:152-199: soft arg-max of the (R,16) pixel features over K <= 1024 canonical
+ *     candidates (the caller draws them: torch.randperm, feature.py:176-178, and gathers their rows),
+ *        score = (feat_px @ feat_c^T) * exp(logsigma);  prob = softmax(score, dim=1);  xyz_matched = prob @ xyz_c.
+ *     forward: out (R,3); stats (R,2) = per-row (max score, sum exp(score - max)), handed back to backward.
+ *     backward: g_feat_c (K,16), g_xyz_c (K,3), g_logsigma (1) are WRITTEN; the pixel features are data (no gradient, as in
+ *     the reference: samples_dict["feature"]).  work: lab4d_global_match_workspace_floats(K) floats.  The (R,K) score / prob
+ *     matrices never exist in memory.  logsigma: device scalar (nn.Parameter, feature.py:86-87).
+ * ------------------------------------------------------------------------------------------ */
+int lab4d_global_match_workspace_floats(int K);
+int lab4d_global_match_forward(const float* feat_px, const float* feat_c, const float* xyz_c, const float* logsigma, int R, int C, int K,
+                               float* out, float* stats, void* stream);
+int lab4d_global_match_backward(const float* feat_px, const float* feat_c, const float* xyz_c, const float* logsigma, const float* out,
+                                const float* stats, const float* g_out, int R, int C, int K, float* g_feat_c, float* g_xyz_c,
+                                float* g_logsigma, float* work, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 4. Fused positional-encoding + MLP stack -- nnutils/embedding.py:69-125 (PosEmbedding),
  *    nnutils/base.py:65-78,123-150 (BaseMLP/CondMLP), as used by nnutils/nerf.py:167-215,
  *    visibility.py:53-63, feature.py:136-150, skinning.py:108-119, warping.py:143-170.

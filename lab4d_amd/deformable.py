@@ -275,13 +275,77 @@ def compute_feat(P, xyz, prec):
     return L2Normalize.apply(f).view(xyz.shape[:-1] + (16,))
 
 
-def global_match(P, feat_px, feat_canonical, xyz_canonical, perm):
-    """FeatureNeRF.global_match (feature.py:152-199): soft arg-max over <= 1024 host-drawn candidates."""
+_lib.register("lab4d_global_match_workspace_floats", [ctypes.c_int])
+_lib.register("lab4d_global_match_forward", [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3)
+_lib.register("lab4d_global_match_backward", [ctypes.c_void_p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5)
+
+
+class GlobalMatch(Function):
+    """softmax((feat_px @ feat_c^T) * exp(logsigma), 1) @ xyz_c (feature.py:180-196) without the (R, K) score matrix: one kernel forward, the
+    candidate-side adjoint + a partial-sum reduction backward (csrc/match.hip).  feat_px: the batch's pixel features (data, no gradient)."""
+
+    @staticmethod
+    def forward(ctx, feat_px, feat_c, xyz_c, logsigma):
+        feat_px, feat_c, xyz_c, logsigma = [t.detach().contiguous().float() for t in (feat_px, feat_c, xyz_c, logsigma)]
+        _lib.require_device(feat_px, feat_c, xyz_c, logsigma)
+        R, C = feat_px.shape
+        K = feat_c.shape[0]
+        out = torch.empty(R, 3, device=feat_px.device)
+        stats = torch.empty(R, 2, device=feat_px.device)
+        with _lib.timed("k_match_fwd", (2.0 * R * K * (C + 3), 4.0 * (R * (C + 5) + K * (C + 3)))):
+            _lib.check(_lib.lib().lab4d_global_match_forward(_lib.ptr(feat_px), _lib.ptr(feat_c), _lib.ptr(xyz_c), _lib.ptr(logsigma), R, C, K,
+                                                             _lib.ptr(out), _lib.ptr(stats), _lib.stream()), "global_match_forward")
+        ctx.save_for_backward(feat_px, feat_c, xyz_c, logsigma, out, stats)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("GlobalMatch: the pixel features are data (samples_dict['feature'], feature.py:127): no gradient path")
+        feat_px, feat_c, xyz_c, logsigma, out, stats = ctx.saved_tensors
+        R, C = feat_px.shape
+        K = feat_c.shape[0]
+        g = g.contiguous().float()
+        g_fc, g_xc, g_ls = torch.empty_like(feat_c), torch.empty_like(xyz_c), torch.empty_like(logsigma)
+        work = torch.empty(_lib.lib().lab4d_global_match_workspace_floats(K), device=g.device)
+        with _lib.timed("k_match_bwd", (2.0 * R * K * (2 * C + 8), 4.0 * (R * (C + 8) + 2 * K * (C + 3)))):
+            _lib.check(_lib.lib().lab4d_global_match_backward(_lib.ptr(feat_px), _lib.ptr(feat_c), _lib.ptr(xyz_c), _lib.ptr(logsigma), _lib.ptr(out),
+                                                              _lib.ptr(stats), _lib.ptr(g), R, C, K, _lib.ptr(g_fc), _lib.ptr(g_xc), _lib.ptr(g_ls),
+                                                              _lib.ptr(work), _lib.stream()), "global_match_backward")
+        return None, g_fc, g_xc, g_ls
+
+
+class RowTap(Function):
+    """(x, x[idx]) for a dense per-sample tensor x (S, C) and <= 1024 drawn rows idx (the matching candidates, feature.py:176-178).  The first
+    output is x itself: every other consumer reads THAT, so autograd hands backward() the summed dense gradient and the few gathered rows'
+    gradient is added into it in place -- instead of a zero-filled (S, C) tensor, a scatter into it and one more dense add (3 GB of traffic per
+    chunk for the (S,16) features)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.x_shape = x.shape
+        return x.view_as(x), x.detach()[idx]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_dense, g_rows):
+        (idx,) = ctx.saved_tensors
+        if g_dense is None:  # nothing else consumed x
+            g_dense = torch.zeros(ctx.x_shape, device=idx.device)
+        elif not g_dense.is_contiguous():
+            g_dense = g_dense.contiguous()
+        if g_rows is not None:
+            g_dense.index_add_(0, idx, g_rows.to(g_dense.dtype))  # in place on the gradient buffer autograd built for this edge
+        return g_dense, None
+
+
+def global_match(P, feat_px, feat_rows, xyz_rows):
+    """FeatureNeRF.global_match (feature.py:152-199): soft arg-max over <= 1024 host-drawn candidates, given their gathered rows."""
     shape = feat_px.shape
-    fc = feat_canonical.reshape(-1, shape[-1])[perm]
-    xc = xyz_canonical.reshape(-1, 3)[perm]
-    prob = torch.softmax(feat_px.reshape(-1, shape[-1]) @ fc.t() * P["logsigma"].exp(), 1)
-    return (prob @ xc).view(shape[:-1] + (3,))
+    out = GlobalMatch.apply(feat_px.reshape(-1, shape[-1]), feat_rows, xyz_rows, P["logsigma"].reshape(1))
+    return out.view(shape[:-1] + (3,))
 
 
 def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32, net=mlp.NET_FG_BASE, prefix="", pf_tables=None):
@@ -454,6 +518,10 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
                                     pre={"se3": (ft["se3_bw.r"], ft["se3_bw.d"]), "gauss": ft["gauss"], "pf": ft["pf.skin_bw"], "tab": ft.get("skinA.bw")})
     else:
         xyz, bw_aux = warp(xyz_t, t_art, rest_art, fr.get("t_embed"), True)
+    matching = fr.get("feature") is not None  # FeatureNeRF.query_field (feature.py:104-107): the matching terms need the pixel features of the batch
+    if matching:  # the drawn candidates' rows of the canonical points (feature.py:176-178); every consumer below reads the tapped tensor
+        xyz_flat, xyz_rows = RowTap.apply(xyz.reshape(-1, 3), rng["match_perm"])
+        xyz = xyz_flat.view(xyz.shape)
     fd = {}
     vis = vis_field(P, xyz, fr, prec, ft)
     rgb, density = nerf_forward(P, xyz, fr, prec, alpha=alpha, ft=ft)
@@ -488,11 +556,13 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     fd["feature"] = compute_feat(P, xyz, prec)
     aux = {}
     has_gauss = motion not in ("rigid", "dense")
-    if fr.get("feature") is None:  # FeatureNeRF.query_field (feature.py:104-107): the matching terms need the pixel features of the batch
+    if not matching:
         if has_gauss:
             fd["gauss_density"] = gauss_density(P, xyz, rest_art, ft)
         return fd, deltas, aux
-    xyz_matches = global_match(P, fr["feature"], fd["feature"], xyz, rng["match_perm"])
+    feat_flat, feat_rows = RowTap.apply(fd["feature"].reshape(-1, fd["feature"].shape[-1]), rng["match_perm"])
+    fd["feature"] = feat_flat.view(fd["feature"].shape)
+    xyz_matches = global_match(P, fr["feature"], feat_rows, xyz_rows)
     if skinning:
         xm_next, _ = skinning_warp(P, xyz_matches[:, :, None], t_art, rest_art, fr["t_embed_mean"], fr["code_skin"], False,
                                    prec, pre=dict(fw_pre, se3=(ft["se3_own.r"], ft["se3_own.d"])))

@@ -28,6 +28,10 @@ def step():
         loss = loss + mlp.run_chain(mlp.NET_FEAT, prec, P, x, spf).sum()
     if "vis" in which:
         loss = loss + mlp.run_chain(mlp.NET_VIS, prec, P, x, spf, conds={0: fr["code_vis"]}).sum()
+    if "skin" in which:  # the delta-skin field (affine form unless LAB4D_SKIN_AFFINE=0)
+        from lab4d_amd import warping
+        raw, _ = warping.skin_logits(P, x, fr["t_articulation"], fr["t_embed"], fr["code_skin"], 2, spf, prec)
+        loss = loss + raw.sum()
     loss.backward()
 
 
