@@ -60,6 +60,14 @@ int lab4d_skin_blend_backward(const float* xyz, const float* art_r, const float*
                               const float* g_ent, const float* g_dskin, int S, int spf, int M, int B, float* g_xyz,
                               float* g_raw, float* g_se3, float* g_art_r, float* g_art_d, float* g_gauss, float* work,
                               void* stream);
+/* The same with accumulate != 0: g_xyz (S,3) and g_raw (S,B) are ADDED to instead of written (they hold the adjoint of an earlier blend of the
+ * same skinning field evaluation: the training graph warps every canonical sample forward twice off ONE delta-skin evaluation, nerf.py:966-973
+ * and deformable.py:173-198); g_se3 / g_art_* / g_gauss are written as above. */
+int lab4d_skin_blend_backward_acc(const float* xyz, const float* art_r, const float* art_d, const float* gauss,
+                                  const float* delta_raw, const float* se3_r, const float* se3_d, const float* g_out,
+                                  const float* g_ent, const float* g_dskin, int S, int spf, int M, int B, float* g_xyz,
+                                  float* g_raw, float* g_se3, float* g_art_r, float* g_art_d, float* g_gauss, float* work,
+                                  int accumulate, void* stream);
 
 /* Gaussian-bone density  max_b exp(-0.5 |x - c_b|^2 / 0.01^2) * ibeta  (nnutils/deformable.py:329-356,
  * warping.py:355-387, utils/transforms.py:28-40).  centres: (B,3); ibeta: device scalar (no host sync).

@@ -76,7 +76,8 @@ struct RowTile {
       for (int e = threadIdx.x; e < total; e += 256) { const int r = e / C; tile[r * CP + e - r * C] = src[e]; }
     }
   }
-  static __device__ __forceinline__ void store(float* __restrict__ g, long s0, int n, const float* __restrict__ tile) {
+  // add != 0: the rows are added to what g holds (read and written in the same coalesced float4 pieces)
+  static __device__ __forceinline__ void store(float* __restrict__ g, long s0, int n, const float* __restrict__ tile, int add = 0) {
     float* dst = g + s0 * C;
     const int total = n * C;
     if ((((size_t)dst) & 15) == 0) {
@@ -85,13 +86,17 @@ struct RowTile {
           float vv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) { const int r = (e + k) / C; vv[k] = tile[r * CP + (e + k) - r * C]; }
+          if (add) {
+            const float4 o = *reinterpret_cast<const float4*>(dst + e);
+            vv[0] += o.x; vv[1] += o.y; vv[2] += o.z; vv[3] += o.w;
+          }
           *reinterpret_cast<float4*>(dst + e) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         } else {
-          for (int k = 0; e + k < total; ++k) { const int r = (e + k) / C; dst[e + k] = tile[r * CP + (e + k) - r * C]; }
+          for (int k = 0; e + k < total; ++k) { const int r = (e + k) / C; dst[e + k] = tile[r * CP + (e + k) - r * C] + (add ? dst[e + k] : 0.f); }
         }
       }
     } else {
-      for (int e = threadIdx.x; e < total; e += 256) { const int r = e / C; dst[e] = tile[r * CP + e - r * C]; }
+      for (int e = threadIdx.x; e < total; e += 256) { const int r = e / C; dst[e] = tile[r * CP + e - r * C] + (add ? dst[e] : 0.f); }
     }
   }
 };
@@ -454,12 +459,15 @@ __global__ void __launch_bounds__(256) k_blend_fwd(const float* __restrict__ xyz
 // read back by k_gram_pf_rb before round 3: 48 of the skinning adjoint's ms per step).  Thread (slice, b) walks every `slices`-th row of the
 // tile with the 8 (10) outputs of bone b in registers; the slices meet in LDS, the block keeps its sums in LDS across its tiles and
 // flushes them with one atomic per output when the frame changes and at the end.
-template <int B, bool UNI, bool FUSE>
-__global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz, const float* __restrict__ aff, const float* __restrict__ raw,
+template <int B, bool UNI, bool FUSE, bool ACC = false>
+__global__ void __launch_bounds__(256, (FUSE ? 2 : 1)) k_blend_bwd(const float* __restrict__ xyz, const float* __restrict__ aff, const float* __restrict__ raw,
                                                     const float* __restrict__ sr, const float* __restrict__ sd, const float* __restrict__ g_out,
                                                     const float* __restrict__ g_ent, const float* __restrict__ g_dskin, long S, int spf,
                                                     float* __restrict__ g_xyz, float* __restrict__ g_raw, float* __restrict__ work,
                                                     float* __restrict__ g_se3, float* __restrict__ Qm) {
+  // ACC: g_xyz and g_raw are ADDED to (the second blend of one skinning field: both adjoints land in one pair of buffers).  A template
+  // parameter: as a runtime flag it cost the fused kernel 8 registers (264: one wave per SIMD instead of two, 35 -> 60 ms per step)
+  constexpr int accumulate = ACC ? 1 : 0;
   static_assert(!FUSE || UNI, "the fused Gram reduction needs frame-uniform tiles");
   // The (S,B) operands -- raw in; coef, gsk, g_raw out -- go through ONE LDS tile of 256 rows, one after the other (RowTile): the
   // per-thread row accesses of the first version ran this kernel at 1.7 TB/s (a third of what its 516 bytes per sample allow).
@@ -587,6 +595,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz
         const float u0 = gsk * c.x, u1 = gsk * c.y, u2 = gsk * c.z;
         gx = gx + V3{A.r0.x * u0 + A.r1.x * u1 + A.r2.x * u2, A.r0.y * u0 + A.r1.y * u1 + A.r2.y * u2, A.r0.z * u0 + A.r1.z * u1 + A.r2.z * u2};
       }
+      if (accumulate) gx = gx + ldv3(g_xyz + s * 3);
       stv3(g_xyz + s * 3, gx);
       if (!FUSE) {
         float* xx = work + S * (2 * B + 8) + s * 10;  // upper triangle of [x,1][x,1]^T, row-major
@@ -630,7 +639,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const float* __restrict__ xyz
       }
     }
     __syncthreads();
-    T::store(g_raw, s0, n, tile);
+    T::store(g_raw, s0, n, tile, accumulate);
     __syncthreads();
   }
   if (FUSE && cur_m >= 0) flush(cur_m);
@@ -828,10 +837,21 @@ extern "C" int lab4d_skin_blend_forward(const float* xyz, const float* art_r, co
   return check_launch("skin_blend_forward");
 }
 
+extern "C" int lab4d_skin_blend_backward_acc(const float* xyz, const float* art_r, const float* art_d, const float* gauss, const float* raw,
+                                             const float* sr, const float* sd, const float* g_out, const float* g_ent, const float* g_dskin, int S,
+                                             int spf, int M, int B, float* g_xyz, float* g_raw, float* g_se3, float* g_art_r, float* g_art_d,
+                                             float* g_gauss, float* work, int accumulate, void* stream);
 extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* art_r, const float* art_d, const float* gauss, const float* raw,
                                          const float* sr, const float* sd, const float* g_out, const float* g_ent, const float* g_dskin, int S,
                                          int spf, int M, int B, float* g_xyz, float* g_raw, float* g_se3, float* g_art_r, float* g_art_d,
                                          float* g_gauss, float* work, void* stream) {
+  return lab4d_skin_blend_backward_acc(xyz, art_r, art_d, gauss, raw, sr, sd, g_out, g_ent, g_dskin, S, spf, M, B, g_xyz, g_raw, g_se3, g_art_r, g_art_d,
+                                       g_gauss, work, 0, stream);
+}
+extern "C" int lab4d_skin_blend_backward_acc(const float* xyz, const float* art_r, const float* art_d, const float* gauss, const float* raw,
+                                             const float* sr, const float* sd, const float* g_out, const float* g_ent, const float* g_dskin, int S,
+                                             int spf, int M, int B, float* g_xyz, float* g_raw, float* g_se3, float* g_art_r, float* g_art_d,
+                                             float* g_gauss, float* work, int accumulate, void* stream) {
   LAB4D_REQUIRE(xyz && art_r && art_d && gauss && raw && sr && sd && g_out && g_xyz && g_raw && work, "skin_blend_backward: null pointer");
   LAB4D_REQUIRE(spf > 0 && (long)M * spf >= S, "skin_blend_backward: M*spf < S");
   if (S == 0) return LAB4D_OK;
@@ -851,12 +871,20 @@ extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* art_r, c
   if (fused) {
     // one resident set of blocks walking the samples (every block ends with B x 18 atomics onto the same M x B x 18 words)
     int grid = sgrid(S); if (grid > 2048) grid = 2048;
-    SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, true, true>), dim3(grid), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
-                                        (long)S, spf, g_xyz, g_raw, ws, g_se3, Q));
-  } else if (spf % 256 == 0) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, true, false>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
-                                      (long)S, spf, g_xyz, g_raw, ws, g_se3, Q)); }
-  else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, false, false>), dim3(sgrid(S)), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, g_ent, g_dskin,
-                                      (long)S, spf, g_xyz, g_raw, ws, g_se3, Q)); }
+#define BLEND_BWD(UNI_, FUSE_, GRID_)                                                                                                              \
+  do {                                                                                                                                              \
+    if (accumulate) { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, UNI_, FUSE_, true>), dim3(GRID_), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out, \
+                                                          g_ent, g_dskin, (long)S, spf, g_xyz, g_raw, ws, g_se3, Q)); }                              \
+    else { SKIN_DISPATCH(B, hipLaunchKernelGGL((k_blend_bwd<NB, UNI_, FUSE_, false>), dim3(GRID_), dim3(256), 0, st, xyz, aff, raw, sr, sd, g_out,       \
+                                               g_ent, g_dskin, (long)S, spf, g_xyz, g_raw, ws, g_se3, Q)); }                                         \
+  } while (0)
+    BLEND_BWD(true, true, grid);
+  } else if (spf % 256 == 0) {
+    BLEND_BWD(true, false, sgrid(S));
+  } else {
+    BLEND_BWD(false, false, sgrid(S));
+  }
+#undef BLEND_BWD
   if (int e = check_launch("skin_blend_backward")) return e;
   if (g_se3 && !fused)
     if (int e = lab4d_gram_per_frame(ws, B, ws + (size_t)S * B, 8, S, spf, M, g_se3, stream)) return e;

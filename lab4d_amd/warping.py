@@ -16,6 +16,7 @@ _lib.register("lab4d_bone_coords_forward", [vp] * 4 + [ci] * 4 + [vp, vp])
 _lib.register("lab4d_bone_coords_backward", [vp] * 5 + [ci] * 4 + [vp] * 4 + [vp])
 _lib.register("lab4d_skin_blend_forward", [vp] * 7 + [ci] * 4 + [vp] * 4 + [vp])
 _lib.register("lab4d_skin_blend_backward", [vp] * 10 + [ci] * 4 + [vp] * 7 + [vp])
+_lib.register("lab4d_skin_blend_backward_acc", [vp] * 10 + [ci] * 4 + [vp] * 7 + [ci, vp])
 _lib.register("lab4d_gram_per_frame", [vp, ci, vp, ci, ci, ci, ci, vp, vp])
 _lib.register("lab4d_bone_params_from_gram", [vp] * 4 + [ci] * 2 + [vp] * 3 + [vp])
 _lib.register("lab4d_bone_affine", [vp] * 3 + [ci] * 2 + [vp, vp])
@@ -235,6 +236,73 @@ class SkinBlend(Function):
         return gx, gr, gar, gad, gg, gse3[..., :4].contiguous(), gse3[..., 4:].contiguous(), None
 
 
+class SkinBlendMulti(Function):
+    """Several blends (SkinBlend) of the SAME points and delta-skin logits to different target transforms -- the two forward warps of a training
+    query (skinning_warp_forward_multi).  Forward: SkinBlend's kernel once per target.  Backward: the adjoints of all targets land in ONE
+    (S,3) / (S,B) pair (lab4d_skin_blend_backward_acc: the second and later launches add), where autograd would sum two (S,B) tensors in a
+    pass of its own (5 GB of traffic per chunk at B = 25).  Arguments: xyz, raw, art_r, art_d, gauss, spf, then (se3_r, se3_d) per target;
+    returns (out, entropy, delta_skin) per target, flattened."""
+
+    @staticmethod
+    def forward(ctx, xyz, raw, art_r, art_d, gauss, spf, *se3s):
+        xyz, raw, art_r, art_d, gauss = [t.contiguous() for t in (xyz, raw, art_r, art_d, gauss)]
+        se3s = [t.contiguous() for t in se3s]
+        _lib.require_device(xyz, raw, art_r, art_d, gauss, *se3s)
+        S, (M, B) = xyz.shape[0], art_r.shape[:2]
+        outs = []
+        for i in range(0, len(se3s), 2):
+            out = torch.empty(S, 3, device=xyz.device)
+            ent = torch.empty(S, 1, device=xyz.device)
+            dsk = torch.empty(S, 1, device=xyz.device)
+            work = torch.empty(M * B * 12, device=xyz.device)
+            with _lib.timed("k_blend_fwd", (0.0, 4.0 * S * (3 + B + 3 + 2))):
+                _lib.check(_lib.lib().lab4d_skin_blend_forward(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
+                                                               _lib.ptr(se3s[i]), _lib.ptr(se3s[i + 1]), S, spf, M, B, _lib.ptr(out), _lib.ptr(ent),
+                                                               _lib.ptr(dsk), _lib.ptr(work), _lib.stream()), "skin_blend_forward")
+            outs += [out, ent, dsk]
+        ctx.save_for_backward(xyz, raw, art_r, art_d, gauss, *se3s)
+        ctx.spf = spf
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        xyz, raw, art_r, art_d, gauss, *se3s = ctx.saved_tensors
+        S, (M, B) = xyz.shape[0], art_r.shape[:2]
+        gx, gr = torch.empty_like(xyz), torch.empty_like(raw)
+        need_p = any(ctx.needs_input_grad[2:5])
+        fused = ctx.spf % 256 == 0 and os.environ.get("LAB4D_BLEND_FUSE", "1") != "0"
+        gar = gad = gg = None
+        gse3s = []
+        first = True
+        for i in range(0, len(se3s), 2):
+            g_out, g_ent, g_dsk = grads[3 * (i // 2):3 * (i // 2) + 3]
+            if g_out is None and g_ent is None and g_dsk is None:
+                gse3s += [None, None]
+                continue
+            g_out = torch.zeros_like(xyz) if g_out is None else g_out.contiguous()
+            g_ent = g_ent.contiguous() if g_ent is not None else None
+            g_dsk = g_dsk.contiguous() if g_dsk is not None else None
+            gse3 = torch.zeros(M, B, 8, device=xyz.device)
+            par = torch.empty_like(art_r) if need_p else None
+            pad = torch.empty_like(art_d) if need_p else None
+            pg = torch.zeros_like(gauss) if need_p else None
+            work = torch.empty(M * B * 34 + (0 if fused else S * (2 * B + 18)), device=xyz.device)
+            with _lib.timed("k_blend_bwd+gram", (0.0, 4.0 * S * ((3 + B + 3 + 2) + (3 + B) * (1 if first else 2) + (0 if fused else 2 * (2 * B + 18))))):
+                _lib.check(_lib.lib().lab4d_skin_blend_backward_acc(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
+                                                                    _lib.ptr(se3s[i]), _lib.ptr(se3s[i + 1]), _lib.ptr(g_out), _lib.ptr(g_ent),
+                                                                    _lib.ptr(g_dsk), S, ctx.spf, M, B, _lib.ptr(gx), _lib.ptr(gr), _lib.ptr(gse3),
+                                                                    _lib.ptr(par), _lib.ptr(pad), _lib.ptr(pg), _lib.ptr(work), 0 if first else 1,
+                                                                    _lib.stream()), "skin_blend_backward_acc")
+            first = False
+            if need_p:  # (M,B)-sized: summed over the targets here
+                gar, gad, gg = (par, pad, pg) if gar is None else (gar + par, gad + pad, gg + pg)
+            gse3s += [gse3[..., :4].contiguous(), gse3[..., 4:].contiguous()]
+        if first:
+            return (None,) * (6 + len(se3s))
+        return (gx, gr, gar, gad, gg, None) + tuple(gse3s)
+
+
 def get_gauss(P):
     """SkinningField.get_gauss (skinning.py:142-153)."""
     lg = P["warp.skinning_model.log_gauss"]
@@ -321,10 +389,11 @@ def skinning_warp_forward_multi(P, xyz, t_articulations, rest_articulation, t_em
     x = xyz.reshape(-1, 3)
     raw, gauss = skin_logits(P, x, rest_articulation, t_embed_mean, code, M, spf, prec, pre)
     rest_inv = None if pre is not None else Q.dual_quaternion_inverse(rest_articulation)
+    se3s = [pre["se3s"][i] if pre is not None else Q.dual_quaternion_mul(t_art, rest_inv) for i, t_art in enumerate(t_articulations)]
+    flat = SkinBlendMulti.apply(x, raw, rest_articulation[0], rest_articulation[1], gauss, spf, *[t for se3 in se3s for t in se3])
     outs = []
-    for i, t_art in enumerate(t_articulations):
-        se3 = pre["se3s"][i] if pre is not None else Q.dual_quaternion_mul(t_art, rest_inv)
-        out, ent, dsk = SkinBlend.apply(x, raw, rest_articulation[0], rest_articulation[1], gauss, se3[0], se3[1], spf)
+    for i in range(len(se3s)):
+        out, ent, dsk = flat[3 * i:3 * i + 3]
         outs.append((out.view(shape), {"skin_entropy": ent.view(shape[:-1] + (1,)), "delta_skin": dsk.view(shape[:-1] + (1,))}))
     return outs
 

@@ -180,3 +180,40 @@ def test_delta_skin_affine_form_inference_matches_training_forward():
         with torch.no_grad():
             b, _ = warping.skin_logits(P, x, art, fr["t_embed"].to(DEV), fr["code_skin"].to(DEV), M, N * D, prec)
         assert torch.equal(a.detach(), b)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 64), (3, 5, 13)])
+def test_forward_multi_equals_separate_forward_warps(shape):
+    """skinning_warp_forward_multi (one delta-skin evaluation, the blends' adjoints accumulated into one gradient pair by
+    lab4d_skin_blend_backward_acc) against two independent skinning_warp(backward=False) calls: outputs bit for bit, gradients to rounding."""
+    from lab4d_amd import warping, mlp
+    M, N, D = shape
+    P0 = synthetic.make_weights(4)
+    fr = synthetic.add_codes(synthetic.make_frames(5, M, 64), P0)
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.randn(M, N, D, 3, generator=g) * 0.08
+    ws = [torch.randn(M, N, D, 3, generator=g).to(DEV) for _ in range(2)]
+    we = [torch.randn(M, N, D, 1, generator=g).to(DEV) for _ in range(2)]
+    pkeys = ["warp.skinning_model.log_gauss", "warp.skinning_model.delta_field.linear_1.0.weight", "warp.skinning_model.delta_field.linear_final.weight"]
+
+    def run(multi):
+        P = {k: (v.to(DEV).clone().requires_grad_(True) if v.dtype.is_floating_point else v.to(DEV)) for k, v in P0.items()}
+        t_art = tuple(t.to(DEV).clone().requires_grad_(True) for t in fr["t_articulation"])
+        nxt = tuple(t.to(DEV).flip(0).clone().requires_grad_(True) for t in fr["t_articulation"])
+        rest = tuple(t.to(DEV).clone().requires_grad_(True) for t in fr["rest_articulation"])
+        x = xyz.to(DEV).clone().requires_grad_(True)
+        te, code = fr["t_embed_mean"].to(DEV), fr["code_skin"].to(DEV)
+        if multi:
+            res = warping.skinning_warp_forward_multi(P, x, [nxt, t_art], rest, te, code, mlp.PREC_F32)
+        else:
+            res = [warping.skinning_warp(P, x, a, rest, te, code, False, mlp.PREC_F32) for a in (nxt, t_art)]
+        loss = sum((o * w).sum() + (aux["skin_entropy"] * e).sum() + (aux["delta_skin"] * e).sum() * 50 for (o, aux), w, e in zip(res, ws, we))
+        gs = torch.autograd.grad(loss, [x, t_art[0], t_art[1], nxt[0], nxt[1], rest[0], rest[1]] + [P[k] for k in pkeys])
+        return [o for o, _ in res] + [aux[k] for _, aux in res for k in ("skin_entropy", "delta_skin")], gs
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for a, b, n in zip(g1, g0, ["x", "t_r", "t_d", "n_r", "n_d", "rest_r", "rest_d"] + pkeys):
+        assert rel(a, b.cpu()) < 1e-5, (n, rel(a, b.cpu()))
