@@ -11,6 +11,7 @@ Heavy per-sample work runs in liblab4d_hip.so; what is left in torch here is per
 a handful of element-wise epilogues that DESIGN.md lists as not yet folded into kernels.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -187,6 +188,10 @@ def volsdf_density(sdf, logibeta):
     return VolSdfDensity.apply(sdf, logibeta.exp())
 
 
+# The eikonal term's primal pass takes its ReLU pattern from the basefield pass over all samples (mlp.EikonalSdf); 0: it runs its own forward (A/B).
+EIK_REUSE = os.environ.get("LAB4D_EIK_REUSE", "1") != "0"
+
+
 def posenc_window(alpha, n_freq, device):
     """PosEmbedding.apply_annealing window (embedding.py:112-125)."""
     if alpha is None:
@@ -195,7 +200,7 @@ def posenc_window(alpha, n_freq, device):
     return 0.5 * (1 + torch.cos(torch.pi * w + torch.pi))
 
 
-def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None, ft=None):
+def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None, ft=None, tap=None):
     """NeRF.forward (nerf.py:167-215), fg configuration (no view dependence, appearance code in the rgb head).
     ft: the step's per-frame terms (frame_terms) -- the per-frame bias tables are taken from there instead of being re-formed."""
     shape = xyz.shape
@@ -203,7 +208,7 @@ def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None
     x = xyz.reshape(-1, 3)
     dev = x.device
     sdf, feat = mlp.run_chain(mlp.NET_FG_BASE, prec, P, x, spf, conds={0: fr["code_base"], 4: fr["code_base"]}, export_layer=8,
-                              freq_w=posenc_window(alpha, 10, dev), pfs_pre=None if ft is None else {0: ft["pf.base0"], 4: ft["pf.base4"]})
+                              freq_w=posenc_window(alpha, 10, dev), pfs_pre=None if ft is None else {0: ft["pf.base0"], 4: ft["pf.base4"]}, tap=tap)
     sdf = sdf.view(shape[:-1] + (1,))
     if get_density:
         out = volsdf_density(sdf, P["logibeta"])  # VolSDF (nerf.py:186-192)
@@ -348,7 +353,7 @@ def global_match(P, feat_px, feat_rows, xyz_rows):
     return out.view(shape[:-1] + (3,))
 
 
-def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32, net=mlp.NET_FG_BASE, prefix="", pf_tables=None):
+def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32, net=mlp.NET_FG_BASE, prefix="", pf_tables=None, tap=None):
     """NeRF.compute_eikonal (nerf.py:416-453) on the host-drawn 1/16 ray subset: (|d sdf/dx| - 1)^2 with gradients to the
     basefield / sdf weights, via the primal + tangent-mode chain kernels (mlp.EikonalSdf) -- no second-order autograd.
     pf_tables = (pf0, pf4): the (M, mout) per-frame bias tables of layers 0 and 4 from the step's prologue; the per-ray rows are
@@ -364,8 +369,11 @@ def eikonal_subsample(P, xyz, code, rand_inds, alpha=None, prec=mlp.PREC_F32, ne
         ray_code, pf_rows = None, (pf_tables[0].index_select(0, ray_frame), pf_tables[1].index_select(0, ray_frame))
     else:
         ray_code, pf_rows = code[ray_frame], None
+    eik_tap = None
+    if tap and D % 64 == 0:  # the field was just evaluated on every sample: ray r = 64-sample blocks r D/64 .. of that pass (mlp.EikonalSdf)
+        eik_tap = (tap, (rand_inds[:, None] * (D // 64) + torch.arange(D // 64, device=xyz.device)).reshape(-1))
     e = mlp.eikonal_sdf(P, x, ray_code, D, prec, freq_w=posenc_window(alpha, mlp.describe(net).n_freq, xyz.device), prefix=prefix, net=net,
-                        pf_rows=pf_rows)
+                        pf_rows=pf_rows, tap=eik_tap)
     out = out.index_put((rand_inds,), e.view(-1, D))
     return out.reshape(M, N, D, 1)
 
@@ -524,7 +532,8 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
         xyz = xyz_flat.view(xyz.shape)
     fd = {}
     vis = vis_field(P, xyz, fr, prec, ft)
-    rgb, density = nerf_forward(P, xyz, fr, prec, alpha=alpha, ft=ft)
+    base_tap = {} if EIK_REUSE else None  # the basefield pass's ReLU pattern, handed to the eikonal term below
+    rgb, density = nerf_forward(P, xyz, fr, prec, alpha=alpha, ft=ft, tap=base_tap)
     fd["rgb"], fd["density"], fd["density_fg"], fd["vis"] = rgb, density, density, vis
     # flow: canonical points into the pair partner's camera (nerf.py:948-997)
     nxt = flip_pair({k: fr.get(k) for k in ["Kinv", "field2cam", "t_articulation", "rest_articulation"]})
@@ -549,7 +558,7 @@ def query_field_train(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None,
     for k in ["skin_entropy", "delta_skin"]:
         # NeRF.cycle_loss's zeros (nerf.py:905-927) unless the warp reports the term (nerf.py:658-664)
         fd[k] = (cyc_aux[k] + bw_aux[k]) / 2 if k in cyc_aux else torch.zeros_like(fd["cyc_dist"])
-    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha, prec, pf_tables=(ft["pf.base0"], ft["pf.base4"]))
+    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds"), alpha, prec, pf_tables=(ft["pf.base0"], ft["pf.base4"]), tap=base_tap)
     fd["xyz"] = xyz
     fd["xyz_cam"] = xyz_cam
     fd["depth"] = depth / ft["scale"]

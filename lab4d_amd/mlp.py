@@ -459,6 +459,11 @@ class MlpChain(Function):
             _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
         ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
+        global _TAP
+        if _TAP is not None:  # run_chain(tap=...): the training-mode pass's ReLU sign words and stored embedding, for EikonalSdf (references, not copies)
+            if need_grad:
+                _TAP.update(net=net, prec=prec, S=S, S_pad=S_pad, masks=list(masks), emb=emb)
+            _TAP = None
         ctx.params = params
         ctx.x_shape = x.shape if aff is None else (S, d.c_in)  # what d_x is the gradient of: the net's own inputs
         ctx.has_x2 = x2 is not None
@@ -589,11 +594,18 @@ class MlpChain(Function):
         return (None, None, None, d_x, ext_g, None, None, None, d_x2, *grads_pf, *grads_params)
 
 
-def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_layer=None, prefix="", x2=None, pfs_pre=None):
+_TAP = None
+
+
+def run_chain(net, prec, P, x, spf, conds=None, ext=None, freq_w=None, export_layer=None, prefix="", x2=None, pfs_pre=None, tap=None):
     """Convenience wrapper: P maps reference state_dict names -> device tensors; conds maps layer index ->
     (M, C) per-frame conditioning input of that layer.  pfs_pre maps layer index -> an already evaluated per-frame bias
     pf_bias_of(net, l, W, conds[l]) (the per-frame prologue of a training step, deformable.frame_terms: the table does not
-    depend on the rays, so it is formed once per step, not once per chunk).  Returns out or (out, exported activation)."""
+    depend on the rays, so it is formed once per step, not once per chunk).  Returns out or (out, exported activation).
+    tap: a dict that receives this (training-mode) pass's stored ReLU sign words and embedding -- eikonal_sdf(tap=...) then takes its primal
+    pattern from them instead of running the primal forward again on its subset of the same samples."""
+    global _TAP
+    _TAP = tap
     d = describe(net)
     bd = bindings(net, prefix)
     pfs = []
@@ -668,6 +680,8 @@ class EikonalSdf(Function):
 
     @staticmethod
     def forward(ctx, net, prec, spf, x, freq_w, pf0, pf4, *params):
+        global _EIK_TAP
+        tap, _EIK_TAP = _EIK_TAP, None
         if net not in (NET_FG_BASE, NET_BG_BASE):
             raise RuntimeError("EikonalSdf: the eikonal term exists for the basefield / sdf networks only (net %d)" % net)
         d = describe(net)
@@ -716,7 +730,26 @@ class EikonalSdf(Function):
             a.act[l] = _lib.dp(tact[l])
         sdf = torch.empty(S, 1, device=dev)
         a.out = _lib.dp(sdf)
-        _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(eikonal primal)")
+        reused = False
+        if tap is not None:
+            # The points are whole 64-sample blocks of a training-mode pass of this very network that has just run (same weights, per-frame
+            # biases and annealing window: deformable.query_field_train evaluates the field on ALL samples and the eikonal term on a drawn 1/16
+            # of the rays): the primal pass's ReLU sign words and stored embedding are GATHERED from that pass's buffers (rows = tiles / blocks)
+            # instead of being recomputed by a forward launch of their own.
+            src, blk_map = tap  # blk_map: (S / 64) int64, 64-sample block of the tapped pass that block i of x is
+            ok = (src.get("net") == net and src.get("prec") == prec and S % 64 == 0 and S_pad == S and blk_map.numel() == S // 64
+                  and src.get("emb") is not None and all((masks[l] is None) == (src["masks"][l] is None) for l in range(NL)))
+            if ok:
+                nb_src = src["S_pad"] // 64
+                tpb = 64 // tile  # tiles per block: 1 (bf16) / 2 (fp32)
+                tile_map = blk_map if tpb == 1 else (blk_map[:, None] * tpb + torch.arange(tpb, device=dev)).reshape(-1)
+                for l in range(NL):
+                    if masks[l] is not None:
+                        masks[l] = src["masks"][l].view(nb_src * tpb, -1).index_select(0, tile_map).reshape(-1)
+                emb = src["emb"].view(nb_src, -1).index_select(0, blk_map).reshape(-1)
+                reused = True
+        if not reused:
+            _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(eikonal primal)")
         bk = BwdArgs()
         bk.net, bk.precision, bk.S, bk.S_pad, bk.ld, bk.spf = net, prec, S, S_pad, S_pad, int(spf)
         dz = [None] * NL
@@ -804,10 +837,15 @@ class EikonalSdf(Function):
         return (None, None, None, None, None, None, None, *grads)
 
 
-def eikonal_sdf(P, x, ray_code, spf, prec, freq_w=None, prefix="", net=NET_FG_BASE, pf_rows=None):
+_EIK_TAP = None
+
+
+def eikonal_sdf(P, x, ray_code, spf, prec, freq_w=None, prefix="", net=NET_FG_BASE, pf_rows=None, tap=None):
     """(|d sdf/dx| - 1)^2 at detached points x (S,3); ray_code (S/spf, 32) = instance code of the ray each group of `spf`
     consecutive samples belongs to.  net = NET_FG_BASE or NET_BG_BASE (both condition layers 0 and 4 on the code).
-    pf_rows = (pf0, pf4) already evaluated per ray (rows of the per-frame tables, deformable.frame_terms) replaces ray_code."""
+    pf_rows = (pf0, pf4) already evaluated per ray (rows of the per-frame tables, deformable.frame_terms) replaces ray_code.
+    tap = (dict filled by run_chain(tap=...) of the SAME network on a superset of these samples, (S/64) int64 block map): the primal pass's
+    ReLU pattern and embedding are taken from that pass."""
     bd = bindings(net, prefix)
     if pf_rows is not None:
         pf0, pf4 = pf_rows
@@ -817,4 +855,6 @@ def eikonal_sdf(P, x, ray_code, spf, prec, freq_w=None, prefix="", net=NET_FG_BA
     params = []
     for l in range(describe(net).n_layers):
         params += [P[bd[l].wname], P[bd[l].bname]]
+    global _EIK_TAP
+    _EIK_TAP = tap  # (tapped pass, block map): see EikonalSdf.forward
     return EikonalSdf.apply(net, prec, spf, x, freq_w, pf0, pf4, *params)

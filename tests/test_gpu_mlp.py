@@ -208,6 +208,35 @@ def test_eikonal_value_and_weight_gradients(prec, tol):
         assert cosine(a, b) > 0.97, f"{k}: cosine {cosine(a, b):.4f}"
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+def test_eikonal_primal_pattern_taken_from_the_field_pass(prec):
+    """The eikonal term's primal pass on a drawn subset of the rays, with its ReLU sign words and stored embedding GATHERED from the training-mode
+    basefield pass over all samples (mlp.run_chain(tap=...) -> mlp.eikonal_sdf(tap=...)) instead of recomputed: values bit for bit
+    equal to the stand-alone form (the same kernel on the same inputs wrote the words that are gathered), weight gradients to rounding."""
+    from lab4d_amd import deformable as DF, mlp
+    M, N, D = 2, 6, 128
+    P, fr, xyz, g = setup(21, M, N, D)
+    inds = torch.tensor([0, 3, 4, 7, 10, 11])
+    w = torch.rand(M, N, D, 1, generator=g).to(DEV)
+    keys = [k for k in P if (k.startswith("basefield.linear_") or k == "sdf.weight") and k.endswith("weight")]
+    Pl = {k: (v.to(DEV).clone().requires_grad_(True) if v.dtype.is_floating_point else v.to(DEV)) for k, v in P.items()}
+    frd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in fr.items()}
+    x = xyz.to(DEV)
+
+    def run(reuse):
+        tap = {} if reuse else None
+        DF.nerf_forward(Pl, x, frd, prec, with_color=False, tap=tap)  # the field pass over all samples (training mode: the weights require grad)
+        assert (not reuse) or tap.get("emb") is not None
+        e = DF.eikonal_subsample(Pl, x, frd["code_base"], inds.to(DEV), prec=prec, tap=tap)
+        return e, torch.autograd.grad((e * w).sum(), [Pl[k] for k in keys])
+
+    e1, g1 = run(True)
+    e0, g0 = run(False)
+    assert torch.equal(e1, e0)  # same sign words, same kernels
+    for k, a, b in zip(keys, g1, g0):  # the weight-gradient kernels add their block partials atomically: equal up to the order of those additions
+        assert rel_err(a, b.cpu()) < 1e-5, (k, rel_err(a, b.cpu()))
+
+
 def test_eikonal_with_a_dead_layer_keeps_gradients_finite():
     """Every unit of the last hidden layer dead => d sdf/dx == 0 exactly: the loss is 1 per sample and its weight gradients are
     finite (the zero subgradient of the norm, as torch's norm backward takes it), not 0/0 spread through the wgrad GEMM."""
