@@ -685,6 +685,11 @@ constexpr unsigned bwd_members(int r) {
   return m;
 }
 
+// heads with many channels (the delta-skin logits: 25 / 18) move their (TILE, COUT) fp32 tiles through the wave's slab (coalesced global IO).
+// (The 16-channel feature head stays on per-lane rows: staged, its two-workgroups-per-CU kernels spill 6-7 more registers.)
+template <class Net>
+constexpr bool head_staged() { return Net::COUT > 16; }
+
 template <class Net, class P>
 struct Slab {
   static constexpr int W = net_wmax<Net>();
@@ -1182,6 +1187,22 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
 #pragma unroll
             for (int q = 0; q < P::UPT; ++q) slab[(t * UW + P::UPT * mt + q) * 64] = u[q];
           }
+        } else if constexpr (head_staged<Net>() && !TAN) {
+          // head with many channels (delta-skin logits, features): written lane by lane the (S, COUT) rows cost COUT 4-byte stores per sample at a
+          // COUT*4-byte stride; the tile goes through the wave's slab (idle: this layer's inputs are in registers, no layer follows) and leaves
+          // as one contiguous, coalesced region
+          static_assert(pad32(Net::COUT) == 32, "one row tile");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int f = drow(r, h);
+              if (f < Net::COUT) stagef[(NT * n + t) * Net::COUT + f] = acc[t][r];
+            }
+          __builtin_amdgcn_wave_barrier();
+          if (a.out) stage_out(stagef, a.out, (long)s0 * Net::COUT, TILE * Net::COUT, (long)S_eff * Net::COUT - 1, lane);
+          __builtin_amdgcn_wave_barrier();
         } else {
           // head: raw outputs (S, COUT) fp32
 #pragma unroll
@@ -1419,6 +1440,19 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
     // ---- head gradient: (S, COUT) fp32 -> accumulator layout -> stored + B units in the slab ----
     {
       f32x16_t g[NT];
+      if constexpr (head_staged<Net>()) {  // the tile's (TILE, COUT) rows: one coalesced copy into the (still idle) slab, then row reads (see the forward head)
+        __builtin_amdgcn_wave_barrier();
+        stage_in<TILE * Net::COUT>(stagef, a.d_out, (long)s0 * Net::COUT, (long)a.S * Net::COUT - 1, lane);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f = drow(r, h);
+            g[t][r] = (f < Net::COUT && sidx[t] < a.S) ? stagef[(NT * n + t) * Net::COUT + (f < Net::COUT ? f : 0)] : 0.f;
+          }
+        __builtin_amdgcn_wave_barrier();
+      } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1426,6 +1460,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
           const int f = drow(r, h);
           g[t][r] = (f < Net::COUT && sidx[t] < a.S) ? a.d_out[(size_t)sidx[t] * Net::COUT + f] : 0.f;
         }
+      }
       store_tile<P>((GLOBAL_AS void*)a.dz[NL - 1], pad32(Net::L[NL - 1].mout), s0, 0, lane, g);  // every dz[l] is required (host-checked): no stores in runtime branches
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
