@@ -129,7 +129,25 @@ def lib():
             fn = getattr(_LIB, name)
             fn.argtypes = at
             fn.restype = ctypes.c_int64 if name in ("lab4d_mlp_packed_bytes", "lab4d_compact_work_ints") else ci
-    return _LIB
+    return _LIB if PROF is None else _ProfiledLib(_LIB)
+
+
+class _ProfiledLib:
+    """While per-kernel profiling is on (PROF is a dict): every entry point that is not already inside a `timed` block is timed under its own
+    name, so the per-kernel table of the bench line accounts for ALL of the library's launches, not only the ones with a work model."""
+
+    def __init__(self, lib_):
+        self._lib = lib_
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if PROF is None or _TIMED_DEPTH > 0 or not name.startswith("lab4d_") or name in ("lab4d_last_error", "lab4d_arch", "lab4d_mlp_describe", "lab4d_mlp_packed_bytes", "lab4d_compact_work_ints", "lab4d_global_match_workspace_floats"):  # host-only
+            return fn
+
+        def call(*a):
+            with timed(name[6:]):
+                return fn(*a)
+        return call
 
 
 # LAB4D_NANCHECK=1 (diagnostic): every tensor whose pointer is handed to the library is remembered, and after each entry point returns
@@ -210,6 +228,7 @@ def require_device(*tensors):
 # --------------------------------------------------------------------------------------------------
 # optional per-kernel-family timing with HIP events on the launch stream (used by bench.py's roofline)
 # --------------------------------------------------------------------------------------------------
+_TIMED_DEPTH = 0
 PROF = None  # set to {} to enable: name -> list of (start_event, end_event, work)
 
 
@@ -221,14 +240,19 @@ class timed:
         self.name, self.work = name, work
 
     def __enter__(self):
-        if PROF is not None:
+        global _TIMED_DEPTH
+        _TIMED_DEPTH += 1
+        self.on = PROF is not None and _TIMED_DEPTH == 1  # nested blocks belong to the outer one
+        if self.on:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
         return self
 
     def __exit__(self, *a):
-        if PROF is not None:
+        global _TIMED_DEPTH
+        _TIMED_DEPTH -= 1
+        if self.on and PROF is not None:
             self.e.record()
             PROF.setdefault(self.name, []).append((self.s, self.e, self.work))
         return False

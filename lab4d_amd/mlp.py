@@ -749,7 +749,8 @@ class EikonalSdf(Function):
                 emb = src["emb"].view(nb_src, -1).index_select(0, blk_map).reshape(-1)
                 reused = True
         if not reused:
-            _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(eikonal primal)")
+            with _lib.timed("k_mlp_fwd<%s>@eik" % KERNEL_NET[net]):
+                _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(eikonal primal)")
         bk = BwdArgs()
         bk.net, bk.precision, bk.S, bk.S_pad, bk.ld, bk.spf = net, prec, S, S_pad, S_pad, int(spf)
         dz = [None] * NL
@@ -771,7 +772,8 @@ class EikonalSdf(Function):
         bk.d_out = _lib.dp(ones)
         g = torch.empty(S, 3, device=dev)
         bk.d_x = _lib.dp(g)
-        _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(bk), _lib.stream()), "mlp_backward(eikonal primal)")
+        with _lib.timed("k_mlp_bwd<%s>@eik" % KERNEL_NET[net]):
+            _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(bk), _lib.stream()), "mlp_backward(eikonal primal)")
         gn = g.norm(2, dim=-1, keepdim=True)
         ctx.meta = (net, prec, int(spf), S, S_pad)
         ctx.saved = (x, fw, g, gn, dz, masks, packed, tact)
@@ -807,7 +809,8 @@ class EikonalSdf(Function):
                 a.act[l] = _lib.dp(tact[l])
         temb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
         a.emb = _lib.dp(temb)
-        _lib.check(_lib.lib().lab4d_mlp_forward_tangent(ctypes.byref(a), _lib.stream()), "mlp_forward_tangent")
+        with _lib.timed("k_mlp_fwd_tangent<%s>@eik" % KERNEL_NET[net]):
+            _lib.check(_lib.lib().lab4d_mlp_forward_tangent(ctypes.byref(a), _lib.stream()), "mlp_forward_tangent")
         sinks = [(_grad_sink(Ws[l]) if ctx.needs_input_grad[7 + 2 * l] else None) for l in range(NL)]
         sizes = [0 if sinks[l] is not None else d.layers[l].mout_pad * (d.layers[l].ke + d.layers[l].kin) for l in range(NL)]
         arena = torch.zeros(sum(sizes), device=dev)
