@@ -221,7 +221,7 @@ def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None
     return torch.sigmoid(rgb).view(shape[:-1] + (3,)), out
 
 
-def nerf_forward_bg(P, xyz, dir, codes, prec, get_density=True, alpha=None, prefix=""):
+def nerf_forward_bg(P, xyz, dir, codes, prec, get_density=True, alpha=None, prefix="", tap=None):
     """NeRF.forward (nerf.py:167-215) for the background field NeRF(num_freq_xyz=6, num_freq_dir=0, appr_channels=0, D=5,
     W=128) (multifields.py:86-93): the rgb head sees [feature | raw view direction].  codes = {"basefield": (M,32),
     "colorfield": (M,32)}; dir (M,N,D,3) or None (sdf / density only)."""
@@ -230,7 +230,7 @@ def nerf_forward_bg(P, xyz, dir, codes, prec, get_density=True, alpha=None, pref
     x = xyz.reshape(-1, 3)
     dev = x.device
     sdf, feat = mlp.run_chain(mlp.NET_BG_BASE, prec, P, x, spf, conds={0: codes["basefield"], 4: codes["basefield"]}, export_layer=5,
-                              freq_w=posenc_window(alpha, 6, dev), prefix=prefix)
+                              freq_w=posenc_window(alpha, 6, dev), prefix=prefix, tap=tap)
     sdf = sdf.view(shape[:-1] + (1,))
     if get_density:
         out = volsdf_density(sdf, P[prefix + "logibeta"])
@@ -941,13 +941,14 @@ def query_field_train_bg(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=No
     xyz_cam, _, deltas, depth, xyz, dirs = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=n_depth)
     fd = {}
     vis = vis_field(P, xyz, fr, prec)
-    rgb, density = nerf_forward_bg(P, xyz, dirs, codes, prec, alpha=alpha, prefix=prefix)
+    base_tap = {} if EIK_REUSE else None  # as in query_field_train: the eikonal term takes its primal ReLU pattern from this pass
+    rgb, density = nerf_forward_bg(P, xyz, dirs, codes, prec, alpha=alpha, prefix=prefix, tap=base_tap)
     fd["rgb"], fd["density"], fd["density_bg"], fd["vis"] = rgb, density, density, vis
     nxt = flip_pair({k: fr[k] for k in ["Kinv", "field2cam"]})
     fd["flow"], _ = FlowCyc.apply(xyz, nxt["field2cam"][0], nxt["field2cam"][1], Q.kmatinv(nxt["Kinv"]), hxy, None, None, flow_thresh)
     for k in ("cyc_dist", "delta_skin", "skin_entropy"):
         fd[k] = torch.zeros_like(density)
-    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds_bg"), alpha, prec, net=mlp.NET_BG_BASE, prefix=prefix)
+    fd["eikonal"] = eikonal_subsample(P, xyz, fr["code_base"], rng.get("eik_inds_bg"), alpha, prec, net=mlp.NET_BG_BASE, prefix=prefix, tap=base_tap)
     fd["xyz"] = xyz
     fd["xyz_cam"] = xyz_cam
     fd["depth"] = depth / P[prefix + "logscale"].exp()
