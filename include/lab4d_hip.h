@@ -191,6 +191,12 @@ int lab4d_compose_gather(const float* a, int Da, const float* b, int Db, const i
 int lab4d_l2_normalize_forward(const float* x, int S, int C, float* y, void* stream);
 int lab4d_l2_normalize_backward(const float* x, const float* g, int S, int C, float* g_x, void* stream);
 
+/* Eikonal term, backward (nnutils/nerf.py:416-453; see lab4d_mlp_forward_tangent in lab4d_mlp.h): from the points x (S,3), the sdf gradient g (S,3)
+ * and the incoming gradient ge (S) of (|g| - 1)^2, the tangent-mode input u (S, ke) = J_e(x) dL/dg in embedding-slot order (n_freq bands, optional
+ * annealing weights freq_w), zero-padded to ke columns. */
+int lab4d_eikonal_tangent_input(const float* x, const float* g, const float* ge, const float* freq_w, int S, int n_freq, int ke, float* u,
+                                void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * 3d. FeatureNeRF.global_match -- nnutils/feature.py:152-199: soft arg-max of the (R,16) pixel features over K <= 1024 canonical
  *     candidates (the caller draws them: torch.randperm, feature.py:176-178, and gathers their rows),

@@ -53,6 +53,7 @@ _lib.register("lab4d_mlp_pack", [ci, ci, ci, ci, vp, ci, vp, vp, vp])
 _lib.register("lab4d_mlp_forward", [ctypes.POINTER(FwdArgs), vp])
 _lib.register("lab4d_mlp_backward", [ctypes.POINTER(BwdArgs), vp])
 _lib.register("lab4d_mlp_forward_tangent", [ctypes.POINTER(FwdArgs), vp])
+_lib.register("lab4d_eikonal_tangent_input", [vp, vp, vp, vp, ci, ci, ci, vp, vp])
 _lib.register("lab4d_mlp_wgrad", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp])
 _lib.register("lab4d_mlp_wgrad_mapped", [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp])
 _lib.SIGNATURES["lab4d_mlp_packed_bytes"] = [ci, ci, ci]
@@ -791,12 +792,9 @@ class EikonalSdf(Function):
         dev, sdt = x.device, store_dtype(prec)
         # dL/dg, then u = J_e(x) dL/dg in embedding-slot order [ (f, a, {sin,cos}) pairs | x | pad ]
         # zero sdf gradient (every unit of a layer dead): torch's norm backward takes the zero subgradient there, not 0/0
-        dLdg = ge * torch.where(gn > 0, 2 * (gn - 1) / gn.clamp_min(1e-38), torch.zeros_like(gn)) * g
-        freq = 2.0 ** torch.arange(L0, dtype=torch.float32, device=dev)
-        wf = freq if fw is None else freq * fw
-        ang = x[:, None, :] * freq[None, :, None]
-        u = torch.stack([wf[None, :, None] * torch.cos(ang) * dLdg[:, None, :], -wf[None, :, None] * torch.sin(ang) * dLdg[:, None, :]], -1)
-        u = torch.cat([u.reshape(S, 6 * L0), dLdg, torch.zeros(S, d.ke - 6 * L0 - 3, device=dev)], -1).contiguous()
+        u = torch.empty(S, d.ke, device=dev)
+        _lib.check(_lib.lib().lab4d_eikonal_tangent_input(_lib.ptr(x), _lib.ptr(g), _lib.ptr(ge.contiguous().float()), _lib.ptr(fw), S, L0, d.ke, _lib.ptr(u),
+                                                          _lib.stream()), "eikonal_tangent_input")
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, S_pad, spf
         a.x = _lib.dp(u)
