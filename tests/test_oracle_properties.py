@@ -136,3 +136,44 @@ def test_gauss_density_peaks_at_a_bone_centre():
     x = centres[0][None, :, None, :]  # (1, B, 1, 3): exactly at the centres
     d = O.gauss_density(P, x, fr["rest_articulation"])
     assert torch.allclose(d, torch.full_like(d, math.exp(float(P["warp.logibeta"]))), rtol=1e-5)
+
+
+def test_delta_skin_first_layer_is_affine_in_the_point():
+    """The identity behind LAB4D_NET_SKIN_A (include/lab4d_mlp.h): SkinningField.forward (skinning.py:89-124, restated in O.skinning_field) feeds
+    linear_1 the gaussian-scaled bone coordinates through PosEmbedding(3B, 0) = identity, and those are affine in the point per (frame, bone),
+    so  linear_1([coords | t_embed | code]) == Wf[frame] [x; 1]  with  Wf = W1[:, :3B] aff[frame]  (+ the conditioning columns and the bias in the
+    last column).  Checked in float64 on the oracle's own functions: the table is read off get_bone_coords by evaluating it at 0, e_x, e_y, e_z."""
+    from lab4d_amd import synthetic
+    M, N, D, B = 3, 4, 5, 25
+    P = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in synthetic.make_weights(2).items()}
+    fr = synthetic.add_codes(synthetic.make_frames(3, M, 64), synthetic.make_weights(2))
+    art = tuple(t.double() for t in fr["t_articulation"])
+    t_embed, code = fr["t_embed"].double(), fr["code_skin"].double()
+    g = torch.Generator().manual_seed(5)
+    xyz = torch.randn(M, N, D, 3, generator=g, dtype=torch.float64) * 0.1
+    q = "warp.skinning_model.delta_field."
+    W1, b1 = P[q + "linear_1.0.weight"], P[q + "linear_1.0.bias"]
+    gauss = O.get_gauss(P)
+
+    def coords(pts):  # (M, K, 3) points -> (M, K, 3B) gaussian-scaled bone coordinates
+        b2o = tuple(a[:, None].expand((M, pts.shape[1]) + a.shape[1:]) for a in art)
+        return (O.get_bone_coords(pts, b2o) / gauss.view(1, 1, -1, 3)).reshape(M, pts.shape[1], 3 * B)
+
+    probe = torch.cat([torch.zeros(1, 3, dtype=torch.float64), torch.eye(3, dtype=torch.float64)])[None].expand(M, 4, 3)
+    c = coords(probe)                                                            # (M, 4, 3B)
+    aff = torch.cat([(c[:, 1:] - c[:, :1]).transpose(1, 2), c[:, 0, :, None]], -1)  # (M, 3B, 4): row = [linear part | offset]
+    pf = torch.cat([t_embed, code], -1) @ W1[:, 3 * B:].t()                       # (M, 64): the per-frame conditioning columns
+    tab = torch.einsum("fc,mcj->mfj", W1[:, :3 * B], aff)
+    tab = torch.cat([tab[..., :3], tab[..., 3:] + (pf + b1)[..., None]], -1)     # what warping.skin_affine_table builds
+    xh = torch.cat([xyz, torch.ones_like(xyz[..., :1])], -1)
+    z_affine = torch.einsum("mfj,mndj->mndf", tab, xh)
+    emb = coords(xyz.reshape(M, N * D, 3)).reshape(M, N, D, 3 * B)
+    cond = torch.cat([t_embed, code], -1)[:, None, None].expand(M, N, D, 160)
+    z_ref = torch.nn.functional.linear(torch.cat([emb, cond], -1), W1, b1)
+    assert float((z_affine - z_ref).abs().max()) < 1e-10 * float(z_ref.abs().max())
+    # and therefore the whole field: the remaining two layers on relu(z) reproduce O.skinning_field's delta
+    h = torch.relu(z_affine)
+    h = torch.relu(torch.nn.functional.linear(h, P[q + "linear_2.0.weight"], P[q + "linear_2.0.bias"]))
+    delta = torch.relu(torch.nn.functional.linear(h, P[q + "linear_final.weight"], P[q + "linear_final.bias"])) * 0.1
+    _, delta_ref = O.skinning_field(P, xyz, art, t_embed, code)
+    assert float((delta - delta_ref).abs().max()) < 1e-10
