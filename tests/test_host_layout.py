@@ -41,6 +41,22 @@ def test_every_reference_weight_column_is_consumed_exactly_once():
             assert bool(L.pf_bias) == bool(bd.cond), bd.wname
 
 
+def test_affine_form_skin_nets_bind_the_reference_layers_two_and_final():
+    """LAB4D_NET_SKIN_A / _SKIN18_A: layers 0 / 1 are the reference's linear_2 / linear_final with identity column maps (the 64 "embedding" slots
+    are the hidden features of the folded linear_1, in order); the folded layer's columns are consumed by warping.skin_affine_table."""
+    for n_bones, net_old in ((25, mlp.NET_SKIN), (18, mlp.NET_SKIN18)):
+        net = mlp.skin_net_for(n_bones, affine=True)
+        assert net in (mlp.NET_SKIN_A, mlp.NET_SKIN18_A) and mlp.skin_net_for(n_bones) == net_old
+        d, old = mlp.describe(net), mlp.describe(net_old)
+        assert d.emb_kind == 2 and d.n_layers == old.n_layers - 1 and d.c_out == n_bones and d.ke == old.layers[0].mout_pad == 64
+        bd, bd_old = mlp.bindings(net), mlp.bindings(net_old)
+        assert [b.wname for b in bd] == [b.wname for b in bd_old[1:]]
+        for layer in range(d.n_layers):
+            L = d.layers[layer]
+            assert (L.mout, L.relu, L.pf_bias) == (old.layers[layer + 1].mout, old.layers[layer + 1].relu, 0)
+            assert mlp.col_map(net, layer, "cpu").tolist() == list(range(L.ke + L.kin))
+
+
 def test_slot_permutation_matches_the_reference_embedding_layout():
     g = torch.Generator().manual_seed(0)
     x = torch.randn(9, 3, generator=g)

@@ -101,7 +101,7 @@ def test_every_name_the_adapters_read_exists_in_the_reference_modules(ns):
     from lab4d_amd import mlp, patch
     fields = _fields(ns)
     scalars_fg = ["logibeta", "logscale", "logsigma", "aabb", "warp.logibeta", "warp.skinning_model.log_gauss", "warp.skinning_model.symm_idx"]
-    nets_fg = [(mlp.NET_FG_BASE, ""), (mlp.NET_FG_COLOR, ""), (mlp.NET_VIS, ""), (mlp.NET_FEAT, ""), (mlp.NET_SKIN, "")]
+    nets_fg = [(mlp.NET_FG_BASE, ""), (mlp.NET_FG_COLOR, ""), (mlp.NET_VIS, ""), (mlp.NET_FEAT, ""), (mlp.NET_SKIN, ""), (mlp.NET_SKIN_A, "")]
     for motion in ("skel-quad", "comp_skel-quad_dense"):
         f = fields[motion]
         assert patch.field_kind(f) == "fg"
