@@ -1956,6 +1956,8 @@ inline int mlp_grid(int ntiles) {
   }
   int g = (ntiles + 3) / 4;
   if (g > n_cu * per_cu) g = n_cu * per_cu;
+  static const int grid_env = getenv("LAB4D_CHAIN_GRID") ? atoi(getenv("LAB4D_CHAIN_GRID")) : 0;  // kernel experiments: a resident grid of this many workgroups (part of the chip)
+  if (grid_env > 0 && g > grid_env * per_cu) g = grid_env * per_cu;
   return g < 1 ? 1 : g;
 }
 #define LAB4D_MLP_LAUNCH(KERNEL, k, st)                                                              \
