@@ -48,7 +48,13 @@ BYTES_PER_SAMPLE = 194.9 * 2**30 / (2 * 128 * 512 * 128)
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks of the data-parallel job, one per GPU.  Without a launcher in front (no WORLD_SIZE in the environment) "
+                                                           "and N > 1 this process starts the N ranks itself (torch.distributed.run, like the reference's scripts/train.sh:12-16) "
+                                                           "after checking that the box has N GPUs; under a launcher N must equal WORLD_SIZE.  Default: WORLD_SIZE, else 1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend: nccl (= RCCL on ROCm) for the GPU job; gloo only with --dry-step")
+    ap.add_argument("--dry-step", action="store_true", help="no GPU work: every rank builds its row plan and the product's flat gradient bucket on the CPU, runs the step's ONE "
+                                                            "collective (allreduce_flat) through the process group and rank 0 prints the JSON line -- the launch / rendezvous / "
+                                                            "collective path of --gpus N exercised where there are no GPUs (CPU tests)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--res", type=int, default=512)
@@ -127,10 +133,30 @@ def chunk_inputs(res, row0, rows, device, seed):
     return hxy.to(device), batch
 
 
+def distinct_indices(S, k, device, gen):
+    """k distinct indices, uniform over [0, S), in draw order -- the distribution of randperm(S)[:k] without permuting S elements.  Shapes are
+    static (graph-friendly): 2k draws, keep each value's first occurrence, take the first k kept (for S >= 2^20 and k = 1,024 fewer than one
+    duplicate is expected among 2k draws)."""
+    if S <= 4 * k:
+        return torch.randperm(S, device=device, generator=gen)[:k]
+    draws = torch.randint(0, S, (2 * k,), device=device, generator=gen)
+    vals, order = torch.sort(draws, stable=True)
+    first = torch.ones_like(vals, dtype=torch.bool)
+    first[1:] = vals[1:] != vals[:-1]
+    keep = torch.zeros(2 * k, dtype=torch.bool, device=device)
+    keep[order] = first  # draw i survives iff it is the first occurrence of its value
+    pos = torch.cumsum(keep.to(torch.int64), 0) - 1
+    out = torch.empty(2 * k, dtype=draws.dtype, device=device)
+    out[torch.where(keep, pos, pos.new_full((), 2 * k - 1))] = draws  # survivors compacted in draw order (the last slot is a dump for the dropped)
+    return out[:k]
+
+
 def draw_rng(M, N, S, device, gen, out=None):
     """Host-independent randomness of one chunk (the reference draws these on the host: nerf.py:438-439, feature.py:177)."""
     eik = torch.randperm(M * N, device=device, generator=gen)[: max(M * N // 16, 1)]
-    perm = torch.randint(0, S, (min(1024, S),), device=device, generator=gen)
+    # the reference draws randperm(S)[:1024] (nnutils/feature.py:177): 1,024 DISTINCT candidates.  A full permutation of 16.8 M indices per chunk is
+    # wasted work; 1,024 distinct uniform indices = the first 1,024 distinct values of a uniform stream (over-draw 2x, stable de-duplication)
+    perm = distinct_indices(S, min(1024, S), device, gen)
     if out is not None:
         out["eik_inds"].copy_(eik)
         out["match_perm"].copy_(perm)
@@ -227,23 +253,29 @@ def eval_rate(DF, P, fr, inputs, spp, prec, use_graph):
 
 
 def psnr_vs_reference(dev):
-    """Second half of BASELINE.json's metric: PSNR of the rendered colour against the REFERENCE's own render on identical
-    rays / weights.  The reference cannot run on the GPU box, so this uses the committed fixture tests/golden/train_small.pt
-    (outputs of the reference's Deformable.query_field + render_pixel, generated by tests/golden/make_golden.py)."""
+    """Second half of BASELINE.json's metric: PSNR of the rendered colour against the REFERENCE's own render on identical rays / weights.  The
+    reference cannot run on the GPU box, so this uses the committed bench-shape fixture tests/golden/train_bench.pt: a 2-row band of a 512x512
+    frame pair x 128 samples/ray (2,048 rays, 262,144 samples) rendered by the reference's Deformable.query_field + render_pixel
+    (tests/golden/make_golden.py), every 16th ray stored.  Both precisions."""
+    import math
     from lab4d_amd import deformable as DF, mlp, synthetic
-    g = torch.load(os.path.join(ROOT, "tests", "golden", "train_small.pt"), weights_only=False)
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "train_bench.pt"), weights_only=False)
     meta = g["meta"]
-    P = synthetic.to_device(synthetic.make_weights(meta["seed"], sdf_bias=meta.get("sdf_bias")), dev)
+    st, M, res, seed = meta["full_grid_stride"], meta["M"], meta["res"], meta["seed"]
+    P = synthetic.to_device(synthetic.make_weights(seed), dev)
+    hxy = synthetic.make_rays(res, M, rows=meta.get("rows"))
+    batch = synthetic.to_device(synthetic.make_targets(seed + 3, M, hxy.shape[1], res, hxy), dev)
     fr = synthetic.add_codes(synthetic.to_device(dict(g["frames"]), dev), P)
-    fr["feature"] = g["batch"]["feature"].to(dev)
+    fr["feature"] = batch["feature"]
     out = {}
     with torch.no_grad():
         for name, prec in (("fp32", mlp.PREC_F32), ("bf16", mlp.PREC_BF16)):
-            r = DF.render_train(P, fr, g["hxy"].to(dev), synthetic.to_device(g["rng"], dev), flow_thresh=meta["flow_thresh"], n_depth=meta["D"],
+            r = DF.render_train(P, fr, hxy.to(dev), synthetic.to_device(g["rng"], dev), flow_thresh=meta["flow_thresh"], n_depth=meta["D"],
                                 alpha=meta["alpha"], prec=prec)
-            mse = float(((r["rendered"]["rgb"].cpu() - g["rendered"]["rgb"]) ** 2).mean())
-            out[name] = round(-10.0 * __import__("math").log10(max(mse, 1e-20)), 1)
-    out["case"] = "tests/golden/train_small.pt (reference-generated render, %d rays x %d samples)" % (g["hxy"].shape[0] * g["hxy"].shape[1], meta["D"])
+            mse = float(((r["rendered"]["rgb"][:, ::st].cpu() - g["rendered"]["rgb"]) ** 2).mean())
+            out[name] = round(-10.0 * math.log10(max(mse, 1e-20)), 1)
+    out["case"] = "tests/golden/train_bench.pt (the reference's own render at the bench shape: %dx%d, %d samples/ray, %d rays rendered, every %dth compared)" \
+                  % (res, res, meta["D"], hxy.shape[0] * hxy.shape[1], st)
     return out
 
 
@@ -454,11 +486,93 @@ def hash_main(a):
     real_stdout.flush()
 
 
+def fail(msg, code=2):
+    print("bench.py: " + msg, file=sys.stderr)
+    sys.exit(code)
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` with no launcher in front: start the N ranks here, one process per GPU, the way the reference starts its own
+    (scripts/train.sh:12-16 `torchrun --nproc_per_node $ngpu`, lab4d/train.py:28-33), and hand rank 0's JSON line through.  Refuses loudly when the
+    box has fewer than N GPUs -- a 1-GPU number labelled as an N-GPU one is worse than no number."""
+    import socket
+    import subprocess
+    if a.backend == "nccl" and not a.dry_step:
+        found = torch.cuda.device_count()
+        if found < a.gpus:
+            fail("--gpus %d needs %d GPUs, found %d" % (a.gpus, a.gpus, found))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def dry_step(a):
+    """--dry-step: the multi-process skeleton of a step without a GPU.  Every rank: its row plan, the product's bucket (FlatAdamW.flat_grad over the fg
+    parameter set) filled with a rank-dependent gradient, the step's ONE collective (allreduce_flat), barrier + max-over-ranks timing as in the real
+    run; rank 0 prints the line with n_gpus = the ranks the process group actually saw."""
+    from lab4d_amd import synthetic
+    from lab4d_amd.optim import FlatAdamW
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")  # gloo announces its connections on fd 1: stdout proper carries the JSON line only (as in rank_main)
+    os.dup2(2, 1)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    torch.set_num_threads(1)
+    dist.init_process_group(a.backend, rank=rank, world_size=world)
+    seen = dist.get_world_size()
+    plan = rank_plan(rank, world, a.res, a.chunk_rows, a.spp)
+    P = synthetic.make_weights(0)
+    params = [v.requires_grad_(True) for k, v in P.items() if v.dtype.is_floating_point and k != "aabb"]
+    opt = FlatAdamW(params, lr=5e-4)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        opt.zero_grad()
+        for p in params:
+            p.grad.fill_(float(rank + 1))  # stands for the rank's accumulated chunk gradients (views of the flat bucket)
+        allreduce_flat(opt.flat_grad, world)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0, float(plan["rays_per_step"])], dtype=torch.float64)
+    ts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(ts, t)
+    ok = bool(torch.allclose(params[0].grad, torch.full_like(params[0].grad, (world + 1) / 2.0)))
+    dist.destroy_process_group()
+    if rank == 0:
+        dt = max(float(x[0]) for x in ts)
+        real_stdout.write(json.dumps({"metric": "dry step (no GPU work): launch + rendezvous + the flat-gradient all-reduce of bench.py --gpus N", "value": 0.0, "unit": "rays/s",
+                          "n_gpus": seen, "ranks_seen_by_process_group": seen, "backend": a.backend, "dry_step": True, "steps": a.steps, "warmup": 0,
+                          "ms_per_step": round(dt / max(a.steps, 1) * 1e3, 3), "rays_per_step_all_ranks": int(sum(float(x[1]) for x in ts)),
+                          "allreduce_is_rank_mean": ok, "bucket_elements": int(opt.n)}) + "\n")
+        real_stdout.flush()
+    if not ok:
+        sys.exit(3)
+
+
 def main():
     a = parse()
     if a.dry_ranks:
         return dry_ranks(a)
+    env_world = os.environ.get("WORLD_SIZE")
+    if a.gpus is None:
+        a.gpus = int(env_world) if env_world else 1
+    if a.gpus < 1:
+        fail("--gpus must be >= 1")
+    if a.backend == "gloo" and not a.dry_step:
+        fail("--backend gloo runs no GPU work: use it with --dry-step")
+    if env_world is None and a.gpus > 1:
+        return launch_ranks(a)  # does not return
+    if env_world is not None and int(env_world) != a.gpus:
+        fail("--gpus %d under a launcher that started %s rank(s): the two must agree" % (a.gpus, env_world))
+    if a.dry_step:
+        return dry_step(a)
     if a.config == "hash":
+        if a.gpus > 1:
+            fail("--config hash is a one-GPU leg")
         return hash_main(a)
     rank_main(a)
 
@@ -609,6 +723,8 @@ def rank_main(a):
         torch.use_deterministic_algorithms(True, warn_only=True)
         torch.utils.deterministic.fill_uninitialized_memory = True
     use_dist = world > 1 or a.force_dist
+    if torch.cuda.device_count() <= local:
+        fail("rank %d (local rank %d) has no GPU: %d visible on this box" % (rank, local, torch.cuda.device_count()))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -616,6 +732,8 @@ def rank_main(a):
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL on ROCm, bound to this rank's GPU
+        if dist.get_world_size() != a.gpus and not a.force_dist:
+            fail("the process group holds %d rank(s), --gpus says %d" % (dist.get_world_size(), a.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -746,7 +864,7 @@ def rank_main(a):
         flop_per_ray = comp_flop_per_ray(spp // 2) if comp else (multi_flop_per_ray(spp) if multi else spp * FLOP_PER_SAMPLE)
         out = {
             "metric": "rendered rays/sec (fwd+bwd) at 512\u00b2 \u00d7 128 samples; PSNR vs ref", "value": round(value, 1), "unit": "rays/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "n_gpus": dist.get_world_size() if use_dist else 1, "rccl_ranks": dist.get_world_size() if use_dist else None, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": ("human-48-shaped fg+bg composite (MultiFields comp: fg Deformable comp_skel-human_dense, 18 bones + dense post-warp; bg NeRF), "
                                     "%dx%d frame pair, %d + %d samples/ray composed, training graph fwd+bwd+AdamW" % (res, res, spp // 2, spp // 2)) if comp else

@@ -69,6 +69,11 @@ int lab4d_skin_blend_backward_acc(const float* xyz, const float* art_r, const fl
                                   float* g_raw, float* g_se3, float* g_art_r, float* g_art_d, float* g_gauss, float* work,
                                   int accumulate, void* stream);
 
+/* Size of `work` (floats) for lab4d_skin_blend_backward[_acc] with these arguments -- the library decides between the fused and the unfused
+ * adjoint (spf, g_se3 given, the LAB4D_BLEND_FUSE experiment switch) in ONE place, and the caller sizes the scratch by asking: M*B*34 for the
+ * fused path, M*B*34 + S*(2B+18) otherwise.  Host-only, no launch. */
+long long lab4d_skin_blend_backward_workspace_floats(int S, int spf, int M, int B, int has_g_se3);
+
 /* Gaussian-bone density  max_b exp(-0.5 |x - c_b|^2 / 0.01^2) * ibeta  (nnutils/deformable.py:329-356,
  * warping.py:355-387, utils/transforms.py:28-40).  centres: (B,3); ibeta: device scalar (no host sync).
  * best: (S) int32 arg-min bone (saved for

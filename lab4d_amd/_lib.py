@@ -106,12 +106,15 @@ SIGNATURES = {
 }
 
 
+INT64_RETURNS = ("lab4d_mlp_packed_bytes", "lab4d_compact_work_ints", "lab4d_skin_blend_backward_workspace_floats")  # host-only size queries
+
+
 def register(name, argtypes):
     SIGNATURES[name] = argtypes
     if _LIB is not None:
         fn = getattr(_LIB, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name in ("lab4d_mlp_packed_bytes", "lab4d_compact_work_ints") else ci
+        fn.restype = ctypes.c_int64 if name in INT64_RETURNS else ci
 
 
 def lib():
@@ -128,7 +131,7 @@ def lib():
         for name, at in SIGNATURES.items():
             fn = getattr(_LIB, name)
             fn.argtypes = at
-            fn.restype = ctypes.c_int64 if name in ("lab4d_mlp_packed_bytes", "lab4d_compact_work_ints") else ci
+            fn.restype = ctypes.c_int64 if name in INT64_RETURNS else ci
     return _LIB if PROF is None else _ProfiledLib(_LIB)
 
 
@@ -141,7 +144,7 @@ class _ProfiledLib:
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if PROF is None or _TIMED_DEPTH > 0 or not name.startswith("lab4d_") or name in ("lab4d_last_error", "lab4d_arch", "lab4d_mlp_describe", "lab4d_mlp_packed_bytes", "lab4d_compact_work_ints", "lab4d_global_match_workspace_floats"):  # host-only
+        if PROF is None or _TIMED_DEPTH > 0 or not name.startswith("lab4d_") or name in ("lab4d_last_error", "lab4d_arch", "lab4d_mlp_describe", "lab4d_mlp_packed_bytes", "lab4d_compact_work_ints", "lab4d_global_match_workspace_floats", "lab4d_skin_blend_backward_workspace_floats"):  # host-only
             return fn
 
         def call(*a):

@@ -178,6 +178,7 @@ extern "C" int lab4d_global_match_forward(const float* feat_px, const float* fea
                                           int K, float* out, float* stats, void* stream) {
   LAB4D_REQUIRE(feat_px && feat_c && xyz_c && logsigma && out && stats, "global_match_forward: null pointer");
   LAB4D_REQUIRE(C == MC && K >= 1 && K <= MKMAX && R >= 0, "global_match_forward: C must be 16 and 1 <= K <= 1024 (C=%d K=%d)", C, K);
+  LAB4D_REQUIRE((((uintptr_t)feat_px | (uintptr_t)feat_c) & 15) == 0, "global_match_forward: feat_px / feat_c must be 16-byte aligned (rows are read as float4)");
   if (R == 0) return LAB4D_OK;
   hipLaunchKernelGGL(k_match_fwd, dim3(div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, feat_px, feat_c, xyz_c, logsigma, R, K, out, stats);
   return check_launch("global_match_forward");
@@ -189,6 +190,7 @@ extern "C" int lab4d_global_match_backward(const float* feat_px, const float* fe
   LAB4D_REQUIRE(feat_px && feat_c && xyz_c && logsigma && out && stats && g_out && g_feat_c && g_xyz_c && g_logsigma && work,
                 "global_match_backward: null pointer");
   LAB4D_REQUIRE(C == MC && K >= 1 && K <= MKMAX && R >= 0, "global_match_backward: C must be 16 and 1 <= K <= 1024 (C=%d K=%d)", C, K);
+  LAB4D_REQUIRE((((uintptr_t)feat_px | (uintptr_t)feat_c) & 15) == 0, "global_match_backward: feat_px / feat_c must be 16-byte aligned (rows are read as float4)");
   hipStream_t st = (hipStream_t)stream;
   int NB = match_blocks();
   if (R == 0) NB = 0;

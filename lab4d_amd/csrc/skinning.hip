@@ -841,6 +841,13 @@ extern "C" int lab4d_skin_blend_backward_acc(const float* xyz, const float* art_
                                              const float* sr, const float* sd, const float* g_out, const float* g_ent, const float* g_dskin, int S,
                                              int spf, int M, int B, float* g_xyz, float* g_raw, float* g_se3, float* g_art_r, float* g_art_d,
                                              float* g_gauss, float* work, int accumulate, void* stream);
+static bool blend_bwd_fused(int spf, bool has_g_se3) {
+  static const int fuse_env = getenv("LAB4D_BLEND_FUSE") ? atoi(getenv("LAB4D_BLEND_FUSE")) : 1;  // 0: the round-2 path (A/B measurements)
+  return fuse_env && spf % 256 == 0 && has_g_se3;
+}
+extern "C" long long lab4d_skin_blend_backward_workspace_floats(int S, int spf, int M, int B, int has_g_se3) {
+  return (long long)M * B * 34 + (blend_bwd_fused(spf, has_g_se3 != 0) ? 0 : (long long)S * (2 * B + 18));
+}
 extern "C" int lab4d_skin_blend_backward(const float* xyz, const float* art_r, const float* art_d, const float* gauss, const float* raw,
                                          const float* sr, const float* sd, const float* g_out, const float* g_ent, const float* g_dskin, int S,
                                          int spf, int M, int B, float* g_xyz, float* g_raw, float* g_se3, float* g_art_r, float* g_art_d,
@@ -862,8 +869,7 @@ extern "C" int lab4d_skin_blend_backward_acc(const float* xyz, const float* art_
   float* Q = work + (size_t)M * B * 12;   // (M,B,10), zero-filled here
   float* G = Q + (size_t)M * B * 10;      // (M,B,3,4)
   float* ws = G + (size_t)M * B * 12;
-  static const int fuse_env = getenv("LAB4D_BLEND_FUSE") ? atoi(getenv("LAB4D_BLEND_FUSE")) : 1;  // 0: the round-2 path (A/B measurements)
-  const bool fused = fuse_env && spf % 256 == 0 && g_se3 != nullptr;
+  const bool fused = blend_bwd_fused(spf, g_se3 != nullptr);
   const bool params = g_art_r || g_art_d || g_gauss;
   hipLaunchKernelGGL(k_bone_affine, dim3(div_up(M * B, 64)), dim3(64), 0, st, art_r, art_d, gauss, M, B, aff);
   if (fused || params)

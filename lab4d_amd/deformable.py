@@ -341,6 +341,11 @@ class RowTap(Function):
             g_dense = torch.zeros(ctx.x_shape, device=idx.device)
         elif not g_dense.is_contiguous():
             g_dense = g_dense.contiguous()
+        elif g_rows is not None and (g_dense._use_count() > 2 or g_dense._is_view()):
+            # autograd does not promise a private buffer: a producer can hand ONE tensor to several edges (AddBackward does), and a
+            # caller-supplied gradient is the caller's.  Owned = this frame's argument + the engine's input buffer hold the only two
+            # references and it is no view of something else; anything else is copied before the rows are added
+            g_dense = g_dense.clone()
         if g_rows is not None:
             g_dense.index_add_(0, idx, g_rows.to(g_dense.dtype))  # in place on the gradient buffer autograd built for this edge
         return g_dense, None

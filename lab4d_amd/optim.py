@@ -149,6 +149,17 @@ class TorchFlatAdamW(torch.optim.Optimizer):
         if any(len(st) for st in opt.state.values()):
             raise RuntimeError("TorchFlatAdamW.adopt: the optimizer has already stepped")
         opt.__class__ = cls
+        # A scheduler built on the AdamW before the swap (Trainer.optimizer_init does: OneCycleLR, engine/trainer.py:199-207) has left an INSTANCE
+        # attribute opt.step behind -- LRScheduler.__init__ wraps the bound AdamW.step it found to set _opt_called -- and an instance attribute
+        # outlives the class swap: optimizer.step() would run torch's Adam.step on this object.  Replace it with the same kind of wrapper around
+        # THIS class's step (the scheduler's "step() before optimizer.step()" warning keeps working).
+        stale = opt.__dict__.pop("step", None)
+        if stale is not None and getattr(stale, "_wrapped_by_lr_sched", False):
+            def step(*args, **kwargs):
+                opt._opt_called = True
+                return cls.step(opt, *args, **kwargs)
+            step._wrapped_by_lr_sched = True
+            opt.step = step
         opt._build()
         return opt
 

@@ -466,8 +466,8 @@ def dvr_compute_loss(self, batch, results):
         per_ray = DF.losses_fg(results, batch, config["train_res"], config)
     elif field_type == "comp":
         per_ray = DF.losses_comp(results, batch, config["train_res"], config)
-    else:
-        raise NotImplementedError("lab4d_amd: the fused loss epilogue is instantiated for field_type fg and comp (got %r)" % (field_type,))
+    else:  # field_type "bg": its render runs on the kernels (query_field_train_bg); the loss epilogue stays the reference's own
+        return _original("lab4d.engine.model.dvr_model.compute_loss")(self, batch, results)
     reg = {}
     self.compute_reg_loss(reg, results)  # the reference's method; the rendered terms it also lists are dropped, the kernel formed them
     reg = {k: v for k, v in reg.items() if k in REG_FIELD_TERMS}

@@ -17,6 +17,14 @@ _lib.register("lab4d_bone_coords_backward", [vp] * 5 + [ci] * 4 + [vp] * 4 + [vp
 _lib.register("lab4d_skin_blend_forward", [vp] * 7 + [ci] * 4 + [vp] * 4 + [vp])
 _lib.register("lab4d_skin_blend_backward", [vp] * 10 + [ci] * 4 + [vp] * 7 + [vp])
 _lib.register("lab4d_skin_blend_backward_acc", [vp] * 10 + [ci] * 4 + [vp] * 7 + [ci, vp])
+_lib.register("lab4d_skin_blend_backward_workspace_floats", [ci] * 5)
+
+
+def _blend_bwd_work(S, spf, M, B, device):
+    """Scratch of the blend adjoint, sized by the library (which also decides fused / unfused: one parse of LAB4D_BLEND_FUSE, include/lab4d_skin.h).
+    Returns (work, fused)."""
+    n = int(_lib.lib().lab4d_skin_blend_backward_workspace_floats(S, spf, M, B, 1))
+    return torch.empty(n, device=device), n == M * B * 34
 _lib.register("lab4d_gram_per_frame", [vp, ci, vp, ci, ci, ci, ci, vp, vp])
 _lib.register("lab4d_bone_params_from_gram", [vp] * 4 + [ci] * 2 + [vp] * 3 + [vp])
 _lib.register("lab4d_bone_affine", [vp] * 3 + [ci] * 2 + [vp, vp])
@@ -224,8 +232,7 @@ class SkinBlend(Function):
         gar = torch.empty_like(art_r) if need_p else None
         gad = torch.empty_like(art_d) if need_p else None
         gg = torch.zeros_like(gauss) if need_p else None
-        fused = ctx.spf % 256 == 0 and os.environ.get("LAB4D_BLEND_FUSE", "1") != "0"  # include/lab4d_skin.h: the per-frame reductions inside the kernel
-        work = torch.empty(M * B * 34 + (0 if fused else S * (2 * B + 18)), device=xyz.device)
+        work, fused = _blend_bwd_work(S, ctx.spf, M, B, xyz.device)  # fused: the per-frame reductions inside the kernel
         # one entry for the whole adjoint (k_blend_bwd incl. its two per-frame Gram reductions): reads xyz, raw, g_out, g_ent, g_dskin; writes
         # g_xyz, g_raw (unfused: also the (S, 2B+18) work arrays, which the Gram kernels read once more)
         with _lib.timed("k_blend_bwd+gram", (0.0, 4.0 * S * ((3 + B + 3 + 2) + (3 + B) + (0 if fused else 2 * (2 * B + 18))))):
@@ -271,7 +278,7 @@ class SkinBlendMulti(Function):
         S, (M, B) = xyz.shape[0], art_r.shape[:2]
         gx, gr = torch.empty_like(xyz), torch.empty_like(raw)
         need_p = any(ctx.needs_input_grad[2:5])
-        fused = ctx.spf % 256 == 0 and os.environ.get("LAB4D_BLEND_FUSE", "1") != "0"
+        fused = _blend_bwd_work(0, ctx.spf, M, B, xyz.device)[1]
         gar = gad = gg = None
         gse3s = []
         first = True
@@ -287,7 +294,7 @@ class SkinBlendMulti(Function):
             par = torch.empty_like(art_r) if need_p else None
             pad = torch.empty_like(art_d) if need_p else None
             pg = torch.zeros_like(gauss) if need_p else None
-            work = torch.empty(M * B * 34 + (0 if fused else S * (2 * B + 18)), device=xyz.device)
+            work = _blend_bwd_work(S, ctx.spf, M, B, xyz.device)[0]
             with _lib.timed("k_blend_bwd+gram", (0.0, 4.0 * S * ((3 + B + 3 + 2) + (3 + B) * (1 if first else 2) + (0 if fused else 2 * (2 * B + 18))))):
                 _lib.check(_lib.lib().lab4d_skin_blend_backward_acc(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
                                                                     _lib.ptr(se3s[i]), _lib.ptr(se3s[i + 1]), _lib.ptr(g_out), _lib.ptr(g_ent),

@@ -44,6 +44,25 @@ def test_dry_ranks_plans():
             assert all(p["uniform"] and p["est_peak_hbm_gib"] <= 200.0 and sum(p["chunk_sizes"]) == p["n_rows"] for p in d["plans"])
 
 
+def test_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus N` with no launcher in front starts N ranks (round 3's flag was parsed and ignored).  On this GPU-less box: the
+    RCCL form refuses loudly (non-zero exit, "needs N GPUs, found K"), the gloo dry step spawns 4 processes, runs the flat-gradient all-reduce and
+    reports the ranks the process group saw; under a launcher a disagreeing --gpus is an error, not a relabelled 1-GPU run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    b = os.path.join(ROOT, "bench.py")
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, b, "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode != 0 and "needs 2 GPUs, found %d" % torch.cuda.device_count() in out.stderr and out.stdout.strip() == ""
+    out = subprocess.run([sys.executable, b, "--gpus", "4", "--backend", "gloo", "--dry-step", "--steps", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, lines  # exactly one JSON line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["ranks_seen_by_process_group"] == 4 and d["allreduce_is_rank_mean"] and d["rays_per_step_all_ranks"] == 2 * 512 * 512
+    out = subprocess.run([sys.executable, b, "--gpus", "2", "--backend", "gloo", "--dry-step"], capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="3", RANK="0"))
+    assert out.returncode != 0 and "must agree" in out.stderr
+
+
 def _params():
     torch.manual_seed(0)  # same weights on every rank
     return [torch.randn(8, 63, requires_grad=True), torch.randn(5, requires_grad=True), torch.randn(3, 7, requires_grad=True), torch.randn(1, requires_grad=True)]

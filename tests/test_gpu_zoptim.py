@@ -122,3 +122,38 @@ def test_repack_all_refreshes_packed_weights_in_place():
         assert buf2.data_ptr() == addr and not torch.equal(buf2, before)
         y1 = mlp.run_chain(mlp.NET_VIS, mlp.PREC_BF16, P, x, 256, conds={0: fr["code_vis"]})
         assert float((y1 - y0).abs().max()) > 1e-4
+
+
+def test_adopted_optimizer_steps_with_the_scheduler_attached():
+    """The reference's order (engine/trainer.py:185-207): AdamW, THEN OneCycleLR on it -- LRScheduler.__init__ leaves an instance attribute
+    opt.step wrapping the bound AdamW.step, which survives a class swap.  After TorchFlatAdamW.adopt() the training loop's
+    check_grad(); optimizer.step(); scheduler.step() must run the flat kernel: weights move, the device step count advances, the next
+    step uploads the scheduler's new rates."""
+    from lab4d_amd.optim import TorchFlatAdamW
+    g = torch.Generator().manual_seed(4)
+    ps = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.2).to(DEV)) for s in [(64, 95), (64,), (3, 64), (1,)]]
+    ref = [p.detach().clone().requires_grad_(True) for p in ps]
+    groups = lambda qs: [{"params": [p], "lr": lr} for p, lr in zip(qs, (5e-4, 5e-4, 1e-3, 5e-3))]  # noqa: E731
+    mk = lambda qs: torch.optim.AdamW(groups(qs), betas=(0.9, 0.999), weight_decay=1e-4)  # noqa: E731
+    sched = lambda o: torch.optim.lr_scheduler.OneCycleLR(o, [5e-4, 5e-4, 1e-3, 5e-3], total_steps=10, pct_start=0.3, cycle_momentum=False)  # noqa: E731
+    opt, ropt = mk(ps), mk(ref)
+    sch, rsch = sched(opt), sched(ropt)
+    assert "step" in opt.__dict__  # the stale wrapper the scheduler installed
+    TorchFlatAdamW.adopt(opt)
+    assert isinstance(opt, TorchFlatAdamW) and sch.optimizer is opt
+    ws = [torch.randn(p.shape, generator=g).to(DEV) for p in ps]
+    for it in range(3):
+        for qs, o in ((ps, opt), (ref, ropt)):
+            o.zero_grad()
+            sum((p * p * w).sum() + (p * w).sum() for p, w in zip(qs, ws)).backward()
+        opt.check_grad(5.0)
+        tn = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        opt.step()
+        sch.step()
+        ropt.step()
+        rsch.step()
+        assert abs(float(opt.flat.norm) - float(tn)) <= 2e-6 * float(tn)
+        assert int(opt.flat.dev_step) == it + 1 and int(opt.skipped) == 0
+        for a, b in zip(ps, ref):
+            assert torch.allclose(a, b, rtol=5e-6, atol=2e-7), it
+    assert getattr(opt, "_opt_called", False)  # the scheduler's call-order bookkeeping still works

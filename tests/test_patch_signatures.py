@@ -228,6 +228,13 @@ def test_optimizer_init_adopts_the_reference_optimizer(ns, patched):
     inside = [p for g in t.optimizer.param_groups for p in g["params"]]
     lo, hi = flat.flat.data_ptr(), flat.flat.data_ptr() + 4 * flat.n
     assert all(lo <= p.data_ptr() < hi for p in inside) and all(p.grad is not None for p in inside)
+    # optimizer.step() must reach TorchFlatAdamW.step: OneCycleLR wrapped the bound AdamW.step as an INSTANCE attribute before the class swap, and
+    # an instance attribute outlives it (the flat kernel itself needs the device: the call is recorded instead)
+    calls = []
+    flat.step = lambda *a, **k: calls.append("flat.step")
+    t.optimizer.step()
+    del flat.step
+    assert calls == ["flat.step"] and t.optimizer._opt_called
     t.scheduler.step()
     assert t.optimizer._lrs() != t.optimizer._lr_sent  # OneCycleLR wrote the groups; the next step() uploads the new rates
     from copy import deepcopy
