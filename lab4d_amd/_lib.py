@@ -24,6 +24,12 @@ CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE
           "-Wno-unused-value", "-Wno-pass-failed"] + os.environ.get("LAB4D_HIPCC_EXTRA", "").split()
 
 
+# the chain-kernel instantiation units only: LLVM's "unclustered high register pressure" rescheduling stage sinks the LDS reads of the shared
+# weight groups next to the MFMAs that use them (exposed LDS latency in the one-wave-per-SIMD kernels); measured with it off, together with
+# the conditional accumulator fence (mlp_kernels.hpp acc_fence_if): 739 vs 756 ms per step (profiles/r04_flag_variants.json)
+MLP_INST_FLAGS = ["-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"]
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -51,7 +57,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + CFLAGS + (MLP_INST_FLAGS if os.path.basename(src).startswith("mlp_inst_") and "LAB4D_HIPCC_EXTRA" not in os.environ else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

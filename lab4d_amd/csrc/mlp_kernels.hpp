@@ -80,6 +80,18 @@ __device__ __forceinline__ void acc_fence(f32x16_t& c) {
                  "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]));
 }
 
+// Kernels built for ONE wave per SIMD use more than 256 registers, so their accumulators live in AGPRs and a compiler-visible v_accvgpr_read
+// (whose hazards the compiler handles) always sits between the MFMA and the asm consumer: the 40 NOP states per step are only needed by the
+// two-waves-per-SIMD builds, or when the MFMA results are forced into VGPRs (-mllvm -amdgpu-mfma-vgpr-form: define LAB4D_MFMA_VGPR_FORM).
+template <bool OCC2>
+__device__ __forceinline__ void acc_fence_if(f32x16_t& c) {
+#if defined(LAB4D_FENCE_ALWAYS) || defined(LAB4D_MFMA_VGPR_FORM)
+  acc_fence(c);
+#else
+  if constexpr (OCC2) acc_fence(c);  // round 4: -2 % of the step together with the scheduler flag of _lib.MLP_INST_FLAGS (profiles/r04_flag_variants.json)
+#endif
+}
+
 // feature (row) held by accumulator register r of lane-half h inside a 32-row tile
 __host__ __device__ __forceinline__ constexpr int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -1113,7 +1125,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
       auto epilogue = [&](int mt, f32x16_t (&acc)[NT], unsigned int (&w)[2][8], unsigned int& wbits) {
         if constexpr (PACKED) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc_fence(acc[t]);  // the packing below is inline asm
+          for (int t = 0; t < NT; ++t) acc_fence_if<(want_occ<Net, P>() == 2)>(acc[t]);  // the packing below is inline asm
           // packed-bf16 epilogue (see pk_* helpers): everything after the one fp32 -> bf16 conversion works on the 16 packed dwords
 #pragma unroll
           for (int t = 0; t < 2; ++t)
@@ -1786,7 +1798,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
 #endif
         if constexpr (P::BF16) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc_fence(acc[t]);  // the packed path converts with inline asm
+          for (int t = 0; t < NT; ++t) acc_fence_if<(want_occ<Net, P, true>() == 2)>(acc[t]);  // the packed path converts with inline asm
         }
         if constexpr (lp.ext_grad != 0) {
           f32x16_t eg[NT];
