@@ -69,6 +69,8 @@ def parse():
                          "multi: BASELINE configs[3]'s per-GPU shape -- the fg field of a 10-video category model (num_inst=10: per-instance codes in every CondMLP, "
                          "fg_motion comp_skel-quad_dense: shared quadruped skeleton + dense post-warp), a frame pair of one of the videos")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed training step: no forward-only rate, no PSNR, no fp32 leg (used by the fp32 leg's own child run)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short fp32 run of the same step that the default bf16 run appends (fp32_leg)")
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays per frame of one CPU-baseline pass (1 warm-up + 3 timed passes)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the gradient all-reduce even at world size 1 "
@@ -242,12 +244,30 @@ def eval_rate(DF, P, fr, inputs, spp, prec, use_graph):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rays = reps * n_ev * st.shape[0] * st.shape[1]
+    # per-kernel table of the same calls, launched eagerly (a replayed graph cannot host events): HIP events around every library entry point
+    from lab4d_amd import _lib
+    _lib.PROF = {}
+    for h in ev_in:
+        DF.render_eval(P, fr, h, n_depth=spp, prec=prec)
+    torch.cuda.synchronize()
+    prof = _lib.prof_summary()
+    _lib.PROF = None
+    kern = {k: round(v[1] / n_ev, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
     skin, base, color, vis = 20736, 573184, 158464 + 37248, 10240
     mac_per_ray = (spp // 2) * (skin + base) + spp * (skin + vis + 2 * base + skin) + valid_frac * spp * (base + color)
     tflops = rays / dt * mac_per_ray * 2 / 1e12
     peak = PEAK_BF16 if prec == 1 else PEAK_F32
+    # roofline of the path's dominant kernel (inference-mode chain kernels store nothing: MFMA-bound by construction)
+    roof = None
+    ranked = sorted(((k, v) for k, v in prof.items() if v[2] > 0), key=lambda kv: -kv[1][1])
+    if ranked:
+        name, (launches, ms, flops, nbytes) = ranked[0]
+        roof = {"bound": "mfma", "kernel": name + " (inference mode)", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": round(flops / (ms * 1e-3) / peak, 4), "launches": launches, "avg_ms": round(ms / launches, 4), "traffic": None,
+                "measured": "HIP events around every launch in an eager re-run of the %d calls" % n_ev}
     return {"value": round(rays / dt, 1), "unit": "rays/s", "launch": launch, "valid_fraction": round(valid_frac, 4),
             "tflops": round(tflops, 1), "frac_of_mfma_peak": round(tflops * 1e12 / peak, 4),
+            "kernels_ms_per_call": kern, "ms_per_call": round(dt / (reps * n_ev) * 1e3, 3), "roofline": roof,
             "what": "render_eval: importance sampling (%d coarse + %d fine samples), backward warp, visibility, normals on every sample, colour / "
                     "density on the valid samples (device-side compaction), compositing; %d calls of %d rays" % (spp // 2, spp // 2, reps * n_ev, st.shape[0] * st.shape[1])}
 
@@ -277,6 +297,24 @@ def psnr_vs_reference(dev):
     out["case"] = "tests/golden/train_bench.pt (the reference's own render at the bench shape: %dx%d, %d samples/ray, %d rays rendered, every %dth compared)" \
                   % (res, res, meta["D"], hxy.shape[0] * hxy.shape[1], st)
     return out
+
+
+def fp32_leg(a):
+    """The same training step with fp32 MFMA chains (`--dtype f32`: v_mfma_f32_32x32x2_f32, fp32 stored activations, 64-row chunks), 1 warm-up
+    + 2 timed steps in a child process once this one has given its device memory back.  fp32 is the precision the reference computes in
+    and the one the 1e-4 parity tests run: its throughput belongs next to the bf16 headline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--dtype", "f32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+           "--res", str(a.res), "--spp", str(a.spp)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": d["value"], "unit": "rays/s", "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": "f32",
+                "frac_of_fp32_mfma_peak": d["whole_graph_frac_of_peak"], "whole_graph_tflops": d["whole_graph_tflops"], "peak_hbm_gib": d["peak_hbm_gib"],
+                "loss_last_chunk": d["loss_last_chunk"], "params_finite": d["params_finite"], "chunk_rays": d["config"]["chunk_rays"],
+                "dominant_kernel": {k: d["roofline"][k] for k in ("kernel", "bound", "frac", "avg_ms")} if d.get("roofline") else None}
+    except Exception as e:  # an extra: report the failure instead of losing the bench line
+        return {"value": None, "error": repr(e)[:300]}
 
 
 def cpu_baseline(res, spp, n_rays, config="fg"):
@@ -752,7 +790,7 @@ def rank_main(a):
     # through one first-order backward, compositing) of the same rays.  Measured before the training graph is captured
     # (its 150 GiB private pool would leave the allocator thrashing), half a training chunk per call.
     eval_result = None
-    if world == 1 and rank == 0 and not comp and not multi and not a.trace:
+    if world == 1 and rank == 0 and not comp and not multi and not a.trace and not a.no_extras:
         try:
             P_e, fr_e = make_problem(res, dev)
             inputs_e = [chunk_inputs(res, None, rows, dev, seed=100 + i) for i, rows in enumerate(plan["chunks"])]
@@ -895,11 +933,19 @@ def rank_main(a):
             out["metric"] = "rendered rays/sec (fwd+bwd), fg+bg composite at 512\u00b2 (BASELINE configs[2] per-GPU shape; not the headline metric)"
         if multi:
             out["metric"] = "rendered rays/sec (fwd+bwd), 10-instance category model at 512\u00b2 (BASELINE configs[3] per-GPU shape; not the headline metric)"
-        if world == 1 and not comp and not multi:
+        if world == 1 and not comp and not multi and not a.no_extras:
             try:
                 out["psnr_vs_ref_db"] = psnr_vs_reference(dev)
             except Exception as e:
                 out["psnr_vs_ref_db"] = {"error": repr(e)[:200]}
+        if world == 1 and a.dtype == "bf16" and a.config == "fg" and not (a.no_extras or a.no_fp32_leg or a.emulate_rank_of or a.trace):
+            # the path that carries the 1e-4 parity claim, at the same shape, in the same line (the reference computes in fp32 only)
+            loop = opt = params = inputs = step = None
+            import gc
+            gc.collect()
+            mlp.clear_caches()
+            torch.cuda.empty_cache()
+            out["fp32_leg"] = fp32_leg(a)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res, spp, a.cpu_rays, a.config)
     if use_dist:

@@ -617,6 +617,44 @@ __device__ __forceinline__ void wg_step_barrier() {
 #endif
 }
 
+// ---- LDS-DMA weight stream (round 4, -DLAB4D_ADMA; backward chain, bf16) -------------------------------------------------------------------
+// The shared A groups of a step go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, lane-linear, no staging registers,
+// no ds_write), issued right behind the step barrier into the buffer the previous step finished reading -- one step of lead instead of two,
+// 16 registers and 4 LDS stores per wave and step less.  Two things make it work with compiler-managed waits: (1) the DMA is the BUILTIN, so the
+// waitcnt pass counts it like any other vector-memory operation (an inline-asm DMA is invisible to it and shifts every counted vmcnt of the step
+// by the number of hidden pieces: each wait then also drains the previous step's tile stores); (2) the two buffers are two separate __shared__
+// arrays selected by compile-time constants, so a read of the buffer that landed a step ago is not ordered behind the DMA that has just been
+// issued into the other one (the pass tracks LDS-DMA destinations per LDS variable).  What the compiler cannot know is the cross-wave part: a
+// wave's pieces must have landed before it arrives at the step barrier (wg_step_barrier_dma: all but the N most recent vector-memory operations --
+// the tile stores issued at the end of the step -- are waited for).
+__device__ __forceinline__ void a_dma_1k(const GLOBAL_AS void* gsrc_lane, __attribute__((address_space(3))) void* lds_base_uniform) {
+#if defined(LAB4D_ADMA) && LAB4D_ADMA == 2  // experiment: the same transfer as inline asm (invisible to the waitcnt pass; M0 is used by nothing else in these kernels)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc_lane), "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)lds_base_uniform)) : "memory");
+#else
+  __builtin_amdgcn_global_load_lds((const GLOBAL_AS unsigned int*)gsrc_lane, (__attribute__((address_space(3))) unsigned int*)lds_base_uniform, 16, 0, 0);
+#endif
+}
+template <int KEEP>
+__device__ __forceinline__ void wg_step_barrier_dma() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+}
+template <class P>
+constexpr int bwd_step_stores() {  // the dZ tile stores flush_act issues at the very end of a backward step (store_tile_packed: four 16-byte stores)
+#if defined(LAB4D_ABL_NOSTORE) || defined(LAB4D_TRSPREAD) || defined(LAB4D_TRSTORE)
+  return 0;
+#else
+  return P::BF16 ? 4 : 0;
+#endif
+}
+template <class P>
+constexpr bool use_adma() {
+#ifdef LAB4D_ADMA
+  return P::BF16;
+#else
+  return false;
+#endif
+}
+
 // One wave per SIMD issues in order: an MFMA that is followed in the instruction stream by a long run of VALU work leaves the matrix pipe
 // idle for the whole run, and a run of back-to-back MFMAs leaves the VALU idle.  The machine scheduler interleaves the two only
 // partly (tools/isa_blocks.py: runs of 40-100 vector instructions without an MFMA at the end of every pipeline step), so the step
@@ -1382,7 +1420,10 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
   constexpr int NT = P::NT, TILE = P::TILE, NL = Net::NL, UW = Slab<Net, P>::UW;
   constexpr int ACG = acache_g<Net, P>();
   __shared__ uint4 slab_all[4 * Slab<Net, P>::UNITS_PER_WAVE];
-  __shared__ uint4 abuf[2 * ACG * 64];  // workgroup-shared A groups (see wg_step_barrier)
+  // workgroup-shared A groups (see wg_step_barrier): two buffers, two LDS variables (the LDS-DMA build relies on the compiler telling them apart)
+  __shared__ uint4 abuf0[ACG * 64];
+  __shared__ uint4 abuf1[ACG * 64];
+#define LAB4D_ABUF(buf) ((buf) ? abuf1 : abuf0)
   __shared__ float4 afftab[Net::EMB == 2 ? 4 * 96 : 1];  // EMB == 2: the current frame's rows of the affine first layer, one copy per wave
   // EMB == 2: per-lane partial of the table gradient, g_aff[frame][32 mt + drow(r, h)][j] += dz0 * [x; 1]_j over this lane's samples; reduced over
   // the 32 lanes of a half and added to g_aff when the wave's tiles move on to another frame (tiles come in increasing order) and at the end
@@ -1520,7 +1561,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
           for (int t = 0; t < NT; ++t) mma_unit<P>(acc[t], A[g], bin[t][g]);
           if constexpr (PRE) {
             if (g >= GL) A[g] = load_a(Wt, GK, pre, g, lane);  // groups beyond the LDS-shared ones
-            else if (rbuf >= 0) A[g] = abuf[(rbuf * ACG + g) * 64 + lane];  // progressive reload (see the forward kernel)
+            else if (rbuf >= 0) A[g] = LAB4D_ABUF(rbuf)[g * 64 + lane];  // progressive reload (see the forward kernel)
           }
           hook(gc);
         });
@@ -1539,42 +1580,64 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
-          abuf[(buf * ACG + g) * 64 + lane] = stg[i];
+          LAB4D_ABUF(buf)[g * 64 + lane] = stg[i];
         }
 #endif
       };
       auto a_grab = [&](int buf, uint4 (&A)[GK]) {
 #pragma unroll
-        for (int g = 0; g < GL; ++g) A[g] = abuf[(buf * ACG + g) * 64 + lane];
+        for (int g = 0; g < GL; ++g) A[g] = LAB4D_ABUF(buf)[g * 64 + lane];
+      };
+      auto a_dma = [&](int mt, int buf) {  // this wave's quarter of row tile mt's shared groups -> LDS buffer `buf` (see a_dma_1k)
+        const GLOBAL_AS char* tile = (const GLOBAL_AS char*)Wt + (size_t)(unsigned)(mt * GK) * 1024u;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          const int g = wid + 4 * i < GL ? wid + 4 * i : GL - 1;
+          a_dma_1k(tile + (unsigned)(g * 1024 + lane * 16), (__attribute__((address_space(3))) void*)(LAB4D_ABUF(buf) + g * 64));
+        }
       };
       // Software pipeline over N row tiles starting at tile0 (same scheme as the forward chain): step k issues the MFMAs
       // of tile k+1 into the other accumulator set in the same basic block as the epilogue of tile k.
       // pre(j) requests the HBM inputs of epi(j) (mask bits, stored embedding / external gradient tile) one step ahead.
-      auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi, auto&& fl, auto&& prem, auto&& sp, auto&& sp_all) {
+      auto pipeline = [&](auto n_c, int tile0, auto&& pre, auto&& epi, auto&& fl, auto&& prem, auto&& sp, auto&& sp_all, auto nst_c) {
         constexpr int N = decltype(n_c)::value;
+        // LDS-DMA weight stream: NST = vector-memory operations a step issues LAST, unconditionally (the 4 dZ tile stores of flush_act; 0 for the
+        // embedding pipeline, whose epilogue stores nothing): the per-step wait leaves exactly those in flight
+        constexpr bool ADMA = use_adma<P>();
+        constexpr int NST = decltype(nst_c)::value;
         if constexpr (N > 0) {
           uint4 A[GK], stg[NQ];
           f32x16_t acc0[NT], acc1[NT];
           unsigned int pw[2][8];  // packed tile waiting for its store (see the forward kernel: weight loads first, stores last)
           wg_step_barrier();  // nobody still reads the buffers for the previous pipeline
-          a_fetch(tile0, stg);
-          a_stash(0, stg);
-          if constexpr (N > 1) {
-            a_fetch(tile0 + 1, stg);
-            a_stash(1, stg);
+          if constexpr (ADMA) {
+            a_dma(tile0, 0);
+            if constexpr (N > 1) a_dma(tile0 + 1, 1);
+          } else {
+            a_fetch(tile0, stg);
+            a_stash(0, stg);
+            if constexpr (N > 1) {
+              a_fetch(tile0 + 1, stg);
+              a_stash(1, stg);
+            }
+            a_fetch(tile0 + (N > 2 ? 2 : N - 1), stg);
           }
-          a_fetch(tile0 + (N > 2 ? 2 : N - 1), stg);
 #pragma unroll
           for (int g = GL; g < GK; ++g) A[g] = load_a(Wt, GK, tile0, g, lane);
           pre(0);
           prem(std::integral_constant<int, 0>{}, 0);  // ReLU sign words: requested TWO steps ahead (see pre_mask)
           prem(std::integral_constant<int, 1>{}, N > 1 ? 1 : 0);
-          wg_step_barrier();
+          if constexpr (ADMA) wg_step_barrier_dma<0>();  // once per pipeline: both buffers landed (this also drains the previous layer's last stores)
+          else wg_step_barrier();
           a_grab(0, A);
           constexpr int NSTEP = N - 1, NPAIR = NSTEP / 2;
 #ifndef LAB4D_ABL_NOPROG
+          if constexpr (ADMA && N > 1) {
+            wg_step_barrier();                      // every wave has grabbed tile 0 out of buffer 0 ...
+            a_dma(tile0 + (N > 2 ? 2 : N - 1), 0);  // ... so tile 2 is requested into it BEFORE tile 0's matrix work: a whole step of lead
+          }
           mfma_tile(std::bool_constant<(N > 1)>{}, tile0 + 1, 1, A, acc0, no_hook);  // tile 0, reloading tile 1 from buffer 1
-          if constexpr (N > 1) {
+          if constexpr (N > 1 && !ADMA) {
             wg_step_barrier();  // every wave has grabbed tile 0 out of buffer 0
             a_stash(0, stg);    // tile 2
             a_fetch(tile0 + (N > 3 ? 3 : N - 1), stg);
@@ -1582,6 +1645,27 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
           if constexpr (NPAIR > 0) {
 #pragma nounroll
             for (int k = 0; k < 2 * NPAIR; k += 2) {
+              if constexpr (ADMA) {
+                // step of tile k+1: its reload source (tile k+2 in buffer 0) was requested one step ago by every wave -> landed before anyone passes;
+                // buffer 1 (tile k+1) was read out during the previous step -> tile k+3 goes there now
+                if (k == 0) wg_step_barrier_dma<0>(); else wg_step_barrier_dma<NST>();
+                a_dma(tile0 + (k + 3 < N ? k + 3 : N - 1), 1);
+                mfma_tile(std::true_type{}, tile0 + (k + 2 < N ? k + 2 : N - 1), 0, A, acc1, no_hook);
+                epi(k, acc0, pw);
+                pre(k + 1);
+                prem(std::integral_constant<int, 0>{}, k + 2 < N ? k + 2 : N - 1);
+                fl(k, pw);
+                if constexpr (P::BF16) sched_interleave<NT * GK, LAB4D_SCHED_NV, sched_il_bwd<Net>()>();
+                wg_step_barrier_dma<NST>();
+                a_dma(tile0 + (k + 4 < N ? k + 4 : N - 1), 0);
+                mfma_tile(std::true_type{}, tile0 + (k + 3 < N ? k + 3 : N - 1), 1, A, acc0, no_hook);
+                epi(k + 1, acc1, pw);
+                pre(k + 2 < N ? k + 2 : N - 1);
+                prem(std::integral_constant<int, 1>{}, k + 3 < N ? k + 3 : N - 1);
+                fl(k + 1, pw);
+                if constexpr (P::BF16) sched_interleave<NT * GK, LAB4D_SCHED_NV, sched_il_bwd<Net>()>();
+                continue;
+              }
               wg_step_barrier();
 #ifdef LAB4D_TRSPREAD  // the epilogue first in program order: its slab writes precede the transposing reads of the hook
               epi(k, acc0, pw);
@@ -1613,7 +1697,9 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
             }
           }
           if constexpr (NSTEP % 2 == 1) {
-            wg_step_barrier();
+            if constexpr (ADMA) {
+              if constexpr (NPAIR == 0) wg_step_barrier_dma<0>(); else wg_step_barrier_dma<NST>();  // (the last reload already happened: only the lock-step matters)
+            } else wg_step_barrier();
 #ifdef LAB4D_TRSPREAD
             epi(N - 2, acc0, pw);
             mfma_tile(std::false_type{}, 0, -1, A, acc1, [&](auto gc) { sp(N - 2, gc); });
@@ -1909,13 +1995,14 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
       // embedding row tiles come first in W^T; they are skipped when no input gradient is wanted
       if constexpr (MTE > 0) {
         if (a.d_x != nullptr) {
-          pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb, no_flush, no_prem, sp_none, sp_all_none);
+          pipeline(std::integral_constant<int, MTE>{}, 0, pre_emb, epi_emb, no_flush, no_prem, sp_none, sp_all_none, std::integral_constant<int, 0>{});
           // raw-input nets: the (TILE, CIN) input-gradient tile sits in the wave's staging area (the slab is idle while the
           // last layer's embedding tiles are processed); one contiguous coalesced copy, rows >= S dropped
           if constexpr (Net::EMB == 1) stage_out(stagef, a.d_x, (long)s0 * Net::CIN, TILE * Net::CIN, (long)a.S * Net::CIN - 1, lane);
         }
       }
-      if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act, flush_act, pre_mask, sp_act, sp_all_act);
+      if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act, flush_act, pre_mask, sp_act, sp_all_act,
+                                     std::integral_constant<int, bwd_step_stores<P>()>{});
     });
 
     if constexpr (Net::EMB != 1) {
@@ -1943,6 +2030,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
     }
   }
   gram_flush();
+#undef LAB4D_ABUF
 }
 
 // launchers implemented by each mlp_inst_<net>.hip

@@ -553,12 +553,16 @@ class MlpChain(Function):
                           M * L.mout_pad if L.pf_bias else 0))
         arena = torch.zeros(sum(sum(t) for t in sizes), device=dev)
         aoff = 0
+        pf_seen = 0
         for l in range(NL):
             L = d.layers[l]
             K = L.ke + L.kin
             need_w = ctx.needs_input_grad[9 + n_pf + 2 * l]
             need_b = ctx.needs_input_grad[9 + n_pf + 2 * l + 1]
-            need_pf = bool(L.pf_bias)
+            # the per-frame bias table is an input of its own (position 9 + its rank among the pf layers): when nothing upstream of it wants a gradient
+            # (the eval path's normals differentiate wrt the points only) its layer needs no weight-gradient launch at all
+            need_pf = bool(L.pf_bias) and bool(ctx.needs_input_grad[9 + pf_seen])
+            pf_seen += 1 if L.pf_bias else 0
             gW = gb = None
             if need_w or need_b or need_pf:
                 n0, n1, n2 = sizes[l]
@@ -584,6 +588,8 @@ class MlpChain(Function):
                     gb = (pfd.sum(0) if need_pf else dbk)[:L.mout].reshape(bs[l].shape)
                 if need_pf:
                     grads_pf.append(pfd)
+            if L.pf_bias and not need_pf:
+                grads_pf.append(None)
             aoff += sum(sizes[l])
             grads_params += [gW, gb]
         # Release the stored activations / masks / embedding NOW.  They are plain attributes of ctx (not save_for_backward tensors),

@@ -513,6 +513,92 @@ def trainer_check_grad(self, thresh=5.0):
 
 
 # ---------------------------------------------------------------------------------------------------
+# proxy-geometry refresh and batch ingestion (row 4)
+# ---------------------------------------------------------------------------------------------------
+def nerf_extract_canonical_mesh(self, grid_size=64, level=0.0, inst_id=None, use_visibility=True, use_extend_aabb=True):
+    """NeRF.extract_canonical_mesh (nnutils/nerf.py:303-343).  The dense grid query -- grid_size^3 evaluations of the sdf head and of the
+    visibility field, the per-sample work of the proxy refresh -- is ONE inference-mode launch per network over the whole grid
+    (lab4d_amd.proxy.grid_query: 0.7 ms at 64^3); iso-surface extraction, the unit-cube -> box transform and the connected-component filter
+    stay the reference's own `geom_utils.marching_cubes` (CPU skimage / trimesh), which is handed the two finished volumes through the
+    sdf_func / visibility_func it asks for chunk by chunk."""
+    import importlib
+    from . import proxy
+    geom = importlib.import_module("lab4d.utils.geom_utils")
+    P = field_params(self)
+    dev = P["logibeta"].device if "logibeta" in P else next(self.parameters()).device
+    iid = None if inst_id is None else torch.tensor([inst_id], device=dev)
+    code_base = inst_code(self.basefield, iid, 1, dev)
+    code_vis = inst_code(self.vis_mlp.basefield, iid, 1, dev)
+    alpha = getattr(self.pos_embedding, "alpha", None)
+    with torch.no_grad():
+        sdf, vis, box = proxy.grid_query(P, self.aabb, grid_size=grid_size, code_base=code_base, code_vis=code_vis, prec=_prec(self),
+                                         use_visibility=use_visibility, extend=0.5 if use_extend_aabb else 0.0, alpha=alpha)
+    sdf, vis = sdf.reshape(-1, 1), vis.reshape(-1, 1)
+
+    def served(vol):  # the volumes are final: marching_cubes' eval_func_chunk walks the grid in order, each call takes the next rows
+        pos = [0]
+
+        def f(xyz):
+            out = vol[pos[0]:pos[0] + xyz.shape[0]]
+            pos[0] += xyz.shape[0]
+            return out
+        return f
+    return geom.marching_cubes(served(sdf), box, visibility_func=served(vis) if use_visibility else None, grid_size=grid_size, level=level,
+                               apply_connected_component=True if self.category == "fg" else False)
+
+
+def nerf_update_aabb(self, beta=0.9):
+    """NeRF.update_aabb (nerf.py:345-356): the bounds of the new proxy mesh blended into the field's box, on the device."""
+    from . import proxy
+    bounds = self.proxy_geometry.bounds
+    if bounds is not None:
+        self.aabb = proxy.update_aabb(self.aabb, torch.as_tensor(bounds, dtype=torch.float32, device=self.aabb.device), beta)
+
+
+def nerf_update_near_far(self, beta=0.9):
+    """NeRF.update_near_far (nerf.py:358-376): depth range of the proxy vertices in every camera (quaternion / translation form straight from
+    CameraMLP.get_vals, no 4x4 matrices), blended into the per-frame near / far table."""
+    from . import proxy
+    verts = self.proxy_geometry.vertices
+    if verts is None:
+        return
+    dev = next(self.parameters()).device
+    with torch.no_grad():
+        quat, trans = self.camera_mlp.get_vals()
+        pts = torch.as_tensor(verts, dtype=torch.float32, device=dev)
+        fm = self.camera_mlp.time_embedding.frame_mapping
+        self.near_far.data.copy_(proxy.update_near_far(self.near_far.data, fm, pts, quat, trans, beta))
+
+
+def device_loader_of(ds, device="cuda"):
+    """A lab4d_amd.ingest.DeviceVidLoader over one reference VidDataset (dataloader/vidloader.py:46-161): the arrays it memory-maps are
+    uploaded once (FrameCache), after which a batch of frame pairs is one gather launch instead of per-pixel numpy reads in worker
+    processes + collate + a host-to-device copy.  Cached on the dataset object."""
+    from . import ingest
+    dl = getattr(ds, "_lab4d_device_loader", None)
+    if dl is None:
+        mm = ds.mmap_list
+        cache = ingest.FrameCache(mm["rgb"], mm["mask"], mm["depth"], mm["flowfw"], mm["flowbw"], mm["feature"], ds.crop2raw, ds.is_detected,
+                                  dataid=ds.dataid, frame_map=list(ds.frame_info.frame_map), device=device)
+        dl = ingest.DeviceVidLoader(cache, ds.delta_list, ds.pixels_per_image, load_pair=ds.load_pair)
+        ds._lab4d_device_loader = dl
+    return dl
+
+
+def vid_load_data(self, im0idx):
+    """VidDataset.load_data (vidloader.py:198-215) served from the HBM-resident frame cache: same keys, shapes and dtypes, DEVICE tensors
+    (torch.utils.data's default collate stacks them as they are).  The pair's delta is drawn with the reference's own sample_delta (numpy
+    RNG, like the reference); the pixels by the device-side sampler.  Opt-in (patch(ingest=True)): it needs the dataset in the process that
+    owns the GPU, i.e. DataLoader(num_workers=0) -- the reference's worker processes never touch the device."""
+    if self.pixels_per_image == -1:
+        return _original("lab4d.dataloader.vidloader.VidDataset.load_data")(self, im0idx)  # full-frame reads (evaluation): the reference's path
+    dl = device_loader_of(self)
+    return dl.load_data(im0idx, delta=int(self.sample_delta(im0idx)))
+
+
+INGEST_BINDINGS = [("lab4d.dataloader.vidloader", "VidDataset", "load_data", vid_load_data, False)]
+
+# ---------------------------------------------------------------------------------------------------
 # per-frame articulation (SURVEY 8f row 1): the kinematic tree behind every SkinningWarp call
 # ---------------------------------------------------------------------------------------------------
 def articulation_skel_forward(self, t_embed, inst_id, return_so3=False, override_so3=None, override_log_bone_len=None,
@@ -580,6 +666,9 @@ def bindings():
         ("lab4d.engine.model", "dvr_model", "compute_loss", dvr_compute_loss, False),
         ("lab4d.engine.trainer", "Trainer", "optimizer_init", trainer_optimizer_init, False),
         ("lab4d.engine.trainer", "Trainer", "check_grad", trainer_check_grad, False),
+        ("lab4d.nnutils.nerf", "NeRF", "extract_canonical_mesh", nerf_extract_canonical_mesh, False),
+        ("lab4d.nnutils.nerf", "NeRF", "update_aabb", nerf_update_aabb, False),
+        ("lab4d.nnutils.nerf", "NeRF", "update_near_far", nerf_update_near_far, False),
     ]
 
 
@@ -599,9 +688,10 @@ def install_quaternion():
     return quaternion
 
 
-def patch(precision="bf16", n_depth=64):
+def patch(precision="bf16", n_depth=64, ingest=False):
     """Rebind the reference's operator API to the HIP library.  `lab4d` must be importable.  Idempotent; `unpatch()`
-    restores the originals.  Returns the list of "module.Class.attr" names that were rebound."""
+    restores the originals.  Returns the list of "module.Class.attr" names that were rebound.
+    ingest=True additionally serves VidDataset.load_data from an HBM-resident frame cache (INGEST_BINDINGS; needs DataLoader(num_workers=0))."""
     import importlib
     global PRECISION, N_DEPTH
     PRECISION = _PREC_NAMES[precision]
@@ -610,7 +700,7 @@ def patch(precision="bf16", n_depth=64):
         return [n for n, *_ in _ORIGINALS]
     install_quaternion()
     done = []
-    for modname, cls, attr, fn, static in bindings():
+    for modname, cls, attr, fn, static in bindings() + (INGEST_BINDINGS if ingest else []):
         mod = importlib.import_module(modname)
         owner = mod if cls is None else getattr(mod, cls)
         # a method inherited from a base class (AppearanceEmbedding.get_vals lives on TimeMLP) is shadowed on the subclass and

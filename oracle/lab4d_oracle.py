@@ -781,7 +781,7 @@ def compute_eikonal_bg(P, xyz, code, rand_inds, alpha=None):
     M, N, D, _ = xyz.shape
     pts = xyz.reshape(M * N, D, 3)
     c = code[:, None, :].expand(M, N, code.shape[-1]).reshape(M * N, -1)
-    out = torch.zeros(M * N, D)
+    out = torch.zeros(M * N, D, dtype=xyz.dtype)
     if rand_inds is None:
         rand_inds = torch.arange(M * N)
 

@@ -29,10 +29,15 @@ def weight_checksum(P):
 
 
 def compress_grad(g):
-    """Big gradients are stored as (norm, strided subsample) to keep the fixture small."""
+    """Big gradients are stored as (norm, strided subsample) to keep the fixture small.  The stride is made coprime with the row length, so the
+    ~1,024 stored entries walk through EVERY input column (round 4: numel // 1024 = 64 on a (256, 256) weight stored columns 0, 64, 128, 192 only,
+    four inputs whose gradients happen to be small for basefield.linear_4 -- the subsample's relative error was 16x the tensor's)."""
     if g.numel() <= 4096:
         return {"full": g.clone()}
-    stride = g.numel() // 1024
+    import math
+    stride, cols = g.numel() // 1024, g.shape[-1]
+    while math.gcd(stride, cols) != 1:
+        stride += 1
     return {"norm": g.double().norm().float(), "stride": stride, "sub": g.flatten()[::stride].clone()}
 
 
@@ -429,16 +434,24 @@ def gen_comp_eval(ns):
           "fg mask", float(r_f["mask"].mean()))
 
 
-def gen_comp_train(ns):
+def gen_comp_train(ns, tag="comp_train", M=2, N=6, D=8, res=64, seed=71, fg_motion="skel-quad", frame_id=None, full_grid_stride=None, rows=None):
     """field_type "comp", training mode: fg Deformable.query_field + bg NeRF.query_field -> compose_fields -> render_pixel ->
     dvr_model.compute_recon_loss / mask_losses / apply_loss_weights with config field_type = "comp", plus gradients of the
-    total loss wrt a few fg and bg weights.  Pins the oracle (render_train_comp / recon_losses_comp) and, through it and
-    directly, the device path (tests/test_gpu_field.py)."""
-    M, N, D, res, seed = 2, 6, 8, 64, 71
-    Pf = synthetic.make_weights(seed)
-    f = build_reference_field(ns, Pf)
+    total loss wrt fg and bg weights.  Pins the oracle (render_train_comp / recon_losses_comp) and, through it and
+    directly, the device path (tests/test_gpu_field.py).
+    full_grid_stride / rows (round 4): the same graph at BASELINE configs[2]'s per-GPU shape -- a band of image rows of a res x res frame pair,
+    D samples per ray and field, fg_motion "comp_skel-human_dense"; every stride-th ray of the three renders is stored, gradients of EVERY
+    fg / bg weight (compressed), inputs are regenerated from the seeds by the tests."""
+    num_bones = 18 if "skel-human" in fg_motion else 25
+    Pf = synthetic.make_weights(seed, num_bones=num_bones)
+    if fg_motion.startswith("comp_"):
+        Pf = synthetic.add_dense_weights(Pf, seed, 1)
+    f = build_reference_field(ns, Pf, 1, fg_motion)
     f.train()
-    frf = frames_from_reference(f, synthetic.make_frames(seed + 1, M, res))
+    fr0 = synthetic.make_frames(seed + 1, M, res, num_bones=num_bones)
+    if frame_id is not None:
+        fr0["frame_id"] = torch.tensor(frame_id, dtype=torch.long)
+    frf = frames_from_reference(f, fr0)
     Pb = synthetic.make_bg_weights(seed)
     Pb["sdf.bias"] = torch.tensor([-0.1])
     torch.manual_seed(0)
@@ -449,7 +462,11 @@ def gen_comp_train(ns):
     b.train()
     frb = synthetic.make_bg_frames(seed + 3, M, res)
     g = torch.Generator().manual_seed(seed + 2)
-    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
+    if full_grid_stride:
+        hxy = synthetic.make_rays(res, M, rows=rows)
+        N = hxy.shape[1]
+    else:
+        hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1)
     batch = synthetic.make_targets(seed + 3, M, N, res, hxy)
     eik_inds = torch.randperm(M * N, generator=g)[: max(M * N // 16, 1)]
     match_perm = torch.randperm(M * N * D, generator=g)[: min(1024, M * N * D)]
@@ -489,24 +506,36 @@ def gen_comp_train(ns):
     model.apply_loss_weights(loss_dict, config)
     total = sum(loss_dict.values())
     pf, pb = dict(f.named_parameters()), dict(b.named_parameters())
-    fnames = ["basefield.linear_1.0.weight", "rgb.0.weight", "warp.skinning_model.delta_field.linear_1.0.weight", "sdf.weight"]
-    bnames = ["basefield.linear_1.0.weight", "basefield.linear_5.0.weight", "colorfield.linear_2.0.weight", "rgb.0.weight", "sdf.weight",
-              "vis_mlp.basefield.linear_1.0.weight"]
+    if full_grid_stride:  # every weight of the path
+        fnames = [k for k in Pf if k in pf and pf[k].requires_grad]
+        bnames = [k for k in Pb if k in pb and pb[k].requires_grad]
+    else:
+        fnames = ["basefield.linear_1.0.weight", "rgb.0.weight", "warp.skinning_model.delta_field.linear_1.0.weight", "sdf.weight"]
+        bnames = ["basefield.linear_1.0.weight", "basefield.linear_5.0.weight", "colorfield.linear_2.0.weight", "rgb.0.weight", "sdf.weight",
+                  "vis_mlp.basefield.linear_1.0.weight"]
     grads = torch.autograd.grad(total, [pf[k] for k in fnames] + [pb[k] for k in bnames], allow_unused=True)
     gd = {}
     for k, gv in zip(["fg:" + k for k in fnames] + ["bg:" + k for k in bnames], grads):
         if gv is not None:
             gd[k] = compress_grad(gv.detach())
-    out = {"meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "bg_sdf_bias": -0.1, "flow_thresh": float(res),
+    out = {"meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "bg_sdf_bias": -0.1, "flow_thresh": float(res), "fg_motion": fg_motion,
                     "weight_checksum_fg": weight_checksum(Pf), "weight_checksum_bg": weight_checksum(Pb)},
            "frames_fg": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in frf.items()},
            "frames_bg": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in frb.items()},
-           "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds, "eik_inds_bg": eik_inds, "match_perm": match_perm},
+           "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds.clone(), "eik_inds_bg": eik_inds.clone(), "match_perm": match_perm.clone()},
            "bg_feat_dict": {k: v.detach() for k, v in fd_b.items()}, **ref_out,
            "loss": {k: v.detach() for k, v in loss_dict.items()}, "grads": gd}
-    path = os.path.join(OUT_DIR, "comp_train.pt")
+    if full_grid_stride:
+        st = full_grid_stride
+        out["meta"]["full_grid_stride"] = st
+        out["meta"]["rows"] = rows
+        for k in ("hxy", "batch", "bg_feat_dict"):
+            out.pop(k)
+        for name in ("rendered", "aux_fg", "aux_bg"):
+            out[name] = {k: (v[:, ::st].clone() if v.dim() >= 2 and v.shape[1] == N else v) for k, v in out[name].items()}
+    path = os.path.join(OUT_DIR, tag + ".pt")
     torch.save(out, path)
-    print("comp_train ->", path, os.path.getsize(path) // 1024, "KiB", {k: round(float(v), 6) for k, v in loss_dict.items()})
+    print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", {k: round(float(v), 6) for k, v in loss_dict.items()})
 
 
 def main(only=None):
@@ -542,6 +571,13 @@ def main(only=None):
         ("bg_field", lambda: gen_bg_field(ns)),
         ("comp_eval", lambda: gen_comp_eval(ns)),
         ("comp_train", lambda: gen_comp_train(ns)),
+        # round 4: BASELINE configs[2] / configs[3] at their per-GPU shapes (like train_bench for configs[1]): a 2-row band of a 512x512 frame pair.
+        # comp_bench: MultiFields "comp" with fg_motion comp_skel-human_dense (18 bones + dense post-warp) + bg, 64 + 64 samples per ray;
+        # train_multi10_bench: the 10-instance category field (comp_skel-quad_dense), 128 samples per ray, a pair of video 3
+        ("comp_bench", lambda: gen_comp_train(ns, "comp_bench", M=2, N=None, D=64, res=512, seed=131, fg_motion="comp_skel-human_dense", frame_id=[10, 11],
+                                              full_grid_stride=16, rows=(255, 257))),
+        ("train_multi10_bench", lambda: gen_train(ns, "multi10_bench", M=2, N=None, D=128, res=512, seed=121, num_inst=10, inst_id=[3, 3], frame_id=[21, 22],
+                                                  fg_motion="comp_skel-quad_dense", full_grid_stride=16, rows=(255, 257))),
     ]
     for name, job in jobs:
         if only is None or name in only:

@@ -19,8 +19,10 @@ from lab4d_amd import synthetic  # noqa: E402
 from oracle import lab4d_oracle as O  # noqa: E402
 
 OUT = os.path.join(HERE, "golden", "fp32_noise_floor.json")
-TRAIN = ["train_small", "train_alpha", "train_multi", "train_multi10", "train_compmotion", "train_human", "train_rigid", "train_dense", "train_c1", "train_bench"]
+TRAIN = ["train_small", "train_alpha", "train_multi", "train_multi10", "train_compmotion", "train_human", "train_rigid", "train_dense", "train_c1", "train_bench",
+         "train_multi10_bench"]
 EVAL = ["eval_small", "eval_rigid", "eval_dense"]
+COMP = ["comp_train", "comp_bench"]  # field_type "comp": fg + bg composite (round 4)
 
 
 def to(x, dt):
@@ -33,7 +35,7 @@ def to(x, dt):
     return x
 
 
-def weights_of(meta):
+def weights_of(meta):  # (= tests/fixture_utils.fg_weights)
     motion = meta.get("fg_motion", "skel-quad")
     P = synthetic.make_weights(meta["seed"], num_inst=meta.get("num_inst", 1), sdf_bias=meta.get("sdf_bias"), num_bones=18 if "skel-human" in motion else 25,
                                motion=motion if motion in ("rigid", "dense") else "skinning")
@@ -48,6 +50,16 @@ def relmax(a, b):
 
 def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+def grad_l2(fix, key, a, b):
+    """Relative L2 of a gradient tensor IN THE METRIC OF THE TESTS: a fixture stores a big gradient as every stride-th entry (make_golden.compress_grad) and the
+    device tests compare that subsample -- whose relative error is not the full tensor's (comp_bench, basefield.linear_4.0.weight: 8.7e-5 over all 65,536 entries,
+    1.4e-3 over the 1,024 stored ones, which sit in four input columns with small gradients).  The floor is taken on the same entries."""
+    ref = fix.get("grads", {}).get(key)
+    if ref is not None and "stride" in ref:
+        return rel_l2(a.flatten()[:: ref["stride"]], b.flatten()[:: ref["stride"]])
+    return rel_l2(a, b)
 
 
 def train_case(name):
@@ -87,7 +99,50 @@ def train_case(name):
         if bool(torch.isfinite(v)):
             out["loss." + k] = relmax(v, l64[k])
     for k, v in g32.items():
-        out["grad." + k] = rel_l2(v, g64[k])
+        out["grad." + k] = grad_l2(g, k, v, g64[k])
+        out["gradmax." + k] = relmax(v, g64[k])
+    return out
+
+
+def comp_case(name):
+    """The comp training graph (fg + bg, compose_fields, comp losses) in float32 against float64: keys as tests/test_gpu_field.py reports them
+    (rendered.* / aux_fg.* / aux_bg.* / loss.* / grad.fg:* / grad.bg:*)."""
+    sys.path.insert(0, HERE)
+    from fixture_utils import bg_weights, fg_weights, rays_and_targets
+    g = torch.load(os.path.join(HERE, "golden", name + ".pt"), weights_only=False)
+    meta = g["meta"]
+    hxy0, batch0 = rays_and_targets(g)
+
+    def run(dt):
+        Pf = {k: (to(v, dt).clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else to(v, dt)) for k, v in fg_weights(meta).items()}
+        Pb = {k: to(v, dt).clone().requires_grad_(True) for k, v in bg_weights(meta).items()}
+        frf = synthetic.add_codes(to(dict(g["frames_fg"]), dt), Pf)
+        batch = to(batch0, dt)
+        frf["feature"] = batch["feature"]
+        frb = synthetic.add_bg_codes(to(dict(g["frames_bg"]), dt), Pb)
+        res = O.render_train_comp(Pf, frf, Pb, frb, to(hxy0, dt), g["rng"], flow_thresh=meta["flow_thresh"], n_depth=meta["D"])
+        if "bg_feat_dict" in g:  # the 12-ray fixture also pins the bg field's per-sample outputs
+            with torch.no_grad():
+                res["bg_feat_dict"] = O.query_field_train_bg(Pb, frb, to(hxy0, dt), g["rng"], flow_thresh=meta["flow_thresh"], n_depth=meta["D"])[0]
+        losses = O.recon_losses_comp(res, batch, meta["res"], O.DEFAULT_LOSS_WT)
+        names = ["fg:" + k for k, v in Pf.items() if v.requires_grad] + ["bg:" + k for k in Pb]
+        gr = torch.autograd.grad(sum(losses.values()), [(Pf if n.startswith("fg:") else Pb)[n[3:]] for n in names], allow_unused=True)
+        return res, losses, {k: v for k, v in zip(names, gr) if v is not None}
+
+    (r32, l32, g32), (r64, l64, g64) = run(torch.float32), run(torch.float64)
+    out = {}
+    for k, v in r32["rendered"].items():
+        out["rendered." + k] = relmax(v, r64["rendered"][k])
+    for k, v in r32.get("bg_feat_dict", {}).items():
+        out["bg_feat_dict." + k] = relmax(v, r64["bg_feat_dict"][k])
+    for cat in ("fg", "bg"):
+        for k, v in r32["aux_dict"][cat].items():
+            if torch.is_tensor(v):
+                out["aux_%s.%s" % (cat, k)] = relmax(v, r64["aux_dict"][cat][k])
+    for k, v in l32.items():
+        out["loss." + k] = relmax(v, l64[k])
+    for k, v in g32.items():
+        out["grad." + k] = grad_l2(g, k, v, g64[k])
         out["gradmax." + k] = relmax(v, g64[k])
     return out
 
@@ -117,10 +172,10 @@ def main(cases):
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for c in cases:
         t = time.time()
-        res[c] = {k: float("%.3e" % v) for k, v in (train_case(c) if c in TRAIN else eval_case(c)).items()}
+        res[c] = {k: float("%.3e" % v) for k, v in (train_case(c) if c in TRAIN else comp_case(c) if c in COMP else eval_case(c)).items()}
         print(c, "%.1f s" % (time.time() - t), "worst:", sorted(((v, k) for k, v in res[c].items() if not k.startswith("gradmax")), reverse=True)[:3])
         json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or TRAIN + EVAL)
+    main(sys.argv[1:] or TRAIN + EVAL + COMP)

@@ -132,11 +132,11 @@ def test_unshared_forward_warps_give_the_reference_rows(golden_dir):
     fr["feature"] = batch["feature"]
     fr["rest_shared_in_pair"] = False
     res = DF.render_train(Pd, fr, g["hxy"].to(DEV), synthetic.to_device(g["rng"], DEV), flow_thresh=meta["flow_thresh"], n_depth=meta["D"], alpha=meta["alpha"])
-    for k, v in g["rendered"].items():
-        assert rel(res["rendered"][k], v) < 2e-4, k
+    measured = {"rendered." + k: rel(res["rendered"][k], v) for k, v in g["rendered"].items()}
     grads = torch.autograd.grad(DF.losses_fg(res, batch, meta["res"], DF.DEFAULT_LOSS_WT).total, list(rest))
-    for i, gv in enumerate(grads):
-        assert rel(gv, g["grads"]["frame:rest_articulation.%d" % i]["full"]) < 5e-3, i
+    frame = {"gradmax.frame:rest_articulation.%d" % i: rel(gv, g["grads"]["frame:rest_articulation.%d" % i]["full"]) for i, gv in enumerate(grads)}
+    check("unshared_train_small", measured, floor_case="train_small", floor_pool=SMALL_FIXTURES)
+    check("unshared_frames_train_small", frame)  # per-frame input gradients have no floor entry: held to the committed measurement
 
 
 def test_training_graph_multi_instance(golden_dir):
@@ -150,10 +150,11 @@ def _run_full_size(golden_dir, name, prec):
     reference's render stored): device render + losses + gradients, returned as measured errors relative to the reference.
     rendered.* / loss.*: max abs error over the largest reference value; grad.*: relative L2 error of the (sub-sampled) tensor."""
     from lab4d_amd import deformable as DF
+    from fixture_utils import fg_weights
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
     meta = g["meta"]
     st, M, res, seed = meta["full_grid_stride"], meta["M"], meta["res"], meta["seed"]
-    P = synthetic.make_weights(seed)
+    P = fg_weights(meta)
     Pd = {k: (v.to(DEV).clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v.to(DEV)) for k, v in P.items()}
     hxy = synthetic.make_rays(res, M, rows=meta.get("rows"))
     batch = synthetic.to_device(synthetic.make_targets(seed + 3, M, hxy.shape[1], res, hxy), DEV)
@@ -213,6 +214,76 @@ def test_training_graph_at_the_bench_shape_fp32(golden_dir):
     check("bench_fp32", _run_full_size(golden_dir, "train_bench.pt", mlp.PREC_F32), floor_case="train_bench", skip=("psnr_rgb_db",))
 
 
+def test_training_graph_at_the_bench_shape_multi10_fp32(golden_dir):
+    """BASELINE.json configs[3]'s field at the bench shape (round 4): 10 instances, fg_motion comp_skel-quad_dense, a 2-row band of a 512x512 pair of
+    video 3 x 128 samples/ray against the reference's own output; every entry within max(1e-4, 2 x measured) AND, above 1e-4, within 4x of the
+    SAME tensor's fp32-vs-fp64 floor on this fixture (no pooled family floor at full size)."""
+    from lab4d_amd import mlp
+    check("multi10_bench_fp32", _run_full_size(golden_dir, "train_multi10_bench.pt", mlp.PREC_F32), floor_case="train_multi10_bench", skip=("psnr_rgb_db",))
+
+
+def _run_comp(golden_dir, name, prec):
+    """field_type "comp", training mode on the device against a reference-generated fixture (comp_train.pt: 12 rays; comp_bench.pt: BASELINE
+    configs[2]'s per-GPU shape, every 16th ray stored): the three renders, the comp losses, gradients of the fg and bg weights.
+    rendered.* / aux_*.* / loss.*: max abs error over the largest reference value; grad.*: relative L2 (of the sub-sampled tensor where the
+    fixture stores one); gradmax.*: max abs error over the largest reference entry (fully stored tensors)."""
+    from lab4d_amd import deformable as DF
+    from fixture_utils import bg_weights, fg_weights, leaf, rays_and_targets, strided
+    g = torch.load(os.path.join(golden_dir, name), weights_only=False)
+    meta = g["meta"]
+    Pf, Pb = leaf(fg_weights(meta), DEV), {k: v.to(DEV).clone().requires_grad_(True) for k, v in bg_weights(meta).items()}
+    hxy, batch = rays_and_targets(g)
+    batch = synthetic.to_device(batch, DEV)
+    frf = synthetic.add_codes(synthetic.to_device(dict(g["frames_fg"]), DEV), Pf)
+    frf["feature"] = batch["feature"]
+    frb = synthetic.add_bg_codes(synthetic.to_device(dict(g["frames_bg"]), DEV), Pb)
+    rng = synthetic.to_device(g["rng"], DEV)
+    hxy = hxy.to(DEV)
+    measured = {}
+    if "bg_feat_dict" in g:
+        fd_b, _, _ = DF.query_field_train_bg(Pb, frb, hxy, rng, flow_thresh=meta["flow_thresh"], n_depth=meta["D"], prec=prec)
+        assert sorted(fd_b.keys()) == sorted(g["bg_feat_dict"].keys())
+        for k, v in g["bg_feat_dict"].items():
+            measured["bg_feat_dict." + k] = rel(fd_b[k], v)
+    res = DF.render_train_comp(Pf, frf, Pb, frb, hxy, rng, flow_thresh=meta["flow_thresh"], n_depth=meta["D"], prec=prec)
+    for name_, ref in (("rendered", g["rendered"]), ("aux_fg", g["aux_fg"]), ("aux_bg", g["aux_bg"])):
+        got = res["rendered"] if name_ == "rendered" else res["aux_dict"][name_[4:]]
+        for k, v in ref.items():
+            measured[name_ + "." + k] = rel(strided(g, got[k]), v)
+    mse = float(((strided(g, res["rendered"]["rgb"]).detach().cpu() - g["rendered"]["rgb"]) ** 2).mean())
+    measured["psnr_rgb_db"] = -10.0 * torch.log10(torch.tensor(max(mse, 1e-20))).item()
+    losses = DF.losses_comp(res, batch, meta["res"], DF.DEFAULT_LOSS_WT)
+    for k, v in g["loss"].items():
+        measured["loss." + k] = rel(losses[k], v)
+    names = list(g["grads"].keys())
+    grads = torch.autograd.grad(sum(losses.values()), [(Pf if n.startswith("fg:") else Pb)[n[3:]] for n in names], allow_unused=True)
+    for n, gv in zip(names, grads):
+        ref = g["grads"][n]
+        assert gv is not None, n
+        a, b = (gv, ref["full"]) if "full" in ref else (gv.flatten()[:: ref["stride"]], ref["sub"])
+        a, b = a.detach().double().cpu().flatten(), b.double().flatten()
+        measured["grad." + n] = float((a - b).norm() / (b.norm() + 1e-30))
+        if "full" in ref:
+            measured["gradmax." + n] = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    return measured
+
+
+def test_comp_training_graph_at_the_bench_shape_fp32(golden_dir):
+    """BASELINE.json configs[2] at its per-GPU shape (round 4): MultiFields "comp" with fg_motion comp_skel-human_dense + bg, a 2-row band of a
+    512x512 frame pair, 64 + 64 samples per ray composed, against the reference's own renders / losses / gradients of EVERY fg and bg weight
+    (tests/golden/comp_bench.pt); same-tensor floors (tests/golden/fp32_noise_floor.json: comp_bench)."""
+    from lab4d_amd import mlp
+    check("comp_bench_fp32", _run_comp(golden_dir, "comp_bench.pt", mlp.PREC_F32), floor_case="comp_bench", skip=("psnr_rgb_db",))
+
+
+def test_comp_training_graph_at_the_bench_shape_bf16(golden_dir):
+    """The benched dtype on the same fixture: bounds = BF16_BOUNDS (measured margins, see below), PSNR of the composite colour vs the reference."""
+    from lab4d_amd import mlp
+    m = _run_comp(golden_dir, "comp_bench.pt", mlp.PREC_BF16)
+    _assert_bounds("comp_bench_bf16", {k: v for k, v in m.items() if not k.startswith("gradmax.")}, BF16_BOUNDS_COMP, 2e-2)
+    assert m["psnr_rgb_db"] > 80.0, m["psnr_rgb_db"]
+
+
 # bf16 path (the dtype bench.py times; BASELINE configs[1] says bf16).  MFMA operands -- weights and every stored activation --
 # are rounded to 8 significant bits (unit roundoff u = 2^-9 = 2.0e-3), accumulation is fp32.  A rendered channel passes through
 # up to 10 (sdf) + 5 (colour) such layers; rounding errors are independent per layer, so the expected relative error of a
@@ -227,6 +298,16 @@ BF16_BOUNDS = {
     "rendered": 2e-4, "rendered.eikonal": 2e-2, "rendered.feature": 1e-2, "rendered.xyz_matches": 5e-3, "rendered.delta_skin": 3e-3,
     "loss": 1.5e-4, "loss.reg_eikonal": 2e-3, "loss.reg_delta_skin": 1e-3, "grad": 2.5e-2,
 }
+
+
+# the comp configuration's rows: the bg scene spans |xyz| ~ 0.6 (its visibility / eikonal channels see the 2^9 posenc band), the composite mixes two fields
+# measured on MI355X (profiles/r04_parity_comp_bench_bf16.json): composite / per-field colour, depth, geometry <= 2.2e-4; the skinning-derived channels of the
+# 18-bone field (cyc_dist, skin_entropy, delta_skin, gauss_mask) 1e-3 .. 2e-3; eikonal 4e-3 .. 9e-3; gradients <= 2.9e-2 relative L2 (basefield.linear_4)
+BF16_BOUNDS_COMP = dict(BF16_BOUNDS, **{"rendered": 5e-4, "rendered.mask_bg": 2e-3, "rendered.cyc_dist": 3e-3, "rendered.skin_entropy": 5e-3, "rendered.delta_skin": 5e-3,
+                                      "rendered.gauss_mask": 4e-3, "rendered.eikonal": 2e-2, "rendered.feature": 1e-2, "rendered.xyz_matches": 5e-3,
+                                      "aux_fg": 5e-4, "aux_fg.cyc_dist": 3e-3, "aux_fg.skin_entropy": 5e-3, "aux_fg.delta_skin": 5e-3, "aux_fg.gauss_mask": 4e-3,
+                                      "aux_fg.eikonal": 2e-2, "aux_fg.feature": 1e-2, "aux_fg.xyz_matches": 5e-3, "aux_bg": 5e-4, "aux_bg.eikonal": 3e-2,
+                                      "loss": 3e-4, "loss.reg_eikonal": 2e-3, "loss.reg_delta_skin": 4e-3, "loss.reg_deform_cyc": 2e-3, "grad": 6e-2})
 
 
 def test_training_graph_at_the_bench_shape_bf16(golden_dir):
@@ -329,44 +410,13 @@ def test_comp_eval_matches_reference_goldens(golden_dir):
 
 
 def test_comp_train_matches_reference_goldens(golden_dir):
-    """field_type "comp", training mode on the device: bg NeRF.query_field (flow, eikonal through the tangent kernel of the bg
-    basefield), compose_fields, the three renders, the comp losses and gradients wrt fg and bg weights vs the
-    reference-generated fixture (fp32)."""
-    from lab4d_amd import deformable as DF
-    g = torch.load(os.path.join(golden_dir, "comp_train.pt"), weights_only=False)
-    meta = g["meta"]
-    Pf = synthetic.make_weights(meta["seed"])
-    Pb = synthetic.make_bg_weights(meta["seed"])
-    Pb["sdf.bias"] = torch.tensor([meta["bg_sdf_bias"]])
-    Pf = {k: (v.to(DEV).clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v.to(DEV)) for k, v in Pf.items()}
-    Pb = {k: v.to(DEV).clone().requires_grad_(True) for k, v in Pb.items()}
-    frf = synthetic.add_codes(synthetic.to_device(dict(g["frames_fg"]), DEV), Pf)
-    batch = synthetic.to_device(g["batch"], DEV)
-    frf["feature"] = batch["feature"]
-    frb = synthetic.add_bg_codes(synthetic.to_device(dict(g["frames_bg"]), DEV), Pb)
-    rng = synthetic.to_device(g["rng"], DEV)
-    hxy = g["hxy"].to(DEV)
-    loose = ("vis", "eikonal")
-    fd_b, _, _ = DF.query_field_train_bg(Pb, frb, hxy, rng, flow_thresh=meta["flow_thresh"], n_depth=meta["D"])
-    assert sorted(fd_b.keys()) == sorted(g["bg_feat_dict"].keys())
-    for k, v in g["bg_feat_dict"].items():
-        assert rel(fd_b[k], v) < (5e-3 if k in loose else 5e-4), f"bg.{k}: {rel(fd_b[k], v):.3e}"
-    res = DF.render_train_comp(Pf, frf, Pb, frb, hxy, rng, flow_thresh=meta["flow_thresh"], n_depth=meta["D"])
-    for name, ref in (("rendered", g["rendered"]), ("fg", g["aux_fg"]), ("bg", g["aux_bg"])):
-        got = res["rendered"] if name == "rendered" else res["aux_dict"][name]
-        for k, v in ref.items():
-            assert rel(got[k], v) < (5e-3 if k in loose else 5e-4), f"{name}.{k}: {rel(got[k], v):.3e}"
-    losses = DF.losses_comp(res, batch, meta["res"], DF.DEFAULT_LOSS_WT)
-    for k, v in g["loss"].items():
-        assert rel(losses[k], v) < 2e-3, f"loss.{k}: {rel(losses[k], v):.3e}"
-    total = sum(losses.values())
-    names = list(g["grads"].keys())
-    grads = torch.autograd.grad(total, [(Pf if n.startswith("fg:") else Pb)[n[3:]] for n in names], allow_unused=True)
-    for n, gv in zip(names, grads):
-        ref = g["grads"][n]
-        assert gv is not None, n
-        e = rel(gv, ref["full"]) if "full" in ref else rel(gv.flatten()[:: ref["stride"]], ref["sub"])
-        assert e < 1e-2, f"grad {n}: {e:.3e}"
+    """field_type "comp", training mode on the device (12 rays): bg NeRF.query_field (flow, eikonal through the tangent kernel of the bg
+    basefield), compose_fields, the three renders, the comp losses and gradients wrt fg and bg weights vs the reference-generated fixture
+    (fp32) -- round 4: in the regime of every other parity test (bound = max(1e-4, 2 x the committed MI355X measurement); what exceeds 1e-4 is
+    held against the fp32-vs-fp64 floor of the same quantity, or of its family over the pool of 12-ray fixtures)."""
+    from lab4d_amd import mlp
+    m = _run_comp(golden_dir, "comp_train.pt", mlp.PREC_F32)
+    check("comp_train_fp32", m, floor_case="comp_train", skip=("psnr_rgb_db",), floor_pool=SMALL_FIXTURES + ("comp_bench",))
 
 
 def test_render_samples_dispatches_comp(golden_dir):
@@ -389,3 +439,72 @@ def test_render_samples_dispatches_comp(golden_dir):
     for k, v in res["rendered"].items():
         if k != "vis":  # vis is normalised by the mean transmittance of the (chunk of) rays
             assert rel(chunked["rendered"][k].cpu(), v.cpu()) < 1e-5, k
+
+
+def _device_relu_pattern(masks, S, widths):
+    """Decode the fp32 chain kernel's stored ReLU sign words (mlp_kernels.hpp: word [(tile * MT + mt) * 64 + lane], fp32 tiles of 32 samples;
+    lane = (n, h), bit r <-> feature 32 mt + (r & 3) + 8 (r >> 2) + 4 h of sample 32 tile + n; 1 = alive) into per-layer (S, width) bools."""
+    out = []
+    r = torch.arange(16)
+    for words, W in zip(masks, widths):
+        if words is None:
+            out.append(None)
+            continue
+        MT = W // 32
+        w = words.cpu().view(-1, MT, 2, 32)  # (tile, mt, h, n)
+        bits = ((w[..., None] >> r) & 1).bool()  # (tile, mt, h, n, r)
+        feat = torch.zeros(MT, 2, 16, dtype=torch.long)
+        for mt in range(MT):
+            for h in range(2):
+                feat[mt, h] = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h
+        alive = torch.zeros(w.shape[0] * 32, W, dtype=torch.bool)
+        samples = (torch.arange(w.shape[0])[:, None] * 32 + torch.arange(32)[None]).reshape(-1)  # (tile, n)
+        for mt in range(MT):
+            for h in range(2):
+                alive[samples[:, None], feat[mt, h][None, :]] = bits[:, mt, h].reshape(-1, 16)
+        out.append(alive[:S])
+    return out
+
+
+@pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_multi10.pt", "train_human.pt", "train_compmotion.pt"])
+def test_relu_patterns_of_the_small_fixtures_agree_with_the_oracle(golden_dir, case):
+    """The 12..20-ray fixtures' gradient deviations above 1e-4 are explained by discrete events -- a ReLU unit of the 8 x 256 basefield that lands on
+    the other side of zero in two fp32 evaluations moves a gradient tensor by 1e-3 .. 1e-2 (tests/parity_report.py, floor_pool).  This TESTS
+    that story instead of telling it: on the reference's own canonical sample points (fixture feat_dict.xyz) the device's stored sign words
+    (training-mode fp32 chain) and the oracle's pre-activations differ in at most 2 of the ~200,000 hidden units, and every flipped unit's
+    pre-activation is within 1e-5 of zero."""
+    import torch.nn.functional as F
+    from lab4d_amd import mlp
+    g, P = load_case(golden_dir, case)
+    meta = g["meta"]
+    xyz = g["feat_dict"]["xyz"]
+    M, N, D = xyz.shape[:3]
+    Pd = synthetic.to_device(P, DEV)
+    fr = synthetic.add_codes(synthetic.to_device(dict(g["frames"]), DEV), Pd)
+    x = xyz.reshape(-1, 3).to(DEV).clone().requires_grad_(True)
+    tap = {}
+    fw = None
+    if meta.get("alpha") is not None:
+        from lab4d_amd import deformable as DF
+        fw = DF.posenc_window(meta["alpha"], 10, DEV)
+    mlp.run_chain(mlp.NET_FG_BASE, mlp.PREC_F32, Pd, x, N * D, conds={0: fr["code_base"], 4: fr["code_base"]}, freq_w=fw, tap=tap)
+    dev_alive = _device_relu_pattern(tap["masks"][:9], M * N * D, [256] * 9)
+    # the oracle's pre-activations, layer by layer (base.py:65-78,123-150: input = [posenc | code], skip concatenates the input first)
+    code = fr["code_base"].cpu()[:, None, None, :].expand(M, N, D, -1).reshape(M * N * D, -1)
+    inp = torch.cat([O.pos_embedding(xyz.reshape(-1, 3), 10, meta.get("alpha")), code], -1)
+    h, flips, near_zero, total = inp, 0, True, 0
+    for i in range(9):
+        name = "basefield.linear_%d.0" % (i + 1) if i < 8 else "basefield.linear_final.0"
+        if i == 4:
+            h = torch.cat([inp, h], -1)
+        z = F.linear(h, P[name + ".weight"], P[name + ".bias"])
+        h = F.relu(z)
+        if dev_alive[i] is None:
+            continue
+        diff = dev_alive[i] != (z > 0)
+        flips += int(diff.sum())
+        total += diff.numel()
+        if diff.any():
+            near_zero = near_zero and bool((z[diff].abs() < 1e-5 * max(float(z.abs().max()), 1.0)).all())
+    report("relu_flips_" + case[:-3], {"flipped_units": float(flips), "hidden_units": float(total)})
+    assert total >= 8 * 256 * M * N * D and flips <= 2 and near_zero, (flips, total, near_zero)

@@ -96,3 +96,27 @@ def test_bad_arguments_fail_loudly():
         ingest.gather([cache], [(0, 0, -1)], torch.tensor([[[0, 0]]], device=DEV))  # no backward flow into frame 0
     with pytest.raises(RuntimeError):
         ingest.gather([cache], [(0, 0, 1)], torch.zeros(1, 4, 3, device=DEV))
+
+
+def test_vid_dataset_adapter_serves_load_data_from_the_frame_cache():
+    """patch.vid_load_data (round 4, opt-in binding of VidDataset.load_data): a stand-in dataset object carrying the attributes the real
+    VidDataset has after __init__ (mmap_list, crop2raw, is_detected, dataid, frame_info.frame_map, delta_list, pixels_per_image, load_pair,
+    sample_delta) -> the pair comes back from the HBM-resident cache with the reference's keys / shapes / dtypes, and every value equals
+    the numpy oracle's for the pixels the device sampler drew."""
+    import types
+    from lab4d_amd import patch
+    T, H, N = 7, 32, 16
+    video = IO.synthetic_video(33, T=T, H=H, W=H, deltas=(1, 2))
+    ds = types.SimpleNamespace(mmap_list={k: video[k] for k in ("rgb", "mask", "depth", "flowfw", "flowbw", "feature")}, crop2raw=video["crop2raw"],
+                               is_detected=video["is_detected"], dataid=5, frame_info=types.SimpleNamespace(frame_map=list(range(100, 100 + T))),
+                               delta_list=[2], pixels_per_image=N, load_pair=True, sample_delta=lambda i: 2 if i % 2 == 0 and i + 2 < T else 1)
+    for im0 in (0, 3, 4):
+        out = patch.vid_load_data(ds, im0)
+        delta = ds.sample_delta(im0)
+        assert out["rgb"].shape == (2, N, 3) and out["hxy"].shape == (2, N, 3) and out["mask"].dtype == torch.bool and out["rgb"].is_cuda
+        assert out["frameid_sub"].tolist() == [100 + im0, 100 + im0 + delta] and out["dataid"].tolist() == [5, 5]
+        xy = out["hxy"][..., :2].cpu().numpy().astype(np.int64)
+        ref = IO.load_pair(video, im0, delta, xy[0], xy[1])
+        for k in ("rgb", "mask", "vis2d", "depth", "flow", "flow_uct", "feature", "hxy", "crop2raw", "is_detected"):
+            assert same(out[k], ref[k]), (k, im0)
+    assert ds._lab4d_device_loader is patch.device_loader_of(ds)  # uploaded once

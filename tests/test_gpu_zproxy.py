@@ -75,3 +75,62 @@ def test_grid_query_rate(G):
     json.dump(res, open(os.path.join(out, "proxy_grid_%d.json" % G), "w"))
     print(res)
     assert sdf.shape == (G, G, G) and bool(torch.isfinite(sdf).all())
+
+
+def test_proxy_bindings_drive_the_grid_query_through_the_reference_entry_points(golden_dir):
+    """patch.nerf_extract_canonical_mesh / nerf_update_aabb / nerf_update_near_far (round 4) on a stand-in field: the adapter hands the
+    reference's own marching_cubes (here: a stand-in that walks the grid chunk by chunk exactly like geom_utils.eval_func_chunk and returns
+    what it was served) the two volumes of ONE grid query -- equal to the reference-generated fixture -- and the bound updates write the
+    module's aabb / near_far like the reference methods do."""
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import standins
+    from lab4d_amd import mlp, patch
+    g = torch.load(os.path.join(golden_dir, "proxy.pt"), weights_only=False)
+    meta = g["meta"]
+    P = synthetic.to_device(synthetic.make_weights(meta["seed"], sdf_bias=meta["sdf_bias"]), DEV)
+    frames = synthetic.to_device(synthetic.make_frames(meta["seed"] + 1, 2, 64), DEV)
+    frames = synthetic.add_codes(frames, P)
+    field = standins.fg_field(P, frames, training=False)
+    field.aabb = g["aabb"].to(DEV)
+    field.category = "fg"
+    patch.configure(field, precision="f32")
+    G = meta["grid_size"]
+    seen = {}
+
+    def marching_cubes(sdf_func, aabb, visibility_func=None, grid_size=64, level=0, chunk_size=64 ** 3, apply_connected_component=False):
+        from lab4d_amd import proxy
+        grid = proxy.sample_grid(aabb, grid_size)
+        chunks = lambda f: torch.cat([f(grid[i:i + chunk_size]) for i in range(0, grid.shape[0], chunk_size)], 0)  # noqa: E731
+        seen.update(sdf=chunks(sdf_func).reshape(grid_size, grid_size, grid_size), vis=chunks(visibility_func).reshape(grid_size, grid_size, grid_size),
+                    box=aabb, level=level, cc=apply_connected_component)
+        return "mesh"
+    saved = {k: sys.modules.get(k) for k in ("lab4d", "lab4d.utils", "lab4d.utils.geom_utils")}
+    geom = types.ModuleType("lab4d.utils.geom_utils")
+    geom.marching_cubes = marching_cubes
+    for k in ("lab4d", "lab4d.utils"):
+        sys.modules.setdefault(k, types.ModuleType(k))
+    sys.modules["lab4d.utils.geom_utils"] = geom
+    try:
+        out = patch.nerf_extract_canonical_mesh(field, grid_size=G, level=0.005)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    assert out == "mesh" and seen["level"] == 0.005 and seen["cc"] is True
+    assert torch.allclose(seen["box"].cpu(), g["box"], atol=1e-7)
+    assert rel(seen["sdf"], g["sdf"]) < 1e-4 and int((seen["vis"].cpu().view(G, G, G) != g["vis"]).sum()) <= 2
+    # bound updates through the method-shaped adapters
+    verts = g["verts"]
+    field.proxy_geometry = types.SimpleNamespace(vertices=verts.numpy(), bounds=torch.stack([verts.min(0)[0], verts.max(0)[0]], 0).numpy())
+    field.aabb = g["aabb_before"].to(DEV)
+    patch.nerf_update_aabb(field)
+    assert torch.allclose(field.aabb.cpu(), g["aabb_after"], rtol=1e-6, atol=1e-7)
+    field.near_far = torch.nn.Parameter(g["near_far_before"].to(DEV).clone(), requires_grad=False)
+    field.camera_mlp = types.SimpleNamespace(get_vals=lambda: (g["cam_quat"].to(DEV), g["cam_trans"].to(DEV)),
+                                             time_embedding=types.SimpleNamespace(frame_mapping=g["frame_mapping"].to(DEV)))
+    patch.nerf_update_near_far(field)
+    assert rel(field.near_far.data, g["near_far_after"]) < 1e-5

@@ -305,6 +305,40 @@ def test_comp_train_against_reference(golden_dir):
             assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 2e-3 * float(ref["norm"]) + 1e-12, n
 
 
+def test_comp_training_graph_at_the_bench_shape(golden_dir):
+    """BASELINE configs[2] at its per-GPU shape (round 4, tests/golden/comp_bench.pt): MultiFields "comp" with fg_motion comp_skel-human_dense
+    (18 bones + dense post-warp) + the bg field, a 2-row band of a 512x512 frame pair, 64 + 64 samples per ray composed -- the reference's
+    three renders (every 16th ray), its comp losses and the gradient of EVERY fg and bg weight against the oracle."""
+    from fixture_utils import bg_weights, fg_weights, leaf, rays_and_targets, strided
+    g = torch.load(os.path.join(golden_dir, "comp_bench.pt"), weights_only=False)
+    meta = g["meta"]
+    Pf0, Pb0 = fg_weights(meta), bg_weights(meta)
+    assert abs(sum(float(v.double().abs().sum()) for k, v in sorted(Pf0.items()) if v.dtype.is_floating_point) - meta["weight_checksum_fg"]) < 1e-6 * meta["weight_checksum_fg"]
+    Pf, Pb = leaf(Pf0), {k: v.clone().requires_grad_(True) for k, v in Pb0.items()}
+    hxy, batch = rays_and_targets(g)
+    frf = synthetic.add_codes(dict(g["frames_fg"]), Pf)
+    frf["feature"] = batch["feature"]
+    frb = synthetic.add_bg_codes(dict(g["frames_bg"]), Pb)
+    res = O.render_train_comp(Pf, frf, Pb, frb, hxy, g["rng"], flow_thresh=meta["flow_thresh"], n_depth=meta["D"])
+    for name, ref in (("rendered", g["rendered"]), ("fg", g["aux_fg"]), ("bg", g["aux_bg"])):
+        got = res["rendered"] if name == "rendered" else res["aux_dict"][name]
+        for k, v in ref.items():
+            close(strided(g, got[k]), v, f"{name}.{k}", rtol=2e-4)
+    losses = O.recon_losses_comp(res, batch, meta["res"], O.DEFAULT_LOSS_WT)
+    for k, v in g["loss"].items():
+        close(losses[k], v, "loss." + k, rtol=5e-4)
+    names = list(g["grads"].keys())
+    grads = torch.autograd.grad(sum(losses.values()), [(Pf if n.startswith("fg:") else Pb)[n[3:]] for n in names], allow_unused=True)
+    for n, gv in zip(names, grads):
+        ref = g["grads"][n]
+        assert gv is not None, n
+        if "full" in ref:
+            close(gv, ref["full"], "grad." + n, rtol=5e-3, atol=1e-4 * max(float(ref["full"].abs().max()), 1e-12))
+        else:
+            close(gv.flatten()[:: ref["stride"]], ref["sub"], "grad." + n, rtol=5e-3, atol=2e-4 * float(ref["sub"].abs().max()) + 1e-10)
+            assert abs(float(gv.double().norm()) - float(ref["norm"])) <= 2e-3 * float(ref["norm"]) + 1e-12, n
+
+
 # ---- per-frame pose / articulation path (SURVEY 8f row 1): oracle/pose_oracle.py vs tests/golden/pose.pt ------------------
 
 
@@ -449,16 +483,18 @@ def test_pose_flat_articulation_and_intrinsics(pose):
     close(PO.intrinsics_vals(P, "intr", None, info_k), pose["intr"]["all_frames"], "intrinsics all")
 
 
-@pytest.mark.parametrize("name", ["train_c1.pt", "train_bench.pt"])
+@pytest.mark.parametrize("name", ["train_c1.pt", "train_bench.pt", "train_multi10_bench.pt"])
 def test_training_graph_at_baseline_sizes(golden_dir, name):
     """BASELINE.json configs[0]: the full 64x64 crop of a frame pair x 64 samples/ray (8,192 rays, 524,288 samples) through the whole
     training graph.  The fixture (reference-generated) stores every 16th ray of the render, the losses and compressed gradients;
     rays and targets are regenerated from the seeds.  ~1 minute on 8 cores.
-    train_bench.pt: configs[1]'s shape (512x512, 128 samples/ray), a 2-row band of a frame pair (262,144 samples)."""
+    train_bench.pt: configs[1]'s shape (512x512, 128 samples/ray), a 2-row band of a frame pair (262,144 samples).
+    train_multi10_bench.pt (round 4): configs[3]'s field at that shape -- 10 instances, fg_motion comp_skel-quad_dense, a pair of video 3."""
+    from fixture_utils import fg_weights
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
     meta = g["meta"]
     st, M, res, seed = meta["full_grid_stride"], meta["M"], meta["res"], meta["seed"]
-    P = synthetic.make_weights(seed)
+    P = fg_weights(meta)
     assert abs(sum(float(v.double().abs().sum()) for k, v in sorted(P.items()) if v.dtype.is_floating_point) - meta["weight_checksum"]) < 1e-6 * meta["weight_checksum"]
     P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and k != "aabb" else v) for k, v in P.items()}
     hxy = synthetic.make_rays(res, M, rows=meta.get("rows"))

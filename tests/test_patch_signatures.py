@@ -47,7 +47,7 @@ def test_every_patched_symbol_keeps_the_reference_signature(ns):
     import importlib
     from lab4d_amd import patch
     checked = 0
-    for modname, cls, attr, fn, static in patch.bindings():
+    for modname, cls, attr, fn, static in patch.bindings() + patch.INGEST_BINDINGS:
         mod = importlib.import_module(modname)
         owner = mod if cls is None else getattr(mod, cls)
         orig = inspect.getattr_static(owner, attr)  # through the MRO: AppearanceEmbedding.get_vals is TimeMLP's
@@ -62,7 +62,7 @@ def test_every_patched_symbol_keeps_the_reference_signature(ns):
         else:
             assert _params(sn) == _params(so), "%s.%s.%s: %s != %s" % (modname, cls, attr, sn, so)
         checked += 1
-    assert checked == len(patch.bindings()) >= 24
+    assert checked == len(patch.bindings()) + len(patch.INGEST_BINDINGS) >= 32
 
 
 def test_patch_rebinds_and_unpatch_restores(ns, patched):
@@ -243,3 +243,50 @@ def test_optimizer_init_adopts_the_reference_optimizer(ns, patched):
     t.optimizer.load_state_dict(sd)
     assert all(float(t.optimizer.state[p]["exp_avg"].abs().max()) == 0.0 for p in inside)
     assert t.optimizer.state[inside[0]]["exp_avg"].data_ptr() == flat.m.data_ptr()  # still views of the flat moment buffer
+
+
+def test_proxy_refresh_and_ingestion_bindings(ns):
+    """Round 4 (SURVEY 8f rows 3-4 through patch()): NeRF.extract_canonical_mesh / update_aabb / update_near_far are rebound by default,
+    VidDataset.load_data only with patch(ingest=True); every attribute the adapters read exists on the real reference classes."""
+    import importlib
+    from lab4d_amd import patch
+    saved_q = sys.modules.get("quaternion")
+    try:
+        names = patch.patch(precision="f32", ingest=True)
+        nerf = importlib.import_module("lab4d.nnutils.nerf")
+        vid = importlib.import_module("lab4d.dataloader.vidloader")
+        assert nerf.NeRF.extract_canonical_mesh is patch.nerf_extract_canonical_mesh and nerf.NeRF.update_aabb is patch.nerf_update_aabb
+        assert nerf.NeRF.update_near_far is patch.nerf_update_near_far and vid.VidDataset.load_data is patch.vid_load_data
+        assert "lab4d.dataloader.vidloader.VidDataset.load_data" in names
+    finally:
+        patch.unpatch()
+        if saved_q is not None:
+            sys.modules["quaternion"] = saved_q
+    vid = importlib.import_module("lab4d.dataloader.vidloader")
+    assert vid.VidDataset.load_data is not patch.vid_load_data
+    patch.patch(precision="f32")
+    try:
+        assert vid.VidDataset.load_data is not patch.vid_load_data  # opt-in only
+    finally:
+        patch.unpatch()
+        if saved_q is not None:
+            sys.modules["quaternion"] = saved_q
+    # names the adapters read on the reference objects
+    src = inspect.getsource(vid.VidDataset)
+    for attr in ("mmap_list", "crop2raw", "is_detected", "dataid", "frame_info", "delta_list", "pixels_per_image", "load_pair", "sample_delta"):
+        assert "self." + attr in src, attr
+    nsrc = inspect.getsource(importlib.import_module("lab4d.nnutils.nerf").NeRF)
+    for attr in ("proxy_geometry", "aabb", "near_far", "camera_mlp", "vis_mlp", "basefield", "pos_embedding", "category"):
+        assert "self." + attr in nsrc, attr
+    geom = importlib.import_module("lab4d.utils.geom_utils")
+    assert list(inspect.signature(geom.marching_cubes).parameters)[:2] == ["sdf_func", "aabb"]
+    # the served-volume closures walk the grid in eval_func_chunk's order: one call per chunk, rows consecutive
+    import torch
+    vol = torch.arange(10.0).reshape(-1, 1)
+    pos = [0]
+
+    def f(xyz):
+        out = vol[pos[0]:pos[0] + xyz.shape[0]]
+        pos[0] += xyz.shape[0]
+        return out
+    assert torch.equal(geom.eval_func_chunk(f, torch.zeros(10, 3), chunk_size=4), vol)
