@@ -5,18 +5,24 @@
 
     bound(key) = max(1e-4, 2 x tests/golden/parity_measured.json[tag][key])          (1e-4 = north_star's fp32 tolerance)
 
-i.e. a quantity the MI355X reproduced to better than 5e-5 is held to 1e-4, anything else to twice what was measured -- and every bound
-above 1e-4 must be explained by the reference's own fp32 noise floor (tests/golden/fp32_noise_floor.json, produced by
-tests/measure_fp32_noise_floor.py: the oracle in float32 against the oracle in float64): the measured deviation may not exceed
-`FLOOR_FACTOR` x the floor of the same quantity on the same fixture.  LAB4D_PARITY_RECORD=1 turns the assertions off and collects the
-measurements in gpurun_out/parity_measured.json (the file that is then committed as tests/golden/parity_measured.json)."""
+i.e. a quantity the MI355X reproduced to better than 5e-5 is held to 1e-4, anything else to twice what was measured -- and every measurement
+above 1e-4 must be explained by the reference's own fp32 noise floor OF THE SAME QUANTITY ON THE SAME FIXTURE, IN THE SAME METRIC
+(tests/golden/fp32_noise_floor.json, produced by tests/measure_fp32_noise_floor.py: the oracle in float32 against the oracle in float64; gradient
+tensors on the same stored subsample the tests compare): measured <= floor_factor x floor, with floor_factor = 2 for the fixtures at BASELINE
+sizes (configs[0..3]: measured worst 1.5) and 8 for the 12..20-ray fixtures, whose `gradmax` entries are a max-statistic over <= 1,024 numbers
+(measured worst 6.1, train_multi10).  Round 4 removed the pooled family floor the small fixtures used to be allowed: the excesses it covered (up to
+240x a tensor's own floor) were an artefact of the instrument -- the stored gradient subsample walked through 4 input columns only -- and the
+"one ReLU flip" story told for them was tested and is false (tests/test_gpu_field.py: 0 flipped units of 221,184 on every small fixture).
+LAB4D_PARITY_RECORD=1 turns the assertions off and collects the measurements in gpurun_out/parity_measured.json (the file that is then
+committed as tests/golden/parity_measured.json)."""
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 NORTH_STAR_TOL = 1e-4
-FLOOR_FACTOR = 4.0
+FLOOR_FACTOR = 8.0        # 12..20-ray fixtures
+FLOOR_FACTOR_FULL = 2.0   # fixtures at BASELINE sizes
 RECORD = os.environ.get("LAB4D_PARITY_RECORD", "0") == "1"
 
 
@@ -40,12 +46,10 @@ def bound_of(tag, key):
     return max(NORTH_STAR_TOL, 2.0 * rec.get(key, 0.0))
 
 
-def check(tag, measured, floor_case=None, skip=(), floor_pool=()):
+def check(tag, measured, floor_case=None, skip=(), floor_factor=FLOOR_FACTOR):
     """Assert measured[key] < bound_of(tag, key) for every key (see the module docstring); floor_case names the fixture's entry of
-    fp32_noise_floor.json that must explain bounds above 1e-4 (None: no such requirement, e.g. for bf16 runs).  Keys in `skip` are
-    reported but not asserted (values that are not errors, e.g. a PSNR).  floor_pool: further fixtures of the same shape class whose floors
-    count for the family-level explanation (a 12-ray fixture realises zero or one ReLU flip between float32 and float64 by chance; the
-    pool of all tiny fixtures shows what one flip costs)."""
+    fp32_noise_floor.json that must explain measurements above 1e-4 (None: no such requirement -- bf16 runs, per-frame input gradients, which
+    have no floor entry).  Keys in `skip` are reported but not asserted (values that are not errors, e.g. a PSNR)."""
     report(tag, measured)
     if RECORD:
         path = os.path.join(ROOT, "gpurun_out", "parity_measured.json")
@@ -53,9 +57,7 @@ def check(tag, measured, floor_case=None, skip=(), floor_pool=()):
         allm[tag] = {k: float("%.3e" % v) for k, v in measured.items() if k not in skip}
         json.dump(allm, open(path, "w"), indent=1, sort_keys=True)
         return
-    floors = _load("fp32_noise_floor.json")
-    floor = floors.get(floor_case, {}) if floor_case else None
-    pooled = [floors.get(c, {}) for c in floor_pool] + ([floor] if floor else [])
+    floor = _load("fp32_noise_floor.json").get(floor_case, {}) if floor_case else None
     bad, unexplained = {}, {}
     for k, e in measured.items():
         if k in skip:
@@ -63,13 +65,7 @@ def check(tag, measured, floor_case=None, skip=(), floor_pool=()):
         b = bound_of(tag, k)
         if not e < b:
             bad[k] = (e, b)
-        if floor is not None and e > NORTH_STAR_TOL:
-            # the floor of the same quantity -- or, for the discrete events of a tiny fixture (one ReLU unit / arg-max bone / sampling bin out
-            # of a few hundred that lands on the other side in the two precisions moves a gradient by 1e-3 .. 1e-2, and WHICH tensor it
-            # shows up in differs between two fp32 implementations), the largest floor among the fixture's entries of the same family
-            fam = k.split(".")[0]
-            fam_floor = max([v for fl in pooled for kk, v in fl.items() if kk.split(".")[0] == fam] or [0.0])
-            if not (e <= FLOOR_FACTOR * floor.get(k, 0.0) or e <= fam_floor):
-                unexplained[k] = (e, floor.get(k), fam_floor)
+        if floor is not None and e > NORTH_STAR_TOL and not e <= floor_factor * floor.get(k, 0.0):
+            unexplained[k] = (e, floor.get(k))
     assert not bad, "above max(1e-4, 2 x the committed hardware measurement): %s" % bad
-    assert not unexplained, "above 1e-4 and not within %.0fx of the reference's own fp32 noise floor: %s" % (FLOOR_FACTOR, unexplained)
+    assert not unexplained, "above 1e-4 and not within %.0fx of the same quantity's fp32 noise floor on this fixture: %s" % (floor_factor, unexplained)
