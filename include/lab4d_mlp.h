@@ -131,6 +131,37 @@ typedef struct {
 } lab4d_mlp_fwd_args;
 int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream);
 
+/* Fused backward of the NARROW networks (every layer <= 64 wide: LAB4D_NET_VIS, LAB4D_NET_SKIN_A, LAB4D_NET_SKIN18_A; bf16): autograd's dgrad
+ * chain + one weight gradient per nn.Linear of VisField / SkinningField.delta_field (nnutils/visibility.py:39-63, skinning.py:70-124) in ONE
+ * launch that needs NOTHING stored by the forward pass: it recomputes the forward of each 64-sample tile in registers (same arithmetic as
+ * lab4d_mlp_forward), runs the dgrad chain, and accumulates every layer's dW = dZ X^T in registers across the tiles of a wave (operands
+ * transposed through LDS, MFMA contraction over samples).  The forward of these nets therefore runs in inference mode (emb = act = mask =
+ * NULL) also during training.  lab4d_mlp_fused_backward_supported(net, precision, spf) tells whether this entry applies (else: the stored-
+ * activation path lab4d_mlp_backward + lab4d_mlp_wgrad).
+ *   x (S,3) points; freq_w / aff / W / bias / pf_bias: exactly what the forward call took (W: forward operands of the hidden layers, WT:
+ *   transposed operands of every layer); d_out (S, c_out) fp32.
+ *   d_x (S,3) written, or NULL.  g_aff (M, 64, 4) accumulated (emb_kind 2 nets), or NULL.
+ *   dW[l] (mout_pad, 64) fp32 in KERNEL column order (as lab4d_mlp_wgrad), db[l] (mout_pad), pf_db[l] (M, mout_pad) for the pf_bias layers
+ *   (their db[l] is not written): all ACCUMULATED with atomics -- zero-fill first.  spf must be a multiple of 64 (a tile lies in one frame). */
+typedef struct {
+  int net, precision, S, spf;
+  const float* x;
+  const float* freq_w;
+  const float* aff;
+  const void* W[LAB4D_MLP_MAX_LAYERS];
+  const void* WT[LAB4D_MLP_MAX_LAYERS];
+  const float* bias[LAB4D_MLP_MAX_LAYERS];
+  const float* pf_bias[LAB4D_MLP_MAX_LAYERS];
+  const float* d_out;
+  float* d_x;
+  float* g_aff;
+  float* dW[LAB4D_MLP_MAX_LAYERS];
+  float* db[LAB4D_MLP_MAX_LAYERS];
+  float* pf_db[LAB4D_MLP_MAX_LAYERS];
+} lab4d_mlp_bwd_fused_args;
+int lab4d_mlp_backward_fused(const lab4d_mlp_bwd_fused_args* a, void* stream);
+int lab4d_mlp_fused_backward_supported(int net, int precision, int spf);
+
 /* Tangent-mode forward of LAB4D_NET_FG_BASE for the eikonal term (nnutils/nerf.py:416-453, utils/torch_utils.py:4-27).
  * The SDF network is piecewise linear in its embedding e(x), so with v = d sdf / d e (the dgrad chain with d_out = 1),
  *   g = d sdf / d x = J_e(x)^T v        and        d L(g) / d theta = d/d theta [ u^T v(theta) ],  u = J_e(x) dL/dg.

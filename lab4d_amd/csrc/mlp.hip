@@ -2,6 +2,7 @@
 // The chain kernels live in mlp_kernels.hpp / mlp_inst_*.hip.
 #include <cstdlib>
 #include "mlp_kernels.hpp"
+#include "mlp_fused_bwd.hpp"
 
 namespace lab4d {
 
@@ -690,6 +691,41 @@ extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
     }
     return launch_mlp_bwd<Net>(a->precision, k, a->S, (hipStream_t)stream);
   });
+}
+
+extern "C" int lab4d_mlp_fused_backward_supported(int net, int precision, int spf) {
+  if (precision != LAB4D_PREC_BF16 || spf <= 0 || spf % 64 != 0) return 0;
+  // measured per 16.7 M samples (profiles/r04_fused_narrow.json): delta-skin net 5.99 -> 4.65 ms per evaluation (forward + backward + weight gradients);
+  // visibility net 5.6 -> 5.9 ms (its posenc is evaluated three times per tile): the fused entry is built and tested for it, and off unless asked for
+  static const int vis_env = getenv("LAB4D_FUSED_VIS") ? atoi(getenv("LAB4D_FUSED_VIS")) : 0;
+  return net == LAB4D_NET_SKIN_A || net == LAB4D_NET_SKIN18_A || (net == LAB4D_NET_VIS && vis_env != 0);
+}
+
+extern "C" int lab4d_mlp_backward_fused(const lab4d_mlp_bwd_fused_args* a, void* stream) {
+  LAB4D_REQUIRE(a, "mlp_backward_fused: null args");
+  LAB4D_REQUIRE(lab4d_mlp_fused_backward_supported(a->net, a->precision, a->spf), "mlp_backward_fused: net %d / precision %d / spf %d not supported (bf16, narrow nets, spf %% 64 == 0)",
+                a->net, a->precision, a->spf);
+  LAB4D_REQUIRE(a->S >= 0 && a->x && a->d_out, "mlp_backward_fused: null x / d_out");
+  if (a->S == 0) return LAB4D_OK;
+  auto run = [&](auto n) {
+    using Net = decltype(n);
+    FusedK k;
+    memset(&k, 0, sizeof(k));
+    k.S = a->S; k.spf = a->spf; k.ntiles = (a->S + 63) / 64; k.x = a->x; k.freq_w = a->freq_w; k.aff = a->aff; k.d_out = a->d_out; k.d_x = a->d_x; k.g_aff = a->g_aff;
+    LAB4D_REQUIRE(Net::EMB != 2 || a->aff, "mlp_backward_fused: this network needs the per-frame affine table aff");
+    for (int l = 0; l < Net::NL; ++l) {
+      LAB4D_REQUIRE(a->WT[l] && a->dW[l], "mlp_backward_fused: layer %d transposed weights / dW missing", l);
+      LAB4D_REQUIRE(l + 1 == Net::NL || (a->W[l] && (Net::L[l].pf ? (const void*)a->pf_bias[l] : (const void*)a->bias[l])), "mlp_backward_fused: layer %d forward weights / bias missing", l);
+      LAB4D_REQUIRE((((uintptr_t)a->W[l] | (uintptr_t)a->WT[l]) & 15) == 0, "mlp_backward_fused: packed weights must be 16-byte aligned");
+      k.W[l] = a->W[l]; k.WT[l] = a->WT[l]; k.bias[l] = a->bias[l]; k.pf_bias[l] = a->pf_bias[l]; k.dW[l] = a->dW[l]; k.db[l] = a->db[l]; k.pf_db[l] = a->pf_db[l];
+    }
+    return launch_mlp_bwd_fused<Net>(k, (hipStream_t)stream);
+  };
+  switch (a->net) {
+    case LAB4D_NET_VIS: return run(NetVis{});
+    case LAB4D_NET_SKIN_A: return run(NetSkinA{});
+    default: return run(NetSkin18A{});
+  }
 }
 
 extern "C" int lab4d_mlp_wgrad(int net, int layer, int precision, int S, int S_pad, int ld, int spf, const void* dz, const void* emb,

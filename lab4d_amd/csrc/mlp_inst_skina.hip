@@ -1,3 +1,6 @@
 // Instantiation of the fused MLP chain kernels for NetSkinA (see mlp_kernels.hpp).
 #include "mlp_kernels.hpp"
 LAB4D_MLP_INSTANTIATE(NetSkinA)
+// ... and the fused backward (recompute + dgrad + in-register weight gradients) of this narrow net (mlp_fused_bwd.hpp)
+#include "mlp_fused_bwd.hpp"
+LAB4D_MLP_INSTANTIATE_FUSED_BWD(NetSkinA)

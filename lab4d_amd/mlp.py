@@ -48,7 +48,15 @@ class BwdArgs(ctypes.Structure):
                 ("d_x2", vp), ("x", vp), ("aff", vp), ("g_aff", vp)]
 
 
+class BwdFusedArgs(ctypes.Structure):  # lab4d_mlp_bwd_fused_args (include/lab4d_mlp.h)
+    _fields_ = [("net", ci), ("precision", ci), ("S", ci), ("spf", ci), ("x", vp), ("freq_w", vp), ("aff", vp), ("W", vp * MAXL), ("WT", vp * MAXL),
+                ("bias", vp * MAXL), ("pf_bias", vp * MAXL), ("d_out", vp), ("d_x", vp), ("g_aff", vp), ("dW", vp * MAXL), ("db", vp * MAXL),
+                ("pf_db", vp * MAXL)]
+
+
 _lib.register("lab4d_mlp_describe", [ci, ctypes.POINTER(NetDesc)])
+_lib.register("lab4d_mlp_backward_fused", [ctypes.POINTER(BwdFusedArgs), vp])
+_lib.register("lab4d_mlp_fused_backward_supported", [ci, ci, ci])
 _lib.register("lab4d_mlp_pack", [ci, ci, ci, ci, vp, ci, vp, vp, vp])
 _lib.register("lab4d_mlp_forward", [ctypes.POINTER(FwdArgs), vp])
 _lib.register("lab4d_mlp_backward", [ctypes.POINTER(BwdArgs), vp])
@@ -263,6 +271,9 @@ def col_map(net, layer, device):
 FUSED_GRAD_ACCUM = False
 
 
+FUSED_NARROW_BWD = os.environ.get("LAB4D_FUSED_NARROW", "1") != "0"  # 0: the stored-activation path for the narrow nets too (A/B measurements, parity tests of both)
+
+
 def _grad_sink(p):
     g = p.grad if FUSED_GRAD_ACCUM else None
     if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
@@ -377,6 +388,7 @@ class MlpChain(Function):
 
     @staticmethod
     def forward(ctx, net, prec, spf, x, ext, freq_w, export_layer, n_pf, x2, *rest, aff=None):
+        global _TAP
         # aff (never passed through apply(); warping.SkinChain calls this body directly): the raw-input nets form their inputs in
         # the kernel from the (S,3) points x and the per-frame affine rows aff (M, c_in, 4) -- lab4d_mlp_fwd_args.aff
         d = describe(net)
@@ -395,6 +407,11 @@ class MlpChain(Function):
         dev = x.device
         sdt = store_dtype(prec)
         need_grad = any(ctx.needs_input_grad)
+        # narrow nets (<= 64 wide, bf16): the backward recomputes the forward and forms the weight gradients in registers (lab4d_mlp_backward_fused), so
+        # the forward stores nothing -- it runs in inference mode also when gradients are wanted
+        fused = bool(need_grad and FUSED_NARROW_BWD and export_layer < 0 and ext is None and x2 is None and _TAP is None
+                     and _lib.lib().lab4d_mlp_fused_backward_supported(net, prec, int(spf)))
+        store = need_grad and not fused
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, ld, int(spf)
         a.x = _lib.dp(x)
@@ -418,6 +435,7 @@ class MlpChain(Function):
         masks = [None] * NL
         pf_i = 0
         pf_used = [None] * NL
+        pw_used, bias_used = [None] * NL, [None] * NL
         for l in range(NL):
             L = d.layers[l]
             pw = packed_weights(net, l, prec, Ws[l], False)
@@ -428,6 +446,7 @@ class MlpChain(Function):
             b = b.contiguous()
             a.bias[l] = _lib.dp(b)
             keep += [pw, b]
+            pw_used[l], bias_used[l] = pw, b
             if L.pf_bias:
                 pf = (pfs[pf_i].detach().float() + b[None]).contiguous()  # kernel contract: the per-frame table includes the bias
                 pf_i += 1
@@ -436,15 +455,15 @@ class MlpChain(Function):
                 a.pf_bias[l] = _lib.dp(pf)
                 pf_used[l] = pf
                 keep.append(pf)
-            if (need_grad and l + 1 < NL) or l == export_layer:
+            if (store and l + 1 < NL) or l == export_layer:
                 acts[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
                 a.act[l] = _lib.dp(acts[l])
-            if need_grad and L.relu and l + 1 < NL:
+            if store and L.relu and l + 1 < NL:
                 tile = 64 if prec == PREC_BF16 else 32
                 masks[l] = torch.empty((S_pad // tile) * (L.mout_pad // 32) * 64, dtype=torch.int32, device=dev)
                 a.mask[l] = _lib.dp(masks[l])
         emb = None
-        if need_grad:
+        if store:
             emb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
             a.emb = _lib.dp(emb)
         if ext is not None:
@@ -456,11 +475,12 @@ class MlpChain(Function):
         a.out = _lib.dp(out)
         # algorithmic HBM bytes of this launch: every stored tensor written once, inputs read once
         nbytes = sum(t.numel() * t.element_size() for t in acts + masks + [emb, ext, out, x] if t is not None)
-        with _lib.timed("k_mlp_fwd<%s>%s" % (KERNEL_NET[net], "" if need_grad else " inference"), (2.0 * S * NET_MACS[net], float(nbytes))):
+        with _lib.timed("k_mlp_fwd<%s>%s" % (KERNEL_NET[net], "" if store else " inference"), (2.0 * S * NET_MACS[net], float(nbytes))):
             _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
         ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
-        global _TAP
+        # what the fused backward reads again: the points, the annealing window, the affine table, packed weights / padded biases as the forward took them
+        ctx.fused = {"x": x, "freq_w": freq_w, "aff": aff, "W": pw_used, "bias": bias_used} if fused else None
         if _TAP is not None:  # run_chain(tap=...): the training-mode pass's ReLU sign words and stored embedding, for EikonalSdf (references, not copies)
             if need_grad:
                 _TAP.update(net=net, prec=prec, S=S, S_pad=S_pad, masks=list(masks), emb=emb)
@@ -486,6 +506,8 @@ class MlpChain(Function):
         Ws, bs = params[0::2], params[1::2]
         dev = d_out.device
         sdt = store_dtype(prec)
+        if getattr(ctx, "fused", None) is not None:
+            return MlpChain._backward_fused(ctx, d_out, d, Ws, bs)
         a = BwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, ld, spf
         keep = []
@@ -599,6 +621,86 @@ class MlpChain(Function):
         ctx.acts = ctx.masks = ctx.emb = ctx.ext = ctx.params = ctx.aff_in = None
         ctx.g_aff = g_aff  # read by the caller that passed aff (warping.SkinChainA)
         return (None, None, None, d_x, ext_g, None, None, None, d_x2, *grads_pf, *grads_params)
+
+    @staticmethod
+    def _backward_fused(ctx, d_out, d, Ws, bs):
+        """The narrow nets' backward in ONE launch (lab4d_mlp_backward_fused, csrc/mlp_fused_bwd.hpp): recompute + dgrad chain + every layer's weight /
+        bias gradient in registers.  Same return tuple as backward()."""
+        net, prec, spf, S, S_pad, ld, export_layer, n_pf, pf_used = ctx.meta
+        NL = d.n_layers
+        f = ctx.fused
+        dev = d_out.device
+        M = (S + spf - 1) // spf
+        a = BwdFusedArgs()
+        a.net, a.precision, a.S, a.spf = net, prec, S, spf
+        a.x = _lib.dp(f["x"])
+        if f["freq_w"] is not None:
+            a.freq_w = _lib.dp(f["freq_w"])
+        g_aff = None
+        if f["aff"] is not None:
+            a.aff = _lib.dp(f["aff"])
+            g_aff = torch.zeros_like(f["aff"])
+            a.g_aff = _lib.dp(g_aff)
+        d_out = d_out.contiguous().float()
+        a.d_out = _lib.dp(d_out)
+        d_x = None
+        if ctx.needs_input_grad[3] or g_aff is not None:
+            d_x = torch.empty(ctx.x_shape, device=dev)
+            a.d_x = _lib.dp(d_x)
+        # one zero-filled arena for every accumulated output: dW (mout_pad, 64) in kernel column order, db (mout_pad), pf_db (M, mout_pad)
+        sizes = [(L.mout_pad * (L.ke + L.kin), L.mout_pad, M * L.mout_pad if L.pf_bias else 0) for L in (d.layers[l] for l in range(NL))]
+        arena = torch.zeros(sum(sum(t) for t in sizes), device=dev)
+        keep, views, aoff = [], [], 0
+        for l in range(NL):
+            L = d.layers[l]
+            n0, n1, n2 = sizes[l]
+            dWk, dbk = arena[aoff:aoff + n0].view(L.mout_pad, L.ke + L.kin), arena[aoff + n0:aoff + n0 + n1]
+            pfd = arena[aoff + n0 + n1:aoff + n0 + n1 + n2].view(M, L.mout_pad) if L.pf_bias else None
+            aoff += n0 + n1 + n2
+            views.append((dWk, dbk, pfd))
+            pwt = packed_weights(net, l, prec, Ws[l], True)
+            keep.append(pwt)
+            a.WT[l], a.dW[l] = _lib.dp(pwt), _lib.dp(dWk)
+            if l + 1 < NL:
+                a.W[l] = _lib.dp(f["W"][l])
+            if L.pf_bias:
+                a.pf_bias[l], a.pf_db[l] = _lib.dp(pf_used[l]), _lib.dp(pfd)
+            else:
+                a.bias[l], a.db[l] = _lib.dp(f["bias"][l]), _lib.dp(dbk)
+        nbytes = 4.0 * S * (3 + d.c_out + (3 if d_x is not None else 0))
+        with _lib.timed("k_mlp_bwd_fused<%s>" % KERNEL_NET[net], (2.0 * S * NET_MACS[net] * 3, nbytes)):  # recompute + dgrad + wgrad
+            _lib.check(_lib.lib().lab4d_mlp_backward_fused(ctypes.byref(a), _lib.stream()), "mlp_backward_fused")
+        grads_pf, grads_params = [], []
+        pf_seen = 0
+        for l in range(NL):
+            L = d.layers[l]
+            dWk, dbk, pfd = views[l]
+            need_w = ctx.needs_input_grad[9 + n_pf + 2 * l]
+            need_b = ctx.needs_input_grad[9 + n_pf + 2 * l + 1]
+            gW = gb = None
+            if need_w:
+                kcols, rcols = col_index(net, l, dev)
+                sw = _grad_sink(Ws[l])
+                if sw is not None:  # FUSED_GRAD_ACCUM: straight into weight.grad (a view of the optimizer's flat buffer)
+                    sw.index_add_(1, rcols, dWk[:L.mout].index_select(1, kcols))
+                else:
+                    gW = torch.zeros_like(Ws[l], dtype=torch.float32)
+                    gW[:, rcols] = dWk[:L.mout][:, kcols]
+            if need_b:
+                gvec = (pfd.sum(0) if L.pf_bias else dbk)[:L.mout].reshape(bs[l].shape)
+                sb = _grad_sink(bs[l]) if need_w and _grad_sink(Ws[l]) is not None else None
+                if sb is not None:
+                    sb.add_(gvec)
+                else:
+                    gb = gvec
+            if L.pf_bias:
+                grads_pf.append(pfd if ctx.needs_input_grad[9 + pf_seen] else None)
+                pf_seen += 1
+            grads_params += [gW, gb]
+        ctx.fused = ctx.params = ctx.aff_in = None
+        ctx.g_aff = g_aff
+        return (None, None, None, d_x if ctx.needs_input_grad[3] or g_aff is not None else None, None, None, None, None, None, *grads_pf, *grads_params)
+
 
 
 _TAP = None
