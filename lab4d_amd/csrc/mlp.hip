@@ -655,7 +655,8 @@ extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
       LAB4D_REQUIRE(!Net::L[l].add_ext || a->ext, "mlp_forward: layer %d needs ext", l);
       // training mode (emb given): the kernel stores every hidden activation and ReLU mask unconditionally
       if (a->emb && l + 1 < Net::NL) {
-        LAB4D_REQUIRE(a->act[l], "mlp_forward: training mode (emb != NULL) needs act[%d]", l);
+        // ... or none of them (point-gradient-only mode: masks + embedding, lab4d_mlp.h)
+        LAB4D_REQUIRE(a->act[l] || (dx_only_ok<Net>() && !a->act[0] && !Net::L[l].ext_grad), "mlp_forward: training mode (emb != NULL) needs act[%d]", l);
         LAB4D_REQUIRE(!Net::L[l].relu || a->mask[l], "mlp_forward: training mode (emb != NULL) needs mask[%d]", l);
       }
       k.W[l] = a->W[l]; k.bias[l] = a->bias[l]; k.pf_bias[l] = a->pf_bias[l]; k.act[l] = a->act[l]; k.mask[l] = (unsigned int*)a->mask[l];
@@ -685,7 +686,7 @@ extern "C" int lab4d_mlp_backward(const lab4d_mlp_bwd_args* a, void* stream) {
       LAB4D_REQUIRE(a->WT[l], "mlp_backward: layer %d transposed weights missing", l);
       LAB4D_REQUIRE(!(Net::L[l].relu && l + 1 < Net::NL) || a->mask[l], "mlp_backward: layer %d ReLU mask missing", l);
       LAB4D_REQUIRE(!Net::L[l].ext_grad || a->ext_gin, "mlp_backward: layer %d needs ext_gin", l);
-      LAB4D_REQUIRE(a->dz[l], "mlp_backward: dz[%d] missing (every layer's dZ is written)", l);
+      LAB4D_REQUIRE(a->dz[l] || (dx_only_ok<Net>() && !a->dz[0] && a->d_x), "mlp_backward: dz[%d] missing (every layer's dZ is written, or none: point gradient only)", l);
       LAB4D_REQUIRE(!Net::L[l].add_ext || a->ext_gout, "mlp_backward: layer %d needs ext_gout", l);
       k.WT[l] = a->WT[l]; k.act[l] = a->act[l]; k.mask[l] = (const unsigned int*)a->mask[l]; k.dz[l] = a->dz[l];
     }

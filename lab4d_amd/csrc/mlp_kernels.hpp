@@ -807,7 +807,9 @@ __device__ __forceinline__ void stage_out(const float* __restrict__ stage, float
 // (all pointers non-NULL, checked by the host).  It is a template parameter, not a runtime test, because a store inside
 // a runtime branch makes the compiler's s_waitcnt vmcnt(N) bookkeeping assume the store-free path: the wait for the
 // prefetched A groups of the next tile then also waits for this tile's activation stores (a full HBM round trip per tile).
-template <class Net, class P, bool TAN = false, bool ST = false>
+// ACTS = false (with ST): only the embedding and the ReLU sign words are stored -- all a backward that wants nothing but d/dx needs (the eval path's
+// normals, nerf.py:455-493: 38 GB of activations per 8.4 M samples neither written nor allocated)
+template <class Net, class P, bool TAN = false, bool ST = false, bool ACTS = true>
 __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
   constexpr int NT = P::NT, TILE = P::TILE, KE = Net::KE, UE = KE / P::FPG, UW = Slab<Net, P>::UW;
   constexpr int ACG = acache_g<Net, P>();
@@ -1224,7 +1226,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
         }
         if constexpr (ST) {
 #ifndef LAB4D_ABL_NOSTORE
-          if constexpr (!LAST) store_tile<P>(actl, 32 * MT, s0, mt, lane, acc);
+          if constexpr (!LAST && ACTS) store_tile<P>(actl, 32 * MT, s0, mt, lane, acc);
 #endif
         } else if constexpr (fwd_any_export<Net>(R)) {
           if (actl) store_tile<P>(actl, 32 * MT, s0, mt, lane, acc);  // inference: only the layer another net consumes
@@ -1272,10 +1274,10 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
 #endif
 #ifndef LAB4D_ABL_NOSTORE
 #ifndef LAB4D_TRSTORE
-            store_tile_packed(actl, 32 * MT, s0, mt, lane, w);
+            if constexpr (ACTS) store_tile_packed(actl, 32 * MT, s0, mt, lane, w);
 #else
             tr_wait(trt);
-            tr_store(actl, 32 * MT, s0, mt, lane, trt);
+            if constexpr (ACTS) tr_store(actl, 32 * MT, s0, mt, lane, trt);
 #endif
 #endif
           } else if constexpr (fwd_any_export<Net>(R)) {
@@ -1414,7 +1416,8 @@ constexpr int emb_layer_count() {
 
 // AU (EMB == 2 nets only): every tile lies in one frame (spf % TILE == 0, the training shapes) -- the frame's table rows are staged in LDS and the
 // table gradient is reduced in registers; false: rows read per sample, element-wise atomics (tiny shapes whose tiles straddle frames)
-template <class Net, class P, bool AU = true>
+// DZ = false: no dZ is stored (nobody takes a weight gradient: the eval path's normals differentiate wrt the points only)
+template <class Net, class P, bool AU = true, bool DZ = true>
 __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(BwdK a) {
   static_assert(Net::EMB == 0 || emb_layer_count<Net>() == 1, "raw-input nets may use the input in one layer only");
   constexpr int NT = P::NT, TILE = P::TILE, NL = Net::NL, UW = Slab<Net, P>::UW;
@@ -1514,7 +1517,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
           g[t][r] = (f < Net::COUT && sidx[t] < a.S) ? a.d_out[(size_t)sidx[t] * Net::COUT + f] : 0.f;
         }
       }
-      store_tile<P>((GLOBAL_AS void*)a.dz[NL - 1], pad32(Net::L[NL - 1].mout), s0, 0, lane, g);  // every dz[l] is required (host-checked): no stores in runtime branches
+      if constexpr (DZ) store_tile<P>((GLOBAL_AS void*)a.dz[NL - 1], pad32(Net::L[NL - 1].mout), s0, 0, lane, g);  // every dz[l] is required (host-checked): no stores in runtime branches
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         uint4 u[P::UPT];
@@ -1934,7 +1937,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               acc[t][r] = __uint_as_float(__float_as_uint(acc[t][r]) & (unsigned int)__builtin_amdgcn_sbfe((int)keep, 16 * t + r, 1));
-          store_tile<P>(dzp, pad32(lp.mout), s0, j, lane, acc);
+          if constexpr (DZ) store_tile<P>(dzp, pad32(lp.mout), s0, j, lane, acc);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             uint4 u[P::UPT];
@@ -1948,7 +1951,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
         if constexpr (P::BF16) {
 #if !defined(LAB4D_ABL_NOSTORE) && !defined(LAB4D_TRSPREAD)
 #ifndef LAB4D_TRSTORE
-          store_tile_packed(dzp, pad32(lp.mout), s0, j, lane, w);
+          if constexpr (DZ) store_tile_packed(dzp, pad32(lp.mout), s0, j, lane, w);
 #else
           tr_wait(trt);
           tr_store(dzp, pad32(lp.mout), s0, j, lane, trt);
@@ -2002,7 +2005,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P, true>())) k_mlp_bwd(Bwd
         }
       }
       if constexpr (DO_ACT) pipeline(std::integral_constant<int, MTA>{}, MTE, pre_act, epi_act, flush_act, pre_mask, sp_act, sp_all_act,
-                                     std::integral_constant<int, bwd_step_stores<P>()>{});
+                                     std::integral_constant<int, (DZ ? bwd_step_stores<P>() : 0)>{});
     });
 
     if constexpr (Net::EMB != 1) {
@@ -2078,6 +2081,10 @@ inline bool bwd_h_enabled() {
   return on != 0;
 }
 
+// the point-gradient-only modes (forward: masks + embedding only; backward: no dZ) are instantiated for the sdf basefields: the eval path's normals
+template <class Net>
+constexpr bool dx_only_ok() { return Net::ID == LAB4D_NET_FG_BASE || Net::ID == LAB4D_NET_BG_BASE; }
+
 #define LAB4D_MLP_INSTANTIATE(Net)                                                                                        \
   namespace lab4d {                                                                                                       \
   template <>                                                                                                             \
@@ -2085,11 +2092,15 @@ inline bool bwd_h_enabled() {
     FwdK k = k0;                                                                                                          \
     if (precision == LAB4D_PREC_BF16) {                                                                                   \
       k.ntiles = k.S_pad / PBF16::TILE; /* padded tail tiles are processed too: they zero-fill dz */                                                                                  \
-      if (k.emb) LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PBF16, false, true>), k, st);  \
+      if (k.emb && !k.act[0]) {                                                                                           \
+        if constexpr (dx_only_ok<Net>()) LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PBF16, false, true, false>), k, st);            \
+      } else if (k.emb) LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PBF16, false, true>), k, st);  \
       else LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PBF16, false, false>), k, st);       \
     } else if (precision == LAB4D_PREC_F32) {                                                                             \
       k.ntiles = k.S_pad / PF32::TILE;                                                                                   \
-      if (k.emb) LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PF32, false, true>), k, st);   \
+      if (k.emb && !k.act[0]) {                                                                                           \
+        if constexpr (dx_only_ok<Net>()) LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PF32, false, true, false>), k, st);             \
+      } else if (k.emb) LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PF32, false, true>), k, st);   \
       else LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PF32, false, false>), k, st);        \
     } else {                                                                                                              \
       set_error("mlp_forward: bad precision %d", precision);                                                              \
@@ -2111,12 +2122,16 @@ inline bool bwd_h_enabled() {
       if constexpr (Net::EMB == 2) {                                                                                      \
         if (k.spf % PBF16::TILE) LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16, false>), k, st);                                 \
         else LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16, true>), k, st);                                                      \
+      } else if (!k.dz[0]) {                                                                                              \
+        if constexpr (dx_only_ok<Net>()) LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16, true, false>), k, st);                   \
       } else LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PBF16>), k, st);                         \
     } else if (precision == LAB4D_PREC_F32) {                                                                             \
       k.ntiles = k.S_pad / PF32::TILE;                                                                                   \
       if constexpr (Net::EMB == 2) {                                                                                      \
         if (k.spf % PF32::TILE) LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PF32, false>), k, st);                                   \
         else LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PF32, true>), k, st);                                                       \
+      } else if (!k.dz[0]) {                                                                                              \
+        if constexpr (dx_only_ok<Net>()) LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PF32, true, false>), k, st);                    \
       } else LAB4D_MLP_LAUNCH((k_mlp_bwd<Net, PF32>), k, st);                          \
     } else {                                                                                                              \
       set_error("mlp_backward: bad precision %d", precision);                                                             \

@@ -412,6 +412,10 @@ class MlpChain(Function):
         fused = bool(need_grad and FUSED_NARROW_BWD and export_layer < 0 and ext is None and x2 is None and _TAP is None
                      and _lib.lib().lab4d_mlp_fused_backward_supported(net, prec, int(spf)))
         store = need_grad and not fused
+        # nothing but d/dx wanted (the eval path's normals, nerf.py:455-493): the sdf basefields then store their ReLU sign words and embedding only, and
+        # their backward writes no dZ (38 GB per 8.4 M samples each that nobody would read)
+        dx_only = bool(store and net in (NET_FG_BASE, NET_BG_BASE) and export_layer < 0 and ext is None and _TAP is None
+                       and not any(ctx.needs_input_grad[i] for i in range(len(ctx.needs_input_grad)) if i != 3))
         a = FwdArgs()
         a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = net, prec, S, S_pad, ld, int(spf)
         a.x = _lib.dp(x)
@@ -455,7 +459,7 @@ class MlpChain(Function):
                 a.pf_bias[l] = _lib.dp(pf)
                 pf_used[l] = pf
                 keep.append(pf)
-            if (store and l + 1 < NL) or l == export_layer:
+            if (store and not dx_only and l + 1 < NL) or l == export_layer:
                 acts[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
                 a.act[l] = _lib.dp(acts[l])
             if store and L.relu and l + 1 < NL:
@@ -479,6 +483,7 @@ class MlpChain(Function):
             _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
         ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
+        ctx.dx_only = dx_only
         # what the fused backward reads again: the points, the annealing window, the affine table, packed weights / padded biases as the forward took them
         ctx.fused = {"x": x, "freq_w": freq_w, "aff": aff, "W": pw_used, "bias": bias_used} if fused else None
         if _TAP is not None:  # run_chain(tap=...): the training-mode pass's ReLU sign words and stored embedding, for EikonalSdf (references, not copies)
@@ -521,8 +526,9 @@ class MlpChain(Function):
                 a.act[l] = _lib.dp(ctx.acts[l])
             if ctx.masks[l] is not None:
                 a.mask[l] = _lib.dp(ctx.masks[l])
-            dz[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
-            a.dz[l] = _lib.dp(dz[l])
+            if not getattr(ctx, "dx_only", False):
+                dz[l] = torch.empty(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
+                a.dz[l] = _lib.dp(dz[l])
             if L.ext_grad:
                 if d_export is None:
                     d_export = torch.zeros(buf_numel(L.mout_pad, S_pad), dtype=sdt, device=dev)
