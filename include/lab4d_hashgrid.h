@@ -14,8 +14,14 @@
 
 int lab4d_hashgrid_forward(const float* x, const float* table, const int32_t* res, int S, int L, int log2_T, int F, float* out,
                            void* stream);
+/* The same for a field that lives on the box only (Mueller et al. 2022, section 5.4 / appendix E; lab4d_amd/hashfield.py): a point with a
+ * coordinate outside [0,1] gets the ZERO encoding without touching the table (the caller masks that sample's outputs, so its row is never
+ * looked at) instead of being clamped onto the boundary cells. */
+int lab4d_hashgrid_forward_inside(const float* x, const float* table, const int32_t* res, int S, int L, int log2_T, int F, float* out,
+                                  void* stream);
 /* g_out (S, L*F) -> g_table (L, 2^log2_T, F) ACCUMULATED with fp32 atomics (zero-fill first; may be NULL) and g_x (S,3) written
- * (may be NULL; the trilinear weights' derivative, piecewise constant in x). */
+ * (may be NULL; the trilinear weights' derivative, piecewise constant in x).  A level whose gradient entries are zero for all 64 samples of a
+ * wave is skipped (no vertex arithmetic, no atomics): the masked samples of a box-only field cost their 128-byte gradient row and nothing else. */
 int lab4d_hashgrid_backward(const float* x, const float* table, const int32_t* res, const float* g_out, int S, int L, int log2_T, int F,
                             float* g_table, float* g_x, void* stream);
 

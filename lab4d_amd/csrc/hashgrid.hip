@@ -10,11 +10,16 @@
 namespace lab4d {
 using namespace lab4d_hash;
 
+template <bool INSIDE_ONLY>
 __global__ void __launch_bounds__(256) k_hashgrid_fwd(const float* __restrict__ x, const float* __restrict__ table, const int* __restrict__ res, int S,
                                                       int L, int log2_T, int F, float* __restrict__ out) {
   const size_t slab = ((size_t)1 << log2_T) * F;
   for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (long)gridDim.x * blockDim.x) {
     const float p[3] = {x[3 * s], x[3 * s + 1], x[3 * s + 2]};
+    if (INSIDE_ONLY && !(p[0] >= 0.f && p[0] <= 1.f && p[1] >= 0.f && p[1] <= 1.f && p[2] >= 0.f && p[2] <= 1.f)) {  // (NaN: outside)
+      for (int k = 0; k < L * F; ++k) out[(size_t)s * L * F + k] = 0.f;
+      continue;
+    }
     for (int l = 0; l < L; ++l) {
       float f[MAXF];
       encode_level(p, table + l * slab, res[l], log2_T, F, f);
@@ -38,7 +43,12 @@ __global__ void __launch_bounds__(256) k_hashgrid_bwd(const float* __restrict__ 
     float gx[3] = {0.f, 0.f, 0.f};
     for (int l = 0; l < L; ++l) {
       float g[MAXF];
-      for (int k = 0; k < F; ++k) g[k] = live ? g_out[(size_t)s * L * F + l * F + k] : 0.f;
+      bool nz = false;
+      for (int k = 0; k < F; ++k) {
+        g[k] = live ? g_out[(size_t)s * L * F + l * F + k] : 0.f;
+        nz = nz || g[k] != 0.f;
+      }
+      if (!__any(nz)) continue;  // wave-uniform: nothing to add for these 64 samples at this level (masked samples of a box-only field)
       encode_level_bwd<true>(p, table + l * slab, res[l], log2_T, F, g, g_table ? g_table + l * slab : nullptr, g_x ? gx : nullptr, lane);
     }
     if (g_x && live) { g_x[3 * s] = gx[0]; g_x[3 * s + 1] = gx[1]; g_x[3 * s + 2] = gx[2]; }
@@ -61,8 +71,18 @@ extern "C" int lab4d_hashgrid_forward(const float* x, const float* table, const 
   LAB4D_REQUIRE(out, "hashgrid_forward: null output");
   long g = (S + 255L) / 256;
   if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(k_hashgrid_fwd, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, table, res, S, L, log2_T, F, out);
+  hipLaunchKernelGGL(k_hashgrid_fwd<false>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, table, res, S, L, log2_T, F, out);
   return check_launch("hashgrid_forward");
+}
+
+extern "C" int lab4d_hashgrid_forward_inside(const float* x, const float* table, const int32_t* res, int S, int L, int log2_T, int F, float* out,
+                                             void* stream) {
+  HASH_CHECKS("hashgrid_forward_inside");
+  LAB4D_REQUIRE(out, "hashgrid_forward_inside: null output");
+  long g = (S + 255L) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_hashgrid_fwd<true>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, table, res, S, L, log2_T, F, out);
+  return check_launch("hashgrid_forward_inside");
 }
 
 extern "C" int lab4d_hashgrid_backward(const float* x, const float* table, const int32_t* res, const float* g_out, int S, int L, int log2_T, int F,

@@ -4,7 +4,7 @@ The reference has NO such field (lab4d/nnutils/nerf.py:98 is a TODO),
 parity against the reference is UNPINNED by nature; the definition follows Mueller et al. 2022 (sections 3 and 5.4) and is checked
 against the independent restatement in oracle/hashgrid_oracle.py.  It is shaped like `NeRF.forward(xyz, dir, ..., get_density)`
 (nnutils/nerf.py:167-215) so that it can stand where the positional-encoding field stands:
-    x in aabb -> [0,1]^3 -> hash_encode (L levels x F features)        csrc/hashgrid.hip
+    x in aabb -> [0,1]^3 -> hash_encode (L levels x F features)        csrc/hashgrid.hip        (x outside the box: density = colour = 0)
       -> geometry net  L*F -> 64 -> 16: sdf = out[0], 15 geometry features     LAB4D_NET_HASH_GEO   (the fused chain kernels)
       -> density = VolSDF(sdf)                                                   csrc/flow.hip (as for the posenc field)
       -> colour net  [16 | view direction] -> 64 -> 64 -> 3, sigmoid            LAB4D_NET_HASH_COLOR
@@ -50,8 +50,13 @@ def forward(P, cfg, xyz, dirs, spf, prec=mlp.PREC_F32, res=None, get_density=Tru
     x01 = (xyz - lo) / (hi - lo)
     if res is None:
         res = resolutions(cfg, xyz.device)
-    enc = hashgrid.hash_encode(x01, P["hash.table"], res, cfg["log2_T"])          # (S, 32)
+    enc = hashgrid.hash_encode(x01, P["hash.table"], res, cfg["log2_T"], inside_only=True)  # (S, 32); zero rows outside the box (masked below)
     geo = mlp.run_chain(mlp.NET_HASH_GEO, prec, P, enc, spf)                       # (S, 16)
     sdf = geo[:, :1]
     rgb = torch.sigmoid(mlp.run_chain(mlp.NET_HASH_COLOR, prec, P, torch.cat([geo, dirs], -1), spf))
-    return rgb, (volsdf_density(sdf, P["logibeta"]) if get_density else sdf)
+    # The grid is defined on the box (Mueller et al. 2022, section 5.4 / appendix E: rays are marched inside the scene's bounding box only): a sample
+    # outside it has no density and no colour.  Its gradient towards the encoding is then exactly zero, and the table-gradient kernel issues no
+    # atomic for a zero update (hashgrid_math.hpp: wave_run_add) -- in rounds 1-3 the 89 % of the bench's samples that lie outside the box were
+    # clamped onto its boundary cells and their atomics were 68 % of that configuration's step.
+    inside = ((x01 >= 0) & (x01 <= 1)).all(-1, keepdim=True).to(rgb.dtype)
+    return rgb * inside, ((volsdf_density(sdf, P["logibeta"]) * inside) if get_density else sdf)

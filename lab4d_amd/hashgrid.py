@@ -13,6 +13,7 @@ from . import _lib
 
 vp, ci = _lib.vp, _lib.ci
 _lib.register("lab4d_hashgrid_forward", [vp, vp, vp, ci, ci, ci, ci, vp, vp])
+_lib.register("lab4d_hashgrid_forward_inside", [vp, vp, vp, ci, ci, ci, ci, vp, vp])
 _lib.register("lab4d_hashgrid_backward", [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp])
 
 
@@ -24,7 +25,7 @@ def level_resolutions(L, n_min, n_max):
 
 class _HashEncode(Function):
     @staticmethod
-    def forward(ctx, x, table, res, log2_T):
+    def forward(ctx, x, table, res, log2_T, inside_only=False):
         x, table = x.contiguous().float(), table.contiguous().float()
         _lib.require_device(x, table, res)
         S, (L, T, F) = x.shape[0], table.shape
@@ -33,8 +34,8 @@ class _HashEncode(Function):
         out = torch.empty(S, L * F, device=x.device)
         # algorithmic bytes: 8 vertices x F floats gathered per level, the point read, L*F floats written
         with _lib.timed("k_hashgrid_fwd", (0.0, 4.0 * S * (8 * L * F + 3 + L * F))):
-            _lib.check(_lib.lib().lab4d_hashgrid_forward(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), S, L, log2_T, F, _lib.ptr(out), _lib.stream()),
-                       "hashgrid_forward")
+            fn = _lib.lib().lab4d_hashgrid_forward_inside if inside_only else _lib.lib().lab4d_hashgrid_forward
+            _lib.check(fn(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), S, L, log2_T, F, _lib.ptr(out), _lib.stream()), "hashgrid_forward")
         ctx.save_for_backward(x, table, res)
         ctx.log2_T = log2_T
         return out
@@ -48,14 +49,15 @@ class _HashEncode(Function):
         g_table = torch.zeros_like(table) if ctx.needs_input_grad[1] else None
         g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         if g_table is None and g_x is None:
-            return None, None, None, None
+            return None, None, None, None, None
         with _lib.timed("k_hashgrid_bwd", (0.0, 4.0 * S * (2 * 8 * L * F + 6 + L * F))):  # vertices read (d/dx) and atomically added to
             _lib.check(_lib.lib().lab4d_hashgrid_backward(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), _lib.ptr(g), S, L, ctx.log2_T, F, _lib.ptr(g_table),
                                                           _lib.ptr(g_x), _lib.stream()), "hashgrid_backward")
-        return g_x, g_table, None, None
+        return g_x, g_table, None, None, None
 
 
-def hash_encode(x, table, res, log2_T):
-    """x (..., 3) in [0,1]^3, table (L, 2^log2_T, F), res: int32 device tensor (L) from level_resolutions -> (..., L*F)."""
-    out = _HashEncode.apply(x.reshape(-1, 3), table, res, log2_T)
+def hash_encode(x, table, res, log2_T, inside_only=False):
+    """x (..., 3) in [0,1]^3, table (L, 2^log2_T, F), res: int32 device tensor (L) from level_resolutions -> (..., L*F).
+    inside_only: points outside [0,1]^3 get the zero encoding and never touch the table (a field defined on the box masks them anyway)."""
+    out = _HashEncode.apply(x.reshape(-1, 3), table, res, log2_T, inside_only)
     return out.view(x.shape[:-1] + (out.shape[-1],))

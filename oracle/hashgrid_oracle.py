@@ -10,6 +10,9 @@ kernel-side header (different code structure: gather over all 8 corners at once,
   vertices of the cell containing x * N_l; 1:1 indexing while (N_l + 1)^3 <= T, else
   h(v) = (v_x * 1  xor  v_y * 2654435761  xor  v_z * 805459861) mod T                     (eq. 4)
   tri-linear interpolation of the F-vectors, levels concatenated.
+The FIELD on it (hash_field_forward) follows the paper's NeRF application (section 5.4 and appendix E: the hash grid is defined on the scene's
+axis-aligned bounding box, mapped to [0,1]^3, and rays are marched INSIDE that box only): a sample outside the box carries no density and no
+colour, and therefore no gradient to the table (round 4; rounds 1-3 clamped outside samples onto the boundary cells and evaluated them).
 """
 import math
 
@@ -61,8 +64,9 @@ def hash_field_forward(P, cfg, xyz, dirs, get_density=True):
     c = F.relu(F.linear(c, P["hash.color.0.weight"], P["hash.color.0.bias"]))
     c = F.relu(F.linear(c, P["hash.color.2.weight"], P["hash.color.2.bias"]))
     rgb = torch.sigmoid(F.linear(c, P["hash.color.4.weight"], P["hash.color.4.bias"]))
+    inside = ((x01 >= 0) & (x01 <= 1)).all(-1, keepdim=True).to(rgb.dtype)  # Mueller et al. 2022, section 5.4 / appendix E: the grid lives on the box
     if not get_density:
-        return rgb, sdf
+        return rgb * inside, sdf
     ibeta = P["logibeta"].exp()
     density = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta  # nerf.py:203-205
-    return rgb, density
+    return rgb * inside, density * inside

@@ -58,7 +58,7 @@ def test_hash_field_matches_the_oracle(prec_name, tol, gtol):
     P["hash.table"] = P["hash.table"] * 3e3  # features of order 0.3 so that the nets see a signal
     g = torch.Generator().manual_seed(5)
     S = 1000
-    xyz = (torch.rand(S, 3, generator=g) * 2 - 1) * 0.11
+    xyz = (torch.rand(S, 3, generator=g) * 2 - 1) * 0.15  # the box is +-0.12: about half of the points lie outside it (no density, no colour, no gradient)
     dirs = torch.nn.functional.normalize(torch.randn(S, 3, generator=g), dim=-1)
     names = [k for k in P if k != "aabb"]
     cw = [torch.randn(S, 3, generator=g), torch.randn(S, 1, generator=g)]
