@@ -866,7 +866,7 @@ def rank_main(a):
         peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32
         # dominant kernel = the kernel symbol with the largest event-measured time; the next three are reported beside it ("rooflines")
         pmc = {}
-        for name_ in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # newest PMC summary of the dominant kernels
+        for name_ in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # newest PMC summary of the dominant kernels
             pmc_path = os.path.join(ROOT, "profiles", name_)
             if os.path.exists(pmc_path):
                 pmc = json.load(open(pmc_path))

@@ -1,9 +1,9 @@
 #!/bin/bash
-# SQ wait / issue breakdown of the chain kernels (separate --pmc passes, kernel-trace only).  -> gpurun_out/r03_sq_counters.txt
+# SQ wait / issue breakdown of the chain kernels (separate --pmc passes, kernel-trace only).  -> gpurun_out/${SQ_OUT:-r04_sq_counters.txt}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 CMD=${1:-"python $R/tools/bench_chain.py 2097152 base"}
-timeout -k 5 60 rocprofv3 -L > $R/gpurun_out/r03_counter_list.txt 2>&1  # every counter this box offers (names for the next round)
+timeout -k 5 60 rocprofv3 -L > $R/gpurun_out/r04_counter_list.txt 2>&1  # every counter this box offers (names for the next round)
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" \
@@ -12,7 +12,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   timeout -k 5 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/sq2_$i -- $CMD > /tmp/sq2_$i.log 2>&1 || tail -3 /tmp/sq2_$i.log
 done
-python - > $R/gpurun_out/r03_sq_counters.txt <<'PY'
+python - > $R/gpurun_out/${SQ_OUT:-r04_sq_counters.txt} <<'PY'
 import csv, glob, re
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
@@ -29,4 +29,4 @@ for k in sorted(acc):
     for n in sorted(c):
         print("   %-28s %.4g %s" % (n, c[n], ("(%.1f%% of wave cycles)" % (100 * c[n] / wc)) if wc and n.startswith(('SQ_WAIT', 'SQ_ACTIVE')) else ""))
 PY
-cat $R/gpurun_out/r03_sq_counters.txt
+cat $R/gpurun_out/${SQ_OUT:-r04_sq_counters.txt}

@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 CMD=${PMC_CMD:-"python $R/tools/bench_mlp.py 16777216 1"}   # PMC_CMD / PMC_OUT / PMC_WHAT: another micro-bench, e.g. the delta-skin chains (tools/bench_chain.py 16777216 skin)
-OUT=${PMC_OUT:-r03_pmc_traffic.json}
+OUT=${PMC_OUT:-r04_pmc_traffic.json}
 timeout -k 5 100 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch -- $CMD > /tmp/pmc_fetch.log 2>&1 || { echo "fetch pass failed"; tail -5 /tmp/pmc_fetch.log; exit 1; }
 timeout -k 5 100 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write -- $CMD > /tmp/pmc_write.log 2>&1 || { echo "write pass failed"; tail -5 /tmp/pmc_write.log; exit 1; }
 mkdir -p $R/gpurun_out
