@@ -2071,7 +2071,32 @@ inline int mlp_grid(int ntiles) {
 
 }  // namespace lab4d
 #include "mlp_kernels_h.hpp"
+#include "mlp_kernels_ws.hpp"
 namespace lab4d {
+// the weights-stationary family (mlp_kernels_ws.hpp) serves the training-mode and inference-mode forward and the training-mode backward of the
+// 256-wide posenc nets; returns false when the launch is not its business (other nets, fp32, the point-gradient-only modes, LAB4D_WS=0)
+template <class Net>
+inline bool launch_ws_bwd(const BwdK& k0, hipStream_t st) {
+  if constexpr (ws_ok<Net>()) {
+    if (!ws_enabled() || !k0.dz[0]) return false;
+    hipLaunchKernelGGL((k_mlp_bwd_ws<Net, true>), dim3(mlp_grid_ws(k0.S_pad / WS_TILE)), dim3(512), 0, st, k0);
+    return true;
+  } else {
+    return false;
+  }
+}
+template <class Net>
+inline bool launch_ws_fwd(const FwdK& k0, hipStream_t st) {
+  if constexpr (ws_ok<Net>()) {
+    if (!ws_enabled() || (k0.emb && !k0.act[0])) return false;
+    FwdK k = k0;
+    if (k.emb) hipLaunchKernelGGL((k_mlp_fwd_ws<Net, true>), dim3(mlp_grid_ws(k.S_pad / WS_TILE)), dim3(512), 0, st, k);
+    else hipLaunchKernelGGL((k_mlp_fwd_ws<Net, false>), dim3(mlp_grid_ws(k.S_pad / WS_TILE)), dim3(512), 0, st, k);
+    return true;
+  } else {
+    return false;
+  }
+}
 // LAB4D_BWD_H=1 routes the 256-wide posenc nets to the 8-wave / 32-sample backward chain (mlp_kernels_h.hpp): parity-green but
 // measured SLOWER than the 4-wave kernel (9.12 vs 7.93 ms per 4.2 M samples), so it is off by default
 template <class Net>
@@ -2091,6 +2116,7 @@ constexpr bool dx_only_ok() { return Net::ID == LAB4D_NET_FG_BASE || Net::ID == 
   int launch_mlp_fwd<Net>(int precision, const FwdK& k0, int S, hipStream_t st) {                                         \
     FwdK k = k0;                                                                                                          \
     if (precision == LAB4D_PREC_BF16) {                                                                                   \
+      if (launch_ws_fwd<Net>(k, st)) return check_launch("mlp_forward");                                                  \
       k.ntiles = k.S_pad / PBF16::TILE; /* padded tail tiles are processed too: they zero-fill dz */                                                                                  \
       if (k.emb && !k.act[0]) {                                                                                           \
         if constexpr (dx_only_ok<Net>()) LAB4D_MLP_LAUNCH((k_mlp_fwd<Net, PBF16, false, true, false>), k, st);            \
@@ -2112,6 +2138,7 @@ constexpr bool dx_only_ok() { return Net::ID == LAB4D_NET_FG_BASE || Net::ID == 
   int launch_mlp_bwd<Net>(int precision, const BwdK& k0, int S, hipStream_t st) {                                         \
     BwdK k = k0;                                                                                                          \
     if (precision == LAB4D_PREC_BF16) {                                                                                   \
+      if (launch_ws_bwd<Net>(k, st)) return check_launch("mlp_backward");                                                 \
       k.ntiles = k.S_pad / PBF16::TILE; /* padded tail tiles are processed too: they zero-fill dz */                                                                                  \
       if constexpr (use_bwd_h<Net>()) {                                                                                   \
         if (bwd_h_enabled()) {                                                                                            \

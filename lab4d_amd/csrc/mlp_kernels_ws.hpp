@@ -1,0 +1,766 @@
+// Weights-stationary chain kernels for the 256-wide posenc nets (bf16): forward chain k_mlp_fwd_ws, backward (dgrad) chain k_mlp_bwd_ws.
+//
+// The wave-resident kernels (mlp_kernels.hpp) give every wave 64 samples and stream each layer's 128 KiB of weights to every wave
+// (L2 -> VGPR -> LDS -> VGPR, a workgroup barrier per 32-row step, one wave per SIMD at ~490 registers): 0.26 of the bf16 MFMA peak for four
+// rounds, and round 4 measured that neither the schedule, nor the stores, nor an LDS-DMA weight stream is what bounds them.
+// Here the dataflow is turned round (probe: tools/probes/ws_core.hip, 0.43-0.50 of the peak with stores and weight fetch):
+//   * a 512-thread workgroup (8 waves, two per SIMD, <= 256 registers) owns 128 samples = two 64-sample blocks = four 32-sample n-tiles;
+//   * wave w keeps ROW TILE w of the layer's weights (32 output features x K) in registers -- the same packed 1-KiB A groups the
+//     wave-resident kernels read, fetched ONCE per layer and workgroup straight into VGPRs (no LDS staging, no per-step barrier);
+//   * the layer input of all 128 samples lives in LDS as B units ([n-tile][unit][lane] x 16 B, the accumulator-layout units of
+//     mlp_kernels.hpp) and is streamed through the MFMAs: one ds_read_b128 per v_mfma_f32_32x32x16_bf16;
+//   * the wave converts / activates its 32 x 64 output slice and writes it as units (2w, 2w+1) of the OTHER half of a double-buffered
+//     2 x 64 KiB activation slab: ONE workgroup barrier per layer (10 per 128 samples instead of 76 per 64);
+//   * the next layer's A groups replace the current ones right behind their last MFMA (the fetch hides behind the last block's matrix work);
+//   * tiles leave for HBM through ds_read_b64_tr_b16 (tr_issue / tr_store of mlp_kernels.hpp: no VALU transposes), and they leave LATE: a
+//     layer's tile / mask stores are issued inside the NEXT layer, behind that layer's bias / mask / ext requests, so no load ever queues
+//     behind a store in the in-order vector-memory counter.
+// Everything that reaches HBM has the layout and the VALUES of the wave-resident kernels (same packed weights, same accumulation order per
+// output element: bias, then the k-groups in ascending order; same packed epilogue), so the two families are interchangeable launch by launch
+// and are held bit-equal to each other in tests/test_gpu_mlp_ws.py.  bf16, EMB == 0 (posenc) nets whose widest layer is 256.
+#pragma once
+#include "mlp_kernels.hpp"
+
+namespace lab4d {
+
+template <class Net>
+constexpr bool ws_ok() {
+  if (!(Net::EMB == 0 && Net::AUX3 == 0 && net_wmax<Net>() == 256 && Net::KE % 32 == 0)) return false;
+  for (int l = 0; l < Net::NL; ++l) {
+    const int mt = pad32(Net::L[l].mout) / 32;
+    if (!(mt == 1 || mt == 2 || mt == 4 || mt == 8)) return false;
+    if (Net::L[l].kin % 32 != 0 || Net::L[l].kin > 256) return false;
+    if (Net::L[l].ke != 0 && Net::L[l].ke != Net::KE) return false;
+  }
+  return true;
+}
+template <class Net>
+constexpr int ws_g(int l) { return (Net::L[l].ke + Net::L[l].kin) / 16; }
+template <class Net>
+constexpr int ws_mt(int l) { return pad32(Net::L[l].mout) / 32; }
+template <class Net>
+constexpr int ws_gmax() {
+  int g = 0;
+  for (int l = 0; l < Net::NL; ++l) g = ws_g<Net>(l) > g ? ws_g<Net>(l) : g;
+  return g;
+}
+// layers that share one copy of the layer code (runtime loop over the layers, see fwd_same): same shape, same number of A groups in the layer
+// that FOLLOWS (its prefetch is unrolled into this layer's last MFMA loop), same shape of the layer in FRONT (whose stores this layer issues)
+template <class Net>
+constexpr bool wsf_same(int a, int b) {
+  if (!fwd_same<Net>(a, b)) return false;
+  const int an = (a + 1) % Net::NL, bn = (b + 1) % Net::NL;
+  if (ws_g<Net>(an) != ws_g<Net>(bn)) return false;
+  if ((a == 0) != (b == 0)) return false;
+  if (a > 0 && ws_mt<Net>(a - 1) != ws_mt<Net>(b - 1)) return false;
+  return true;
+}
+template <class Net>
+constexpr int wsf_rep(int l) {
+  for (int j = 0; j < l; ++j)
+    if (wsf_same<Net>(j, l)) return j;
+  return l;
+}
+template <class Net>
+constexpr unsigned wsf_members(int r) {
+  unsigned m = 0;
+  for (int l = 0; l < Net::NL; ++l)
+    if (wsf_rep<Net>(l) == r) m |= 1u << l;
+  return m;
+}
+// row tiles of layer l as a runtime value (the layer loop is a runtime loop; l is wave-uniform)
+template <class Net>
+__device__ __forceinline__ int ws_mt_rt(int l) {
+  int v = 1;
+  sfor<0, Net::NL>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if (l == i) v = ws_mt<Net>(i);
+  });
+  return v;
+}
+
+constexpr int WS_TILE = 128;       // samples per workgroup tile
+#ifndef LAB4D_WS_BD
+#define LAB4D_WS_BD 4
+#endif
+constexpr int WS_BD = LAB4D_WS_BD;  // depth (k-groups) of the B-operand ring between LDS and the MFMAs
+constexpr int WS_BUF = 4 * 16 * 64;  // uint4 slots of one activation buffer: [n-tile 4][unit 16][lane 64] = 64 KiB
+
+// this wave's work items of a layer with MT row tiles: an item = (row tile mt, 64-sample block b).  2 MT items over 8 waves:
+// MT = 8: two items per wave (mt = w, b = 0, 1); MT = 4: one (mt = w & 3, b = w >> 2); fewer: waves >= 2 MT idle
+template <int MT>
+struct WsItems {
+  static constexpr int ITEMS = 2 * MT, IPW = ITEMS >= 8 ? ITEMS / 8 : 1;
+  __device__ __forceinline__ static bool active(int w) { return ITEMS >= 8 || w < ITEMS; }
+  __device__ __forceinline__ static int mt(int w) { return w & (MT - 1); }
+  __device__ __forceinline__ static int blk(int w, int k) { return MT >= 8 ? k : ((w / MT) & 1); }
+};
+
+// B-operand reads of the MFMA loops: volatile asm, so that they stay where they are written (ahead of their use by the depth of the ring)
+template <int OFF>
+__device__ __forceinline__ void ws_lds_read(u32x4_t& d, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// all but the N most recent LDS operations of this wave have returned (LDS returns in order; the operands tie the wait to its consumers)
+template <int N>
+__device__ __forceinline__ void ws_lds_wait(u32x4_t& a, u32x4_t& b) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt field");
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+__device__ __forceinline__ void mma_b(f32x16_t& acc, const uint4& a, const u32x4_t& b) {
+  bf16x8_t av;
+  __builtin_memcpy(&av, &a, 16);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+
+// ---- LDS byte address of the uint4 array element (address space 3 pointers are 32 bit) ----
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
+
+// =================================================================================================
+// forward chain, weights stationary
+// =================================================================================================
+// ST = training mode: embedding, every hidden post-activation and every ReLU sign word are stored (pointers host-checked);
+// !ST = inference: only a layer another net consumes (act[l] != NULL) is stored.
+template <class Net, bool ST>
+__global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
+  static_assert(ws_ok<Net>(), "weights-stationary chain: 256-wide posenc nets only");
+  using P = PBF16;
+  constexpr int NL = Net::NL, KE = Net::KE, UE = KE / 16, GMAX = ws_gmax<Net>(), L = Net::NFREQ;
+  constexpr int ESTR = KE + 4;  // fp32 row stride of the posenc scratch (conflict-free 16-byte row reads for KE = 64 and 96)
+  static_assert(WS_TILE * ESTR * 4 <= WS_BUF * 16, "posenc scratch aliases one activation buffer");
+  __shared__ uint4 xbuf[2 * WS_BUF];
+  __shared__ uint4 ebuf[4 * UE * 64];  // embedding as B units: [n-tile][unit][lane]
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned xbuf_lds = lds_addr(xbuf), ebuf_lds = lds_addr(ebuf);
+  const unsigned trl = tr_lane_base(0u, 16, lane);  // per-lane part of the transposing tile reads (unit stride 16 per n-tile)
+
+  int S_eff = a.S, ntw = a.S_pad / WS_TILE;
+  if (a.S_dev) {
+    const int sd = *(const GLOBAL_AS int*)a.S_dev;
+    S_eff = sd < a.S ? sd : a.S;
+    const int nt = (S_eff + WS_TILE - 1) / WS_TILE;
+    ntw = nt < ntw ? nt : ntw;
+  }
+
+  uint4 A[GMAX];  // this wave's row tile of the current layer's weights
+  auto a_load = [&](auto g0c, auto g1c, const GLOBAL_AS void* Wp, int G, int mt) {
+    constexpr int G0 = decltype(g0c)::value, G1 = decltype(g1c)::value;
+#pragma unroll
+    for (int g = G0; g < G1; ++g) A[g] = load_a(Wp, G, mt, g, lane);
+  };
+  if ((int)blockIdx.x < ntw) {
+    constexpr int G0 = ws_g<Net>(0), MT0 = ws_mt<Net>(0);
+    a_load(std::integral_constant<int, 0>{}, std::integral_constant<int, G0>{}, KARG_PTR(FwdK, const void*, W, 0), G0, w & (MT0 - 1));
+  }
+  unsigned int pbits[2] = {0u, 0u};  // ReLU sign words of the layer just finished, waiting for their (deferred) store
+  TrTile trt;
+
+  for (int tile = blockIdx.x; tile < ntw; tile += gridDim.x) {
+    const int s0 = tile * WS_TILE;
+    // frame of this lane's sample in (block b, n-tile t): sample s0 + 64 b + 2 n + t
+    int frame[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int s = s0 + 64 * b + 2 * n + t;
+        const int sc = s < S_eff ? s : S_eff - 1;  // padded tail recomputes the last sample (finite, never written out)
+        frame[b][t] = a.frame_idx ? ((const GLOBAL_AS int*)a.frame_idx)[sc] : sc / a.spf;
+      }
+
+    // ---- positional encoding, once per sample and axis: thread (sample sl, axis q) -> fp32 scratch rows (aliasing activation buffer 1) ----
+    // Same arithmetic as k_mlp_fwd's bf16 path: one accurate sincos per axis, angle doubling per octave, times the annealing weight.
+    float* scr = reinterpret_cast<float*>(xbuf + WS_BUF);
+    {
+      const int sl = tid & 127, q = __builtin_amdgcn_readfirstlane(tid >> 7);
+      const int row = 64 * (sl >> 6) + 32 * (sl & 1) + ((sl & 63) >> 1);  // rows ordered (block, n-tile, lane n)
+      const int s = s0 + sl, sc = s < S_eff ? s : S_eff - 1;
+      float* dst = scr + row * ESTR;
+      if (q < 3) {
+        const float xa = a.x[(size_t)sc * 3 + q];
+        float sn, cs;
+        sincosf(xa, &sn, &cs);
+#pragma unroll
+        for (int f = 0; f < L; ++f) {
+          const float wf = a.freq_w ? a.freq_w[f] : 1.0f;
+          *reinterpret_cast<float2*>(dst + 6 * f + 2 * q) = make_float2(sn * wf, cs * wf);
+          const float s2 = 2.f * sn * cs, c2 = 1.f - 2.f * sn * sn;
+          sn = s2; cs = c2;
+        }
+      } else {
+        dst[6 * L + 0] = a.x[(size_t)sc * 3 + 0];
+        dst[6 * L + 1] = a.x[(size_t)sc * 3 + 1];
+        dst[6 * L + 2] = a.x[(size_t)sc * 3 + 2];
+#pragma unroll
+        for (int c = 6 * L + 3; c < KE; ++c) dst[c] = 0.f;
+      }
+    }
+    wg_step_barrier();
+    // ---- scratch -> B units (identity slot order: unit g of lane (n, h) = slots 16 g + 8 h + 0..7) + the stored [slot][sample] embedding ----
+    for (int p = w; p < 2 * UE; p += 8) {
+      const int b = p & 1, g = p >> 1;
+      uint4 emb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float4* r = reinterpret_cast<const float4*>(scr + (64 * b + 32 * t + n) * ESTR + 16 * g + 8 * h);
+        const float4 v0 = r[0], v1 = r[1];
+        emb[t] = make_uint4(pack2bf(v0.x, v0.y), pack2bf(v0.z, v0.w), pack2bf(v1.x, v1.y), pack2bf(v1.z, v1.w));
+        ebuf[((2 * b + t) * UE + g) * 64 + lane] = emb[t];
+      }
+      if constexpr (ST) {
+        const int q = n & 3, kq = n >> 2;
+        GLOBAL_AS char* base = (GLOBAL_AS char*)a.emb + tile_base_offset<P>(KE, s0 + 64 * b, 0);
+        const unsigned int w0[4] = {emb[0].x, emb[0].y, emb[0].z, emb[0].w};
+        const unsigned int w1[4] = {emb[1].x, emb[1].y, emb[1].z, emb[1].w};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          unsigned int d[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * half + jj;
+            const unsigned int lo = (w0[j >> 1] >> (16 * (j & 1))) & 0xffffu, hi = (w1[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            d[jj] = lo | (hi << 16);
+          }
+          quad_transpose(d, q);
+          gst16(base + tile_lane_offset<P>(16 * g + 8 * h + 4 * half + q, kq), d[0], d[1], d[2], d[3]);
+        }
+      }
+    }
+    wg_step_barrier();
+
+    // ---- layers ----
+#pragma nounroll
+    for (int l = 0; l < NL; ++l)
+    sfor<0, NL>([&](auto ri) {
+      constexpr int R = decltype(ri)::value;
+      if constexpr (wsf_rep<Net>(R) != R) return;
+      constexpr unsigned MEMBERS = wsf_members<Net>(R);
+      if (!((MEMBERS >> l) & 1u)) return;
+      constexpr LS ls = Net::L[R];
+      constexpr bool LAST = (R == NL - 1);
+      constexpr int MT = ws_mt<Net>(R), GE = ls.ke / 16, GA = ls.kin / 16, G = GE + GA;
+      constexpr int Gn = ws_g<Net>((R + 1) % NL);  // A groups of the layer that follows (layer 0 of the next tile behind the last)
+      using IT = WsItems<MT>;
+      const GLOBAL_AS float* bl = KARG_PTR(FwdK, const float*, bias, l);
+      const GLOBAL_AS float* pfl = KARG_PTR(FwdK, const float*, pf_bias, l);
+      const int ln = l + 1 < NL ? l + 1 : 0;
+      const GLOBAL_AS void* Wn = KARG_PTR(FwdK, const void*, W, ln);
+      const int mtn = w & (ws_mt_rt<Net>(ln) - 1);
+      const int ib = l & 1;
+      const uint4* xin = xbuf + ib * WS_BUF;
+      uint4* xout = xbuf + (ib ^ 1) * WS_BUF;
+      const int mt = IT::mt(w);
+      const bool active = IT::active(w);
+
+      // bias (+ per-frame bias, which already contains the shared one: host contract) of item (mt, b) in accumulator layout
+      auto load_bias = [&](int b, f32x16_t (&bv)[2]) {
+#pragma unroll
+        for (int t = 0; t < (ls.pf != 0 ? 2 : 1); ++t) {
+          const int fr = frame[0][t] + b * (frame[1][t] - frame[0][t]);  // b is 0 / 1 (arithmetic, not an index: an indexed private array goes to LDS / scratch)
+          const GLOBAL_AS float* src = (ls.pf != 0) ? pfl + (size_t)fr * (32 * MT) : bl;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4_t v = *(const GLOBAL_AS f32x4_t*)(src + 32 * mt + 8 * i + 4 * h);
+            bv[t][4 * i + 0] = v.x; bv[t][4 * i + 1] = v.y; bv[t][4 * i + 2] = v.z; bv[t][4 * i + 3] = v.w;
+          }
+        }
+        if constexpr (ls.pf == 0) bv[1] = bv[0];
+      };
+      uint4 ext_raw[4];
+      auto load_ext = [&](int b) {
+        if constexpr (ls.add_ext != 0) load_tile_raw<P>((const GLOBAL_AS void*)a.ext, 32 * MT, s0 + 64 * b, mt, lane, ext_raw);
+      };
+
+      // ---- requests go out BEFORE the stores of the layer in front: the next layer's A groups this layer has no use for, the first item's bias / ext tile ----
+#pragma unroll
+      for (int g = G; g < Gn; ++g) A[g] = load_a(Wn, Gn, mtn, g, lane);
+      f32x16_t bv[2];
+      if (active) {
+        load_bias(IT::blk(w, 0), bv);
+        load_ext(IT::blk(w, 0));
+      }
+      // ---- deferred stores of the layer in front: its tiles sit in this layer's input buffer ----
+      if constexpr (R > 0) {
+        constexpr int MTp = ws_mt<Net>(R - 1);
+        using ITp = WsItems<MTp>;
+        GLOBAL_AS void* actp = KARG_PTR(FwdK, void*, act, l - 1);
+        GLOBAL_AS unsigned int* maskp = KARG_PTR(FwdK, unsigned int*, mask, l - 1);
+        const int mtp = ITp::mt(w);
+        auto flush_prev = [&]() {
+#pragma unroll
+          for (int k = 0; k < ITp::IPW; ++k) {
+            const int b = ITp::blk(w, k);
+            tr_issue(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + b * 2 * 16 * 1024 + mtp * 2048) + trl, trt);
+            tr_wait(trt);
+            tr_store(actp, 32 * MTp, s0 + 64 * b, mtp, lane, trt);
+            if constexpr (ST && Net::L[R - 1].relu != 0) maskp[((size_t)(2 * tile + b) * MTp + mtp) * 64 + lane] = pbits[k];
+          }
+        };
+        if constexpr (ST) {
+          if (ITp::active(w)) flush_prev();
+        } else {
+          if (actp != nullptr && ITp::active(w)) flush_prev();  // inference: only the layer another net consumes
+        }
+      }
+
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < IT::IPW; ++k) {
+          const int b = IT::blk(w, k);
+          constexpr int KL = IT::IPW - 1;
+          f32x16_t acc[2];
+          acc[0] = bv[0];
+          acc[1] = bv[1];
+          // B units stream from LDS through a ring of WS_BD k-groups (two n-tiles each): the read of group g + WS_BD is issued right behind the
+          // MFMAs of group g.  Reads and waits are volatile asm (program order kept, counted waits written by hand): left to the scheduler the
+          // reads sink next to their MFMAs (lgkmcnt(1) in front of every MFMA pair) and the LDS latency is exposed once per k-group.
+          constexpr int BD = G < WS_BD ? G : WS_BD;
+          u32x4_t bq[BD][2];
+          const unsigned pe_a = ebuf_lds + (unsigned)((2 * b * UE) * 1024 + lane * 16), px_a = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + (2 * b * 16) * 1024 + lane * 16);
+          auto b_read = [&](auto gc, u32x4_t (&dst)[2]) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < GE) {
+              ws_lds_read<g * 1024>(dst[0], pe_a);
+              ws_lds_read<(UE + g) * 1024>(dst[1], pe_a);
+            } else {
+              ws_lds_read<(g - GE) * 1024>(dst[0], px_a);
+              ws_lds_read<(16 + g - GE) * 1024>(dst[1], px_a);
+            }
+          };
+          sfor<0, BD>([&](auto gc) { b_read(gc, bq[decltype(gc)::value]); });
+          sfor<0, G>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int NEWER = 2 * ((G - 1 - g) < (BD - 1) ? (G - 1 - g) : (BD - 1));  // reads issued behind group g's
+            ws_lds_wait<NEWER>(bq[g % BD][0], bq[g % BD][1]);
+            mma_b(acc[0], A[g], bq[g % BD][0]);
+            mma_b(acc[1], A[g], bq[g % BD][1]);
+            if constexpr (g + BD < G) b_read(std::integral_constant<int, g + BD>{}, bq[g % BD]);
+            if (k == KL && g < Gn) A[g] = load_a(Wn, Gn, mtn, g, lane);  // the next layer's group g, right behind the last use of this one
+          });
+          // requests of the next item (they have that item's matrix work to arrive)
+          if (k < KL) {
+            if constexpr (ls.pf != 0) load_bias(IT::blk(w, k + 1), bv);
+          }
+          // ---- epilogue ----
+          if constexpr (!LAST && ls.add_ext == 0) {
+            // packed-bf16 epilogue (pk_* helpers of mlp_kernels.hpp)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc_fence(acc[t]);
+            unsigned int pw[2][8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int kk = 0; kk < 8; ++kk) pw[t][kk] = pack2bf_op(acc[t][2 * kk], acc[t][2 * kk + 1]);
+            if constexpr (ls.relu != 0) {
+              if constexpr (ST) pbits[k] = pk_alive_bits(pw);
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) pw[t][kk] = pk_relu_bf16(pw[t][kk]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                xout[((2 * b + t) * 16 + 2 * mt + q) * 64 + lane] = make_uint4(pw[t][4 * q], pw[t][4 * q + 1], pw[t][4 * q + 2], pw[t][4 * q + 3]);
+          } else if constexpr (!LAST) {
+            // layer with an external add (colour net: + basefield feature): fp32 ReLU, sign word by comparison, + ext, then the units
+            if constexpr (ls.relu != 0) {
+              if constexpr (ST) {
+                unsigned int bits = 0;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) bits |= (acc[t][r] > 0.f ? 1u : 0u) << mask_bit<P>(t, r);
+                pbits[k] = bits;
+              }
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = relu1(acc[t][r]);
+            }
+            {
+              f32x16_t e[2];
+              tile_from_raw<P>(ext_raw, lane, e);
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += e[t][r];
+            }
+            if (k < KL) load_ext(IT::blk(w, k + 1));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              uint4 u[2];
+              tile_to_units<P>(acc[t], u);
+#pragma unroll
+              for (int q = 0; q < 2; ++q) xout[((2 * b + t) * 16 + 2 * mt + q) * 64 + lane] = u[q];
+            }
+          } else {
+            // head: raw outputs (S, COUT) fp32
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int s = s0 + 64 * b + 2 * n + t;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int f = 32 * mt + drow(r, h);
+                if (f < Net::COUT && s < S_eff && a.out) a.out[(size_t)s * Net::COUT + f] = acc[t][r];
+              }
+            }
+          }
+        }
+      } else {
+        // a wave without an item in this layer still needs the next layer's weights
+        a_load(std::integral_constant<int, 0>{}, std::integral_constant<int, (Gn < G ? Gn : G)>{}, Wn, Gn, mtn);
+      }
+      wg_step_barrier();
+    });
+  }
+}
+
+// =================================================================================================
+// backward (dgrad) chain, weights stationary
+// =================================================================================================
+// Same dataflow with W^T: wave w keeps row tile (MTE + w) of W^T[l] (32 features of layer l-1's output x the K = mout_pad contraction) in
+// registers, dZ_l of all 128 samples streams from LDS, the masked dZ_{l-1} slice goes to the other buffer.  The embedding row tiles of W^T
+// (layers that consume the posenc: input gradient) are 2 MTE more items, taken by waves 0 .. 2 MTE - 1 in front of their activation items.
+template <class Net>
+constexpr int wsb_gk(int l) { return pad32(Net::L[l].mout) / 16; }
+template <class Net>
+constexpr bool wsb_same(int a, int b) {
+  if (!bwd_same<Net>(a, b)) return false;
+  if ((a == Net::NL - 1) != (b == Net::NL - 1)) return false;
+  const int an = a > 0 ? a - 1 : Net::NL - 1, bn = b > 0 ? b - 1 : Net::NL - 1;
+  return wsb_gk<Net>(an) == wsb_gk<Net>(bn);
+}
+template <class Net>
+constexpr int wsb_rep(int l) {
+  for (int j = Net::NL - 1; j > l; --j)
+    if (wsb_same<Net>(j, l)) return j;
+  return l;
+}
+template <class Net>
+constexpr unsigned wsb_members(int r) {
+  unsigned m = 0;
+  for (int l = 0; l < Net::NL; ++l)
+    if (wsb_rep<Net>(l) == r) m |= 1u << l;
+  return m;
+}
+// row tile of W^T[l] wave w starts layer l with: its embedding item's if it has one, else its activation item's
+template <class Net>
+__device__ __forceinline__ int wsb_first_tile(int l, int w, bool want_dx) {
+  int v = 0;
+  sfor<0, Net::NL>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int MTE = Net::L[i].ke / 32, MTA = Net::L[i].kin / 32;
+    if (l == i) {
+      if (MTE > 0 && want_dx && w < 2 * MTE) v = w % (MTE > 0 ? MTE : 1);
+      else v = (i > 0 && MTA > 0) ? MTE + (w & ((MTA > 0 ? MTA : 1) - 1)) : 0;  // (a layer without activation rows: any valid tile, the fetch is ignored)
+    }
+  });
+  return v;
+}
+// row tiles of the activation part of layer l (0: none), runtime
+template <class Net>
+__device__ __forceinline__ int wsb_mta_rt(int l) {
+  int v = 0;
+  sfor<0, Net::NL>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if (l == i) v = i > 0 ? Net::L[i].kin / 32 : 0;
+  });
+  return v;
+}
+
+template <class Net, bool DZ = true>
+__global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
+  static_assert(ws_ok<Net>(), "weights-stationary chain: 256-wide posenc nets only");
+  using P = PBF16;
+  constexpr int NL = Net::NL, KE = Net::KE, GMAX = 16;
+  constexpr int MTE_ANY = KE / 32;
+  __shared__ uint4 xbuf[2 * WS_BUF];
+  __shared__ float red[8 * 2 * 3 * 32];  // input-gradient partials of the embedding items: [wave][n-tile][axis][lane n]
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned xbuf_lds = lds_addr(xbuf);
+  const unsigned trl = tr_lane_base(0u, 16, lane);
+  const int ntw = a.S_pad / WS_TILE;
+  const bool want_dx = a.d_x != nullptr;
+
+  uint4 A[GMAX];
+  auto a_load = [&](auto g1c, const GLOBAL_AS void* Wp, int G, int rt) {
+    constexpr int G1 = decltype(g1c)::value;
+#pragma unroll
+    for (int g = 0; g < G1; ++g) A[g] = load_a(Wp, G, rt, g, lane);
+  };
+  if ((int)blockIdx.x < ntw) {
+    constexpr int GK0 = wsb_gk<Net>(NL - 1);
+    a_load(std::integral_constant<int, GK0>{}, KARG_PTR(BwdK, const void*, WT, NL - 1), GK0, wsb_first_tile<Net>(NL - 1, w, want_dx));
+  }
+  TrTile trt;
+  // ReLU sign words of this wave's activation items: requested one layer ahead (they come from HBM, written a whole chunk earlier)
+  auto mask_req = [&](int lq /* layer whose activation items want them: words of mask[lq - 1] */, int tile, unsigned int (&m)[2]) {
+    const int lm = lq >= 1 ? lq - 1 : 0;  // clamped: a layer without activation items requests (and ignores) valid words
+    const GLOBAL_AS unsigned int* mp = KARG_PTR(BwdK, const unsigned int*, mask, lm);
+    int mta = wsb_mta_rt<Net>(lq >= 1 ? lq : 1);
+    mta = mta > 0 ? mta : 8;
+    const int j = w & (mta - 1);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int b = mta >= 8 ? k : ((w / mta) & 1);
+      m[k] = mp[((size_t)(2 * tile + b) * mta + j) * 64 + lane];
+    }
+  };
+
+  for (int tile = blockIdx.x; tile < ntw; tile += gridDim.x) {
+    const int s0 = tile * WS_TILE;
+    float dx[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) dx[t][0] = dx[t][1] = dx[t][2] = 0.f;
+    unsigned int mcur[2], mnext[2];
+    mask_req(NL - 1, tile, mcur);
+
+    // ---- head gradient: (S, COUT) fp32 -> accumulator layout -> stored + B units of buffer 0 (waves 0, 1: one 64-sample block each) ----
+    if (w < 2) {
+      const int b = w;
+      f32x16_t g[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int s = s0 + 64 * b + 2 * n + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int f = drow(r, h);
+          g[t][r] = (f < Net::COUT && s < a.S) ? a.d_out[(size_t)s * Net::COUT + f] : 0.f;
+        }
+      }
+      if constexpr (DZ) store_tile<P>((GLOBAL_AS void*)a.dz[NL - 1], pad32(Net::L[NL - 1].mout), s0 + 64 * b, 0, lane, g);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        uint4 u[2];
+        tile_to_units<P>(g[t], u);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) xbuf[((2 * b + t) * 16 + q) * 64 + lane] = u[q];
+      }
+    }
+    wg_step_barrier();
+
+#pragma nounroll
+    for (int l = NL - 1; l >= 0; --l)
+    sfor<0, NL>([&](auto ri) {
+      constexpr int R = NL - 1 - decltype(ri)::value;
+      if constexpr (wsb_rep<Net>(R) != R) return;
+      constexpr unsigned MEMBERS = wsb_members<Net>(R);
+      if (!((MEMBERS >> l) & 1u)) return;
+      constexpr LS ls = Net::L[R];
+      constexpr LS lp = Net::L[R > 0 ? R - 1 : 0];
+      constexpr int GK = wsb_gk<Net>(R);
+      constexpr int MTE = ls.ke / 32, MTA = ls.kin / 32;
+      constexpr bool DO_ACT = (R > 0 && MTA > 0);
+      constexpr int GKn = wsb_gk<Net>(R > 0 ? R - 1 : NL - 1);  // K groups of the layer below (the top layer of the next tile below layer 0)
+      using IT = WsItems<(DO_ACT ? MTA : 1)>;
+      const int lm1 = l > 0 ? l - 1 : 0;
+      const int ln = l > 0 ? l - 1 : NL - 1;
+      const GLOBAL_AS void* Wt = KARG_PTR(BwdK, const void*, WT, l);
+      const GLOBAL_AS void* Wn = KARG_PTR(BwdK, const void*, WT, ln);
+      const int rtn = wsb_first_tile<Net>(ln, w, want_dx);
+      const int ib = (NL - 1 - l) & 1;
+      uint4* xout = xbuf + (ib ^ 1) * WS_BUF;
+      const bool act_on = DO_ACT && IT::active(w);
+      const bool emb_on = MTE > 0 && want_dx && w < 2 * MTE;
+      const int j = IT::mt(w);              // activation row tile of this wave
+      const int me = MTE > 0 ? w % (MTE > 0 ? MTE : 1) : 0, be = MTE > 0 ? (w / (MTE > 0 ? MTE : 1)) & 1 : 0;  // embedding item
+
+      // ---- requests first: the next layer's A groups this layer has no use for, its sign words, this layer's stored embedding / external gradient tile ----
+#pragma unroll
+      for (int g = GK; g < GKn; ++g) A[g] = load_a(Wn, GKn, rtn, g, lane);
+      mask_req(lm1, tile, mnext);
+      uint4 raw[4];
+      if constexpr (MTE > 0) {
+        if (emb_on) load_tile_raw<P>((const GLOBAL_AS void*)a.emb, KE, s0 + 64 * be, me, lane, raw);
+      }
+      if constexpr (DO_ACT && lp.ext_grad != 0) {
+        if (act_on && !emb_on) load_tile_raw<P>((const GLOBAL_AS void*)a.ext_gin, pad32(lp.mout), s0 + 64 * IT::blk(w, 0), j, lane, raw);
+      }
+      static_assert(!(MTE > 0 && DO_ACT && lp.ext_grad != 0), "one prefetched tile per layer");
+      // ---- deferred stores: dZ_l (this layer's input, written by the layer above) ----
+      if constexpr (DZ && R < NL - 1) {
+        constexpr int MTp = GK / 2;
+        using ITp = WsItems<MTp>;
+        GLOBAL_AS void* dzl = KARG_PTR(BwdK, void*, dz, l);
+        if (ITp::active(w)) {
+          const int jp = ITp::mt(w);
+#pragma unroll
+          for (int k = 0; k < ITp::IPW; ++k) {
+            const int b = ITp::blk(w, k);
+            tr_issue(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + b * 2 * 16 * 1024 + jp * 2048) + trl, trt);
+            tr_wait(trt);
+            tr_store(dzl, 32 * MTp, s0 + 64 * b, jp, lane, trt);
+          }
+        }
+      }
+
+      // one item: acc = W^T[row tile in A] dZ_l over block b; PF: the groups of (Wp, GP groups, row tile rt) replace A behind their last use
+      auto mfma_item = [&](int b, f32x16_t (&acc)[2], auto pf_c, auto gp_c, const GLOBAL_AS void* Wp, int rt) {
+        constexpr bool PF = decltype(pf_c)::value;
+        constexpr int GP = decltype(gp_c)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        constexpr int BD = GK < WS_BD ? GK : WS_BD;
+        u32x4_t bq[BD][2];
+        const unsigned px_a = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + (2 * b * 16) * 1024 + lane * 16);
+        auto b_read = [&](auto gc, u32x4_t (&dst)[2]) {
+          constexpr int g = decltype(gc)::value;
+          ws_lds_read<g * 1024>(dst[0], px_a);
+          ws_lds_read<(16 + g) * 1024>(dst[1], px_a);
+        };
+        sfor<0, BD>([&](auto gc) { b_read(gc, bq[decltype(gc)::value]); });
+        sfor<0, GK>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          constexpr int NEWER = 2 * ((GK - 1 - g) < (BD - 1) ? (GK - 1 - g) : (BD - 1));
+          ws_lds_wait<NEWER>(bq[g % BD][0], bq[g % BD][1]);
+          mma_b(acc[0], A[g], bq[g % BD][0]);
+          mma_b(acc[1], A[g], bq[g % BD][1]);
+          if constexpr (g + BD < GK) b_read(std::integral_constant<int, g + BD>{}, bq[g % BD]);
+          if constexpr (PF && g < GP) A[g] = load_a(Wp, GP, rt, g, lane);
+        });
+      };
+
+      bool loaded_next = false;
+      // ---- (a) embedding rows: gradient wrt the posenc slots -> input gradient ----
+      if constexpr (MTE > 0) {
+        if (emb_on) {
+          f32x16_t acc[2];
+          if constexpr (DO_ACT) mfma_item(be, acc, std::true_type{}, std::integral_constant<int, GK>{}, Wt, MTE + j);
+          else { mfma_item(be, acc, std::true_type{}, std::integral_constant<int, GKn>{}, Wn, rtn); loaded_next = true; }
+          f32x16_t e[2];
+          tile_from_raw<P>(raw, lane, e);
+          constexpr int L = Net::NFREQ;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int slot = 32 * me + drow(r, h);
+              const float gv = acc[t][r];
+              // me is a runtime value: the slot class is resolved per register by comparison (slot < 6 L etc. are cheap scalar-ish selects)
+              const int pair = slot >> 1, f = pair / 3, ax = pair - 3 * f;
+              const float partner = e[t][r ^ 1];
+              const float cs = ldexpf((r & 1) ? -partner : partner, f) * gv;   // d/dx [w sin(2^f x)] = 2^f (w cos) ; d/dx [w cos(2^f x)] = -2^f (w sin)
+              const bool is_sc = slot < 6 * L, is_raw = slot >= 6 * L && slot < 6 * L + 3;
+              const int axr = slot - 6 * L;
+              const float c = is_sc ? cs : (is_raw ? gv : 0.f);
+              const int axx = is_sc ? ax : axr;
+              dx[t][0] += axx == 0 ? c : 0.f;
+              dx[t][1] += axx == 1 ? c : 0.f;
+              dx[t][2] += axx == 2 ? c : 0.f;
+            }
+        }
+      }
+      // ---- (b) activation rows: masked dZ_{l-1} ----
+      if constexpr (DO_ACT) {
+        if (act_on) {
+#pragma unroll
+          for (int k = 0; k < IT::IPW; ++k) {
+            const int b = IT::blk(w, k);
+            constexpr int KL = IT::IPW - 1;
+            f32x16_t acc[2];
+            if (k == KL) mfma_item(b, acc, std::true_type{}, std::integral_constant<int, GKn>{}, Wn, rtn);
+            else mfma_item(b, acc, std::false_type{}, std::integral_constant<int, 0>{}, Wn, rtn);
+            if constexpr (lp.ext_grad != 0) {
+              f32x16_t eg[2];
+              tile_from_raw<P>(raw, lane, eg);
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += eg[t][r];
+              if (k < KL) load_tile_raw<P>((const GLOBAL_AS void*)a.ext_gin, pad32(lp.mout), s0 + 64 * IT::blk(w, k + 1), j, lane, raw);
+            }
+            if constexpr (lp.add_ext != 0) store_tile<P>((GLOBAL_AS void*)a.ext_gout, pad32(lp.mout), s0 + 64 * b, j, lane, acc);  // y = relu(z) + ext -> dL/dext = dL/dy
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc_fence(acc[t]);
+            unsigned int pw[2][8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int kk = 0; kk < 8; ++kk) pw[t][kk] = pack2bf_op(acc[t][2 * kk], acc[t][2 * kk + 1]);
+            {
+              unsigned int alive = lp.relu != 0 ? mcur[k] : 0xffffffffu;
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+                if (s0 + 64 * b + 2 * n + t >= a.S) alive &= ~(0x00ff00ffu << (8 * t));
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) pw[t][kk] = pk_mask_bf16(pw[t][kk], pk_m01(alive, t, kk));
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                xout[((2 * b + t) * 16 + 2 * j + q) * 64 + lane] = make_uint4(pw[t][4 * q], pw[t][4 * q + 1], pw[t][4 * q + 2], pw[t][4 * q + 3]);
+          }
+          loaded_next = true;
+        }
+      }
+      if (!loaded_next) a_load(std::integral_constant<int, (GKn < GK ? GKn : GK)>{}, Wn, GKn, rtn);  // a wave without an item here still needs its next weights
+      mcur[0] = mnext[0];
+      mcur[1] = mnext[1];
+      wg_step_barrier();
+    });
+
+    // ---- input gradient: partials of the embedding items -> one sum per sample ----
+    if (want_dx) {
+      if (w < 2 * MTE_ANY) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float v = dx[t][k] + __shfl_xor(dx[t][k], 32, 64);
+            if (h == 0) red[((w * 2 + t) * 3 + k) * 32 + n] = v;
+          }
+      }
+      wg_step_barrier();
+      if (w < 2 && h == 0) {  // wave b sums the MTE partials of block b
+        const int b = w;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int s = s0 + 64 * b + 2 * n + t;
+          float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+          for (int m = 0; m < MTE_ANY; ++m)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] += red[(((b * MTE_ANY + m) * 2 + t) * 3 + k) * 32 + n];
+          if (s < a.S) {
+            a.d_x[(size_t)s * 3 + 0] = v[0];
+            a.d_x[(size_t)s * 3 + 1] = v[1];
+            a.d_x[(size_t)s * 3 + 2] = v[2];
+          }
+        }
+      }
+    }
+  }
+}
+
+// 8-wave persistent grid: one workgroup per CU
+inline int mlp_grid_ws(int ntiles) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  static const int grid_env = getenv("LAB4D_CHAIN_GRID") ? atoi(getenv("LAB4D_CHAIN_GRID")) : 0;
+  int g = ntiles < n_cu ? ntiles : n_cu;
+  if (grid_env > 0 && g > grid_env) g = grid_env;
+  return g < 1 ? 1 : g;
+}
+
+// LAB4D_WS=0 routes the 256-wide nets back to the wave-resident kernels (read per launch: the tests run both families in one process)
+inline bool ws_enabled() {
+  const char* e = getenv("LAB4D_WS");
+  return e == nullptr || atoi(e) != 0;
+}
+
+}  // namespace lab4d
