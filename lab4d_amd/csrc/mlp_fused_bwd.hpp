@@ -234,8 +234,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp_bwd_fused(FusedK a) {
 #pragma unroll
         for (int f = 0; f < Net::NFREQ; ++f) {
           sv[f][ax] = sn; cv[f][ax] = cs;
-          const float s2 = 2.f * sn * cs, c2 = 1.f - 2.f * sn * sn;
-          sn = s2; cs = c2;
+          sincos_double(sn, cs);
         }
       }
     };

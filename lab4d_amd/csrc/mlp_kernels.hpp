@@ -59,6 +59,17 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
   return __builtin_bit_cast(unsigned int, v);
 }
 
+// One octave of the angle-doubling recurrence of the bf16 posenc (sin 2a = 2 s c, cos 2a = 1 - 2 s^2) with its roundings pinned: 2 s is exact, one
+// multiply, one fma.  Written as plain arithmetic the optimiser picks per call site between the fma and a packed multiply + add (v_pk_mul_f32 /
+// v_pk_add_f32 once the SLP vectoriser pairs the two lines), and two kernels evaluating the same samples disagreed in the last bit of 0.1 % of the
+// stored embedding (found round 4 when the weights-stationary kernels were held bit-equal to these).
+__device__ __forceinline__ void sincos_double(float& sn, float& cs) {
+  const float t = sn + sn;
+  const float s2 = t * cs, c2 = __builtin_fmaf(-t, sn, 1.f);
+  sn = s2;
+  cs = c2;
+}
+
 // max(x, 0) in ONE v_max_f32: fmaxf() first canonicalises its argument (a second v_max) to quiet signalling NaNs, which an
 // MFMA result never is
 __device__ __forceinline__ float relu1(float x) {
@@ -959,8 +970,7 @@ __global__ void __launch_bounds__(256, (want_occ<Net, P>())) k_mlp_fwd(FwdK a) {
 #pragma unroll
             for (int f = 0; f < Net::NFREQ; ++f) {
               sv[f][ax] = sn; cv[f][ax] = cs;
-              const float s2 = 2.f * sn * cs, c2 = 1.f - 2.f * sn * sn;
-              sn = s2; cs = c2;
+              sincos_double(sn, cs);
             }
           }
 #pragma unroll

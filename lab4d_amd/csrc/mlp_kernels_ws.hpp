@@ -114,6 +114,53 @@ __device__ __forceinline__ void mma_b(f32x16_t& acc, const uint4& a, const u32x4
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 
+// One quarter of a finished 32 x 64 tile on its way to HBM (rows 16 q + 8 a + .., qa = 2 q + a): two transposing LDS reads (see tr_issue) and, a few
+// k-groups later, one 16-byte store per lane.  Issued BETWEEN the MFMAs of the layer that follows: a CU writes 64 KiB per layer, which at the chip's
+// HBM write rate takes as long as the layer's matrix work -- issued as one burst at the top of the layer the stores block the wave's memory issue
+// and the matrix pipe idles meanwhile (measured: 6.4 ms per 4.2 M samples with the burst, 4.2 ms with the stores removed).
+template <int QA>
+__device__ __forceinline__ void ws_trp_issue(unsigned addr /* tile base + lane part */, TrPiece& r) {
+  constexpr int OFF = 1024 * (QA >> 1) + 8 * (QA & 1);
+#ifdef LAB4D_WSABL_NOTR  // timing experiment (results wrong): no transposing reads, the stores write whatever the registers hold
+  r.a = addr; r.b = addr + OFF;
+  return;
+#endif
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\t"
+               "ds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(r.a), "=&v"(r.b)
+               : "v"(addr), "n"(OFF), "n"(OFF + 32));
+}
+// N = LDS operations this wave has certainly issued behind the piece's reads (a lower bound keeps the wait safe)
+template <int QA, int N>
+__device__ __forceinline__ void ws_trp_store(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, TrPiece& r) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt field");
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r.a), "+v"(r.b) : "n"(N));
+#ifdef LAB4D_WSABL_NOST  // timing experiment (results wrong): reads and waits, no store
+  return;
+#endif
+#ifdef LAB4D_ABL_L2STORE  // timing experiment (results wrong): every wave keeps writing the same 2048-sample window, so the stores never reach HBM
+  s0 &= 0x7ff;
+#endif
+  const int i = lane & 15, G = lane >> 4, h = G & 1, S = G >> 1;
+  GLOBAL_AS char* base = (GLOBAL_AS char*)buf + tile_base_offset<PBF16>(F, s0, 32 * mt);
+  const unsigned lo = (unsigned)((4 * h + (i & 3)) * 128 + (32 * S + 8 * (i >> 2)) * 2);
+  gst16(base + (lo + (unsigned)((16 * (QA >> 1) + 8 * (QA & 1)) * 128)), (unsigned)r.a, (unsigned)(r.a >> 32), (unsigned)r.b, (unsigned)(r.b >> 32));
+}
+// Where the NPI pieces of one hosted tile set go in a loop of G k-groups with a B ring of depth BD: piece i is read at group (i G) / NPI and stored two
+// groups later (the last one at the latest at G - 1); two piece buffers alternate, so a store may share its group with the next read.
+template <int G, int NPI>
+struct WsSpread {
+  static constexpr bool OK = NPI > 0 && G >= 2 * NPI;
+  static constexpr int issue_at(int i) { return (i * G) / NPI; }
+  static constexpr int store_at(int i) { return issue_at(i) + 2 < G ? issue_at(i) + 2 : G - 1; }
+  // LDS operations certainly issued between piece i's reads and its store: the B reads (two per group) of groups issue_at .. store_at that still read ahead
+  static constexpr int newer(int i, int BD) {
+    int c = 0;
+    for (int j = issue_at(i); j <= store_at(i); ++j) c += (j + BD < G) ? 2 : 0;
+    return c;
+  }
+};
+
 // ---- LDS byte address of the uint4 array element (address space 3 pointers are 32 bit) ----
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
 
@@ -173,6 +220,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
     // ---- positional encoding, once per sample and axis: thread (sample sl, axis q) -> fp32 scratch rows (aliasing activation buffer 1) ----
     // Same arithmetic as k_mlp_fwd's bf16 path: one accurate sincos per axis, angle doubling per octave, times the annealing weight.
     float* scr = reinterpret_cast<float*>(xbuf + WS_BUF);
+#ifndef LAB4D_WSABL_NOPOSENC
     {
       const int sl = tid & 127, q = __builtin_amdgcn_readfirstlane(tid >> 7);
       const int row = 64 * (sl >> 6) + 32 * (sl & 1) + ((sl & 63) >> 1);  // rows ordered (block, n-tile, lane n)
@@ -186,8 +234,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
         for (int f = 0; f < L; ++f) {
           const float wf = a.freq_w ? a.freq_w[f] : 1.0f;
           *reinterpret_cast<float2*>(dst + 6 * f + 2 * q) = make_float2(sn * wf, cs * wf);
-          const float s2 = 2.f * sn * cs, c2 = 1.f - 2.f * sn * sn;
-          sn = s2; cs = c2;
+          sincos_double(sn, cs);
         }
       } else {
         dst[6 * L + 0] = a.x[(size_t)sc * 3 + 0];
@@ -197,6 +244,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
         for (int c = 6 * L + 3; c < KE; ++c) dst[c] = 0.f;
       }
     }
+#endif
     wg_step_barrier();
     // ---- scratch -> B units (identity slot order: unit g of lane (n, h) = slots 16 g + 8 h + 0..7) + the stored [slot][sample] embedding ----
     for (int p = w; p < 2 * UE; p += 8) {
@@ -277,17 +325,29 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
 #pragma unroll
       for (int g = G; g < Gn; ++g) A[g] = load_a(Wn, Gn, mtn, g, lane);
       f32x16_t bv[2];
+#ifdef LAB4D_WSABL_NOBIAS
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[0][r] = bv[1][r] = 0.25f;
+#else
       if (active) {
         load_bias(IT::blk(w, 0), bv);
         load_ext(IT::blk(w, 0));
       }
-      // ---- deferred stores of the layer in front: its tiles sit in this layer's input buffer ----
-      if constexpr (R > 0) {
-        constexpr int MTp = ws_mt<Net>(R - 1);
-        using ITp = WsItems<MTp>;
-        GLOBAL_AS void* actp = KARG_PTR(FwdK, void*, act, l - 1);
-        GLOBAL_AS unsigned int* maskp = KARG_PTR(FwdK, unsigned int*, mask, l - 1);
-        const int mtp = ITp::mt(w);
+#endif
+      // ---- deferred stores of the layer in front: its tiles sit in this layer's input buffer.  Where this layer's MFMA loops can host them
+      // (every wave has items here and had items there) they leave in pieces between the MFMAs (WsSpread); else as one burst here.
+      constexpr int MTp = R > 0 ? ws_mt<Net>(R > 0 ? R - 1 : 0) : 1;
+      using ITp = WsItems<MTp>;
+      constexpr int NP = R > 0 ? 4 * ITp::IPW : 0;                           // pieces per wave
+      // hosting items: all but the last one (which issues the next layer's A loads: every store is then OLDER than every A load, and the in-order
+      // wait for the weights at the top of the next layer only covers stores issued a whole item earlier); a single item hosts them itself
+      constexpr int NHOST = IT::IPW > 1 ? IT::IPW - 1 : 1;
+      constexpr int NPI = NP / NHOST;                                        // ... per hosting item
+      constexpr bool SPREAD = ST && R > 0 && !LAST && IT::ITEMS >= 8 && ITp::ITEMS >= 8 && NP % NHOST == 0 && WsSpread<G, (NPI > 0 ? NPI : 1)>::OK;
+      GLOBAL_AS void* actp = KARG_PTR(FwdK, void*, act, (l > 0 ? l - 1 : 0));
+      GLOBAL_AS unsigned int* maskp = KARG_PTR(FwdK, unsigned int*, mask, (l > 0 ? l - 1 : 0));
+      const int mtp = ITp::mt(w);
+      if constexpr (R > 0 && !SPREAD) {
         auto flush_prev = [&]() {
 #pragma unroll
           for (int k = 0; k < ITp::IPW; ++k) {
@@ -295,19 +355,22 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
             tr_issue(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + b * 2 * 16 * 1024 + mtp * 2048) + trl, trt);
             tr_wait(trt);
             tr_store(actp, 32 * MTp, s0 + 64 * b, mtp, lane, trt);
-            if constexpr (ST && Net::L[R - 1].relu != 0) maskp[((size_t)(2 * tile + b) * MTp + mtp) * 64 + lane] = pbits[k];
+            if constexpr (ST && Net::L[R > 0 ? R - 1 : 0].relu != 0) maskp[((size_t)(2 * tile + b) * MTp + mtp) * 64 + lane] = pbits[k];
           }
         };
         if constexpr (ST) {
+#ifndef LAB4D_WSABL_NOFLUSH
           if (ITp::active(w)) flush_prev();
+#endif
         } else {
           if (actp != nullptr && ITp::active(w)) flush_prev();  // inference: only the layer another net consumes
         }
       }
+      TrPiece tp[2];
 
       if (active) {
-#pragma unroll
-        for (int k = 0; k < IT::IPW; ++k) {
+        sfor<0, IT::IPW>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
           const int b = IT::blk(w, k);
           constexpr int KL = IT::IPW - 1;
           f32x16_t acc[2];
@@ -336,12 +399,36 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
             ws_lds_wait<NEWER>(bq[g % BD][0], bq[g % BD][1]);
             mma_b(acc[0], A[g], bq[g % BD][0]);
             mma_b(acc[1], A[g], bq[g % BD][1]);
+            if constexpr (SPREAD && k < NHOST) {  // hosted pieces: global piece index k NPI + i = tile (i NP-relative) / 4 of the layer in front, quarter % 4
+              using SP = WsSpread<G, (NPI > 0 ? NPI : 1)>;
+              sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, pi = k * NPI + i, kp = pi / 4, qa = pi % 4;
+                if constexpr (SP::issue_at(i) == g)
+                  ws_trp_issue<qa>(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + mtp * 2048) + trl, tp[i & 1]);
+              });
+            }
             if constexpr (g + BD < G) b_read(std::integral_constant<int, g + BD>{}, bq[g % BD]);
+            if constexpr (SPREAD && k < NHOST) {
+              using SP = WsSpread<G, (NPI > 0 ? NPI : 1)>;
+              sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, pi = k * NPI + i, kp = pi / 4, qa = pi % 4;
+                if constexpr (SP::store_at(i) == g) {
+#ifndef LAB4D_WSABL_NOFLUSH
+                  ws_trp_store<qa, SP::newer(i, BD)>(actp, 32 * MTp, s0 + 64 * ITp::blk(w, kp), mtp, lane, tp[i & 1]);
+                  if constexpr (qa == 3 && Net::L[R > 0 ? R - 1 : 0].relu != 0) maskp[((size_t)(2 * tile + ITp::blk(w, kp)) * MTp + mtp) * 64 + lane] = pbits[kp];
+#endif
+                }
+              });
+            }
+#ifndef LAB4D_WSABL_NOAPF
             if (k == KL && g < Gn) A[g] = load_a(Wn, Gn, mtn, g, lane);  // the next layer's group g, right behind the last use of this one
+#endif
           });
           // requests of the next item (they have that item's matrix work to arrive)
           if (k < KL) {
+#ifndef LAB4D_WSABL_NOBIAS
             if constexpr (ls.pf != 0) load_bias(IT::blk(w, k + 1), bv);
+#endif
           }
           // ---- epilogue ----
           if constexpr (!LAST && ls.add_ext == 0) {
@@ -409,7 +496,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
               }
             }
           }
-        }
+        });
       } else {
         // a wave without an item in this layer still needs the next layer's weights
         a_load(std::integral_constant<int, 0>{}, std::integral_constant<int, (Gn < G ? Gn : G)>{}, Wn, Gn, mtn);
@@ -582,13 +669,18 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
         if (act_on && !emb_on) load_tile_raw<P>((const GLOBAL_AS void*)a.ext_gin, pad32(lp.mout), s0 + 64 * IT::blk(w, 0), j, lane, raw);
       }
       static_assert(!(MTE > 0 && DO_ACT && lp.ext_grad != 0), "one prefetched tile per layer");
-      // ---- deferred stores: dZ_l (this layer's input, written by the layer above) ----
-      if constexpr (DZ && R < NL - 1) {
-        constexpr int MTp = GK / 2;
-        using ITp = WsItems<MTp>;
-        GLOBAL_AS void* dzl = KARG_PTR(BwdK, void*, dz, l);
+      // ---- deferred stores: dZ_l (this layer's input, written by the layer above): in pieces between the MFMAs of the activation items where
+      // they can host them (WsSpread), else as one burst here ----
+      constexpr int MTp = GK / 2;
+      using ITp = WsItems<MTp>;
+      constexpr int NP = (DZ && R < NL - 1) ? 4 * ITp::IPW : 0;
+      constexpr int NHOST = IT::IPW > 1 ? IT::IPW - 1 : 1;  // all but the last item host (see the forward kernel)
+      constexpr int NPI = NP / NHOST;
+      constexpr bool SPREAD = NP > 0 && DO_ACT && IT::ITEMS >= 8 && ITp::ITEMS >= 8 && NP % NHOST == 0 && WsSpread<GK, (NPI > 0 ? NPI : 1)>::OK;
+      GLOBAL_AS void* dzl = KARG_PTR(BwdK, void*, dz, l);
+      const int jp = ITp::mt(w);
+      if constexpr (NP > 0 && !SPREAD) {
         if (ITp::active(w)) {
-          const int jp = ITp::mt(w);
 #pragma unroll
           for (int k = 0; k < ITp::IPW; ++k) {
             const int b = ITp::blk(w, k);
@@ -598,11 +690,13 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
           }
         }
       }
+      TrPiece tp[2];
 
       // one item: acc = W^T[row tile in A] dZ_l over block b; PF: the groups of (Wp, GP groups, row tile rt) replace A behind their last use
-      auto mfma_item = [&](int b, f32x16_t (&acc)[2], auto pf_c, auto gp_c, const GLOBAL_AS void* Wp, int rt) {
+      auto mfma_item = [&](int b, f32x16_t (&acc)[2], auto pf_c, auto gp_c, const GLOBAL_AS void* Wp, int rt, auto host_c) {
         constexpr bool PF = decltype(pf_c)::value;
         constexpr int GP = decltype(gp_c)::value;
+        constexpr int HK = decltype(host_c)::value;  // >= 0: this loop hosts the pieces HK NPI .. of the deferred dZ tiles
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -622,7 +716,22 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
           ws_lds_wait<NEWER>(bq[g % BD][0], bq[g % BD][1]);
           mma_b(acc[0], A[g], bq[g % BD][0]);
           mma_b(acc[1], A[g], bq[g % BD][1]);
+          if constexpr (SPREAD && HK >= 0 && HK < NHOST) {
+            using SP = WsSpread<GK, (NPI > 0 ? NPI : 1)>;
+            sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
+              constexpr int i = decltype(ic)::value, pi = (HK >= 0 ? HK : 0) * NPI + i, kp = pi / 4, qa = pi % 4;
+              if constexpr (SP::issue_at(i) == g)
+                ws_trp_issue<qa>(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + jp * 2048) + trl, tp[i & 1]);
+            });
+          }
           if constexpr (g + BD < GK) b_read(std::integral_constant<int, g + BD>{}, bq[g % BD]);
+          if constexpr (SPREAD && HK >= 0 && HK < NHOST) {
+            using SP = WsSpread<GK, (NPI > 0 ? NPI : 1)>;
+            sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
+              constexpr int i = decltype(ic)::value, pi = (HK >= 0 ? HK : 0) * NPI + i, kp = pi / 4, qa = pi % 4;
+              if constexpr (SP::store_at(i) == g) ws_trp_store<qa, SP::newer(i, BD)>(dzl, 32 * MTp, s0 + 64 * ITp::blk(w, kp), jp, lane, tp[i & 1]);
+            });
+          }
           if constexpr (PF && g < GP) A[g] = load_a(Wp, GP, rt, g, lane);
         });
       };
@@ -632,8 +741,8 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       if constexpr (MTE > 0) {
         if (emb_on) {
           f32x16_t acc[2];
-          if constexpr (DO_ACT) mfma_item(be, acc, std::true_type{}, std::integral_constant<int, GK>{}, Wt, MTE + j);
-          else { mfma_item(be, acc, std::true_type{}, std::integral_constant<int, GKn>{}, Wn, rtn); loaded_next = true; }
+          if constexpr (DO_ACT) mfma_item(be, acc, std::true_type{}, std::integral_constant<int, GK>{}, Wt, MTE + j, std::integral_constant<int, -1>{});
+          else { mfma_item(be, acc, std::true_type{}, std::integral_constant<int, GKn>{}, Wn, rtn, std::integral_constant<int, -1>{}); loaded_next = true; }
           f32x16_t e[2];
           tile_from_raw<P>(raw, lane, e);
           constexpr int L = Net::NFREQ;
@@ -660,13 +769,13 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       // ---- (b) activation rows: masked dZ_{l-1} ----
       if constexpr (DO_ACT) {
         if (act_on) {
-#pragma unroll
-          for (int k = 0; k < IT::IPW; ++k) {
+          sfor<0, IT::IPW>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
             const int b = IT::blk(w, k);
             constexpr int KL = IT::IPW - 1;
             f32x16_t acc[2];
-            if (k == KL) mfma_item(b, acc, std::true_type{}, std::integral_constant<int, GKn>{}, Wn, rtn);
-            else mfma_item(b, acc, std::false_type{}, std::integral_constant<int, 0>{}, Wn, rtn);
+            if constexpr (k == KL) mfma_item(b, acc, std::true_type{}, std::integral_constant<int, GKn>{}, Wn, rtn, kc);
+            else mfma_item(b, acc, std::false_type{}, std::integral_constant<int, 0>{}, Wn, rtn, kc);
             if constexpr (lp.ext_grad != 0) {
               f32x16_t eg[2];
               tile_from_raw<P>(raw, lane, eg);
@@ -699,7 +808,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
 #pragma unroll
               for (int q = 0; q < 2; ++q)
                 xout[((2 * b + t) * 16 + 2 * j + q) * 64 + lane] = make_uint4(pw[t][4 * q], pw[t][4 * q + 1], pw[t][4 * q + 2], pw[t][4 * q + 3]);
-          }
+          });
           loaded_next = true;
         }
       }
