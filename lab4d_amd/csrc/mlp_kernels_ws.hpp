@@ -114,12 +114,22 @@ __device__ __forceinline__ void mma_b(f32x16_t& acc, const uint4& a, const u32x4
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 
-// One quarter of a finished 32 x 64 tile on its way to HBM (rows 16 q + 8 a + .., qa = 2 q + a): two transposing LDS reads (see tr_issue) and, a few
-// k-groups later, one 16-byte store per lane.  Issued BETWEEN the MFMAs of the layer that follows: a CU writes 64 KiB per layer, which at the chip's
-// HBM write rate takes as long as the layer's matrix work -- issued as one burst at the top of the layer the stores block the wave's memory issue
-// and the matrix pipe idles meanwhile (measured: 6.4 ms per 4.2 M samples with the burst, 4.2 ms with the stores removed).
+// One quarter of a finished 32 x 64 tile on its way to HBM (rows 16 q + 8 a + .., qa = 2 q + a; 8 rows x 128 B = 1 KiB), in three stages placed
+// BETWEEN the MFMAs of the layer that follows:
+//   issue: two transposing LDS reads (see tr_issue): lane i of 16-lane group (h, S) then holds samples 32 S + 8 (i >> 2) .. + 7 of row 4 h + (i & 3);
+//   perm (-DLAB4D_WS_LINEAR_STORE only): four ds_bpermute_b32 make the piece LANE-LINEAR (lane L holds bytes 16 L .. 16 L + 15 of the 1 KiB).
+//          Straight out of the transposing reads the four lanes of a quad hold four different rows, and in isolation such a store costs the CU's
+//          address path ~1.4x the cycles of a lane-linear one (tools/probes/store_pattern.hip: 47 vs 34 cycles per store beside MFMAs, 4.8 vs
+//          5.5 TB/s); in the real kernels the four permutes cost 0.4 ms per 4.2 M samples and the linear stores save < 0.1 ms: off;
+//   store: one global_store_dwordx4 per lane.
+// Why spread at all: a CU writes 64 KiB per layer; issued as one burst at the top of the layer the stores block every wave's memory issue while
+// the matrix pipe idles (measured: 6.4 ms per 4.2 M samples with the burst, 4.2 ms with the stores removed).
+struct WsPiece {
+  unsigned long long a, b;  // transposing reads
+  unsigned int d[4];        // lane-linear dwords
+};
 template <int QA>
-__device__ __forceinline__ void ws_trp_issue(unsigned addr /* tile base + lane part */, TrPiece& r) {
+__device__ __forceinline__ void ws_trp_issue(unsigned addr /* tile base + lane part */, WsPiece& r) {
   constexpr int OFF = 1024 * (QA >> 1) + 8 * (QA & 1);
 #ifdef LAB4D_WSABL_NOTR  // timing experiment (results wrong): no transposing reads, the stores write whatever the registers hold
   r.a = addr; r.b = addr + OFF;
@@ -130,36 +140,83 @@ __device__ __forceinline__ void ws_trp_issue(unsigned addr /* tile base + lane p
                : "=&v"(r.a), "=&v"(r.b)
                : "v"(addr), "n"(OFF), "n"(OFF + 32));
 }
-// N = LDS operations this wave has certainly issued behind the piece's reads (a lower bound keeps the wait safe)
-template <int QA, int N>
-__device__ __forceinline__ void ws_trp_store(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, TrPiece& r) {
+// byte address (lane * 4) of the lane whose transposed piece lane L wants: L = 8 row + piece16  <-  group (h = row >> 2, S = piece16 >> 2), lane (row & 3) + 4 (piece16 & 3)
+__device__ __forceinline__ unsigned ws_perm_addr(int lane) {
+  const int row = lane >> 3, pc = lane & 7;
+  return (unsigned)(4 * (16 * ((row >> 2) + 2 * (pc >> 2)) + (row & 3) + 4 * (pc & 3)));
+}
+// N = LDS operations this wave has certainly issued behind the stage's inputs (a lower bound keeps the wait safe)
+template <int N>
+__device__ __forceinline__ void ws_trp_perm(unsigned perm_addr, WsPiece& r) {
   static_assert(N >= 0 && N <= 15, "lgkmcnt field");
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r.a), "+v"(r.b) : "n"(N));
+  const unsigned a0 = (unsigned)r.a, a1 = (unsigned)(r.a >> 32), b0 = (unsigned)r.b, b1 = (unsigned)(r.b >> 32);
+#ifndef LAB4D_WS_LINEAR_STORE
+  r.d[0] = a0; r.d[1] = a1; r.d[2] = b0; r.d[3] = b1;  // the piece keeps the lane order of the transposing reads (ws_trp_store addresses it accordingly)
+  return;
+#endif
+  asm volatile("ds_bpermute_b32 %0, %4, %5\n\t"
+               "ds_bpermute_b32 %1, %4, %6\n\t"
+               "ds_bpermute_b32 %2, %4, %7\n\t"
+               "ds_bpermute_b32 %3, %4, %8"
+               : "=&v"(r.d[0]), "=&v"(r.d[1]), "=&v"(r.d[2]), "=&v"(r.d[3])
+               : "v"(perm_addr), "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+}
+template <int QA, int N>
+__device__ __forceinline__ void ws_trp_store(GLOBAL_AS void* buf, int F, int s0, int mt, int lane, WsPiece& r) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt field");
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r.d[0]), "+v"(r.d[1]), "+v"(r.d[2]), "+v"(r.d[3]) : "n"(N));
 #ifdef LAB4D_WSABL_NOST  // timing experiment (results wrong): reads and waits, no store
   return;
 #endif
 #ifdef LAB4D_ABL_L2STORE  // timing experiment (results wrong): every wave keeps writing the same 2048-sample window, so the stores never reach HBM
   s0 &= 0x7ff;
 #endif
-  const int i = lane & 15, G = lane >> 4, h = G & 1, S = G >> 1;
   GLOBAL_AS char* base = (GLOBAL_AS char*)buf + tile_base_offset<PBF16>(F, s0, 32 * mt);
+#ifdef LAB4D_WS_LINEAR_STORE
+  const unsigned lo = (unsigned)(lane * 16);
+#else
+  const int i = lane & 15, G = lane >> 4, h = G & 1, S = G >> 1;
   const unsigned lo = (unsigned)((4 * h + (i & 3)) * 128 + (32 * S + 8 * (i >> 2)) * 2);
-  gst16(base + (lo + (unsigned)((16 * (QA >> 1) + 8 * (QA & 1)) * 128)), (unsigned)r.a, (unsigned)(r.a >> 32), (unsigned)r.b, (unsigned)(r.b >> 32));
+#endif
+  gst16(base + (lo + (unsigned)((16 * (QA >> 1) + 8 * (QA & 1)) * 128)), r.d[0], r.d[1], r.d[2], r.d[3]);
 }
-// Where the NPI pieces of one hosted tile set go in a loop of G k-groups with a B ring of depth BD: piece i is read at group (i G) / NPI and stored two
-// groups later (the last one at the latest at G - 1); two piece buffers alternate, so a store may share its group with the next read.
+// Where the NPI pieces of one hosted tile set go in a loop of G k-groups with a B ring of depth BD: piece i is read at group I = (i G) / NPI, made
+// lane-linear at I + 1 and stored at I + 3 (one piece in flight: G / NPI >= 4).
 template <int G, int NPI>
 struct WsSpread {
-  static constexpr bool OK = NPI > 0 && G >= 2 * NPI;
+  static constexpr bool OK = NPI > 0 && G >= 4 * NPI;
   static constexpr int issue_at(int i) { return (i * G) / NPI; }
-  static constexpr int store_at(int i) { return issue_at(i) + 2 < G ? issue_at(i) + 2 : G - 1; }
-  // LDS operations certainly issued between piece i's reads and its store: the B reads (two per group) of groups issue_at .. store_at that still read ahead
-  static constexpr int newer(int i, int BD) {
+  static constexpr int perm_at(int i) { return issue_at(i) + 1; }
+  static constexpr int store_at(int i) { return issue_at(i) + 3; }
+  // LDS operations certainly issued between a stage placed in group g0 (in front of that group's B read-ahead) / g0 (behind it) and a stage behind the
+  // read-ahead of group g1: the B reads (two per group) of the groups in between that still read ahead
+  static constexpr int newer(int g0, bool g0_incl, int g1, int BD) {
     int c = 0;
-    for (int j = issue_at(i); j <= store_at(i); ++j) c += (j + BD < G) ? 2 : 0;
+    for (int j = g0_incl ? g0 : g0 + 1; j <= g1; ++j) c += (j + BD < G) ? 2 : 0;
     return c;
   }
 };
+
+// -DLAB4D_WS_TRACE (measurement build, outputs wrong): the forward kernel sums, per wave, the shader cycles it spends in the phases of a layer
+// and waves 0 and 4 of workgroup 0 leave the sums in the first floats of `out` (tools/ws_compare.py --trace prints them)
+__device__ __forceinline__ unsigned long long ws_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#ifdef LAB4D_WS_TRACE
+#define WS_T(i)                                   \
+  do {                                            \
+    const unsigned long long t_ = ws_clock();     \
+    tacc[i] += (float)(unsigned)(t_ - tlast);     \
+    tlast = t_;                                   \
+  } while (0)
+#else
+#define WS_T(i) \
+  do {          \
+  } while (0)
+#endif
 
 // ---- LDS byte address of the uint4 array element (address space 3 pointers are 32 bit) ----
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
@@ -178,10 +235,21 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   static_assert(WS_TILE * ESTR * 4 <= WS_BUF * 16, "posenc scratch aliases one activation buffer");
   __shared__ uint4 xbuf[2 * WS_BUF];
   __shared__ uint4 ebuf[4 * UE * 64];  // embedding as B units: [n-tile][unit][lane]
+  // every layer's bias row (shared bias: filled once per workgroup; per-frame bias: the current tile's frame, refilled per tile when the tile lies in one
+  // frame).  Read from here a bias costs LDS reads, not vector-memory loads that queue -- in the in-order memory counter -- behind the tile stores
+  // of the layer in front and hold up the first MFMA of every layer.
+  __shared__ float bias_lds[NL * 256];
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned xbuf_lds = lds_addr(xbuf), ebuf_lds = lds_addr(ebuf);
+  sfor<0, NL>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if constexpr (Net::L[l].pf == 0) {
+      if (tid < 32 * ws_mt<Net>(l)) bias_lds[l * 256 + tid] = ((const GLOBAL_AS float*)a.bias[l])[tid];
+    }
+  });
   const unsigned trl = tr_lane_base(0u, 16, lane);  // per-lane part of the transposing tile reads (unit stride 16 per n-tile)
+  const unsigned perm_a = ws_perm_addr(lane);
 
   int S_eff = a.S, ntw = a.S_pad / WS_TILE;
   if (a.S_dev) {
@@ -203,6 +271,10 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   }
   unsigned int pbits[2] = {0u, 0u};  // ReLU sign words of the layer just finished, waiting for their (deferred) store
   TrTile trt;
+#ifdef LAB4D_WS_TRACE
+  float tacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  unsigned long long tlast = ws_clock();
+#endif
 
   for (int tile = blockIdx.x; tile < ntw; tile += gridDim.x) {
     const int s0 = tile * WS_TILE;
@@ -217,6 +289,23 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
         frame[b][t] = a.frame_idx ? ((const GLOBAL_AS int*)a.frame_idx)[sc] : sc / a.spf;
       }
 
+    // per-frame bias rows of this tile's frame -> LDS (tiles inside one frame: the training shapes); tiles that straddle frames (and the compacted
+    // evaluation, whose samples name their frames one by one) read theirs per lane from global memory
+    bool tile_uni = false;
+    if (a.frame_idx == nullptr) {
+      const int sl_ = s0 + WS_TILE - 1 < S_eff ? s0 + WS_TILE - 1 : S_eff - 1, sf_ = s0 < S_eff ? s0 : S_eff - 1;
+      const int f0 = sf_ / a.spf, f1 = sl_ / a.spf;
+      tile_uni = f0 == f1;
+      if (tile_uni) {
+        sfor<0, NL>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          if constexpr (Net::L[l].pf != 0) {
+            constexpr int MO = 32 * ws_mt<Net>(l);
+            if (tid < MO) bias_lds[l * 256 + tid] = ((const GLOBAL_AS float*)a.pf_bias[l])[(size_t)f0 * MO + tid];
+          }
+        });
+      }
+    }
     // ---- positional encoding, once per sample and axis: thread (sample sl, axis q) -> fp32 scratch rows (aliasing activation buffer 1) ----
     // Same arithmetic as k_mlp_fwd's bf16 path: one accurate sincos per axis, angle doubling per octave, times the annealing weight.
     float* scr = reinterpret_cast<float*>(xbuf + WS_BUF);
@@ -277,6 +366,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       }
     }
     wg_step_barrier();
+    WS_T(6);
 
     // ---- layers ----
 #pragma nounroll
@@ -290,6 +380,10 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       constexpr bool LAST = (R == NL - 1);
       constexpr int MT = ws_mt<Net>(R), GE = ls.ke / 16, GA = ls.kin / 16, G = GE + GA;
       constexpr int Gn = ws_g<Net>((R + 1) % NL);  // A groups of the layer that follows (layer 0 of the next tile behind the last)
+#ifdef LAB4D_WS_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trace build: how long the layer's first instructions would wait for the weights / the stores in front of them
+      WS_T(7);
+#endif
       using IT = WsItems<MT>;
       const GLOBAL_AS float* bl = KARG_PTR(FwdK, const float*, bias, l);
       const GLOBAL_AS float* pfl = KARG_PTR(FwdK, const float*, pf_bias, l);
@@ -304,6 +398,16 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
 
       // bias (+ per-frame bias, which already contains the shared one: host contract) of item (mt, b) in accumulator layout
       auto load_bias = [&](int b, f32x16_t (&bv)[2]) {
+        if (ls.pf == 0 || tile_uni) {
+          const float4* p = reinterpret_cast<const float4*>(bias_lds + l * 256 + 32 * mt + 4 * h);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 v = p[2 * i];
+            bv[0][4 * i + 0] = v.x; bv[0][4 * i + 1] = v.y; bv[0][4 * i + 2] = v.z; bv[0][4 * i + 3] = v.w;
+          }
+          bv[1] = bv[0];
+          return;
+        }
 #pragma unroll
         for (int t = 0; t < (ls.pf != 0 ? 2 : 1); ++t) {
           const int fr = frame[0][t] + b * (frame[1][t] - frame[0][t]);  // b is 0 / 1 (arithmetic, not an index: an indexed private array goes to LDS / scratch)
@@ -339,9 +443,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       constexpr int MTp = R > 0 ? ws_mt<Net>(R > 0 ? R - 1 : 0) : 1;
       using ITp = WsItems<MTp>;
       constexpr int NP = R > 0 ? 4 * ITp::IPW : 0;                           // pieces per wave
-      // hosting items: all but the last one (which issues the next layer's A loads: every store is then OLDER than every A load, and the in-order
-      // wait for the weights at the top of the next layer only covers stores issued a whole item earlier); a single item hosts them itself
-      constexpr int NHOST = IT::IPW > 1 ? IT::IPW - 1 : 1;
+      constexpr int NHOST = IT::IPW;  // (hosting only the items in front of the one that issues the next layer's A loads was tried: no difference)
       constexpr int NPI = NP / NHOST;                                        // ... per hosting item
       constexpr bool SPREAD = ST && R > 0 && !LAST && IT::ITEMS >= 8 && ITp::ITEMS >= 8 && NP % NHOST == 0 && WsSpread<G, (NPI > 0 ? NPI : 1)>::OK;
       GLOBAL_AS void* actp = KARG_PTR(FwdK, void*, act, (l > 0 ? l - 1 : 0));
@@ -366,7 +468,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
           if (actp != nullptr && ITp::active(w)) flush_prev();  // inference: only the layer another net consumes
         }
       }
-      TrPiece tp[2];
+      WsPiece tp;
 
       if (active) {
         sfor<0, IT::IPW>([&](auto kc) {
@@ -404,7 +506,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
               sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
                 constexpr int i = decltype(ic)::value, pi = k * NPI + i, kp = pi / 4, qa = pi % 4;
                 if constexpr (SP::issue_at(i) == g)
-                  ws_trp_issue<qa>(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + mtp * 2048) + trl, tp[i & 1]);
+                  ws_trp_issue<qa>(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + mtp * 2048) + trl, tp);
               });
             }
             if constexpr (g + BD < G) b_read(std::integral_constant<int, g + BD>{}, bq[g % BD]);
@@ -412,9 +514,10 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
               using SP = WsSpread<G, (NPI > 0 ? NPI : 1)>;
               sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
                 constexpr int i = decltype(ic)::value, pi = k * NPI + i, kp = pi / 4, qa = pi % 4;
+                if constexpr (SP::perm_at(i) == g) ws_trp_perm<SP::newer(SP::issue_at(i), true, g, BD)>(perm_a, tp);
                 if constexpr (SP::store_at(i) == g) {
 #ifndef LAB4D_WSABL_NOFLUSH
-                  ws_trp_store<qa, SP::newer(i, BD)>(actp, 32 * MTp, s0 + 64 * ITp::blk(w, kp), mtp, lane, tp[i & 1]);
+                  ws_trp_store<qa, SP::newer(SP::perm_at(i), false, g, BD)>(actp, 32 * MTp, s0 + 64 * ITp::blk(w, kp), mtp, lane, tp);
                   if constexpr (qa == 3 && Net::L[R > 0 ? R - 1 : 0].relu != 0) maskp[((size_t)(2 * tile + ITp::blk(w, kp)) * MTp + mtp) * 64 + lane] = pbits[kp];
 #endif
                 }
@@ -424,6 +527,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
             if (k == KL && g < Gn) A[g] = load_a(Wn, Gn, mtn, g, lane);  // the next layer's group g, right behind the last use of this one
 #endif
           });
+          WS_T(1 + 2 * (k & 1));
           // requests of the next item (they have that item's matrix work to arrive)
           if (k < KL) {
 #ifndef LAB4D_WSABL_NOBIAS
@@ -496,14 +600,24 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
               }
             }
           }
+          WS_T(2 + 2 * (k & 1));
         });
       } else {
         // a wave without an item in this layer still needs the next layer's weights
         a_load(std::integral_constant<int, 0>{}, std::integral_constant<int, (Gn < G ? Gn : G)>{}, Wn, Gn, mtn);
       }
       wg_step_barrier();
+      WS_T(5);
     });
   }
+#ifdef LAB4D_WS_TRACE
+  if (blockIdx.x == 0 && (w == 0 || w == 4) && lane < 8 && a.out) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v = lane == i ? tacc[i] : v;
+    a.out[(w >> 2) * 8 + lane] = v;
+  }
+#endif
 }
 
 // =================================================================================================
@@ -571,6 +685,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned xbuf_lds = lds_addr(xbuf);
   const unsigned trl = tr_lane_base(0u, 16, lane);
+  const unsigned perm_a = ws_perm_addr(lane);
   const int ntw = a.S_pad / WS_TILE;
   const bool want_dx = a.d_x != nullptr;
 
@@ -674,7 +789,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       constexpr int MTp = GK / 2;
       using ITp = WsItems<MTp>;
       constexpr int NP = (DZ && R < NL - 1) ? 4 * ITp::IPW : 0;
-      constexpr int NHOST = IT::IPW > 1 ? IT::IPW - 1 : 1;  // all but the last item host (see the forward kernel)
+      constexpr int NHOST = IT::IPW;
       constexpr int NPI = NP / NHOST;
       constexpr bool SPREAD = NP > 0 && DO_ACT && IT::ITEMS >= 8 && ITp::ITEMS >= 8 && NP % NHOST == 0 && WsSpread<GK, (NPI > 0 ? NPI : 1)>::OK;
       GLOBAL_AS void* dzl = KARG_PTR(BwdK, void*, dz, l);
@@ -690,7 +805,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
           }
         }
       }
-      TrPiece tp[2];
+      WsPiece tp;
 
       // one item: acc = W^T[row tile in A] dZ_l over block b; PF: the groups of (Wp, GP groups, row tile rt) replace A behind their last use
       auto mfma_item = [&](int b, f32x16_t (&acc)[2], auto pf_c, auto gp_c, const GLOBAL_AS void* Wp, int rt, auto host_c) {
@@ -721,7 +836,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
             sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
               constexpr int i = decltype(ic)::value, pi = (HK >= 0 ? HK : 0) * NPI + i, kp = pi / 4, qa = pi % 4;
               if constexpr (SP::issue_at(i) == g)
-                ws_trp_issue<qa>(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + jp * 2048) + trl, tp[i & 1]);
+                ws_trp_issue<qa>(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + jp * 2048) + trl, tp);
             });
           }
           if constexpr (g + BD < GK) b_read(std::integral_constant<int, g + BD>{}, bq[g % BD]);
@@ -729,7 +844,8 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
             using SP = WsSpread<GK, (NPI > 0 ? NPI : 1)>;
             sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
               constexpr int i = decltype(ic)::value, pi = (HK >= 0 ? HK : 0) * NPI + i, kp = pi / 4, qa = pi % 4;
-              if constexpr (SP::store_at(i) == g) ws_trp_store<qa, SP::newer(i, BD)>(dzl, 32 * MTp, s0 + 64 * ITp::blk(w, kp), jp, lane, tp[i & 1]);
+              if constexpr (SP::perm_at(i) == g) ws_trp_perm<SP::newer(SP::issue_at(i), true, g, BD)>(perm_a, tp);
+              if constexpr (SP::store_at(i) == g) ws_trp_store<qa, SP::newer(SP::perm_at(i), false, g, BD)>(dzl, 32 * MTp, s0 + 64 * ITp::blk(w, kp), jp, lane, tp);
             });
           }
           if constexpr (PF && g < GP) A[g] = load_a(Wp, GP, rt, g, lane);

@@ -79,6 +79,25 @@ NET_MACS = {0: 572928 + 256, 1: 158464 + 37248, 2: 10240, 3: 77568, 4: 20736, 5:
 KERNEL_NET = {0: "FgBase", 1: "FgColor", 2: "Vis", 3: "Feat", 4: "Skin", 5: "Dense", 6: "BgBase", 7: "BgColor", 8: "Skin18", 9: "HashGeo", 10: "HashColor", 11: "Dense6", 12: "SkinA", 13: "Skin18A"}  # template argument names in csrc/mlp_nets.hpp
 
 
+WS_NETS = (0, 1, 5, 11)  # fg_base, fg_color, dense, dense6: the 256-wide posenc nets (csrc/mlp_kernels_ws.hpp ws_ok<Net>())
+
+
+def ws_active(net, prec, dx_only=False):
+    """Whether lab4d_mlp_forward / _backward launch the weights-stationary chain kernels for this call (mirrors launch_ws_fwd / launch_ws_bwd in
+    csrc/mlp_kernels.hpp: bf16, the 256-wide posenc nets, not the point-gradient-only modes, LAB4D_WS unset or non-zero)."""
+    e = os.environ.get("LAB4D_WS")
+    try:
+        on = e is None or int(e.strip() or "0") != 0
+    except ValueError:
+        on = False  # atoi() of a non-number is 0
+    return bool(on and prec == PREC_BF16 and net in WS_NETS and not dx_only)
+
+
+def chain_kernel_name(kind, net, prec, dx_only=False):
+    """Kernel symbol (as the profiles name it) behind a chain launch: k_mlp_fwd<Net> / k_mlp_fwd_ws<Net> / ..."""
+    return "k_mlp_%s%s<%s>" % (kind, "_ws" if ws_active(net, prec, dx_only) else "", KERNEL_NET[net])
+
+
 def wgrad_kernel_name(L, prec):
     """Which kernel lab4d_mlp_wgrad dispatches to for this layer (mirrors the dispatch in csrc/mlp.hip)."""
     if prec == PREC_BF16 and L.mout_pad == 32 and os.environ.get("LAB4D_WGRAD_HEAD_DMA", "1") not in ("", "0") and L.ke + L.kin <= 256:
@@ -479,7 +498,7 @@ class MlpChain(Function):
         a.out = _lib.dp(out)
         # algorithmic HBM bytes of this launch: every stored tensor written once, inputs read once
         nbytes = sum(t.numel() * t.element_size() for t in acts + masks + [emb, ext, out, x] if t is not None)
-        with _lib.timed("k_mlp_fwd<%s>%s" % (KERNEL_NET[net], "" if store else " inference"), (2.0 * S * NET_MACS[net], float(nbytes))):
+        with _lib.timed(chain_kernel_name("fwd", net, prec, dx_only) + ("" if store else " inference"), (2.0 * S * NET_MACS[net], float(nbytes))):
             _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward")
         ctx.meta = (net, prec, int(spf), S, S_pad, ld, export_layer, n_pf, pf_used)
         ctx.acts, ctx.masks, ctx.emb, ctx.ext = acts, masks, emb, ext
@@ -562,7 +581,7 @@ class MlpChain(Function):
                      if t is not None)
         if d_export is not None:
             nbytes += d_export.numel() * d_export.element_size()
-        with _lib.timed("k_mlp_bwd<%s>" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], float(nbytes))):
+        with _lib.timed(chain_kernel_name("bwd", net, prec, getattr(ctx, "dx_only", False)), (2.0 * S * NET_MACS[net], float(nbytes))):
             _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(a), _lib.stream()), "mlp_backward")
         # weight / bias gradients
         M = (S + spf - 1) // spf
@@ -781,7 +800,7 @@ def run_chain_compacted(net, prec, P, x, frame_idx, count, conds=None, ext=None,
         a.ext = _lib.dp(ext)
     out = torch.empty(S, d.c_out, device=dev)
     a.out = _lib.dp(out)
-    with _lib.timed("k_mlp_fwd<%s> inference" % KERNEL_NET[net], (2.0 * S * NET_MACS[net], 0.0)):
+    with _lib.timed(chain_kernel_name("fwd", net, prec) + " inference", (2.0 * S * NET_MACS[net], 0.0)):
         _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(compacted)")
     return (out, exported) if exported is not None else out
 
@@ -864,7 +883,7 @@ class EikonalSdf(Function):
                 emb = src["emb"].view(nb_src, -1).index_select(0, blk_map).reshape(-1)
                 reused = True
         if not reused:
-            with _lib.timed("k_mlp_fwd<%s>@eik" % KERNEL_NET[net]):
+            with _lib.timed(chain_kernel_name("fwd", net, prec) + "@eik"):
                 _lib.check(_lib.lib().lab4d_mlp_forward(ctypes.byref(a), _lib.stream()), "mlp_forward(eikonal primal)")
         bk = BwdArgs()
         bk.net, bk.precision, bk.S, bk.S_pad, bk.ld, bk.spf = net, prec, S, S_pad, S_pad, int(spf)
@@ -887,7 +906,7 @@ class EikonalSdf(Function):
         bk.d_out = _lib.dp(ones)
         g = torch.empty(S, 3, device=dev)
         bk.d_x = _lib.dp(g)
-        with _lib.timed("k_mlp_bwd<%s>@eik" % KERNEL_NET[net]):
+        with _lib.timed(chain_kernel_name("bwd", net, prec) + "@eik"):
             _lib.check(_lib.lib().lab4d_mlp_backward(ctypes.byref(bk), _lib.stream()), "mlp_backward(eikonal primal)")
         gn = g.norm(2, dim=-1, keepdim=True)
         ctx.meta = (net, prec, int(spf), S, S_pad)

@@ -1,0 +1,40 @@
+"""CPU: the host side's mirror of the weights-stationary dispatch (lab4d_amd.mlp.ws_active / chain_kernel_name) against the rule in
+csrc/mlp_kernels.hpp (launch_ws_fwd / launch_ws_bwd) and csrc/mlp_kernels_ws.hpp (ws_ok<Net>(), ws_enabled())."""
+import os
+import re
+
+from lab4d_amd import mlp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ws_nets_are_the_256_wide_posenc_nets():
+    got = set()
+    for net in mlp.NET_NAMES:
+        d = mlp.describe(net)
+        widest = max(max(L.kin, L.mout_pad) for L in d.layers[:d.n_layers])
+        if d.emb_kind == 0 and widest == 256 and net not in (mlp.NET_BG_COLOR,):
+            got.add(net)
+    assert got == set(mlp.WS_NETS), (got, mlp.WS_NETS)
+
+
+def test_env_switch_follows_atoi(monkeypatch):
+    for val, on in ((None, True), ("1", True), ("0", False), ("", False), ("off", False), ("2", True)):
+        if val is None:
+            monkeypatch.delenv("LAB4D_WS", raising=False)
+        else:
+            monkeypatch.setenv("LAB4D_WS", val)
+        assert mlp.ws_active(mlp.NET_FG_BASE, mlp.PREC_BF16) is on, val
+    monkeypatch.delenv("LAB4D_WS", raising=False)
+    assert not mlp.ws_active(mlp.NET_FG_BASE, mlp.PREC_F32)
+    assert not mlp.ws_active(mlp.NET_FG_BASE, mlp.PREC_BF16, dx_only=True)
+    assert not mlp.ws_active(mlp.NET_VIS, mlp.PREC_BF16)
+
+
+def test_dispatch_rule_in_the_sources():
+    src = open(os.path.join(ROOT, "lab4d_amd", "csrc", "mlp_kernels.hpp")).read()
+    # forward: not the point-gradient-only mode; backward: dZ wanted
+    assert re.search(r"launch_ws_fwd.*?if \(!ws_enabled\(\) \|\| \(k0\.emb && !k0\.act\[0\]\)\) return false;", src, re.S)
+    assert re.search(r"launch_ws_bwd.*?if \(!ws_enabled\(\) \|\| !k0\.dz\[0\]\) return false;", src, re.S)
+    ws = open(os.path.join(ROOT, "lab4d_amd", "csrc", "mlp_kernels_ws.hpp")).read()
+    assert "return e == nullptr || atoi(e) != 0;" in ws

@@ -20,6 +20,8 @@ def short(name):
         flags = re.findall(r"\b(true|false)\b", targs)  # k_mlp_fwd<Net, P, TAN, ST>
         tan = base == "k_mlp_fwd" and len(flags) >= 1 and flags[0] == "true"
         return "%s<%s>%s" % (base, net.group(1), "@tangent" if tan else "")
+    if base in ("k_mlp_fwd_ws", "k_mlp_bwd_ws") and net:  # the weights-stationary chains (csrc/mlp_kernels_ws.hpp)
+        return "%s<%s>" % (base, net.group(1))
     if base == "k_mlp_wgrad_dma":
         nums = re.findall(r"\d+", targs)
         return "k_mlp_wgrad_dma<%s>" % ",".join(nums[:2])
