@@ -81,9 +81,9 @@ __device__ __forceinline__ int ws_mt_rt(int l) {
 
 constexpr int WS_TILE = 128;       // samples per workgroup tile
 #ifndef LAB4D_WS_BD
-#define LAB4D_WS_BD 4
+#define LAB4D_WS_BD 2
 #endif
-constexpr int WS_BD = LAB4D_WS_BD;  // depth (k-groups) of the B-operand ring between LDS and the MFMAs
+constexpr int WS_BD = LAB4D_WS_BD;  // depth (k-groups) of the B-operand ring between LDS and the MFMAs (2 / 4 / 8 measured: the same time; 2 keeps the colour net free of spills)
 constexpr int WS_BUF = 4 * 16 * 64;  // uint4 slots of one activation buffer: [n-tile 4][unit 16][lane 64] = 64 KiB
 
 // this wave's work items of a layer with MT row tiles: an item = (row tile mt, 64-sample block b).  2 MT items over 8 waves:
@@ -107,6 +107,11 @@ template <int N>
 __device__ __forceinline__ void ws_lds_wait(u32x4_t& a, u32x4_t& b) {
   static_assert(N >= 0 && N <= 15, "lgkmcnt field");
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void ws_lds_wait4(u32x4_t (&r)[4]) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt field");
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
 }
 __device__ __forceinline__ void mma_b(f32x16_t& acc, const uint4& a, const u32x4_t& b) {
   bf16x8_t av;
@@ -218,6 +223,21 @@ __device__ __forceinline__ unsigned long long ws_clock() {
   } while (0)
 #endif
 
+// End-of-layer barrier that also settles the scalar loads of the NEXT layer's pointers: the wait is the BUILTIN (the compiler's counter model
+// sees it: nothing scalar is pending afterwards), so the first LDS waits of the next layer are the hand-counted ones of the B ring and the first MFMA
+// waits for its own two reads only -- with a pointer load in flight the compiler has to wait lgkmcnt(0) (scalar loads return out of order), i.e. for
+// the whole ring prologue of all eight waves (trace build: 500-900 cycles per layer between the barrier and the first MFMA).
+__device__ __forceinline__ void ws_layer_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt / expcnt untouched
+  asm volatile("s_barrier" ::: "memory");
+}
+template <class T>
+__device__ __forceinline__ void ws_pin_sgpr(T*& p) {
+  unsigned long long v = (unsigned long long)p;
+  asm volatile("" : "+s"(v));
+  p = (T*)v;
+}
+
 // ---- LDS byte address of the uint4 array element (address space 3 pointers are 32 bit) ----
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
 
@@ -271,6 +291,11 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   }
   unsigned int pbits[2] = {0u, 0u};  // ReLU sign words of the layer just finished, waiting for their (deferred) store
   TrTile trt;
+  // pointers the NEXT layer needs, loaded (scalar) in front of this layer's closing barrier: the following layer's weights, this layer's activation /
+  // sign-word buffers (the next layer issues their stores)
+  const GLOBAL_AS void* Wn_c = KARG_PTR(FwdK, const void*, W, (NL > 1 ? 1 : 0));
+  GLOBAL_AS void* act_c = nullptr;
+  GLOBAL_AS unsigned int* mask_c = nullptr;
 #ifdef LAB4D_WS_TRACE
   float tacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   unsigned long long tlast = ws_clock();
@@ -388,7 +413,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       const GLOBAL_AS float* bl = KARG_PTR(FwdK, const float*, bias, l);
       const GLOBAL_AS float* pfl = KARG_PTR(FwdK, const float*, pf_bias, l);
       const int ln = l + 1 < NL ? l + 1 : 0;
-      const GLOBAL_AS void* Wn = KARG_PTR(FwdK, const void*, W, ln);
+      const GLOBAL_AS void* Wn = Wn_c;
       const int mtn = w & (ws_mt_rt<Net>(ln) - 1);
       const int ib = l & 1;
       const uint4* xin = xbuf + ib * WS_BUF;
@@ -397,17 +422,11 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       const bool active = IT::active(w);
 
       // bias (+ per-frame bias, which already contains the shared one: host contract) of item (mt, b) in accumulator layout
+      // bias row from LDS (shared bias, or a tile inside one frame): four reads issued here, waited for (counted) behind the first item's ring prologue
+      const bool bias_lds_path = ls.pf == 0 || tile_uni;
+      u32x4_t br[4];
       auto load_bias = [&](int b, f32x16_t (&bv)[2]) {
-        if (ls.pf == 0 || tile_uni) {
-          const float4* p = reinterpret_cast<const float4*>(bias_lds + l * 256 + 32 * mt + 4 * h);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float4 v = p[2 * i];
-            bv[0][4 * i + 0] = v.x; bv[0][4 * i + 1] = v.y; bv[0][4 * i + 2] = v.z; bv[0][4 * i + 3] = v.w;
-          }
-          bv[1] = bv[0];
-          return;
-        }
+        if (bias_lds_path) return;  // (same row for every item)
 #pragma unroll
         for (int t = 0; t < (ls.pf != 0 ? 2 : 1); ++t) {
           const int fr = frame[0][t] + b * (frame[1][t] - frame[0][t]);  // b is 0 / 1 (arithmetic, not an index: an indexed private array goes to LDS / scratch)
@@ -434,7 +453,15 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       for (int r = 0; r < 16; ++r) bv[0][r] = bv[1][r] = 0.25f;
 #else
       if (active) {
-        load_bias(IT::blk(w, 0), bv);
+        if (bias_lds_path) {
+          const unsigned ba = lds_addr(bias_lds) + (unsigned)((l * 256 + 32 * mt + 4 * h) * 4);
+          ws_lds_read<0>(br[0], ba);
+          ws_lds_read<32>(br[1], ba);
+          ws_lds_read<64>(br[2], ba);
+          ws_lds_read<96>(br[3], ba);
+        } else {
+          load_bias(IT::blk(w, 0), bv);
+        }
         load_ext(IT::blk(w, 0));
       }
 #endif
@@ -446,8 +473,12 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       constexpr int NHOST = IT::IPW;  // (hosting only the items in front of the one that issues the next layer's A loads was tried: no difference)
       constexpr int NPI = NP / NHOST;                                        // ... per hosting item
       constexpr bool SPREAD = ST && R > 0 && !LAST && IT::ITEMS >= 8 && ITp::ITEMS >= 8 && NP % NHOST == 0 && WsSpread<G, (NPI > 0 ? NPI : 1)>::OK;
-      GLOBAL_AS void* actp = KARG_PTR(FwdK, void*, act, (l > 0 ? l - 1 : 0));
-      GLOBAL_AS unsigned int* maskp = KARG_PTR(FwdK, unsigned int*, mask, (l > 0 ? l - 1 : 0));
+      GLOBAL_AS void* actp = act_c;
+      GLOBAL_AS unsigned int* maskp = mask_c;
+      // the next layer's pointers are requested NOW (scalar loads; they have the whole layer to arrive) and become current behind the closing barrier
+      const GLOBAL_AS void* Wn_n = KARG_PTR(FwdK, const void*, W, (ln + 1 < NL ? ln + 1 : 0));
+      GLOBAL_AS void* act_n = KARG_PTR(FwdK, void*, act, l);
+      GLOBAL_AS unsigned int* mask_n = KARG_PTR(FwdK, unsigned int*, mask, l);
       const int mtp = ITp::mt(w);
       if constexpr (R > 0 && !SPREAD) {
         auto flush_prev = [&]() {
@@ -476,8 +507,6 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
           const int b = IT::blk(w, k);
           constexpr int KL = IT::IPW - 1;
           f32x16_t acc[2];
-          acc[0] = bv[0];
-          acc[1] = bv[1];
           // B units stream from LDS through a ring of WS_BD k-groups (two n-tiles each): the read of group g + WS_BD is issued right behind the
           // MFMAs of group g.  Reads and waits are volatile asm (program order kept, counted waits written by hand): left to the scheduler the
           // reads sink next to their MFMAs (lgkmcnt(1) in front of every MFMA pair) and the LDS latency is exposed once per k-group.
@@ -495,6 +524,21 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
             }
           };
           sfor<0, BD>([&](auto gc) { b_read(gc, bq[decltype(gc)::value]); });
+#ifndef LAB4D_WSABL_NOBIAS
+          if constexpr (k == 0) {
+            if (bias_lds_path) {
+              ws_lds_wait4<2 * BD>(br);  // the ring prologue (2 BD reads) was issued behind the four bias reads
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                bv[0][4 * i + 0] = __uint_as_float(br[i].x); bv[0][4 * i + 1] = __uint_as_float(br[i].y);
+                bv[0][4 * i + 2] = __uint_as_float(br[i].z); bv[0][4 * i + 3] = __uint_as_float(br[i].w);
+              }
+              bv[1] = bv[0];
+            }
+          }
+#endif
+          acc[0] = bv[0];
+          acc[1] = bv[1];
           sfor<0, G>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int NEWER = 2 * ((G - 1 - g) < (BD - 1) ? (G - 1 - g) : (BD - 1));  // reads issued behind group g's
@@ -606,16 +650,22 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
         // a wave without an item in this layer still needs the next layer's weights
         a_load(std::integral_constant<int, 0>{}, std::integral_constant<int, (Gn < G ? Gn : G)>{}, Wn, Gn, mtn);
       }
-      wg_step_barrier();
+      ws_layer_barrier();
+      Wn_c = Wn_n;
+      act_c = act_n;
+      mask_c = mask_n;
+      ws_pin_sgpr(Wn_c);
+      ws_pin_sgpr(act_c);
+      ws_pin_sgpr(mask_c);
       WS_T(5);
     });
   }
 #ifdef LAB4D_WS_TRACE
-  if (blockIdx.x == 0 && (w == 0 || w == 4) && lane < 8 && a.out) {
+  if (blockIdx.x == 0 && lane < 8 && a.out) {
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v = lane == i ? tacc[i] : v;
-    a.out[(w >> 2) * 8 + lane] = v;
+    a.out[w * 8 + lane] = v;
   }
 #endif
 }
@@ -700,10 +750,13 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
     a_load(std::integral_constant<int, GK0>{}, KARG_PTR(BwdK, const void*, WT, NL - 1), GK0, wsb_first_tile<Net>(NL - 1, w, want_dx));
   }
   TrTile trt;
+  // pointers the NEXT layer needs (see the forward kernel): the weights of the layer below it, its own dZ buffer, the sign words its successor's items want
+  auto mask_slot_after = [](int ln_) { const int q = ln_ > 0 ? ln_ - 1 : 0; return q >= 1 ? q - 1 : 0; };
+  const GLOBAL_AS void* Wn_c = KARG_PTR(BwdK, const void*, WT, (NL >= 2 ? NL - 2 : 0));
+  GLOBAL_AS void* dz_c = KARG_PTR(BwdK, void*, dz, NL - 1);
+  const GLOBAL_AS unsigned int* maskq_c = KARG_PTR(BwdK, const unsigned int*, mask, mask_slot_after(NL - 1));
   // ReLU sign words of this wave's activation items: requested one layer ahead (they come from HBM, written a whole chunk earlier)
-  auto mask_req = [&](int lq /* layer whose activation items want them: words of mask[lq - 1] */, int tile, unsigned int (&m)[2]) {
-    const int lm = lq >= 1 ? lq - 1 : 0;  // clamped: a layer without activation items requests (and ignores) valid words
-    const GLOBAL_AS unsigned int* mp = KARG_PTR(BwdK, const unsigned int*, mask, lm);
+  auto mask_req = [&](int lq /* layer whose activation items want them: words of mask[lq - 1] */, int tile, unsigned int (&m)[2], const GLOBAL_AS unsigned int* mp) {
     int mta = wsb_mta_rt<Net>(lq >= 1 ? lq : 1);
     mta = mta > 0 ? mta : 8;
     const int j = w & (mta - 1);
@@ -720,7 +773,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) dx[t][0] = dx[t][1] = dx[t][2] = 0.f;
     unsigned int mcur[2], mnext[2];
-    mask_req(NL - 1, tile, mcur);
+    mask_req(NL - 1, tile, mcur, KARG_PTR(BwdK, const unsigned int*, mask, (NL >= 2 ? NL - 2 : 0)));
 
     // ---- head gradient: (S, COUT) fp32 -> accumulator layout -> stored + B units of buffer 0 (waves 0, 1: one 64-sample block each) ----
     if (w < 2) {
@@ -762,8 +815,11 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       using IT = WsItems<(DO_ACT ? MTA : 1)>;
       const int lm1 = l > 0 ? l - 1 : 0;
       const int ln = l > 0 ? l - 1 : NL - 1;
-      const GLOBAL_AS void* Wt = KARG_PTR(BwdK, const void*, WT, l);
-      const GLOBAL_AS void* Wn = KARG_PTR(BwdK, const void*, WT, ln);
+      const GLOBAL_AS void* Wn = Wn_c;
+      // the next layer's pointers are requested now and become current behind the closing barrier
+      const GLOBAL_AS void* Wn_n = KARG_PTR(BwdK, const void*, WT, (ln > 0 ? ln - 1 : NL - 1));
+      GLOBAL_AS void* dz_n = KARG_PTR(BwdK, void*, dz, ln);
+      const GLOBAL_AS unsigned int* maskq_n = KARG_PTR(BwdK, const unsigned int*, mask, mask_slot_after(ln));
       const int rtn = wsb_first_tile<Net>(ln, w, want_dx);
       const int ib = (NL - 1 - l) & 1;
       uint4* xout = xbuf + (ib ^ 1) * WS_BUF;
@@ -775,7 +831,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       // ---- requests first: the next layer's A groups this layer has no use for, its sign words, this layer's stored embedding / external gradient tile ----
 #pragma unroll
       for (int g = GK; g < GKn; ++g) A[g] = load_a(Wn, GKn, rtn, g, lane);
-      mask_req(lm1, tile, mnext);
+      mask_req(lm1, tile, mnext, maskq_c);
       uint4 raw[4];
       if constexpr (MTE > 0) {
         if (emb_on) load_tile_raw<P>((const GLOBAL_AS void*)a.emb, KE, s0 + 64 * be, me, lane, raw);
@@ -792,7 +848,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       constexpr int NHOST = IT::IPW;
       constexpr int NPI = NP / NHOST;
       constexpr bool SPREAD = NP > 0 && DO_ACT && IT::ITEMS >= 8 && ITp::ITEMS >= 8 && NP % NHOST == 0 && WsSpread<GK, (NPI > 0 ? NPI : 1)>::OK;
-      GLOBAL_AS void* dzl = KARG_PTR(BwdK, void*, dz, l);
+      GLOBAL_AS void* dzl = dz_c;
       const int jp = ITp::mt(w);
       if constexpr (NP > 0 && !SPREAD) {
         if (ITp::active(w)) {
@@ -857,7 +913,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       if constexpr (MTE > 0) {
         if (emb_on) {
           f32x16_t acc[2];
-          if constexpr (DO_ACT) mfma_item(be, acc, std::true_type{}, std::integral_constant<int, GK>{}, Wt, MTE + j, std::integral_constant<int, -1>{});
+          if constexpr (DO_ACT) mfma_item(be, acc, std::true_type{}, std::integral_constant<int, GK>{}, KARG_PTR(BwdK, const void*, WT, l), MTE + j, std::integral_constant<int, -1>{});
           else { mfma_item(be, acc, std::true_type{}, std::integral_constant<int, GKn>{}, Wn, rtn, std::integral_constant<int, -1>{}); loaded_next = true; }
           f32x16_t e[2];
           tile_from_raw<P>(raw, lane, e);
@@ -931,7 +987,13 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       if (!loaded_next) a_load(std::integral_constant<int, (GKn < GK ? GKn : GK)>{}, Wn, GKn, rtn);  // a wave without an item here still needs its next weights
       mcur[0] = mnext[0];
       mcur[1] = mnext[1];
-      wg_step_barrier();
+      ws_layer_barrier();
+      Wn_c = Wn_n;
+      dz_c = dz_n;
+      maskq_c = maskq_n;
+      ws_pin_sgpr(Wn_c);
+      ws_pin_sgpr(dz_c);
+      ws_pin_sgpr(maskq_c);
     });
 
     // ---- input gradient: partials of the embedding items -> one sum per sample ----

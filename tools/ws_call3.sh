@@ -6,7 +6,8 @@ for net in fg_base fg_color dense dense6; do
 done
 echo "######## timing"
 timeout 200 python tools/ws_compare.py --nets fg_base,fg_color --quick --time 4194304 --json gpurun_out/ws_time.json 2>&1 | grep '"net"'
-for v in gpurun_abl/lib_*.so; do echo "## $v"; LAB4D_SO_PATH=$R/$v timeout 100 python tools/ws_compare.py --nets fg_base --quick --time 4194304 2>&1 | grep '"net"' | python -c "
+for v in gpurun_abl/lib_*.so; do echo "## $v"; LAB4D_WS_TRACE_PRINT=1 LAB4D_SO_PATH=$R/$v timeout 100 python tools/ws_compare.py --nets fg_base --quick --time 4194304 2>&1 | grep '"net"' | python -c "
 import sys,json
 for l in sys.stdin:
-    d=json.loads(l); print({k:v for k,v in d.items() if k.endswith('_ms')})"; done
+    d=json.loads(l); print({k:v for k,v in d.items() if k.endswith('_ms')})
+    for k,v in d.get('trace_cycles_per_tile',{}).items(): print(k, v, sum(v.values()))"; done

@@ -203,10 +203,10 @@ def time_case(net, S, report):
             out["%s_%s_ms" % (what, "ws" if ws else "wave")] = round(ms, 3)
             out["%s_%s_frac_of_bf16_mfma_peak" % (what, "ws" if ws else "wave")] = round(tf / 2500.0, 4)
         if ws and os.environ.get("LAB4D_WS_TRACE_PRINT"):
-            t = f["out"].view(-1)[:16].tolist()
+            t = f["out"].view(-1)[:64].tolist()
             ntile = (c["S_pad"] // 128 + 255) // 256
-            names = ["layer top (pointers, bias, first B reads)", "item 0 MFMA loop", "item 0 epilogue", "item 1 MFMA loop", "item 1 epilogue", "barrier", "posenc phase", "vmcnt(0) at layer entry"]
-            out["trace_cycles_per_tile"] = {"wave%d" % (4 * wv): {names[i]: round(t[8 * wv + i] / ntile) for i in range(8)} for wv in (0, 1)}
+            names = ["top", "loop0", "epi0", "loop1", "epi1", "barrier", "posenc", "vmcnt@entry"]
+            out["trace_cycles_per_tile"] = {"wave%d" % wv: {names[i]: round(t[8 * wv + i] / ntile) for i in range(8)} for wv in range(8)}
         del f, b
         torch.cuda.empty_cache()
     print(json.dumps(out), flush=True)
