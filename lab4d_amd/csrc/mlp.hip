@@ -656,7 +656,9 @@ extern "C" int lab4d_mlp_forward(const lab4d_mlp_fwd_args* a, void* stream) {
       // training mode (emb given): the kernel stores every hidden activation and ReLU mask unconditionally
       if (a->emb && l + 1 < Net::NL) {
         // ... or none of them (point-gradient-only mode: masks + embedding, lab4d_mlp.h)
-        LAB4D_REQUIRE(a->act[l] || (dx_only_ok<Net>() && !a->act[0] && !Net::L[l].ext_grad), "mlp_forward: training mode (emb != NULL) needs act[%d]", l);
+        // (the layer another net consumes is not exported in that mode either: round 4 found the mode unreachable for the sdf basefields, whose
+        // layer 8 / 5 feeds the colour net, because this check still asked for its buffer)
+        LAB4D_REQUIRE(a->act[l] || (dx_only_ok<Net>() && !a->act[0]), "mlp_forward: training mode (emb != NULL) needs act[%d]", l);
         LAB4D_REQUIRE(!Net::L[l].relu || a->mask[l], "mlp_forward: training mode (emb != NULL) needs mask[%d]", l);
       }
       k.W[l] = a->W[l]; k.bias[l] = a->bias[l]; k.pf_bias[l] = a->pf_bias[l]; k.act[l] = a->act[l]; k.mask[l] = (unsigned int*)a->mask[l];

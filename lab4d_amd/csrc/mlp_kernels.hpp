@@ -2083,12 +2083,22 @@ inline int mlp_grid(int ntiles) {
 #include "mlp_kernels_h.hpp"
 #include "mlp_kernels_ws.hpp"
 namespace lab4d {
-// the weights-stationary family (mlp_kernels_ws.hpp) serves the training-mode and inference-mode forward and the training-mode backward of the
-// 256-wide posenc nets; returns false when the launch is not its business (other nets, fp32, the point-gradient-only modes, LAB4D_WS=0)
+// the point-gradient-only modes (forward: masks + embedding only; backward: no dZ) are instantiated for the sdf basefields: the eval path's normals
+template <class Net>
+constexpr bool dx_only_ok() { return Net::ID == LAB4D_NET_FG_BASE || Net::ID == LAB4D_NET_BG_BASE; }
+// the weights-stationary family (mlp_kernels_ws.hpp) serves the training-mode, inference-mode and point-gradient-only forward and backward of the
+// 256-wide posenc nets; returns false when the launch is not its business (other nets, fp32, LAB4D_WS=0)
 template <class Net>
 inline bool launch_ws_bwd(const BwdK& k0, hipStream_t st) {
   if constexpr (ws_ok<Net>()) {
-    if (!ws_enabled() || !k0.dz[0]) return false;
+    if (!ws_enabled()) return false;
+    if (!k0.dz[0]) {  // point gradient only (host-checked: the sdf basefields, d_x given)
+      if constexpr (dx_only_ok<Net>()) {
+        hipLaunchKernelGGL((k_mlp_bwd_ws<Net, false>), dim3(mlp_grid_ws(k0.S_pad / WS_TILE)), dim3(512), 0, st, k0);
+        return true;
+      }
+      return false;
+    }
     hipLaunchKernelGGL((k_mlp_bwd_ws<Net, true>), dim3(mlp_grid_ws(k0.S_pad / WS_TILE)), dim3(512), 0, st, k0);
     return true;
   } else {
@@ -2098,8 +2108,15 @@ inline bool launch_ws_bwd(const BwdK& k0, hipStream_t st) {
 template <class Net>
 inline bool launch_ws_fwd(const FwdK& k0, hipStream_t st) {
   if constexpr (ws_ok<Net>()) {
-    if (!ws_enabled() || (k0.emb && !k0.act[0])) return false;
+    if (!ws_enabled()) return false;
     FwdK k = k0;
+    if (k.emb && !k.act[0]) {  // point-gradient-only mode (host-checked: the sdf basefields)
+      if constexpr (dx_only_ok<Net>()) {
+        hipLaunchKernelGGL((k_mlp_fwd_ws<Net, true, false>), dim3(mlp_grid_ws(k.S_pad / WS_TILE)), dim3(512), 0, st, k);
+        return true;
+      }
+      return false;
+    }
     if (k.emb) hipLaunchKernelGGL((k_mlp_fwd_ws<Net, true>), dim3(mlp_grid_ws(k.S_pad / WS_TILE)), dim3(512), 0, st, k);
     else hipLaunchKernelGGL((k_mlp_fwd_ws<Net, false>), dim3(mlp_grid_ws(k.S_pad / WS_TILE)), dim3(512), 0, st, k);
     return true;
@@ -2116,9 +2133,6 @@ inline bool bwd_h_enabled() {
   return on != 0;
 }
 
-// the point-gradient-only modes (forward: masks + embedding only; backward: no dZ) are instantiated for the sdf basefields: the eval path's normals
-template <class Net>
-constexpr bool dx_only_ok() { return Net::ID == LAB4D_NET_FG_BASE || Net::ID == LAB4D_NET_BG_BASE; }
 
 #define LAB4D_MLP_INSTANTIATE(Net)                                                                                        \
   namespace lab4d {                                                                                                       \

@@ -246,7 +246,8 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // =================================================================================================
 // ST = training mode: embedding, every hidden post-activation and every ReLU sign word are stored (pointers host-checked);
 // !ST = inference: only a layer another net consumes (act[l] != NULL) is stored.
-template <class Net, bool ST>
+// ACTS = false (with ST): the point-gradient-only mode of the sdf basefields (eval normals, nerf.py:455-493): embedding and sign words only
+template <class Net, bool ST, bool ACTS = true>
 __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   static_assert(ws_ok<Net>(), "weights-stationary chain: 256-wide posenc nets only");
   using P = PBF16;
@@ -472,7 +473,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       constexpr int NP = R > 0 ? 4 * ITp::IPW : 0;                           // pieces per wave
       constexpr int NHOST = IT::IPW;  // (hosting only the items in front of the one that issues the next layer's A loads was tried: no difference)
       constexpr int NPI = NP / NHOST;                                        // ... per hosting item
-      constexpr bool SPREAD = ST && R > 0 && !LAST && IT::ITEMS >= 8 && ITp::ITEMS >= 8 && NP % NHOST == 0 && WsSpread<G, (NPI > 0 ? NPI : 1)>::OK;
+      constexpr bool SPREAD = ST && ACTS && R > 0 && !LAST && IT::ITEMS >= 8 && ITp::ITEMS >= 8 && NP % NHOST == 0 && WsSpread<G, (NPI > 0 ? NPI : 1)>::OK;
       GLOBAL_AS void* actp = act_c;
       GLOBAL_AS unsigned int* maskp = mask_c;
       // the next layer's pointers are requested NOW (scalar loads; they have the whole layer to arrive) and become current behind the closing barrier
@@ -485,9 +486,11 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
 #pragma unroll
           for (int k = 0; k < ITp::IPW; ++k) {
             const int b = ITp::blk(w, k);
-            tr_issue(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + b * 2 * 16 * 1024 + mtp * 2048) + trl, trt);
-            tr_wait(trt);
-            tr_store(actp, 32 * MTp, s0 + 64 * b, mtp, lane, trt);
+            if constexpr (ACTS) {
+              tr_issue(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + b * 2 * 16 * 1024 + mtp * 2048) + trl, trt);
+              tr_wait(trt);
+              tr_store(actp, 32 * MTp, s0 + 64 * b, mtp, lane, trt);
+            }
             if constexpr (ST && Net::L[R > 0 ? R - 1 : 0].relu != 0) maskp[((size_t)(2 * tile + b) * MTp + mtp) * 64 + lane] = pbits[k];
           }
         };

@@ -207,8 +207,11 @@ def nerf_forward(P, xyz, fr, prec, with_color=True, get_density=True, alpha=None
     spf = _spf(xyz)
     x = xyz.reshape(-1, 3)
     dev = x.device
-    sdf, feat = mlp.run_chain(mlp.NET_FG_BASE, prec, P, x, spf, conds={0: fr["code_base"], 4: fr["code_base"]}, export_layer=8,
-                              freq_w=posenc_window(alpha, 10, dev), pfs_pre=None if ft is None else {0: ft["pf.base0"], 4: ft["pf.base4"]}, tap=tap)
+    # without the colour net nobody consumes layer 8: no export (inference mode then stores nothing at all; with only the points requiring a
+    # gradient -- the eval path's normals -- the chain runs in its point-gradient-only mode: sign words + embedding, no activations, no dZ)
+    r = mlp.run_chain(mlp.NET_FG_BASE, prec, P, x, spf, conds={0: fr["code_base"], 4: fr["code_base"]}, export_layer=8 if with_color else None,
+                      freq_w=posenc_window(alpha, 10, dev), pfs_pre=None if ft is None else {0: ft["pf.base0"], 4: ft["pf.base4"]}, tap=tap)
+    sdf, feat = r if with_color else (r, None)
     sdf = sdf.view(shape[:-1] + (1,))
     if get_density:
         out = volsdf_density(sdf, P["logibeta"])  # VolSDF (nerf.py:186-192)
@@ -229,8 +232,9 @@ def nerf_forward_bg(P, xyz, dir, codes, prec, get_density=True, alpha=None, pref
     spf = _spf(xyz)
     x = xyz.reshape(-1, 3)
     dev = x.device
-    sdf, feat = mlp.run_chain(mlp.NET_BG_BASE, prec, P, x, spf, conds={0: codes["basefield"], 4: codes["basefield"]}, export_layer=5,
-                              freq_w=posenc_window(alpha, 6, dev), prefix=prefix, tap=tap)
+    r = mlp.run_chain(mlp.NET_BG_BASE, prec, P, x, spf, conds={0: codes["basefield"], 4: codes["basefield"]}, export_layer=5 if dir is not None else None,
+                      freq_w=posenc_window(alpha, 6, dev), prefix=prefix, tap=tap)  # (no export without the colour net: see nerf_forward)
+    sdf, feat = r if dir is not None else (r, None)
     sdf = sdf.view(shape[:-1] + (1,))
     if get_density:
         out = volsdf_density(sdf, P[prefix + "logibeta"])

@@ -84,13 +84,13 @@ WS_NETS = (0, 1, 5, 11)  # fg_base, fg_color, dense, dense6: the 256-wide posenc
 
 def ws_active(net, prec, dx_only=False):
     """Whether lab4d_mlp_forward / _backward launch the weights-stationary chain kernels for this call (mirrors launch_ws_fwd / launch_ws_bwd in
-    csrc/mlp_kernels.hpp: bf16, the 256-wide posenc nets, not the point-gradient-only modes, LAB4D_WS unset or non-zero)."""
+    csrc/mlp_kernels.hpp: bf16, the 256-wide posenc nets -- training, inference and point-gradient-only modes -- LAB4D_WS unset or non-zero)."""
     e = os.environ.get("LAB4D_WS")
     try:
         on = e is None or int(e.strip() or "0") != 0
     except ValueError:
         on = False  # atoi() of a non-number is 0
-    return bool(on and prec == PREC_BF16 and net in WS_NETS and not dx_only)
+    return bool(on and prec == PREC_BF16 and net in WS_NETS)
 
 
 def chain_kernel_name(kind, net, prec, dx_only=False):

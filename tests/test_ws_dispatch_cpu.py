@@ -27,14 +27,15 @@ def test_env_switch_follows_atoi(monkeypatch):
         assert mlp.ws_active(mlp.NET_FG_BASE, mlp.PREC_BF16) is on, val
     monkeypatch.delenv("LAB4D_WS", raising=False)
     assert not mlp.ws_active(mlp.NET_FG_BASE, mlp.PREC_F32)
-    assert not mlp.ws_active(mlp.NET_FG_BASE, mlp.PREC_BF16, dx_only=True)
+    assert mlp.ws_active(mlp.NET_FG_BASE, mlp.PREC_BF16, dx_only=True)  # the point-gradient-only modes have weights-stationary kernels too
     assert not mlp.ws_active(mlp.NET_VIS, mlp.PREC_BF16)
 
 
 def test_dispatch_rule_in_the_sources():
     src = open(os.path.join(ROOT, "lab4d_amd", "csrc", "mlp_kernels.hpp")).read()
     # forward: not the point-gradient-only mode; backward: dZ wanted
-    assert re.search(r"launch_ws_fwd.*?if \(!ws_enabled\(\) \|\| \(k0\.emb && !k0\.act\[0\]\)\) return false;", src, re.S)
-    assert re.search(r"launch_ws_bwd.*?if \(!ws_enabled\(\) \|\| !k0\.dz\[0\]\) return false;", src, re.S)
+    assert re.search(r"launch_ws_fwd.*?if \(!ws_enabled\(\)\) return false;", src, re.S)
+    assert re.search(r"launch_ws_bwd.*?if \(!ws_enabled\(\)\) return false;", src, re.S)
+    assert "k_mlp_fwd_ws<Net, true, false>" in src and "k_mlp_bwd_ws<Net, false>" in src  # point-gradient-only variants
     ws = open(os.path.join(ROOT, "lab4d_amd", "csrc", "mlp_kernels_ws.hpp")).read()
     assert "return e == nullptr || atoi(e) != 0;" in ws

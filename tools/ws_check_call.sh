@@ -1,4 +1,6 @@
 #!/bin/bash
+# Weights-stationary chains on the GPU box (one gpurun call): bit comparison against the wave-resident kernels per net, timing of both families,
+# and -- for every kernel-experiment build under gpurun_abl/ (tools/build_variants.sh =WS_TRACE ...) -- its timing / cycle trace.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R && mkdir -p gpurun_out
 for net in fg_base fg_color dense dense6; do

@@ -18,13 +18,13 @@ NETS = {"fg_base": mlp.NET_FG_BASE, "fg_color": mlp.NET_FG_COLOR, "dense": mlp.N
 BF = mlp.PREC_BF16
 
 
-def make_case(net, S, spf, seed, with_freq_w=False, train=True, want_dx=True):
+def make_case(net, S, spf, seed, with_freq_w=False, train=True, want_dx=True, dx_only=False):
     g = torch.Generator(device="cuda").manual_seed(seed)
     d = mlp.describe(net)
     NL = d.n_layers
     S_pad = mlp.s_pad_of(S)
     M = (S + spf - 1) // spf
-    c = {"net": net, "S": S, "S_pad": S_pad, "spf": spf, "NL": NL, "d": d, "train": train, "want_dx": want_dx}
+    c = {"net": net, "S": S, "S_pad": S_pad, "spf": spf, "NL": NL, "d": d, "train": train, "want_dx": want_dx, "dx_only": dx_only}
     c["x"] = (torch.rand(S, 3, device="cuda", generator=g) * 0.6 - 0.3).contiguous()
     c["freq_w"] = torch.rand(d.n_freq, device="cuda", generator=g).contiguous() if with_freq_w else None
     c["W"], c["WT"], c["bias"], c["pf"] = [], [], [], []
@@ -61,7 +61,7 @@ def run_fwd(c, ws):
         a.bias[l] = _lib.dp(c["bias"][l])
         if L.pf_bias:
             a.pf_bias[l] = _lib.dp(c["pf"][l])
-        if (c["train"] and l + 1 < NL) or l == c["export"]:
+        if ((c["train"] and l + 1 < NL) or l == c["export"]) and not c["dx_only"]:
             r["act"][l] = torch.zeros(mlp.buf_numel(L.mout_pad, S_pad), dtype=torch.bfloat16, device="cuda")
             a.act[l] = _lib.dp(r["act"][l])
         if c["train"] and L.relu and l + 1 < NL:
@@ -93,8 +93,9 @@ def run_bwd(c, f, ws):
             a.act[l] = _lib.dp(f["act"][l])
         if f["mask"][l] is not None:
             a.mask[l] = _lib.dp(f["mask"][l])
-        r["dz"][l] = torch.zeros(mlp.buf_numel(L.mout_pad, S_pad), dtype=torch.bfloat16, device="cuda")
-        a.dz[l] = _lib.dp(r["dz"][l])
+        if not c["dx_only"]:
+            r["dz"][l] = torch.zeros(mlp.buf_numel(L.mout_pad, S_pad), dtype=torch.bfloat16, device="cuda")
+            a.dz[l] = _lib.dp(r["dz"][l])
     if c["ext_gin"] is not None:
         a.ext_gin = _lib.dp(c["ext_gin"])
     a.emb = _lib.dp(f["emb"])
@@ -166,7 +167,8 @@ def compare(c, tag, report):
         # backward of both families on the SAME (wave-resident) forward state
         b0, b1 = run_bwd(c, f0, False), run_bwd(c, f0, True)
         for l in range(NL - 1, -1, -1):
-            ok &= cmp_bits("dz[%d]" % l, b0["dz"][l], b1["dz"][l], d.layers[l].mout_pad, rep)
+            if b0["dz"][l] is not None:
+                ok &= cmp_bits("dz[%d]" % l, b0["dz"][l], b1["dz"][l], d.layers[l].mout_pad, rep)
         if b0["ext_gout"] is not None:
             le = [l for l in range(NL) if d.layers[l].add_ext][0]
             ok &= cmp_bits("ext_gout", b0["ext_gout"], b1["ext_gout"], d.layers[le].mout_pad, rep)
@@ -225,14 +227,16 @@ if __name__ == "__main__":
     all_ok = True
     for name in a.nets.split(","):
         net = NETS[name]
-        cases = [(1000, 300, False, True, True), (128 * 37 + 77, 1000, True, True, True), (4096, 2048, False, True, False), (700, 128, False, False, True)]
+        cases = [(1000, 300, False, True, True, False), (128 * 37 + 77, 1000, True, True, True, False), (4096, 2048, False, True, False, False), (700, 128, False, False, True, False)]
+        if name == "fg_base":
+            cases.append((128 * 21 + 5, 512, True, True, True, True))  # point-gradient-only mode (sign words + embedding only, no dZ): the sdf basefields
         if a.quick:
             cases = cases[:1]
-        for i, (S, spf, fw, train, dx) in enumerate(cases):
-            tag = "%s S=%d spf=%d freq_w=%s train=%s dx=%s" % (name, S, spf, fw, train, dx)
+        for i, (S, spf, fw, train, dx, dxo) in enumerate(cases):
+            tag = "%s S=%d spf=%d freq_w=%s train=%s dx=%s dx_only=%s" % (name, S, spf, fw, train, dx, dxo)
             print("== " + tag, flush=True)
             try:
-                all_ok &= compare(make_case(net, S, spf, 11 + i, fw, train, dx), tag, report)
+                all_ok &= compare(make_case(net, S, spf, 11 + i, fw, train, dx, dxo), tag, report)
             except Exception as e:  # a failing launch must not hide the other cases
                 print("EXC  " + repr(e), flush=True)
                 report.append({"case": tag, "ok": False, "exception": repr(e)})
