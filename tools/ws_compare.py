@@ -183,9 +183,9 @@ def compare(c, tag, report):
     return ok
 
 
-def time_case(net, S, report):
-    c = make_case(net, S, S // 2, 7)
-    out = {"net": mlp.NET_NAMES[net], "S": S}
+def time_case(net, S, report, dx_only=False):
+    c = make_case(net, S, S // 2, 7, dx_only=dx_only)
+    out = {"net": mlp.NET_NAMES[net], "S": S, "dx_only": dx_only}
     for ws in (False, True):
         f = run_fwd(c, ws)
         b = run_bwd(c, f, ws)
@@ -221,6 +221,7 @@ if __name__ == "__main__":
     ap.add_argument("--nets", default="fg_base,fg_color,dense,dense6")
     ap.add_argument("--json", default=None)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--time-dx-only", action="store_true")
     a = ap.parse_args()
     _lib.lib()
     report, timing = [], []
@@ -244,6 +245,8 @@ if __name__ == "__main__":
     if a.time:
         for name in a.nets.split(","):
             time_case(NETS[name], a.time, timing)
+            if name == "fg_base" and a.time_dx_only:
+                time_case(NETS[name], a.time, timing, dx_only=True)
     if a.json:
         json.dump({"all_bit_equal": bool(all_ok), "cases": report, "timing": timing}, open(a.json, "w"), indent=1)
     print("ALL_OK" if all_ok else "SOME_DIFF")
