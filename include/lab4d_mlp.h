@@ -112,7 +112,10 @@ typedef struct {
   const float* pf_bias[LAB4D_MLP_MAX_LAYERS]; /* (M, mout_pad) fp32 per-frame bias of the pf_bias layers.  It REPLACES bias[l]
                                                  there (the host adds the shared bias into every row: the kernel fetches
                                                  one bias vector per tile, not two)                                   */
-  void* act[LAB4D_MLP_MAX_LAYERS];  /* stored post-activation (blocked [64-sample block][mout_pad][64] + skew) or NULL */
+  void* act[LAB4D_MLP_MAX_LAYERS];  /* stored post-activation (blocked [64-sample block][mout_pad][64] + skew) or NULL.  Training mode (emb given): every
+                                       hidden layer's buffer, or NONE (act[0] == NULL: the point-gradient-only mode of the sdf basefields LAB4D_NET_FG_BASE /
+                                       _BG_BASE -- sign words + embedding stored, nothing else; no export buffer either).  Inference (emb NULL): only the
+                                       layer another net consumes, if wanted */
   void* mask[LAB4D_MLP_MAX_LAYERS]; /* ReLU sign bits, uint32 [S_pad/TILE][mout_pad/32][64] (TILE = 64 bf16 / 32 fp32), or NULL */
   void* emb;                        /* [ke][ld] stored embedding or NULL                                */
   const void* ext;                  /* [mout_pad][ld] tensor added at the add_ext layer                 */
@@ -181,7 +184,8 @@ typedef struct {
   const float* d_out;                          /* (S, c_out) gradient of the head output                   */
   const void* ext_gin;                         /* [mout_pad][ld] gradient added at the ext_grad layer   */
   void* ext_gout;                              /* [mout_pad][ld] gradient wrt `ext` (written) or NULL   */
-  void* dz[LAB4D_MLP_MAX_LAYERS];              /* [mout_pad][ld] dL/d(pre-activation) (written)         */
+  void* dz[LAB4D_MLP_MAX_LAYERS];              /* [mout_pad][ld] dL/d(pre-activation) (written): every layer's, or NONE (dz[0] == NULL with d_x given:
+                                                  point gradient only, the sdf basefields -- nothing for a weight gradient is written) */
   float* d_x;                                  /* (S,3) or (S,c_in) gradient wrt the input, or NULL        */
   float* d_x2;                                 /* LAB4D_NET_BG_COLOR: (S,3) gradient wrt x2 (written with d_x), or NULL */
   /* emb_kind 2 nets only (NULL otherwise): the adjoint of the per-frame affine first layer is taken inside the chain kernel */
