@@ -948,7 +948,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
             constexpr int k = decltype(kc)::value;
             const int b = IT::blk(w, k);
             constexpr int KL = IT::IPW - 1;
-            f32x16_t acc[2];
+              f32x16_t acc[2];
             if constexpr (k == KL) mfma_item(b, acc, std::true_type{}, std::integral_constant<int, GKn>{}, Wn, rtn, kc);
             else mfma_item(b, acc, std::false_type{}, std::integral_constant<int, 0>{}, Wn, rtn, kc);
             if constexpr (lp.ext_grad != 0) {
