@@ -238,6 +238,24 @@ __device__ __forceinline__ void ws_pin_sgpr(T*& p) {
   p = (T*)v;
 }
 
+// compile-time checks of the piece schedule for every (G, NPI) the kernels instantiate: one piece in flight (a piece is stored before the next one is
+// read), every stage inside its loop, every counted wait encodable and never above what was really issued in between
+template <int G, int NPI>
+constexpr bool ws_spread_ok() {
+  using SP = WsSpread<G, NPI>;
+  for (int i = 0; i < NPI; ++i) {
+    if (!(SP::issue_at(i) < SP::perm_at(i) && SP::perm_at(i) < SP::store_at(i) && SP::store_at(i) < G)) return false;
+    if (i + 1 < NPI && !(SP::store_at(i) < SP::issue_at(i + 1))) return false;
+    for (int bd = 1; bd <= 8; ++bd) {
+      const int n0 = SP::newer(SP::issue_at(i), true, SP::perm_at(i), bd), n1 = SP::newer(SP::perm_at(i), false, SP::store_at(i), bd);
+      if (n0 < 0 || n0 > 4 || n1 < 0 || n1 > 4) return false;  // two groups at two reads each, at most
+    }
+  }
+  return true;
+}
+static_assert(ws_spread_ok<16, 4>() && ws_spread_ok<20, 4>() && ws_spread_ok<8, 2>() && ws_spread_ok<16, 2>(), "WsSpread schedule");
+static_assert(!WsSpread<16, 8>::OK && !WsSpread<4, 4>::OK, "layers too short to host their pieces fall back to the burst");
+
 // ---- LDS byte address of the uint4 array element (address space 3 pointers are 32 bit) ----
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
 
