@@ -912,6 +912,8 @@ def rank_main(a):
                                    % (res, res, spp), "rays_per_step": rays_per_step, "chunk_rays": 2 * a.chunk_rows * res,
                        "parallelism": "rows dealt round-robin to %d rank(s) and to each rank's chunks, one RCCL all-reduce of the flat fp32 gradient (%d elements) per step" % (world, opt.n),
                        "launch": launch_mode,
+                       "chain_kernels": ("weights-stationary (csrc/mlp_kernels_ws.hpp) for the 256-wide nets, wave-resident for the others"
+                                         if (a.dtype == "bf16" and mlp.ws_active(mlp.NET_FG_BASE, mlp.PREC_BF16)) else "wave-resident (csrc/mlp_kernels.hpp)"),
                        "optimizer": "lab4d_amd.optim.FlatAdamW: clip_grad_norm_(5.0) + AdamW in 3 launches over one flat buffer; "
                                     "weight gradients accumulated into it by the wgrad kernels; a step whose pre-clip norm exceeds 5 (or is not finite) is "
                                     "discarded on the device like Trainer.check_grad does (steps_discarded below)"},
