@@ -39,3 +39,16 @@ def test_dispatch_rule_in_the_sources():
     assert "k_mlp_fwd_ws<Net, true, false>" in src and "k_mlp_bwd_ws<Net, false>" in src  # point-gradient-only variants
     ws = open(os.path.join(ROOT, "lab4d_amd", "csrc", "mlp_kernels_ws.hpp")).read()
     assert "return e == nullptr || atoi(e) != 0;" in ws
+
+
+def test_profile_names_of_the_weights_stationary_kernels():
+    """rocprofv3 kernel symbols -> the names bench.py reports (tools/pmc_summary.short): the PMC traffic of a kernel is looked up under that name."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.short("void lab4d::k_mlp_fwd_ws<lab4d::NetFgBase, true, true>(lab4d::FwdK)") == "k_mlp_fwd_ws<FgBase>"
+    assert m.short("void lab4d::k_mlp_bwd_ws<lab4d::NetFgColor, true>(lab4d::BwdK)") == "k_mlp_bwd_ws<FgColor>"
+    assert m.short("void lab4d::k_mlp_fwd<lab4d::NetFeat, lab4d::PBF16, false, true, true>(lab4d::FwdK)") == "k_mlp_fwd<Feat>"
+    assert m.short("void lab4d::k_mlp_wgrad_dma<8, 4, 8, 2>(unsigned short const*)") == "k_mlp_wgrad_dma<8,4>"
+    assert mlp.chain_kernel_name("fwd", mlp.NET_FG_BASE, mlp.PREC_BF16) == "k_mlp_fwd_ws<FgBase>"
