@@ -12,12 +12,18 @@
 //   * the wave converts / activates its 32 x 64 output slice and writes it as units (2w, 2w+1) of the OTHER half of a double-buffered
 //     2 x 64 KiB activation slab: ONE workgroup barrier per layer (10 per 128 samples instead of 76 per 64);
 //   * the next layer's A groups replace the current ones right behind their last MFMA (the fetch hides behind the last block's matrix work);
-//   * tiles leave for HBM through ds_read_b64_tr_b16 (tr_issue / tr_store of mlp_kernels.hpp: no VALU transposes), and they leave LATE: a
-//     layer's tile / mask stores are issued inside the NEXT layer, behind that layer's bias / mask / ext requests, so no load ever queues
-//     behind a store in the in-order vector-memory counter.
+//   * tiles leave for HBM through ds_read_b64_tr_b16 (no VALU transposes), LATE and in PIECES: a layer's tile / sign-word stores are issued inside
+//     the NEXT layer, a quarter tile every four k-groups between its MFMAs (WsSpread), behind that layer's own requests;
+//   * shared bias rows live in LDS for the life of the workgroup, per-frame rows per tile (tiles inside one frame); the next layer's pointers are
+//     scalar-loaded a layer ahead; the positional encoding is evaluated once per (sample, axis) into a scratch that aliases an activation buffer.
 // Everything that reaches HBM has the layout and the VALUES of the wave-resident kernels (same packed weights, same accumulation order per
 // output element: bias, then the k-groups in ascending order; same packed epilogue), so the two families are interchangeable launch by launch
-// and are held bit-equal to each other in tests/test_gpu_mlp_ws.py.  bf16, EMB == 0 (posenc) nets whose widest layer is 256.
+// and are held bit-equal to each other in tests/test_gpu_mlp_ws.py.  bf16, EMB == 0 (posenc) nets whose widest layer is 256; training, inference
+// and point-gradient-only modes.
+// Measured (profiles/r04_ws_*.json, r04_clock_under_load.json): -25 % / -17 % shader cycles against the wave-resident forward /
+// backward, -10 % time -- these kernels hold the package at its power cap and the denser one is clocked lower.
+// Build switches: -DLAB4D_WS_TRACE (per-wave cycle trace, outputs wrong), -DLAB4D_WSABL_{NOFLUSH,NOST,NOTR,NOAPF,NOBIAS,NOPOSENC} and -DLAB4D_ABL_L2STORE
+// (timing-only ablations, results wrong), -DLAB4D_WS_LINEAR_STORE (lane-linear stores through ds_bpermute: correct, slower), -DLAB4D_WS_BD=n (B ring depth).
 #pragma once
 #include "mlp_kernels.hpp"
 
