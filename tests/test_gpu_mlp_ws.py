@@ -70,3 +70,43 @@ def test_the_dispatch_really_switches_kernels():
         torch.cuda.synchronize()
         t[ws] = e0.elapsed_time(e1)
     assert t[True] < 0.9 * t[False], t
+
+
+def test_a_training_pass_is_the_same_on_both_families():
+    """End to end (rays -> warp -> chains -> compositing -> losses -> backward) with LAB4D_WS = 0 / 1: every rendered channel is bit-equal (every chain launch
+    is) except the eikonal term, which is formed from d_x; the parameter gradients agree to fp32 summation order (d_x partials per row tile, atomics in the weight-gradient kernels)."""
+    from lab4d_amd import deformable as DF
+    from lab4d_amd import mlp, synthetic
+    M, N, D, res = 2, 64, 16, 64
+    P0 = synthetic.make_weights(3)
+    g = torch.Generator().manual_seed(5)
+    hxy = torch.cat([torch.rand(M, N, 2, generator=g) * res, torch.ones(M, N, 1)], -1).cuda()
+    rng = synthetic.to_device({"eik_inds": torch.arange(8), "match_perm": torch.randperm(M * N * D, generator=g)[:1024]}, "cuda")
+    res_by = {}
+    for ws in ("0", "1"):
+        os.environ["LAB4D_WS"] = ws
+        mlp.clear_caches()
+        Pd = synthetic.to_device(P0, "cuda")
+        for v in Pd.values():
+            if v.dtype.is_floating_point:
+                v.requires_grad_(True)
+        frd = synthetic.add_codes(synthetic.to_device(synthetic.make_frames(4, M, res), "cuda"), Pd)
+        bd = synthetic.to_device(synthetic.make_targets(6, M, N, res, hxy.cpu()), "cuda")
+        frd["feature"] = bd["feature"]
+        out = DF.render_train(Pd, frd, hxy, rng, flow_thresh=float(res), n_depth=D, prec=mlp.PREC_BF16)
+        loss = sum(DF.losses_fg(out, bd, res, DF.DEFAULT_LOSS_WT).values())
+        loss.backward()
+        res_by[ws] = ({k: v.detach().clone() for k, v in out["rendered"].items() if torch.is_tensor(v)}, float(loss.detach()),
+                      {k: v.grad.detach().clone() for k, v in Pd.items() if v.grad is not None})
+    r0, l0, g0 = res_by["0"]
+    r1, l1, g1 = res_by["1"]
+    for k in r0:
+        if k == "eikonal":  # |d sdf / dx| of the drawn rays: a function of d_x, whose row-tile partials add up in another order
+            assert float((r0[k] - r1[k]).abs().max()) <= 1e-5 * (float(r0[k].abs().max()) + 1e-20), k
+        else:
+            assert torch.equal(r0[k], r1[k]), "rendered[%s] differs between the kernel families" % k
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    assert set(g0) == set(g1)
+    for k in g0:
+        den = float(g0[k].abs().max()) + 1e-20
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-3 * den, (k, float((g0[k] - g1[k]).abs().max()), den)
