@@ -22,7 +22,7 @@
 // and point-gradient-only modes.
 // Measured (profiles/r04_ws_*.json, r04_clock_under_load.json): -25 % / -17 % shader cycles against the wave-resident forward /
 // backward, -10 % time -- these kernels hold the package at its power cap and the denser one is clocked lower.
-// Build switches: -DLAB4D_WS_TRACE (per-wave cycle trace, outputs wrong), -DLAB4D_WSABL_{NOFLUSH,NOST,NOTR,NOAPF,NOBIAS,NOPOSENC} and -DLAB4D_ABL_L2STORE
+// Build switches: -DLAB4D_WS_TRACE (per-wave cycle trace, outputs wrong), -DLAB4D_WSABL_{NOFLUSH,NOST,NOTR,NOAPF,NOBIAS,NOPOSENC,HALFB} and -DLAB4D_ABL_L2STORE
 // (timing-only ablations, results wrong), -DLAB4D_WS_LINEAR_STORE (lane-linear stores through ds_bpermute: correct, slower), -DLAB4D_WS_BD=n (B ring depth).
 #pragma once
 #include "mlp_kernels.hpp"
@@ -542,6 +542,9 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
           const unsigned pe_a = ebuf_lds + (unsigned)((2 * b * UE) * 1024 + lane * 16), px_a = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + (2 * b * 16) * 1024 + lane * 16);
           auto b_read = [&](auto gc, u32x4_t (&dst)[2]) {
             constexpr int g = decltype(gc)::value;
+#ifdef LAB4D_WSABL_HALFB  // timing experiment (results wrong): every second k-group reuses whatever the ring slot holds -- half the B reads, as if one read fed two MFMAs
+            if constexpr (g % 2 == 1) return;
+#endif
             if constexpr (g < GE) {
               ws_lds_read<g * 1024>(dst[0], pe_a);
               ws_lds_read<(UE + g) * 1024>(dst[1], pe_a);
@@ -904,6 +907,9 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
         const unsigned px_a = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + (2 * b * 16) * 1024 + lane * 16);
         auto b_read = [&](auto gc, u32x4_t (&dst)[2]) {
           constexpr int g = decltype(gc)::value;
+#ifdef LAB4D_WSABL_HALFB
+          if constexpr (g % 2 == 1) return;
+#endif
           ws_lds_read<g * 1024>(dst[0], px_a);
           ws_lds_read<(16 + g) * 1024>(dst[1], px_a);
         };
