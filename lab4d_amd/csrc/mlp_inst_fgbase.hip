@@ -8,6 +8,10 @@ template <>
 int launch_mlp_fwd_tangent<NetFgBase>(int precision, const FwdK& k0, int S, hipStream_t st) {
   FwdK k = k0;
   if (precision == LAB4D_PREC_BF16) {
+    if (ws_enabled()) {  // the weights-stationary family (mlp_kernels_ws.hpp), bit-equal
+      hipLaunchKernelGGL((k_mlp_fwd_ws<NetFgBase, true, true, true>), dim3(mlp_grid_ws(k.S_pad / WS_TILE)), dim3(512), 0, st, k);
+      return check_launch("mlp_forward_tangent");
+    }
     k.ntiles = k.S_pad / PBF16::TILE;
     LAB4D_MLP_LAUNCH((k_mlp_fwd<NetFgBase, PBF16, true, true>), k, st);
   } else if (precision == LAB4D_PREC_F32) {

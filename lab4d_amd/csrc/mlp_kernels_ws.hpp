@@ -271,7 +271,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // ST = training mode: embedding, every hidden post-activation and every ReLU sign word are stored (pointers host-checked);
 // !ST = inference: only a layer another net consumes (act[l] != NULL) is stored.
 // ACTS = false (with ST): the point-gradient-only mode of the sdf basefields (eval normals, nerf.py:455-493): embedding and sign words only
-template <class Net, bool ST, bool ACTS = true>
+// TAN = tangent mode (the eikonal term, see k_mlp_fwd): the input is a raw (S, KE) tangent vector in embedding-slot order, no biases, ReLU replaced by the
+// sign words the primal pass stored (read, not written); the tangent activations and the tangent embedding are stored for the weight gradients
+template <class Net, bool ST, bool ACTS = true, bool TAN = false>
 __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   static_assert(ws_ok<Net>(), "weights-stationary chain: 256-wide posenc nets only");
   using P = PBF16;
@@ -289,7 +291,9 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   const unsigned xbuf_lds = lds_addr(xbuf), ebuf_lds = lds_addr(ebuf);
   sfor<0, NL>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
-    if constexpr (Net::L[l].pf == 0) {
+    if constexpr (TAN) {
+      if (tid < 256) bias_lds[l * 256 + tid] = 0.f;  // tangent mode: no bias anywhere
+    } else if constexpr (Net::L[l].pf == 0) {
       if (tid < 32 * ws_mt<Net>(l)) bias_lds[l * 256 + tid] = ((const GLOBAL_AS float*)a.bias[l])[tid];
     }
   });
@@ -341,8 +345,8 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
 
     // per-frame bias rows of this tile's frame -> LDS (tiles inside one frame: the training shapes); tiles that straddle frames (and the compacted
     // evaluation, whose samples name their frames one by one) read theirs per lane from global memory
-    bool tile_uni = false;
-    if (a.frame_idx == nullptr) {
+    bool tile_uni = TAN;
+    if (!TAN && a.frame_idx == nullptr) {
       const int sl_ = s0 + WS_TILE - 1 < S_eff ? s0 + WS_TILE - 1 : S_eff - 1, sf_ = s0 < S_eff ? s0 : S_eff - 1;
       const int f0 = sf_ / a.spf, f1 = sl_ / a.spf;
       tile_uni = f0 == f1;
@@ -360,7 +364,25 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
     // Same arithmetic as k_mlp_fwd's bf16 path: one accurate sincos per axis, angle doubling per octave, times the annealing weight.
     float* scr = reinterpret_cast<float*>(xbuf + WS_BUF);
 #ifndef LAB4D_WSABL_NOPOSENC
-    {
+    if constexpr (TAN) {
+      // raw (S, KE) tangent rows -> the scratch rows the assembly below reads (16-byte pieces, coalesced; elements behind the last valid one repeat it,
+      // like stage_in of the wave-resident kernel)
+      const long e_last = (long)S_eff * KE - 1;
+      for (int p = tid; p < WS_TILE * (KE / 4); p += 512) {
+        const int sl = p / (KE / 4), c4 = p - sl * (KE / 4);
+        const int row = 64 * (sl >> 6) + 32 * (sl & 1) + ((sl & 63) >> 1);
+        const long e0 = (long)(s0 + sl) * KE + 4 * c4;
+        float4 v;
+        if (e0 + 3 <= e_last) {
+          const f32x4_t g4 = *(const GLOBAL_AS f32x4_t*)((const GLOBAL_AS float*)a.x + e0);
+          v = make_float4(g4.x, g4.y, g4.z, g4.w);
+        } else {
+          const GLOBAL_AS float* gx = (const GLOBAL_AS float*)a.x;
+          v = make_float4(gx[e0 <= e_last ? e0 : e_last], gx[e0 + 1 <= e_last ? e0 + 1 : e_last], gx[e0 + 2 <= e_last ? e0 + 2 : e_last], gx[e0 + 3 <= e_last ? e0 + 3 : e_last]);
+        }
+        *reinterpret_cast<float4*>(scr + row * ESTR + 4 * c4) = v;
+      }
+    } else {
       const int sl = tid & 127, q = __builtin_amdgcn_readfirstlane(tid >> 7);
       const int row = 64 * (sl >> 6) + 32 * (sl & 1) + ((sl & 63) >> 1);  // rows ordered (block, n-tile, lane n)
       const int s = s0 + sl, sc = s < S_eff ? s : S_eff - 1;
@@ -472,6 +494,14 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       // ---- requests go out BEFORE the stores of the layer in front: the next layer's A groups this layer has no use for, the first item's bias / ext tile ----
 #pragma unroll
       for (int g = G; g < Gn; ++g) A[g] = load_a(Wn, Gn, mtn, g, lane);
+      unsigned int tbits[2] = {0xffffffffu, 0xffffffffu};  // tangent mode: the primal's sign words of this wave's items
+      if constexpr (TAN && ls.relu != 0 && !LAST) {
+        if (active) {
+          const GLOBAL_AS unsigned int* mown = KARG_PTR(FwdK, unsigned int*, mask, l);
+#pragma unroll
+          for (int k = 0; k < IT::IPW; ++k) tbits[k] = mown[((size_t)(2 * tile + IT::blk(w, k)) * MT + mt) * 64 + lane];
+        }
+      }
       f32x16_t bv[2];
 #ifdef LAB4D_WSABL_NOBIAS
 #pragma unroll
@@ -515,7 +545,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
               tr_wait(trt);
               tr_store(actp, 32 * MTp, s0 + 64 * b, mtp, lane, trt);
             }
-            if constexpr (ST && Net::L[R > 0 ? R - 1 : 0].relu != 0) maskp[((size_t)(2 * tile + b) * MTp + mtp) * 64 + lane] = pbits[k];
+            if constexpr (ST && !TAN && Net::L[R > 0 ? R - 1 : 0].relu != 0) maskp[((size_t)(2 * tile + b) * MTp + mtp) * 64 + lane] = pbits[k];
           }
         };
         if constexpr (ST) {
@@ -592,7 +622,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
                 if constexpr (SP::store_at(i) == g) {
 #ifndef LAB4D_WSABL_NOFLUSH
                   ws_trp_store<qa, SP::newer(SP::perm_at(i), false, g, BD)>(actp, 32 * MTp, s0 + 64 * ITp::blk(w, kp), mtp, lane, tp);
-                  if constexpr (qa == 3 && Net::L[R > 0 ? R - 1 : 0].relu != 0) maskp[((size_t)(2 * tile + ITp::blk(w, kp)) * MTp + mtp) * 64 + lane] = pbits[kp];
+                  if constexpr (!TAN && qa == 3 && Net::L[R > 0 ? R - 1 : 0].relu != 0) maskp[((size_t)(2 * tile + ITp::blk(w, kp)) * MTp + mtp) * 64 + lane] = pbits[kp];
 #endif
                 }
               });
@@ -618,7 +648,12 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
               for (int kk = 0; kk < 8; ++kk) pw[t][kk] = pack2bf_op(acc[t][2 * kk], acc[t][2 * kk + 1]);
-            if constexpr (ls.relu != 0) {
+            if constexpr (ls.relu != 0 && TAN) {
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) pw[t][kk] = pk_mask_bf16(pw[t][kk], pk_m01(tbits[k], t, kk));
+            } else if constexpr (ls.relu != 0) {
               if constexpr (ST) pbits[k] = pk_alive_bits(pw);
 #pragma unroll
               for (int t = 0; t < 2; ++t)

@@ -940,7 +940,7 @@ class EikonalSdf(Function):
                 a.act[l] = _lib.dp(tact[l])
         temb = torch.empty(buf_numel(d.ke, S_pad), dtype=sdt, device=dev)
         a.emb = _lib.dp(temb)
-        with _lib.timed("k_mlp_fwd_tangent<%s>@eik" % KERNEL_NET[net]):
+        with _lib.timed(("k_mlp_fwd_ws_tangent<%s>@eik" if (ws_active(net, prec) and net == NET_FG_BASE) else "k_mlp_fwd_tangent<%s>@eik") % KERNEL_NET[net]):
             _lib.check(_lib.lib().lab4d_mlp_forward_tangent(ctypes.byref(a), _lib.stream()), "mlp_forward_tangent")
         sinks = [(_grad_sink(Ws[l]) if ctx.needs_input_grad[7 + 2 * l] else None) for l in range(NL)]
         sizes = [0 if sinks[l] is not None else d.layers[l].mout_pad * (d.layers[l].ke + d.layers[l].kin) for l in range(NL)]

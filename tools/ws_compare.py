@@ -115,6 +115,32 @@ def run_bwd(c, f, ws):
     return r
 
 
+def run_tangent(c, f, ws):
+    """lab4d_mlp_forward_tangent (the eikonal term's forward): raw (S, ke) tangent input, the primal's sign words as input, tangent activations / embedding / output written"""
+    os.environ["LAB4D_WS"] = "1" if ws else "0"
+    d, NL, S, S_pad = c["d"], c["NL"], c["S"], c["S_pad"]
+    a = mlp.FwdArgs()
+    a.net, a.precision, a.S, a.S_pad, a.ld, a.spf = c["net"], BF, S, S_pad, S_pad, c["spf"]
+    a.x = _lib.dp(c["x_tan"])
+    r = {"act": [None] * NL, "mask": [None] * NL}
+    for l in range(NL):
+        L = d.layers[l]
+        a.W[l] = _lib.dp(c["W"][l])
+        if f["mask"][l] is not None:
+            a.mask[l] = _lib.dp(f["mask"][l])
+        if l + 1 < NL:
+            r["act"][l] = torch.zeros(mlp.buf_numel(L.mout_pad, S_pad), dtype=torch.bfloat16, device="cuda")
+            a.act[l] = _lib.dp(r["act"][l])
+    r["emb"] = torch.zeros(mlp.buf_numel(d.ke, S_pad), dtype=torch.bfloat16, device="cuda")
+    a.emb = _lib.dp(r["emb"])
+    r["out"] = torch.zeros(S, d.c_out, device="cuda")
+    a.out = _lib.dp(r["out"])
+    r["args"] = a
+    _lib.check(_lib.lib().lab4d_mlp_forward_tangent(ctypes.byref(a), _lib.stream()), "mlp_forward_tangent")
+    torch.cuda.synchronize()
+    return r
+
+
 def cmp_bits(name, x, y, F=None, report=None):
     """bit comparison of two buffers; F: feature rows of a blocked [64-sample block][feature][64] buffer (decodes the first mismatches)"""
     if x is None and y is None:
@@ -163,6 +189,14 @@ def compare(c, tag, report):
         if f0["mask"][l] is not None:
             ok &= cmp_bits("mask[%d]" % l, f0["mask"][l], f1["mask"][l], None, rep)
     ok &= cmp_bits("out", f0["out"], f1["out"], None, rep)
+    if c.get("tangent"):
+        g = torch.Generator(device="cuda").manual_seed(99)
+        c["x_tan"] = torch.randn(c["S"], d.ke, device="cuda", generator=g).contiguous()
+        t0, t1 = run_tangent(c, f0, False), run_tangent(c, f0, True)
+        ok &= cmp_bits("tangent emb", t0["emb"], t1["emb"], d.ke, rep)
+        for l in range(NL - 1):
+            ok &= cmp_bits("tangent act[%d]" % l, t0["act"][l], t1["act"][l], d.layers[l].mout_pad, rep)
+        ok &= cmp_bits("tangent out", t0["out"], t1["out"], None, rep)
     if c["train"]:
         # backward of both families on the SAME (wave-resident) forward state
         b0, b1 = run_bwd(c, f0, False), run_bwd(c, f0, True)
@@ -230,6 +264,7 @@ if __name__ == "__main__":
         net = NETS[name]
         cases = [(1000, 300, False, True, True, False), (128 * 37 + 77, 1000, True, True, True, False), (4096, 2048, False, True, False, False), (700, 128, False, False, True, False)]
         if name == "fg_base":
+            cases.append((128 * 9 + 37, 700, False, True, True, False))  # + the tangent-mode forward of the eikonal term on this case's sign words (flag set below)
             cases.append((128 * 21 + 5, 512, True, True, True, True))  # point-gradient-only mode (sign words + embedding only, no dZ): the sdf basefields
         if a.quick:
             cases = cases[:1]
@@ -237,7 +272,9 @@ if __name__ == "__main__":
             tag = "%s S=%d spf=%d freq_w=%s train=%s dx=%s dx_only=%s" % (name, S, spf, fw, train, dx, dxo)
             print("== " + tag, flush=True)
             try:
-                all_ok &= compare(make_case(net, S, spf, 11 + i, fw, train, dx, dxo), tag, report)
+                cs = make_case(net, S, spf, 11 + i, fw, train, dx, dxo)
+                cs["tangent"] = (name == "fg_base" and S == 128 * 9 + 37)
+                all_ok &= compare(cs, tag, report)
             except Exception as e:  # a failing launch must not hide the other cases
                 print("EXC  " + repr(e), flush=True)
                 report.append({"case": tag, "ok": False, "exception": repr(e)})
