@@ -317,6 +317,68 @@ def fp32_leg(a):
         return {"value": None, "error": repr(e)[:300]}
 
 
+def other_configs_legs():
+    """BASELINE configs[2] / [3] / [4] at their per-GPU shapes (--config comp | multi | hash), 1 warm-up + 2 timed steps each in child processes after
+    the headline run has given its device memory back: the driver-visible line carries every configuration BASELINE.json names, not only the fg one."""
+    import subprocess
+    out = {}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for cfg in ("comp", "multi", "hash"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            leg = {"value": d["value"], "unit": "rays/s", "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
+                   "workload": d["config"]["workload"], "rays_per_step": d["config"]["rays_per_step"], "peak_hbm_gib": d.get("peak_hbm_gib"),
+                   "loss_last_chunk": d.get("loss_last_chunk"), "params_finite": d.get("params_finite"), "wall_s": round(time.perf_counter() - t0, 1)}
+            if d.get("whole_graph_frac_of_peak") is not None:
+                leg["whole_graph_frac_of_peak"] = d["whole_graph_frac_of_peak"]
+            if d.get("roofline"):
+                leg["dominant_kernel"] = {k: d["roofline"][k] for k in ("kernel", "bound", "frac", "avg_ms")}
+            if cfg == "hash":
+                leg["parity"] = "unpinned (the reference has no hash grid: nnutils/nerf.py:98 is a comment)"
+                leg["inside_box_fraction"] = d["config"].get("inside_box_fraction")
+                top = sorted(((v["ms_per_step"], k) for k, v in d.get("kernels", {}).items()), reverse=True)[:3]
+                leg["top_kernels_ms_per_step"] = {k: ms for ms, k in top}
+            out[cfg] = leg
+        except Exception as e:  # an extra: report the failure instead of losing the bench line
+            out[cfg] = {"value": None, "error": repr(e)[:300], "wall_s": round(time.perf_counter() - t0, 1)}
+    return out
+
+
+def pmc_traffic_in_run():
+    """HBM traffic of the chain / weight-gradient kernels measured IN THIS RUN (the line used to quote profiles/r04_pmc_traffic.json):
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (each with --kernel-trace only) over tools/bench_mlp.py at the bench's launch
+    size, summarised by tools/pmc_summary.py with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE x 2; KiB units).  The
+    passes profile the micro-bench, not this process (rocprofv3 --pmc around the whole bench.py has hung on this pool), each under its own timeout.
+    Returns the summary dict or None (no rocprofv3 on the box / a pass failed / LAB4D_BENCH_PMC=0)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("LAB4D_BENCH_PMC", "1") == "0" or shutil.which("rocprofv3") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="lab4d_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_mlp.py"), "16777216", "1"]
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            r = subprocess.run(["timeout", "-k", "5", "90", "rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "--"] + cmd,
+                               capture_output=True, text=True, cwd="/tmp", env=env, timeout=120)
+            if r.returncode != 0:
+                return None
+        outp = os.path.join(tmp, "pmc.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"), outp,
+                            "measured in this bench.py run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/bench_mlp.py 16777216 1"],
+                           capture_output=True, text=True, timeout=60)
+        return json.load(open(outp)) if r.returncode == 0 and os.path.exists(outp) else None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(res, spp, n_rays, config="fg"):
     """The oracle (CPU port of the reference algorithm) on a bounded sample of the same workload (same field configuration)."""
     from lab4d_amd import synthetic
@@ -510,13 +572,24 @@ def hash_main(a):
     _lib.PROF = None
     rays = 2 * res * res
     value = rays * a.steps / dt
+    with torch.no_grad():  # how much of the step carries a field at all: the grid is defined on the box only (hashfield.forward)
+        n_in = n_all = 0
+        for hxy, _ in inputs[:: max(len(inputs) // 8, 1)]:
+            xyz = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=spp)[4].reshape(-1, 3)
+            x01 = (xyz - P["aabb"][0]) / (P["aabb"][1] - P["aabb"][0])
+            n_in += int(((x01 >= 0) & (x01 <= 1)).all(-1).sum())
+            n_all += x01.shape[0]
     kern = {k: {"ms_per_step": round(v[1] / 4 * len(inputs), 2), "GBps": round(v[3] / v[1] / 1e6, 1) if v[3] else None} for k, v in sorted(prof.items())}
     out = {"metric": "rendered rays/sec (fwd+bwd), hash-grid field at %dx%d x %d samples (BASELINE configs[4] per-GPU shape; no reference counterpart, not the headline metric)" % (res, res, spp),
            "value": round(value, 1), "unit": "rays/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
            "config": {"workload": "hash-grid field (L=16, F=2, T=2^19, 16..2048; geometry net 32-64-16, colour net 19-64-64-3), %dx%d frame pair, %d samples/ray, "
                                   "rays -> samples -> field -> compositing -> rgb + mask loss -> backward -> AdamW" % (res, res, spp),
-                      "rays_per_step": rays, "chunk_rays": 2 * rows * res, "launch": "hipGraph replay per chunk" if graph is not None else "eager"},
+                      "rays_per_step": rays, "chunk_rays": 2 * rows * res, "launch": "hipGraph replay per chunk" if graph is not None else "eager",
+                      "inside_box_fraction": round(n_in / max(n_all, 1), 4),
+                      "field_support": "the box only (Instant-NGP 5.4): samples outside carry no density / colour and no table gradient -- not comparable with the "
+                                       "rounds 1-3 numbers of this leg, which clamped them onto the boundary cells",
+                      "parity": "unpinned: the reference has no hash grid"},
            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1), "kernels": kern,
            "loss_last_chunk": float(last), "params_finite": bool(all(bool(torch.isfinite(p).all()) for p in params))}
     sys.stdout.flush()
@@ -865,13 +938,9 @@ def rank_main(a):
     if rank == 0:
         peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32
         # dominant kernel = the kernel symbol with the largest event-measured time; the next three are reported beside it ("rooflines")
+        # HBM traffic of the dominant kernels (`traffic`): filled in below -- measured in this run when the box has rocprofv3 (default single-GPU fg run,
+        # once the training loop has given its memory back), else, declared in traffic_source, the newest committed PMC summary
         pmc = {}
-        for name_ in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # newest PMC summary of the dominant kernels
-            pmc_path = os.path.join(ROOT, "profiles", name_)
-            if os.path.exists(pmc_path):
-                pmc = json.load(open(pmc_path))
-                break
-
         def roof(name, launches, ms, flops, nbytes):
             # the roofline that binds a kernel = the larger of its two time floors (HBM bytes at 8 TB/s, FLOPs at the dense bf16/fp32
             # MFMA peak).  Training-mode chain kernels write every activation / dZ once: 48.6 GB against 9.6 TFLOP per 8.4 M-sample
@@ -896,7 +965,7 @@ def rank_main(a):
         if ranked:
             name, (launches, ms, flops, nbytes) = ranked[0]
             roofline = roof(name, launches, ms, flops, nbytes)
-            roofline.update({"traffic_source": pmc.get("_source") if roofline["traffic"] else None, "measured": prof_src,
+            roofline.update({"traffic_source": None, "measured": prof_src,
                              "others": [roof(k, *v) for k, v in ranked[1:4]],
                              "kernels_ms_per_step": {k: round(v[1] / n_prof_chunks * len(inputs), 2) for k, v in sorted(prof.items())}})
         flop_per_ray = comp_flop_per_ray(spp // 2) if comp else (multi_flop_per_ray(spp) if multi else spp * FLOP_PER_SAMPLE)
@@ -947,7 +1016,23 @@ def rank_main(a):
             gc.collect()
             mlp.clear_caches()
             torch.cuda.empty_cache()
+            pmc = pmc_traffic_in_run()
             out["fp32_leg"] = fp32_leg(a)
+            out["other_configs"] = other_configs_legs()
+        else:
+            pmc = None
+        if roofline is not None:
+            if pmc is None:
+                pmc = {}
+                for name_ in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                    pmc_path = os.path.join(ROOT, "profiles", name_)
+                    if os.path.exists(pmc_path):
+                        pmc = json.load(open(pmc_path))
+                        pmc["_source"] = "NOT measured in this run (no rocprofv3 on the box, a pass failed, or not the default run): committed profiles/%s -- %s" % (name_, pmc.get("_source"))
+                        break
+            for r_ in [roofline] + roofline.get("others", []):
+                r_["traffic"] = pmc.get(r_["kernel"], {}).get("hbm_bytes_per_launch")
+            roofline["traffic_source"] = pmc.get("_source") if roofline["traffic"] else None
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res, spp, a.cpu_rays, a.config)
     if use_dist:

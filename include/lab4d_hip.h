@@ -34,6 +34,9 @@ const char* lab4d_last_error(void);
 int lab4d_version(void);
 /* returns the gfx arch string the library was compiled for ("gfx950") */
 const char* lab4d_arch(void);
+/* the kernel-experiment macros (LAB4D_ABL_*, LAB4D_WSABL_*, LAB4D_WS_TRACE, ... with the LAB4D_ prefix dropped, blank separated) the library was
+ * compiled with; "" for the shipped build.  Most of them give WRONG results (timing ablations): callers refuse a library that reports any. */
+const char* lab4d_build_flags(void);
 
 /* ------------------------------------------------------------------------------------------
  * 1. dqtorch replacement -- third_party/quaternion/src/bindings.cpp:8-16, quaternion.h:11-24,

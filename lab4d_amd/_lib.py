@@ -57,7 +57,10 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + CFLAGS + (MLP_INST_FLAGS if os.path.basename(src).startswith("mlp_inst_") and "LAB4D_HIPCC_EXTRA" not in os.environ else []) + ["-c", src, "-o", obj]
+        # (round 5: the instantiation flags used to be dropped silently whenever LAB4D_HIPCC_EXTRA was set -- an experiment build then differed from
+        # the shipped one in more than its -D; LAB4D_NO_INST_FLAGS=1 is the explicit way to build without them)
+        inst = os.path.basename(src).startswith("mlp_inst_") and os.environ.get("LAB4D_NO_INST_FLAGS", "0") != "1"
+        cmd = [HIPCC] + CFLAGS + (MLP_INST_FLAGS if inst else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
@@ -134,6 +137,12 @@ def lib():
         _LIB = ctypes.CDLL(SO_PATH)
         _LIB.lab4d_last_error.restype = ctypes.c_char_p
         _LIB.lab4d_arch.restype = ctypes.c_char_p
+        _LIB.lab4d_build_flags.restype = ctypes.c_char_p
+        flags = _LIB.lab4d_build_flags().decode().split()
+        if flags and os.environ.get("LAB4D_ALLOW_EXPERIMENT_BUILD", "0") != "1":
+            # kernel-experiment builds (tools/build_variants.sh) are loaded through LAB4D_SO_PATH by the timing tools only, which set the override
+            raise RuntimeError("%s was compiled with kernel-experiment macros %s (most of them give wrong results); rebuild without them, or set "
+                               "LAB4D_ALLOW_EXPERIMENT_BUILD=1 for a timing experiment" % (SO_PATH, flags))
         for name, at in SIGNATURES.items():
             fn = getattr(_LIB, name)
             fn.argtypes = at
@@ -150,7 +159,7 @@ class _ProfiledLib:
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if PROF is None or _TIMED_DEPTH > 0 or not name.startswith("lab4d_") or name in ("lab4d_last_error", "lab4d_arch", "lab4d_mlp_describe", "lab4d_mlp_packed_bytes", "lab4d_compact_work_ints", "lab4d_global_match_workspace_floats", "lab4d_skin_blend_backward_workspace_floats"):  # host-only
+        if PROF is None or _TIMED_DEPTH > 0 or not name.startswith("lab4d_") or name in ("lab4d_last_error", "lab4d_arch", "lab4d_build_flags", "lab4d_mlp_fused_backward_supported", "lab4d_mlp_describe", "lab4d_mlp_packed_bytes", "lab4d_compact_work_ints", "lab4d_global_match_workspace_floats", "lab4d_skin_blend_backward_workspace_floats"):  # host-only
             return fn
 
         def call(*a):

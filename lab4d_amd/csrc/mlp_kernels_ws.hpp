@@ -237,6 +237,38 @@ __device__ __forceinline__ void ws_layer_barrier() {
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt / expcnt untouched
   asm volatile("s_barrier" ::: "memory");
 }
+// ---- per-block progress counters (LAB4D_WS_SYNC = 1, round 5) -------------------------------------------------------------------------------
+// The per-layer s_barrier keeps all eight waves in lock-step: the two waves of a SIMD enter their MFMA loops together and leave them together, so the
+// matrix pipe idles while both run their epilogues (profiles/r04_ws_trace.json: the older wave of every SIMD parks 22-28 k of ~88 k cycles per tile at
+// the barrier).  What a layer really needs is per 64-sample BLOCK: item (layer l, block b) reads block b of layer l-1's output (all eight row tiles) and
+// overwrites block b of the buffer layer l-1 read -- both settled once every wave has finished ITS item (l-1, b).  So each wave counts itself into
+// cnt[b] when it is done with block b of a layer (its LDS writes are performed: the LDS pipe is in-order per wave and the wait in front of the add makes
+// it explicit) and polls cnt[b] before it touches block b of the next layer.  A wave that finishes early runs up to one item ahead of the slowest one;
+// the two waves of a SIMD drift out of phase and one's epilogue runs under the other's MFMAs.  Counters are monotone over the life of the workgroup
+// (8 arrivals per block and layer); the tile boundary keeps its full barriers (posenc scratch / embedding / head-gradient staging alias the buffers).
+#ifndef LAB4D_WS_SYNC
+#define LAB4D_WS_SYNC 1
+#endif
+constexpr bool WS_SYNC = LAB4D_WS_SYNC != 0;
+__device__ __forceinline__ void ws_arrive(unsigned cnt_addr, int lane) {
+  // (memory clobber: the epilogue's LDS stores are emitted in front of this; lgkmcnt(0): they have been performed)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    const unsigned one = 1u;
+    asm volatile("ds_add_u32 %0, %1" ::"v"(cnt_addr), "v"(one) : "memory");
+  }
+}
+__device__ __forceinline__ void ws_wait_block(unsigned cnt_addr, unsigned target) {
+  unsigned v;
+  int spins = 0;
+  for (;;) {
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cnt_addr) : "memory");
+    if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - target) >= 0) break;
+    if (++spins > (1 << 22)) __builtin_trap();  // a lost arrival must fail loudly, not hang the device
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 template <class T>
 __device__ __forceinline__ void ws_pin_sgpr(T*& p) {
   unsigned long long v = (unsigned long long)p;
@@ -286,9 +318,12 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   // frame).  Read from here a bias costs LDS reads, not vector-memory loads that queue -- in the in-order memory counter -- behind the tile stores
   // of the layer in front and hold up the first MFMA of every layer.
   __shared__ float bias_lds[NL * 256];
+  __shared__ unsigned int blk_cnt[2];  // per 64-sample block: waves that have finished it, summed over the layers (see ws_arrive)
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned xbuf_lds = lds_addr(xbuf), ebuf_lds = lds_addr(ebuf);
+  const unsigned xbuf_lds = lds_addr(xbuf), ebuf_lds = lds_addr(ebuf), cnt_lds = lds_addr(blk_cnt);
+  if (tid < 2) blk_cnt[tid] = 0u;  // (the tile loop's first barrier is in front of every use)
+  unsigned cnt_base = 0u;          // arrivals per block before the current tile
   sfor<0, NL>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
     if constexpr (TAN) {
@@ -467,6 +502,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       uint4* xout = xbuf + (ib ^ 1) * WS_BUF;
       const int mt = IT::mt(w);
       const bool active = IT::active(w);
+      const unsigned cnt_tgt = cnt_base + 8u * (unsigned)l;  // every wave has finished layer l - 1 on a block once its counter reads this
 
       // bias (+ per-frame bias, which already contains the shared one: host contract) of item (mt, b) in accumulator layout
       // bias row from LDS (shared bias, or a tile inside one frame): four reads issued here, waited for (counted) behind the first item's ring prologue
@@ -535,6 +571,9 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       GLOBAL_AS void* act_n = KARG_PTR(FwdK, void*, act, l);
       GLOBAL_AS unsigned int* mask_n = KARG_PTR(FwdK, unsigned int*, mask, l);
       const int mtp = ITp::mt(w);
+      // a wave may count itself out of block b right behind item (l, b) when nothing it does later in this layer reads block b of the input buffer:
+      // two items per wave (one per block, in block order) whose hosted pieces -- the wave's own tiles of the layer in front -- belong to the item's block
+      constexpr bool EARLY = MT == 8 && (R == 0 || !SPREAD || MTp == 8);
       if constexpr (R > 0 && !SPREAD) {
         auto flush_prev = [&]() {
 #pragma unroll
@@ -564,6 +603,11 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
           const int b = IT::blk(w, k);
           constexpr int KL = IT::IPW - 1;
           f32x16_t acc[2];
+          if constexpr (WS_SYNC) {
+            WS_T(7);
+            if (l > 0) ws_wait_block(cnt_lds + 4u * (unsigned)b, cnt_tgt);
+            WS_T(0);
+          }
           // B units stream from LDS through a ring of WS_BD k-groups (two n-tiles each): the read of group g + WS_BD is issued right behind the
           // MFMAs of group g.  Reads and waits are volatile asm (program order kept, counted waits written by hand): left to the scheduler the
           // reads sink next to their MFMAs (lgkmcnt(1) in front of every MFMA pair) and the LDS latency is exposed once per k-group.
@@ -709,13 +753,22 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
               }
             }
           }
+          if constexpr (WS_SYNC && EARLY && !LAST) ws_arrive(cnt_lds + 4u * (unsigned)b, lane);
           WS_T(2 + 2 * (k & 1));
         });
       } else {
         // a wave without an item in this layer still needs the next layer's weights
         a_load(std::integral_constant<int, 0>{}, std::integral_constant<int, (Gn < G ? Gn : G)>{}, Wn, Gn, mtn);
       }
-      ws_layer_barrier();
+      if constexpr (WS_SYNC && !LAST) {
+        if (!(EARLY && active)) {  // counted out of both blocks at the end of the layer
+          ws_arrive(cnt_lds, lane);
+          ws_arrive(cnt_lds + 4u, lane);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // the scalar loads of the next layer's pointers (see ws_layer_barrier)
+      } else {
+        ws_layer_barrier();  // tile boundary (and every layer with LAB4D_WS_SYNC=0)
+      }
       Wn_c = Wn_n;
       act_c = act_n;
       mask_c = mask_n;
@@ -724,6 +777,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       ws_pin_sgpr(mask_c);
       WS_T(5);
     });
+    cnt_base += 8u * (unsigned)(NL - 1);  // NL - 1 counted layer ends per tile (the last layer ends at the tile's barrier)
   }
 #ifdef LAB4D_WS_TRACE
   if (blockIdx.x == 0 && lane < 8 && a.out) {
@@ -796,9 +850,12 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
   constexpr int MTE_ANY = KE / 32;
   __shared__ uint4 xbuf[2 * WS_BUF];
   __shared__ float red[8 * 2 * 3 * 32];  // input-gradient partials of the embedding items: [wave][n-tile][axis][lane n]
+  __shared__ unsigned int blk_cnt[2];    // per-block progress counters (see ws_arrive)
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned xbuf_lds = lds_addr(xbuf);
+  const unsigned xbuf_lds = lds_addr(xbuf), cnt_lds = lds_addr(blk_cnt);
+  if (tid < 2) blk_cnt[tid] = 0u;
+  unsigned cnt_base = 0u;
   const unsigned trl = tr_lane_base(0u, 16, lane);
   const unsigned perm_a = ws_perm_addr(lane);
   const int ntw = a.S_pad / WS_TILE;
@@ -888,6 +945,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       const int rtn = wsb_first_tile<Net>(ln, w, want_dx);
       const int ib = (NL - 1 - l) & 1;
       uint4* xout = xbuf + (ib ^ 1) * WS_BUF;
+      const unsigned cnt_tgt = cnt_base + 8u * (unsigned)(NL - 1 - l);  // every wave has finished the layer above on a block once its counter reads this
       const bool act_on = DO_ACT && IT::active(w);
       const bool emb_on = MTE > 0 && want_dx && w < 2 * MTE;
       const int j = IT::mt(w);              // activation row tile of this wave
@@ -915,6 +973,8 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       constexpr bool SPREAD = NP > 0 && DO_ACT && IT::ITEMS >= 8 && ITp::ITEMS >= 8 && NP % NHOST == 0 && WsSpread<GK, (NPI > 0 ? NPI : 1)>::OK;
       GLOBAL_AS void* dzl = dz_c;
       const int jp = ITp::mt(w);
+      constexpr bool EARLY = DO_ACT && MTA == 8 && (NP == 0 || !SPREAD || MTp == 8);  // (see the forward kernel)
+      constexpr bool TOP = R == NL - 1, BOTTOM = R == 0;
       if constexpr (NP > 0 && !SPREAD) {
         if (ITp::active(w)) {
 #pragma unroll
@@ -933,6 +993,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
         constexpr bool PF = decltype(pf_c)::value;
         constexpr int GP = decltype(gp_c)::value;
         constexpr int HK = decltype(host_c)::value;  // >= 0: this loop hosts the pieces HK NPI .. of the deferred dZ tiles
+        if constexpr (WS_SYNC && !TOP) ws_wait_block(cnt_lds + 4u * (unsigned)b, cnt_tgt);  // (the top layer's input is staged in front of the tile's barrier)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1048,6 +1109,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
 #pragma unroll
               for (int q = 0; q < 2; ++q)
                 xout[((2 * b + t) * 16 + 2 * j + q) * 64 + lane] = make_uint4(pw[t][4 * q], pw[t][4 * q + 1], pw[t][4 * q + 2], pw[t][4 * q + 3]);
+            if constexpr (WS_SYNC && EARLY && !BOTTOM) ws_arrive(cnt_lds + 4u * (unsigned)b, lane);
           });
           loaded_next = true;
         }
@@ -1055,7 +1117,15 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       if (!loaded_next) a_load(std::integral_constant<int, (GKn < GK ? GKn : GK)>{}, Wn, GKn, rtn);  // a wave without an item here still needs its next weights
       mcur[0] = mnext[0];
       mcur[1] = mnext[1];
-      ws_layer_barrier();
+      if constexpr (WS_SYNC && !BOTTOM) {
+        if (!(EARLY && act_on)) {
+          ws_arrive(cnt_lds, lane);
+          ws_arrive(cnt_lds + 4u, lane);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+      } else {
+        ws_layer_barrier();  // tile boundary (and every layer with LAB4D_WS_SYNC=0)
+      }
       Wn_c = Wn_n;
       dz_c = dz_n;
       maskq_c = maskq_n;
@@ -1064,6 +1134,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       ws_pin_sgpr(maskq_c);
     });
 
+    cnt_base += 8u * (unsigned)(NL - 1);
     // ---- input gradient: partials of the embedding items -> one sum per sample ----
     if (want_dx) {
       if (w < 2 * MTE_ANY) {
@@ -1106,7 +1177,9 @@ inline int mlp_grid_ws(int ntiles) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  static const int grid_env = getenv("LAB4D_CHAIN_GRID") ? atoi(getenv("LAB4D_CHAIN_GRID")) : 0;
+  // read per launch (like LAB4D_WS): tests/test_gpu_mlp_ws.py forces a 3-workgroup grid so that every workgroup runs several tiles of a small case
+  const char* ge = getenv("LAB4D_CHAIN_GRID");
+  const int grid_env = ge ? atoi(ge) : 0;
   int g = ntiles < n_cu ? ntiles : n_cu;
   if (grid_env > 0 && g > grid_env) g = grid_env;
   return g < 1 ? 1 : g;

@@ -811,7 +811,7 @@ def get_valid_idx(P, xyz, xyz_t, t_articulation):
 @torch.no_grad()
 def importance_sampling(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
     """NeRF.importance_sampling (nerf.py:686-738): n/2 uniform samples -> density -> weights -> inverse-CDF samples
-    (sample_pdf, det=True) -> merge-sort -> 64 depths.  Returns (xyz_cam, dir_cam, deltas, depth, xyz_t), inds."""
+    (sample_pdf, det=True) -> merge-sort -> 64 depths.  Returns (xyz_cam, dir_cam, deltas, depth, xyz_t, .), (inds, coarse weights)."""
     nc = n_depth // 2
     cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
     xyz_cam, _, deltas, depth, xyz_t, _ = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=nc)
@@ -821,7 +821,7 @@ def importance_sampling(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
     depth_mid = (0.5 * (depth[:, :, :-1] + depth[:, :, 1:])).reshape(-1, nc - 1)
     new, inds = RU.sample_pdf(depth_mid, weights.reshape(-1, nc)[:, 1:-1].contiguous(), nc, det=True, return_inds=True)
     depth_all = RU.sort_depth(depth.reshape(-1, nc), new).view(depth.shape[0], depth.shape[1], n_depth, 1)
-    return RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, depth=depth_all), inds
+    return RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, depth=depth_all), (inds, weights)
 
 
 def nerf_forward_compacted(P, x_k, fr, frame_k, count, prec, alpha=None):
@@ -841,7 +841,7 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
     visibility, get_valid_idx + query_nerf (the field's colour / density only on the VALID samples: mask, stream compaction and
     scatter on the device, no host synchronisation -- nerf.py:495-528, 769-819), normals / eikonal on every sample
     (compute_normal, nerf.py:455-493)."""
-    (xyz_cam, dir_cam, deltas, depth, _, _), inds = importance_sampling(P, fr, hxy, n_depth, alpha, prec)
+    (xyz_cam, dir_cam, deltas, depth, _, _), (inds, weights_coarse) = importance_sampling(P, fr, hxy, n_depth, alpha, prec)
     # normals need d sdf / d xyz_cam through the rigid transform and the warp (nerf.py:455-493): one first-order
     # backward pass through the same kernels, so the sdf pass below is run under autograd with xyz_cam as the leaf.
     # Only d sdf / d xyz_cam is wanted: parameters and per-frame inputs are detached, otherwise the backward below would
@@ -883,7 +883,8 @@ def query_field_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
         fd["depth"] = depth / P["logscale"].exp()
         if has_bones:
             fd["gauss_density"] = gauss_density(P, xyz, fr["rest_articulation"])
-    return fd, deltas, {"valid": mask.view(shape).bool(), "inds": inds, "valid_count": count}
+    # debug outputs (the parity tests read them): sample_pdf's indices, the coarse pass's compositing weights its pdf was formed from, the valid mask
+    return fd, deltas, {"valid": mask.view(shape).bool(), "inds": inds, "weights_coarse": weights_coarse, "valid_count": count}
 
 
 @torch.no_grad()
@@ -909,7 +910,7 @@ def importance_sampling_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32
     depth_mid = (0.5 * (depth[:, :, :-1] + depth[:, :, 1:])).reshape(-1, nc - 1)
     new, inds = RU.sample_pdf(depth_mid, weights.reshape(-1, nc)[:, 1:-1].contiguous(), nc, det=True, return_inds=True)
     depth_all = RU.sort_depth(depth.reshape(-1, nc), new).view(depth.shape[0], depth.shape[1], n_depth, 1)
-    return RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, depth=depth_all), inds
+    return RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, depth=depth_all), (inds, weights)
 
 
 def query_field_eval_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32, prefix=""):

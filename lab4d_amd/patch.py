@@ -531,8 +531,9 @@ def nerf_extract_canonical_mesh(self, grid_size=64, level=0.0, inst_id=None, use
     code_vis = inst_code(self.vis_mlp.basefield, iid, 1, dev)
     alpha = getattr(self.pos_embedding, "alpha", None)
     with torch.no_grad():
+        # (round 5, ADVICE r04: the bg field is a NeRF too -- multifields.py:86-93 -- and MultiFields.update_geometry_aux meshes every field)
         sdf, vis, box = proxy.grid_query(P, self.aabb, grid_size=grid_size, code_base=code_base, code_vis=code_vis, prec=_prec(self),
-                                         use_visibility=use_visibility, extend=0.5 if use_extend_aabb else 0.0, alpha=alpha)
+                                         use_visibility=use_visibility, extend=0.5 if use_extend_aabb else 0.0, alpha=alpha, kind=field_kind(self))
     sdf, vis = sdf.reshape(-1, 1), vis.reshape(-1, 1)
 
     def served(vol):  # the volumes are final: marching_cubes' eval_func_chunk walks the grid in order, each call takes the next rows

@@ -21,13 +21,18 @@ def sample_grid(aabb, grid_size):
 
 
 @torch.no_grad()
-def grid_query(P, aabb, grid_size=64, code_base=None, code_vis=None, prec=mlp.PREC_BF16, use_visibility=True, extend=0.5, chunk=1 << 22, alpha=None):
+def grid_query(P, aabb, grid_size=64, code_base=None, code_vis=None, prec=mlp.PREC_BF16, use_visibility=True, extend=0.5, chunk=1 << 22, alpha=None,
+               kind="fg"):
     """The volume `marching_cubes` meshes (geom_utils.py:445-476): sdf (G,G,G) fp32 and visibility mask (G,G,G) bool over
     extend_aabb(aabb, extend) (extract_canonical_mesh's `use_extend_aabb`, nerf.py:333-336).  code_base / code_vis: (1,32) instance
     codes of the basefield / visibility CondMLPs -- `inst_embedding(inst_id)` or the mean embedding for inst_id=None
     (base.py:130-134); default: the mean of P's embedding tables.  alpha: the live annealing state `pos_embedding.alpha` of
     the field (embedding.py:112-125; MultiFields.set_alpha, multifields.py:108-116, ramps it over the first steps, and
-    extract_canonical_mesh calls self.forward, which applies it; the visibility field's own embedding is never annealed); None = no window.  Returns (sdf, vis, grid_aabb)."""
+    extract_canonical_mesh calls self.forward, which applies it; the visibility field's own embedding is never annealed); None = no window.
+    kind: "fg" (NeRF W=256, D=8, 10 frequencies: LAB4D_NET_FG_BASE) or "bg" (multifields.py:86-93: W=128, D=5, 6 frequencies: LAB4D_NET_BG_BASE) --
+    MultiFields.update_geometry_aux (trainer.py:247) and MultiFields.extract_canonical_meshes mesh EVERY field, the background included; both
+    kinds carry the same VisField (95 -> 64 -> 64 -> 1).  Returns (sdf, vis, grid_aabb)."""
+    net = {"fg": mlp.NET_FG_BASE, "bg": mlp.NET_BG_BASE}[kind]
     box = DF.extend_aabb(aabb, extend) if extend else aabb
     pts = sample_grid(box, grid_size)
     if code_base is None:
@@ -35,10 +40,10 @@ def grid_query(P, aabb, grid_size=64, code_base=None, code_vis=None, prec=mlp.PR
     if code_vis is None:
         code_vis = P["vis_mlp.basefield.inst_embedding.mapping.weight"].mean(0, keepdim=True)
     sdf, vis = [], []
-    fw = DF.posenc_window(alpha, mlp.describe(mlp.NET_FG_BASE).n_freq, pts.device)
+    fw = DF.posenc_window(alpha, mlp.describe(net).n_freq, pts.device)
     for i in range(0, pts.shape[0], chunk):  # eval_func_chunk (geom_utils.py:425-440); one chunk up to 128^3
         x = pts[i:i + chunk].contiguous()
-        sdf.append(mlp.run_chain(mlp.NET_FG_BASE, prec, P, x, x.shape[0], conds={0: code_base, 4: code_base}, freq_w=fw))
+        sdf.append(mlp.run_chain(net, prec, P, x, x.shape[0], conds={0: code_base, 4: code_base}, freq_w=fw))
         if use_visibility:
             vis.append(mlp.run_chain(mlp.NET_VIS, prec, P, x, x.shape[0], conds={0: code_vis}) > 0)
     G = grid_size

@@ -22,6 +22,7 @@ from oracle import ref_shim  # noqa: E402
 from lab4d_amd import synthetic  # noqa: E402
 
 torch.set_num_threads(8)
+_REAL_MULTINOMIAL = torch.multinomial  # gen_train / gen_comp_train replace torch.multinomial by the fixture's injected draw
 
 
 def weight_checksum(P):
@@ -102,14 +103,54 @@ def leafify(fr, names):
     return out, leaves
 
 
+def w1_weights():
+    """The fitted part of the W1 weight set (gen_w1_weights below), as committed."""
+    return torch.load(os.path.join(HERE, "w1_weights.pt"), weights_only=False)
+
+
+def gen_w1_weights(ns, seed=61):
+    """SURVEY 8d's second weight set: W0 = make_weights(seed) after the REFERENCE'S OWN NeRF.geometry_init (nerf.py:251-295) driven by the Deformable
+    override of get_init_sdf_fn (deformable.py:95-117: for skel-* motions the Gaussian-bone SDF of warping.py:338-353, no pysdf) -- 500 Adam steps at
+    lr 1e-3 on 256 random points per step: sdf fit (scale-aligned), visibility prior, eikonal term.  Only tensors that moved are stored (the basefield,
+    the sdf head, the visibility net and their instance codes: ~590 k numbers); fixture_utils.fg_weights(meta) overlays them when meta["w1"] is set.
+    The fit is a chaotic iteration (500 optimiser steps): it is stored, not regenerated, by the generator test."""
+    torch.multinomial = _REAL_MULTINOMIAL  # compute_eikonal's own draw (nerf.py:438-439), not a fixture's injected one
+    P = synthetic.make_weights(seed)
+    f = build_reference_field(ns, P)
+    f.train()
+    before = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    torch.manual_seed(seed)  # geometry_init draws its points / instance ids from the global generator
+    with torch.no_grad():
+        pts = f.sample_points_aabb(4096, extend_factor=0.25)
+        sdf_gt = f.get_init_sdf_fn()(pts)
+        sdf0 = f.forward(pts, inst_id=None, get_density=False)
+    f.geometry_init(f.get_init_sdf_fn())
+    with torch.no_grad():
+        sdf1 = f.forward(pts, inst_id=None, get_density=False)
+    after = f.state_dict()
+    changed = {k: after[k].detach().clone() for k in P if k in after and not torch.equal(after[k], before[k])}
+    corr = lambda a, b: float(torch.corrcoef(torch.stack([a.flatten(), b.flatten()]))[0, 1])
+    out = {"seed": seed, "changed": changed, "weight_checksum_w0": weight_checksum(P),
+           "weight_checksum_w1": weight_checksum(dict(P, **changed)),
+           "fit": {"corr_before": corr(sdf0, sdf_gt), "corr_after": corr(sdf1, sdf_gt), "inside_frac_gt": float((sdf_gt < 0).float().mean()),
+                   "inside_frac_after": float((sdf1 < 0).float().mean())}}
+    path = os.path.join(OUT_DIR, "w1_weights.pt")
+    torch.save(out, path)
+    print("w1_weights ->", path, os.path.getsize(path) // 1024, "KiB", sorted(changed)[:4], "...", len(changed), "tensors", out["fit"])
+
+
 def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None, frame_id=None, full_grid_stride=None, fg_motion="skel-quad",
-              rows=None):
+              rows=None, w1=False):
     """num_inst > 1 / inst_id: the multi-instance configuration (BASELINE config 4): per-instance codes in every CondMLP
     (base.py:123-150), frames of one pair share their video's instance id."""
     num_bones = 18 if "skel-human" in fg_motion else 25  # utils/skel_utils.py:348-351
     P = synthetic.make_weights(seed, num_inst=num_inst, num_bones=num_bones, motion=fg_motion if fg_motion in ("rigid", "dense") else "skinning")
     if fg_motion.startswith("comp_"):  # fg_motion "comp_skel-quad_dense" (BASELINE configs 2-3): skinning + dense post-warp
         P = synthetic.add_dense_weights(P, seed, num_inst)
+    if w1:  # the fitted weight set (gen_w1_weights): a sharp surface instead of the raw initialisation's flat field
+        w = w1_weights()
+        assert w["seed"] == seed and abs(w["weight_checksum_w0"] - weight_checksum(P)) <= 1e-6 * w["weight_checksum_w0"]
+        P.update(w["changed"])
     f = build_reference_field(ns, P, num_inst, fg_motion)
     f.train()
     f.pos_embedding.set_alpha(alpha)
@@ -175,7 +216,7 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
             gd[k] = compress_grad(gv.detach())
     out = {
         "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "alpha": alpha, "num_inst": num_inst, "fg_motion": fg_motion,
-                 "weight_checksum": weight_checksum(P), "flow_thresh": float(res)},
+                 "weight_checksum": weight_checksum(P), "flow_thresh": float(res), "w1": bool(w1)},
         "frames": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in fr.items()},
         "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds.clone(), "match_perm": match_perm.clone()},
         "feat_dict": {k: v.detach() for k, v in feat_dict.items()}, "deltas": deltas.detach(),
@@ -244,6 +285,82 @@ def gen_eval(ns, tag, M, N, D, res, seed, fg_motion="skel-quad"):
     path = os.path.join(OUT_DIR, f"eval_{tag}.pt")
     torch.save(out, path)
     print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "valid frac", float(captured["valid"].float().mean()))
+
+
+def gen_eval_bench(ns, tag, res=512, D=128, seed=61, rows=(252, 260), band=2, stride=16, w1=False, tie_window=1e-4):
+    """The eval path (render.py:183 -> dvr_model.evaluate -> NeRF.query_field in eval mode) at BASELINE configs[1]'s size: `rows` image rows of a
+    512x512 frame pair, importance sampling with n_depth = 128 (64 uniform + 64 inverse-cdf samples, nerf.py:686-738), compute_normal on every
+    sample (nerf.py:455-493), get_valid_idx + query_nerf compaction (nerf.py:495-528, 769-819) -- run through the reference band by band
+    (`band` rows = 2 x 1,024 rays per call: the reference itself renders big inputs chunk by chunk, engine/model.py:259-326; rays are independent
+    except for the mean-transmittance normaliser of `vis`, which is per call).  Stored for EVERY ray: the importance indices (uint8) and the valid
+    mask (bit-packed); every `stride`-th ray of the render; and the reference's cdf at its NEAR TIES -- every cdf entry within `tie_window` of one
+    of the 64 query points u: an index can differ between two fp32 implementations only at such an entry, and the device test asserts exactly that."""
+    import numpy as np
+    M = 2
+    P = synthetic.make_weights(seed, sdf_bias=None if w1 else -0.02)
+    if w1:
+        w = w1_weights()
+        assert w["seed"] == seed
+        P.update(w["changed"])
+    f = build_reference_field(ns, P)
+    f.eval()
+    fr = synthetic.make_frames(seed + 1, M, res)
+    fr = frames_from_reference(f, fr)
+    orig = f.importance_sampling
+    f.importance_sampling = lambda *a, **k: orig(*a, n_depth=D, **k)
+    captured = {}
+    _ss = torch.searchsorted
+
+    def searchsorted(cdf, u, right=False):
+        r = _ss(cdf, u, right=right)
+        captured["inds"], captured["cdf"], captured["u"] = r.clone(), cdf.clone(), u.clone()
+        return r
+
+    _gv = f.get_valid_idx
+
+    def get_valid_idx(*a, **k):
+        v = _gv(*a, **k)
+        captured["valid"] = v.clone()
+        return v
+
+    f.get_valid_idx = get_valid_idx
+    inds, valid, rendered, ties = [], [], [], []
+    ns.render_utils.torch.searchsorted = searchsorted
+    try:
+        for r0 in range(rows[0], rows[1], band):
+            hxy = synthetic.make_rays(res, M, rows=(r0, r0 + band))
+            sd = samples_dict_of(fr, hxy, None)
+            del sd["feature"]
+            feat_dict, deltas, aux = f.query_field(sd)
+            out = ns.render_utils.render_pixel(feat_dict, deltas)
+            inds.append(captured["inds"].view(M, -1, D // 2))
+            valid.append(captured["valid"].view(M, -1, D))
+            rendered.append({k: v.detach()[:, ::stride].clone() for k, v in out.items()})
+            cdf, u = captured["cdf"].view(M, -1, D // 2 - 1), captured["u"][0]
+            assert torch.equal(captured["u"], u[None].expand_as(captured["u"]))
+            near = (cdf[..., None] - u).abs().min(-1)[0] < tie_window
+            m, n, k = near.nonzero(as_tuple=True)
+            ties.append({"band": torch.full_like(m, (r0 - rows[0]) // band), "m": m, "n": n, "k": k, "cdf": cdf[m, n, k].clone()})
+            print("  band", r0, "valid frac %.3f" % float(captured["valid"].float().mean()), "near ties", int(near.sum()), flush=True)
+    finally:
+        ns.render_utils.torch.searchsorted = _ss
+    inds = torch.cat(inds, 1)    # (M, N, D/2): bands are consecutive rows, so this is the ray order of make_rays(res, M, rows)
+    valid = torch.cat(valid, 1)  # (M, N, D)
+    assert int(inds.max()) < 256
+    out = {
+        "meta": {"M": M, "N": inds.shape[1], "D": D, "res": res, "seed": seed, "rows": rows, "band": band, "full_grid_stride": stride,
+                 "weight_checksum": weight_checksum(P), "sdf_bias": None if w1 else -0.02, "fg_motion": "skel-quad", "w1": bool(w1), "tie_window": tie_window},
+        "frames": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in fr.items()},
+        "inds_u8": inds.to(torch.uint8), "valid_bits": torch.from_numpy(np.packbits(valid.numpy().reshape(-1))), "valid_shape": tuple(valid.shape),
+        "u": u.clone(),
+        # per band: the renders are per call (the `vis` channel is normalised by the call's mean transmittance, render_utils.py:89)
+        "rendered_bands": rendered,
+        "ties": {k: torch.cat([t[k] for t in ties]).to(torch.int32 if k != "cdf" else torch.float32) for k in ties[0]},
+    }
+    path = os.path.join(OUT_DIR, f"eval_{tag}.pt")
+    torch.save(out, path)
+    print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "valid frac", float(valid.float().mean()), "indices", inds.numel(), "samples", valid.numel(),
+          "near ties", out["ties"]["k"].numel(), "mask mean", float(torch.cat([r["mask"] for r in rendered], 1).mean()))
 
 
 def gen_ops(ns):
@@ -578,6 +695,13 @@ def main(only=None):
                                               full_grid_stride=16, rows=(255, 257))),
         ("train_multi10_bench", lambda: gen_train(ns, "multi10_bench", M=2, N=None, D=128, res=512, seed=121, num_inst=10, inst_id=[3, 3], frame_id=[21, 22],
                                                   fg_motion="comp_skel-quad_dense", full_grid_stride=16, rows=(255, 257))),
+        # round 5.  w1_weights: SURVEY 8d's fitted weight set (the reference's own geometry_init on seed 61's W0).  train_bench_w1: the bench-shape
+        # training fixture on it.  eval_bench / eval_bench_w1: the eval path at the bench size -- 8 rows of a 512x512 pair = 8,192 rays, 524,288
+        # importance indices, 1,048,576 valid-mask bits -- on W0 (+ sdf bias nudge, like eval_small) and on W1.
+        ("w1_weights", lambda: gen_w1_weights(ns)),
+        ("train_bench_w1", lambda: gen_train(ns, "bench_w1", M=2, N=None, D=128, res=512, seed=61, full_grid_stride=16, rows=(255, 257), w1=True)),
+        ("eval_bench", lambda: gen_eval_bench(ns, "bench")),
+        ("eval_bench_w1", lambda: gen_eval_bench(ns, "bench_w1", w1=True)),
     ]
     for name, job in jobs:
         if only is None or name in only:

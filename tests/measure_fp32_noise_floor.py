@@ -20,8 +20,9 @@ from oracle import lab4d_oracle as O  # noqa: E402
 
 OUT = os.path.join(HERE, "golden", "fp32_noise_floor.json")
 TRAIN = ["train_small", "train_alpha", "train_multi", "train_multi10", "train_compmotion", "train_human", "train_rigid", "train_dense", "train_c1", "train_bench",
-         "train_multi10_bench"]
+         "train_multi10_bench", "train_bench_w1"]
 EVAL = ["eval_small", "eval_rigid", "eval_dense"]
+EVAL_BENCH = ["eval_bench", "eval_bench_w1"]  # round 5: the eval path at the bench size (band by band, like the fixture)
 COMP = ["comp_train", "comp_bench"]  # field_type "comp": fg + bg composite (round 4)
 
 
@@ -35,13 +36,10 @@ def to(x, dt):
     return x
 
 
-def weights_of(meta):  # (= tests/fixture_utils.fg_weights)
-    motion = meta.get("fg_motion", "skel-quad")
-    P = synthetic.make_weights(meta["seed"], num_inst=meta.get("num_inst", 1), sdf_bias=meta.get("sdf_bias"), num_bones=18 if "skel-human" in motion else 25,
-                               motion=motion if motion in ("rigid", "dense") else "skinning")
-    if motion.startswith("comp_"):
-        P = synthetic.add_dense_weights(P, meta["seed"], meta.get("num_inst", 1))
-    return P
+def weights_of(meta):
+    sys.path.insert(0, HERE)
+    from fixture_utils import fg_weights
+    return fg_weights(meta)
 
 
 def relmax(a, b):
@@ -167,15 +165,42 @@ def eval_case(name):
     return out
 
 
+def eval_bench_case(name):
+    """The eval path at the bench size: the oracle in float32 against float64 band by band, on the rays the fixture stores (every stride-th), concatenated
+    over the bands -- the metric of tests/test_gpu_field.py::test_eval_graph_at_the_bench_size; plus how many importance indices / mask bits the two
+    precisions themselves disagree on (the discrete part of the floor)."""
+    sys.path.insert(0, HERE)
+    from fixture_utils import eval_bench_bands
+    g = torch.load(os.path.join(HERE, "golden", name + ".pt"), weights_only=False)
+    meta = g["meta"]
+    st = meta["full_grid_stride"]
+    acc = {32: {}, 64: {}}
+    idx_mis = mask_mis = 0
+    for band, hxy, _ in eval_bench_bands(g):
+        outs = {}
+        for bits, dt in ((32, torch.float32), (64, torch.float64)):
+            P = to(weights_of(meta), dt)
+            fr = synthetic.add_codes(to(dict(g["frames"]), dt), P)
+            outs[bits] = O.render_eval(P, fr, to(hxy, dt), n_depth=meta["D"])
+            for k, v in outs[bits]["rendered"].items():
+                acc[bits].setdefault(k, []).append(v[:, ::st])
+        idx_mis += int((outs[32]["debug"]["inds"] != outs[64]["debug"]["inds"]).sum())
+        mask_mis += int((outs[32]["debug"]["valid"] != outs[64]["debug"]["valid"]).sum())
+    out = {"index_mismatch_count": float(idx_mis), "valid_mask_mismatch_count": float(mask_mis)}
+    for k in acc[32]:
+        out["rendered." + k] = relmax(torch.cat(acc[32][k], 1), torch.cat(acc[64][k], 1))
+    return out
+
+
 def main(cases):
     torch.set_num_threads(os.cpu_count() or 8)
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for c in cases:
         t = time.time()
-        res[c] = {k: float("%.3e" % v) for k, v in (train_case(c) if c in TRAIN else comp_case(c) if c in COMP else eval_case(c)).items()}
+        res[c] = {k: float("%.3e" % v) for k, v in (train_case(c) if c in TRAIN else comp_case(c) if c in COMP else eval_bench_case(c) if c in EVAL_BENCH else eval_case(c)).items()}
         print(c, "%.1f s" % (time.time() - t), "worst:", sorted(((v, k) for k, v in res[c].items() if not k.startswith("gradmax")), reverse=True)[:3])
         json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or TRAIN + EVAL + COMP)
+    main(sys.argv[1:] or TRAIN + EVAL + COMP + EVAL_BENCH)

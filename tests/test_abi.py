@@ -45,7 +45,7 @@ def test_python_signatures_cover_the_header():
     import lab4d_amd.pose  # noqa: F401
     import lab4d_amd.warping  # noqa: F401
     sig = set(_lib.SIGNATURES)
-    hdr = set(declared_symbols()) - {"lab4d_last_error", "lab4d_version", "lab4d_arch"}
+    hdr = set(declared_symbols()) - {"lab4d_last_error", "lab4d_version", "lab4d_arch", "lab4d_build_flags"}
     assert hdr <= sig, sorted(hdr - sig)
 
 
@@ -53,6 +53,24 @@ def test_library_targets_gfx950(so):
     so.lab4d_arch.restype = ctypes.c_char_p
     assert so.lab4d_arch() == b"gfx950"
     assert so.lab4d_version() >= 1
+
+
+def test_shipped_library_has_no_experiment_macros(so):
+    """The 40-odd LAB4D_ABL_* / LAB4D_WSABL_* / LAB4D_WS_TRACE ... switches in csrc/ are timing experiments (most give wrong results): the library the
+    product loads must have been compiled with none of them, and lab4d_build_flags() must know every such macro the sources test."""
+    import re
+    so.lab4d_build_flags.restype = ctypes.c_char_p
+    assert so.lab4d_build_flags() == b"", so.lab4d_build_flags()
+    csrc = os.path.join(ROOT, "lab4d_amd", "csrc")
+    tested = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")):
+            src = open(os.path.join(csrc, f)).read()
+            tested |= set(re.findall(r"#\s*ifn?def\s+(LAB4D_[A-Z0-9_]+)", src)) | set(re.findall(r"defined\((LAB4D_[A-Z0-9_]+)\)", src))
+    tested -= {"LAB4D_HIP_H"}
+    runtime = open(os.path.join(csrc, "runtime.hip")).read()
+    reported = set(re.findall(r"#ifdef (LAB4D_[A-Z0-9_]+)", runtime))
+    assert tested <= reported, sorted(tested - reported)
 
 
 def test_bad_arguments_are_rejected_without_a_gpu(so):

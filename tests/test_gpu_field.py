@@ -32,13 +32,9 @@ EVAL_INDEX_MISMATCH_MAX = 2  # measured: 1 of 128
 
 
 def load_case(golden_dir, name):
+    from fixture_utils import fg_weights
     g = torch.load(os.path.join(golden_dir, name), weights_only=False)
-    motion = g["meta"].get("fg_motion", "skel-quad")
-    P = synthetic.make_weights(g["meta"]["seed"], num_inst=g["meta"].get("num_inst", 1), sdf_bias=g["meta"].get("sdf_bias"),
-                               num_bones=18 if "skel-human" in motion else 25, motion=motion if motion in ("rigid", "dense") else "skinning")
-    if g["meta"].get("fg_motion", "skel-quad").startswith("comp_"):
-        P = synthetic.add_dense_weights(P, g["meta"]["seed"], g["meta"].get("num_inst", 1))
-    return g, P
+    return g, fg_weights(g["meta"])
 
 
 @pytest.mark.parametrize("case", ["train_small.pt", "train_alpha.pt", "train_compmotion.pt", "train_human.pt", "train_rigid.pt", "train_dense.pt",
@@ -212,6 +208,20 @@ def test_training_graph_at_the_bench_shape_fp32(golden_dir):
     check("bench_fp32", _run_full_size(golden_dir, "train_bench.pt", mlp.PREC_F32), floor_case="train_bench", skip=("psnr_rgb_db",), floor_factor=FLOOR_FACTOR_FULL)
 
 
+def test_training_graph_at_the_bench_shape_w1_fp32(golden_dir):
+    """Round 5: the bench-shape training fixture on W1 -- seed 61's weights after the reference's own geometry_init (nerf.py:251-295 with the Gaussian-bone
+    SDF of deformable.py:95-117; tests/golden/make_golden.py: gen_w1_weights): a fitted, sharp surface, where compositing weights are peaked."""
+    from lab4d_amd import mlp
+    check("bench_w1_fp32", _run_full_size(golden_dir, "train_bench_w1.pt", mlp.PREC_F32), floor_case="train_bench_w1", skip=("psnr_rgb_db",), floor_factor=FLOOR_FACTOR_FULL)
+
+
+def test_training_graph_at_the_bench_shape_w1_bf16(golden_dir):
+    from lab4d_amd import mlp
+    m = _run_full_size(golden_dir, "train_bench_w1.pt", mlp.PREC_BF16)
+    check("bench_w1_bf16", m, skip=("psnr_rgb_db",))
+    assert m["psnr_rgb_db"] > 60.0, m["psnr_rgb_db"]
+
+
 def test_training_graph_at_the_bench_shape_multi10_fp32(golden_dir):
     """BASELINE.json configs[3]'s field at the bench shape (round 4): 10 instances, fg_motion comp_skel-quad_dense, a 2-row band of a 512x512 pair of
     video 3 x 128 samples/ray against the reference's own output; every entry within max(1e-4, 2 x measured) AND, above 1e-4, within 4x of the
@@ -279,7 +289,8 @@ def test_comp_training_graph_at_the_bench_shape_bf16(golden_dir):
     """The benched dtype on the same fixture: bounds = BF16_BOUNDS (measured margins, see below), PSNR of the composite colour vs the reference."""
     from lab4d_amd import mlp
     m = _run_comp(golden_dir, "comp_bench.pt", mlp.PREC_BF16)
-    _assert_bounds("comp_bench_bf16", {k: v for k, v in m.items() if not k.startswith("gradmax.")}, BF16_BOUNDS_COMP, 2e-2)
+    _assert_bounds("comp_bench_bf16_ceiling", {k: v for k, v in m.items() if not k.startswith("gradmax.")}, BF16_BOUNDS_COMP, 2e-2)
+    check("comp_bench_bf16", {k: v for k, v in m.items() if not k.startswith("gradmax.")}, skip=("psnr_rgb_db",))  # per entry: 2 x the committed measurement
     assert m["psnr_rgb_db"] > 80.0, m["psnr_rgb_db"]
 
 
@@ -313,7 +324,8 @@ def test_training_graph_at_the_bench_shape_bf16(golden_dir):
     """The benched dtype at the benched shape against the reference (fp32) render of the same rays / weights."""
     from lab4d_amd import mlp
     m = _run_full_size(golden_dir, "train_bench.pt", mlp.PREC_BF16)
-    _assert_bounds("bench_bf16", m, BF16_BOUNDS, 2e-2)
+    _assert_bounds("bench_bf16_ceiling", m, BF16_BOUNDS, 2e-2)   # the a-priori ceilings of the analysis below ...
+    check("bench_bf16", m, skip=("psnr_rgb_db",))                # ... and, per entry, max(1e-4, 2 x the committed MI355X measurement) (round 5)
     assert m["psnr_rgb_db"] > 90.0, m["psnr_rgb_db"]  # measured 99.3 dB vs the reference render
 
 
@@ -360,6 +372,87 @@ def test_eval_graph_matches_reference_goldens(golden_dir):
     # index differences are confined to exact cdf ties (the u = 1 end point): the resulting samples coincide, so every
     # rendered channel must still match the reference render at 1e-4 (fp32 path)
     check("eval_small", {"rendered." + k: rel(out["rendered"][k], v) for k, v in g["rendered"].items()}, floor_case="eval_small")
+
+
+def _run_eval_bench(golden_dir, name, prec):
+    """An eval_bench fixture on the device, band by band like the reference rendered it: returns (measured render errors over the stored rays of all
+    bands, index statistics, mask mismatches)."""
+    from lab4d_amd import deformable as DF
+    from fixture_utils import cdf_of_weights, check_index_mismatches, eval_bench_bands, eval_bench_unpack
+    g, P = load_case(golden_dir, name)
+    meta = g["meta"]
+    M, D, st = meta["M"], meta["D"], meta["full_grid_stride"]
+    Pd = synthetic.to_device(P, DEV)
+    fr = synthetic.add_codes(synthetic.to_device(dict(g["frames"]), DEV), Pd)
+    inds_ref, valid_ref = eval_bench_unpack(g)
+    got, ref = {}, {}
+    stats = {"index_total": 0, "index_mismatch": 0, "index_cdf_gap_max": 0.0, "valid_total": 0, "valid_mismatch": 0, "valid_fraction": 0.0}
+    for band, hxy, sl in eval_bench_bands(g):
+        out = DF.render_eval(Pd, fr, hxy.to(DEV), n_depth=D, prec=prec)
+        n = hxy.shape[1]
+        inds = out["debug"]["inds"].cpu().view(M, n, D // 2)
+        valid = out["debug"]["valid"].cpu().view(M, n, D)
+        stats["index_total"] += inds.numel()
+        stats["valid_total"] += valid.numel()
+        stats["valid_mismatch"] += int((valid != valid_ref[:, sl]).sum())
+        stats["valid_fraction"] += float(valid.float().sum())
+        if prec == 0:  # fp32: every differing index must be a one-bin shift at a near tie of the reference's cdf, the two cdfs equal to the fp32 floor
+            cdf = cdf_of_weights(out["debug"]["weights_coarse"].reshape(M * n, D // 2)).view(M, n, -1)
+            k, gap = check_index_mismatches(g, band, inds, cdf, tol=INDEX_CDF_TOL)
+        else:
+            k, gap = int((inds != inds_ref[:, sl]).sum()), 0.0
+        stats["index_mismatch"] += k
+        stats["index_cdf_gap_max"] = max(stats["index_cdf_gap_max"], gap)
+        for ch, v in g["rendered_bands"][band].items():
+            got.setdefault(ch, []).append(out["rendered"][ch][:, ::st].detach().float().cpu())
+            ref.setdefault(ch, []).append(v)
+    stats["valid_fraction"] /= stats["valid_total"]
+    measured = {"rendered." + ch: rel(torch.cat(got[ch], 1), torch.cat(ref[ch], 1)) for ch in got}
+    mse = float(((torch.cat(got["rgb"], 1) - torch.cat(ref["rgb"], 1)) ** 2).mean())
+    measured["psnr_rgb_db"] = -10.0 * torch.log10(torch.tensor(max(mse, 1e-20))).item()
+    return measured, stats
+
+
+# |cdf_device - cdf_reference| allowed at a cdf entry where the two implementations' importance indices differ: the cdf is a running sum of <= 62
+# normalised weights, each carrying the fp32 rounding of ten 256-wide layers upstream (density ~1e-6 relative); measured worst on MI355X: see
+# profiles/r05_parity_eval_bench_indices*.json
+INDEX_CDF_TOL = 2e-5
+# fraction of the 524,288 importance indices of a fixture that may differ (each one verified to be a one-bin shift at a near tie, see above)
+INDEX_MISMATCH_FRAC_MAX = 2e-3
+
+
+@pytest.mark.parametrize("name", ["eval_bench", "eval_bench_w1"])
+def test_eval_graph_at_the_bench_size_fp32(golden_dir, name):
+    """Round 5: the eval path -- importance sampling, compute_normal on every sample, get_valid_idx + query_nerf compaction -- at the
+    size bench.py's eval leg runs (512x512, 64 + 64 samples per ray), 8 image rows of a frame pair = 8,192 rays, against the reference's own output:
+    * the valid mask, 1,048,576 bits: BIT-EXACT;
+    * the importance indices, 524,288: every index that differs from the reference's is ASSERTED to be a one-bin shift at a cdf entry the fixture lists
+      as a near tie (within 1e-4 of a query point u), where the device's cdf (re-formed from the device's coarse weights with the arithmetic the
+      kernel is held to bit for bit) and the reference's straddle u and agree to INDEX_CDF_TOL; their number is bounded and reported;
+    * every rendered channel over the stored rays: max(1e-4, 2 x measured) AND within 2x of the same channel's fp32-vs-fp64 floor on this fixture.
+    eval_bench: raw seeded init + sdf bias nudge (a flat field); eval_bench_w1: W1, the reference's geometry_init fit (a sharp surface)."""
+    from lab4d_amd import mlp
+    measured, stats = _run_eval_bench(golden_dir, name + ".pt", mlp.PREC_F32)
+    report(name + "_indices_fp32", {k: float(v) for k, v in stats.items()})
+    assert stats["valid_total"] >= 1_000_000 and stats["index_total"] >= 500_000
+    assert stats["valid_mismatch"] == 0, "valid mask must be identical (bit-exact bool): %d of %d differ" % (stats["valid_mismatch"], stats["valid_total"])
+    assert stats["index_mismatch"] <= INDEX_MISMATCH_FRAC_MAX * stats["index_total"], stats
+    check(name + "_fp32", measured, floor_case=name, skip=("psnr_rgb_db",), floor_factor=FLOOR_FACTOR_FULL)
+
+
+# bf16 eval path (what bench.py's eval leg times) against the fp32 reference render: the coarse densities carry bf16 rounding, so importance samples
+# move by more than a tie (indices are reported, not asserted) and the valid mask -- a function of the warped sample POSITIONS, which bf16 touches only
+# through the delta-skin MLP -- may flip for samples within rounding of a box face.  Bounds = 2 x the MI355X measurement (profiles/r05_parity_eval_bench*_bf16.json).
+
+
+@pytest.mark.parametrize("name", ["eval_bench", "eval_bench_w1"])
+def test_eval_graph_at_the_bench_size_bf16(golden_dir, name):
+    from lab4d_amd import mlp
+    measured, stats = _run_eval_bench(golden_dir, name + ".pt", mlp.PREC_BF16)
+    report(name + "_indices_bf16", {k: float(v) for k, v in stats.items()})
+    check(name + "_bf16", measured, skip=("psnr_rgb_db",))
+    assert stats["valid_mismatch"] <= 1e-4 * stats["valid_total"], stats
+    assert measured["psnr_rgb_db"] > 40.0, measured["psnr_rgb_db"]
 
 
 def test_render_samples_chunk_equals_unchunked_eval(golden_dir):

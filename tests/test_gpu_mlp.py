@@ -108,11 +108,17 @@ def test_chain_forward_backward(name, cin, shape, prec):
 
     ro, rg = run(lambda P_, f_, x_: ref_net(name, P_, f_, x_), "cpu")
     do, dg = run(lambda P_, f_, x_: dev_net(name, prec, P_, f_, x_), DEV)
-    assert rel_err(do, ro) < ftol, f"{name} forward rel err {rel_err(do, ro):.3e}"
+    measured = {"forward": rel_err(do, ro)}
+    assert measured["forward"] < ftol, f"{name} forward rel err {rel_err(do, ro):.3e}"
     for nme, a, b in zip(["x"] + keys + cond_keys, dg, rg):
-        e = rel_err(a, b)
+        e = measured["grad." + nme] = rel_err(a, b)
         assert e < gtol, f"{name} grad {nme} rel err {e:.3e}"
         assert cosine(a, b) > 0.98, f"{name} grad {nme} cosine {cosine(a, b):.4f}"
+    if prec == 1:
+        # round 5: the benched dtype is held per entry to max(1e-4, 2 x the committed MI355X measurement) like the fp32 path
+        # (tests/parity_report.py); TOL[1] above stays as the a-priori ceiling
+        from parity_report import check
+        check("mlp_bf16_%s_%dx%dx%d" % (name, M, N, D), measured)
 
 
 @pytest.mark.parametrize("prec", [0, 1])

@@ -26,12 +26,13 @@ CASES = [(1000, 300, False, True, True),        # ragged tail, tiles that stradd
 
 @pytest.fixture(autouse=True)
 def _restore_env():
-    old = os.environ.get("LAB4D_WS")
+    old = {k: os.environ.get(k) for k in ("LAB4D_WS", "LAB4D_CHAIN_GRID")}
     yield
-    if old is None:
-        os.environ.pop("LAB4D_WS", None)
-    else:
-        os.environ["LAB4D_WS"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("net", ["fg_base", "fg_color", "dense", "dense6"])
@@ -45,6 +46,38 @@ def test_weights_stationary_chains_are_bit_equal_to_the_wave_resident_ones(net, 
     cs = W.make_case(W.NETS[net], S, spf, 11 + case, fw, train, dx, dx_only)
     cs["tangent"] = (net == "fg_base" and case == 0)  # + lab4d_mlp_forward_tangent (the eikonal term's forward) on this case's sign words
     ok = W.compare(cs, "%s case %d" % (net, case), report)
+    bad = [b for b in report[-1]["buffers"] if b.get("mismatches") or b.get("ok") is False]
+    assert ok, bad
+
+
+@pytest.mark.parametrize("net", ["fg_base", "fg_color", "dense", "dense6"])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_weights_stationary_chains_are_bit_equal_across_tiles(net, case):
+    """Round 5: the comparison above launches min(tiles, CUs) workgroups, so every workgroup ran ONE tile -- the persistent loop
+    (next-tile weight reload, per-tile bias refill, the last layer's deferred stores flushed into the next tile, the sign-word carry, the posenc scratch
+    aliasing an activation buffer, and since round 5 the per-block progress counters that run on across tiles) executed once.  Here the weights-stationary
+    launch is forced onto a 3-workgroup grid (LAB4D_CHAIN_GRID, read per launch): 8 .. 38 tiles -> every workgroup runs 2 .. 13 tiles, all five modes
+    (training, annealing, tile-uniform frames, inference, point-gradient-only) and the tangent forward, bit for bit against the wave-resident family."""
+    S, spf, fw, train, dx = CASES[case]
+    dx_only = case == 4
+    if dx_only and net != "fg_base":
+        pytest.skip("point-gradient-only mode: the sdf basefields")
+    os.environ["LAB4D_CHAIN_GRID"] = "3"
+    report = []
+    cs = W.make_case(W.NETS[net], S, spf, 31 + case, fw, train, dx, dx_only)
+    cs["tangent"] = (net == "fg_base" and case == 0)
+    ok = W.compare(cs, "%s case %d, 3-workgroup grid" % (net, case), report)
+    bad = [b for b in report[-1]["buffers"] if b.get("mismatches") or b.get("ok") is False]
+    assert ok, bad
+
+
+@pytest.mark.parametrize("net", ["fg_base", "fg_color"])
+def test_weights_stationary_chains_are_bit_equal_on_a_full_grid_of_several_tiles(net):
+    """... and without the override at a size where the default grid (one workgroup per CU, 256) runs 2-3 tiles each: 128 x 600 + 77 samples."""
+    os.environ.pop("LAB4D_CHAIN_GRID", None)
+    report = []
+    cs = W.make_case(W.NETS[net], 128 * 600 + 77, 20000, 41, True, True, True, False)
+    ok = W.compare(cs, "%s, 601 tiles" % net, report)
     bad = [b for b in report[-1]["buffers"] if b.get("mismatches") or b.get("ok") is False]
     assert ok, bad
 

@@ -28,6 +28,7 @@ def gen(seed):
 def test_library_loaded_is_the_in_tree_hip_library():
     from lab4d_amd import _lib
     assert _lib.lib().lab4d_arch() == b"gfx950"
+    assert _lib.lib().lab4d_build_flags() == b"", "kernel-experiment macros in the shipped library: %r" % _lib.lib().lab4d_build_flags()
     assert os.path.samefile(_lib.SO_PATH, os.path.join(os.path.dirname(_lib.__file__), "liblab4d_hip.so"))
 
 

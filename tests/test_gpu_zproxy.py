@@ -134,3 +134,54 @@ def test_proxy_bindings_drive_the_grid_query_through_the_reference_entry_points(
                                              time_embedding=types.SimpleNamespace(frame_mapping=g["frame_mapping"].to(DEV)))
     patch.nerf_update_near_far(field)
     assert rel(field.near_far.data, g["near_far_after"]) < 1e-5
+
+
+def test_proxy_binding_meshes_the_background_field_too():
+    """NeRF.extract_canonical_mesh is bound for EVERY NeRF, and the reference bg field is one (multifields.py:86-93: D=5, W=128,
+    6 frequencies); MultiFields.update_geometry_aux (trainer.py:247) meshes it every round.  The binding dispatches on field_kind: the bg stand-in's
+    grid query runs LAB4D_NET_BG_BASE (+ the shared VisField) and equals the oracle's bg forward on the same grid."""
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import standins
+    from lab4d_amd import patch, proxy
+    from oracle import lab4d_oracle as O
+    Pc = synthetic.make_bg_weights(7)
+    Pc["sdf.bias"] = torch.tensor([-0.05])
+    P = synthetic.to_device(Pc, DEV)
+    field = standins.bg_field(P, training=False)
+    field.aabb = torch.tensor([[-0.5, -0.4, -0.45], [0.55, 0.45, 0.5]], device=DEV)
+    field.category = "bg"
+    patch.configure(field, precision="f32")
+    assert patch.field_kind(field) == "bg"
+    G = 24
+    seen = {}
+
+    def marching_cubes(sdf_func, aabb, visibility_func=None, grid_size=64, level=0, chunk_size=64 ** 3, apply_connected_component=False):
+        grid = proxy.sample_grid(aabb, grid_size)
+        seen.update(sdf=sdf_func(grid).reshape(grid_size, grid_size, grid_size), vis=visibility_func(grid).reshape(grid_size, grid_size, grid_size), box=aabb,
+                    cc=apply_connected_component, grid=grid)
+        return "mesh"
+    saved = {k: sys.modules.get(k) for k in ("lab4d", "lab4d.utils", "lab4d.utils.geom_utils")}
+    geom = types.ModuleType("lab4d.utils.geom_utils")
+    geom.marching_cubes = marching_cubes
+    for k in ("lab4d", "lab4d.utils"):
+        sys.modules.setdefault(k, types.ModuleType(k))
+    sys.modules["lab4d.utils.geom_utils"] = geom
+    try:
+        out = patch.nerf_extract_canonical_mesh(field, grid_size=G, level=0.005)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    assert out == "mesh" and seen["cc"] is False  # (connected-component filter: fg only, nerf.py:339-342)
+    pts = seen["grid"].cpu()
+    code_b = Pc["basefield.inst_embedding.mapping.weight"].mean(0, keepdim=True)
+    code_v = Pc["vis_mlp.basefield.inst_embedding.mapping.weight"].mean(0, keepdim=True)
+    with torch.no_grad():
+        sdf_ref = O.nerf_forward(Pc, pts[None], {"basefield": code_b}, with_color=False, get_density=False, cfg=O.BG_CFG)[0, :, 0]
+        vis_ref = O.vis_field(Pc, pts[None], code_v)[0, :, 0] > 0
+    assert rel(seen["sdf"].reshape(-1), sdf_ref) < 1e-4
+    assert int((seen["vis"].reshape(-1).cpu() != vis_ref).sum()) <= 2

@@ -483,7 +483,30 @@ def test_pose_flat_articulation_and_intrinsics(pose):
     close(PO.intrinsics_vals(P, "intr", None, info_k), pose["intr"]["all_frames"], "intrinsics all")
 
 
-@pytest.mark.parametrize("name", ["train_c1.pt", "train_bench.pt", "train_multi10_bench.pt"])
+@pytest.mark.parametrize("name", ["eval_bench.pt", "eval_bench_w1.pt"])
+def test_eval_graph_at_the_bench_size(golden_dir, name):
+    """Round 5: the eval path at BASELINE configs[1]'s size (512x512, 64 + 64 samples per ray; 8 image rows of a frame pair = 8,192 rays) on the raw
+    initialisation (W0 + sdf bias nudge) and on W1 (the reference's own geometry_init fit, a sharp surface).  The oracle runs ONE band (2,048 rays,
+    131,072 indices, 262,144 mask bits -- the CPU budget) and must reproduce the reference bit for bit in the indices and the mask, and the
+    stored rays of the render to 2e-4; the device test covers all four bands."""
+    from fixture_utils import eval_bench_bands, eval_bench_unpack, fg_weights, weight_checksum
+    g = torch.load(os.path.join(golden_dir, name), weights_only=False)
+    meta = g["meta"]
+    P = fg_weights(meta)
+    assert abs(weight_checksum(P) - meta["weight_checksum"]) < 1e-6 * meta["weight_checksum"]
+    fr = synthetic.add_codes(dict(g["frames"]), P)
+    inds, valid = eval_bench_unpack(g)
+    assert inds.numel() >= 500_000 and valid.numel() >= 1_000_000
+    band, hxy, sl = eval_bench_bands(g)[1 if meta["w1"] else 2]
+    out = O.render_eval(P, fr, hxy, n_depth=meta["D"])
+    assert torch.equal(out["debug"]["inds"].view(meta["M"], -1, meta["D"] // 2), inds[:, sl]), "importance-sampling indices must be bit-exact"
+    assert torch.equal(out["debug"]["valid"], valid[:, sl]), "valid mask must be bit-exact"
+    st = meta["full_grid_stride"]
+    for k, v in g["rendered_bands"][band].items():
+        close(out["rendered"][k][:, ::st], v, "rendered." + k, rtol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["train_c1.pt", "train_bench.pt", "train_multi10_bench.pt", "train_bench_w1.pt"])
 def test_training_graph_at_baseline_sizes(golden_dir, name):
     """BASELINE.json configs[0]: the full 64x64 crop of a frame pair x 64 samples/ray (8,192 rays, 524,288 samples) through the whole
     training graph.  The fixture (reference-generated) stores every 16th ray of the render, the losses and compressed gradients;
