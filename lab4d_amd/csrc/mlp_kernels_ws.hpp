@@ -246,8 +246,17 @@ __device__ __forceinline__ void ws_layer_barrier() {
 // it explicit) and polls cnt[b] before it touches block b of the next layer.  A wave that finishes early runs up to one item ahead of the slowest one;
 // the two waves of a SIMD drift out of phase and one's epilogue runs under the other's MFMAs.  Counters are monotone over the life of the workgroup
 // (8 arrivals per block and layer); the tile boundary keeps its full barriers (posenc scratch / embedding / head-gradient staging alias the buffers).
+// MEASURED (round 5, profiles/r05_ws_sync_token.json; ms per 4.2 M samples, fg base forward / backward, fg colour forward / backward):
+//   barrier (shipped)        5.996 / 6.796   3.142 / 3.100
+//   counters                 5.988 / 6.937   3.400 / 3.415
+//   counters + token         6.003 / 7.014   3.137 / 3.586
+//   barrier + token          6.427 / 7.278   3.212 / 3.273
+// i.e. NOT a win: the older wave of a SIMD no longer parks at the barrier, it parks in ws_wait_block instead (14-17 k of 86 k cycles per tile) -- the
+// critical path is the YOUNGER wave of each SIMD, which is busy the whole tile (its two loops run at half rate while the older wave's run beside them), and
+// one item of slack does not move work from it.  Bit-equal to the barrier build on hardware in every mode (tests/test_gpu_mlp_ws.py ran with
+// counters + token).  Kept as an experiment switch, default OFF.
 #ifndef LAB4D_WS_SYNC
-#define LAB4D_WS_SYNC 1
+#define LAB4D_WS_SYNC 0
 #endif
 constexpr bool WS_SYNC = LAB4D_WS_SYNC != 0;
 __device__ __forceinline__ void ws_arrive(unsigned cnt_addr, int lane) {
@@ -267,6 +276,37 @@ __device__ __forceinline__ void ws_wait_block(unsigned cnt_addr, unsigned target
     if (++spins > (1 << 22)) __builtin_trap();  // a lost arrival must fail loudly, not hang the device
     __builtin_amdgcn_s_sleep(1);
   }
+}
+
+// ---- matrix-pipe token (LAB4D_WS_TOKEN = 1, round 5) ------------------------------------------------------------------------------------------
+// Two waves share a SIMD (wave w and w + 4).  Left alone they enter their MFMA loops together (each at half rate), leave them together and run their
+// epilogues together with the matrix pipe idle: profiles/r05_ws_trace_*.json -- the SIMD's pipe is busy 41 k of 85 k cycles per tile.  What
+// the dataflow wants is ALTERNATION: one wave streams its item through the pipe at full rate while the other converts / stores / waits.  The token is a
+// per-SIMD lock in LDS taken in front of an item's MFMA loop (behind the block wait) and dropped behind its last MFMA; nothing is waited for while it is
+// held (no deadlock), and the counters above let the other wave run its epilogue and the next item's entry in the meantime.
+// MEASURED (table above): slower.  A lone wave streams an item in ~1.45 k cycles (1,024 of them MFMA: the depth-2 B ring does not cover the LDS latency
+// without a second wave's instructions in between), so serialising the two waves' loops costs more than their overlapping epilogues return
+// (95 k instead of 85 k cycles per tile).  Experiment switch, default OFF.
+#ifndef LAB4D_WS_TOKEN
+#define LAB4D_WS_TOKEN 0
+#endif
+constexpr bool WS_TOKEN = LAB4D_WS_TOKEN != 0;
+__device__ __forceinline__ void ws_token_acquire(unsigned tok_addr, int lane) {
+  if constexpr (!WS_TOKEN) return;
+  const unsigned one = 1u;
+  int spins = 0;
+  for (;;) {
+    unsigned old = 1u;
+    if (lane == 0) asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(tok_addr), "v"(one) : "memory");
+    if (__builtin_amdgcn_readfirstlane((int)old) == 0) break;  // (lane 0 is the first active lane)
+    if (++spins > (1 << 22)) __builtin_trap();
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ void ws_token_release(unsigned tok_addr, int lane) {
+  if constexpr (!WS_TOKEN) return;
+  const unsigned zero = 0u;
+  if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(tok_addr), "v"(zero) : "memory");
 }
 
 template <class T>
@@ -318,11 +358,11 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   // frame).  Read from here a bias costs LDS reads, not vector-memory loads that queue -- in the in-order memory counter -- behind the tile stores
   // of the layer in front and hold up the first MFMA of every layer.
   __shared__ float bias_lds[NL * 256];
-  __shared__ unsigned int blk_cnt[2];  // per 64-sample block: waves that have finished it, summed over the layers (see ws_arrive)
+  __shared__ unsigned int blk_cnt[2 + 4];  // [0..1] per 64-sample block: waves that have finished it, summed over the layers (see ws_arrive); [2..5] per SIMD: the matrix-pipe token
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned xbuf_lds = lds_addr(xbuf), ebuf_lds = lds_addr(ebuf), cnt_lds = lds_addr(blk_cnt);
-  if (tid < 2) blk_cnt[tid] = 0u;  // (the tile loop's first barrier is in front of every use)
+  const unsigned xbuf_lds = lds_addr(xbuf), ebuf_lds = lds_addr(ebuf), cnt_lds = lds_addr(blk_cnt), tok_lds = cnt_lds + 4u * (2u + (unsigned)(w & 3));
+  if (tid < 6) blk_cnt[tid] = 0u;  // (the tile loop's first barrier is in front of every use)
   unsigned cnt_base = 0u;          // arrivals per block before the current tile
   sfor<0, NL>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
@@ -603,9 +643,12 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
           const int b = IT::blk(w, k);
           constexpr int KL = IT::IPW - 1;
           f32x16_t acc[2];
-          if constexpr (WS_SYNC) {
+          if constexpr (WS_SYNC || WS_TOKEN) {
             WS_T(7);
-            if (l > 0) ws_wait_block(cnt_lds + 4u * (unsigned)b, cnt_tgt);
+            if constexpr (WS_SYNC) {
+              if (l > 0) ws_wait_block(cnt_lds + 4u * (unsigned)b, cnt_tgt);
+            }
+            ws_token_acquire(tok_lds, lane);
             WS_T(0);
           }
           // B units stream from LDS through a ring of WS_BD k-groups (two n-tiles each): the read of group g + WS_BD is issued right behind the
@@ -675,6 +718,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
             if (k == KL && g < Gn) A[g] = load_a(Wn, Gn, mtn, g, lane);  // the next layer's group g, right behind the last use of this one
 #endif
           });
+          ws_token_release(tok_lds, lane);
           WS_T(1 + 2 * (k & 1));
           // requests of the next item (they have that item's matrix work to arrive)
           if (k < KL) {
@@ -762,6 +806,12 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       }
       if constexpr (WS_SYNC && !LAST) {
         if (!(EARLY && active)) {  // counted out of both blocks at the end of the layer
+          // ... and not before the layer in front is complete on BOTH: a wave with one item (or none) never waited on the other block, and its
+          // arrival there would be taken for a missing one of the layer in front (the counters are sums; found on hardware: fg_color's 4-row-tile layer)
+          if (l > 0) {
+            ws_wait_block(cnt_lds, cnt_tgt);
+            ws_wait_block(cnt_lds + 4u, cnt_tgt);
+          }
           ws_arrive(cnt_lds, lane);
           ws_arrive(cnt_lds + 4u, lane);
         }
@@ -850,11 +900,11 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
   constexpr int MTE_ANY = KE / 32;
   __shared__ uint4 xbuf[2 * WS_BUF];
   __shared__ float red[8 * 2 * 3 * 32];  // input-gradient partials of the embedding items: [wave][n-tile][axis][lane n]
-  __shared__ unsigned int blk_cnt[2];    // per-block progress counters (see ws_arrive)
+  __shared__ unsigned int blk_cnt[2 + 4];  // per-block progress counters (see ws_arrive) + per-SIMD matrix-pipe tokens
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned xbuf_lds = lds_addr(xbuf), cnt_lds = lds_addr(blk_cnt);
-  if (tid < 2) blk_cnt[tid] = 0u;
+  const unsigned xbuf_lds = lds_addr(xbuf), cnt_lds = lds_addr(blk_cnt), tok_lds = cnt_lds + 4u * (2u + (unsigned)(w & 3));
+  if (tid < 6) blk_cnt[tid] = 0u;
   unsigned cnt_base = 0u;
   const unsigned trl = tr_lane_base(0u, 16, lane);
   const unsigned perm_a = ws_perm_addr(lane);
@@ -994,6 +1044,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
         constexpr int GP = decltype(gp_c)::value;
         constexpr int HK = decltype(host_c)::value;  // >= 0: this loop hosts the pieces HK NPI .. of the deferred dZ tiles
         if constexpr (WS_SYNC && !TOP) ws_wait_block(cnt_lds + 4u * (unsigned)b, cnt_tgt);  // (the top layer's input is staged in front of the tile's barrier)
+        ws_token_acquire(tok_lds, lane);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1035,6 +1086,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
           }
           if constexpr (PF && g < GP) A[g] = load_a(Wp, GP, rt, g, lane);
         });
+        ws_token_release(tok_lds, lane);
       };
 
       bool loaded_next = false;
@@ -1119,6 +1171,10 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
       mcur[1] = mnext[1];
       if constexpr (WS_SYNC && !BOTTOM) {
         if (!(EARLY && act_on)) {
+          if constexpr (!TOP) {  // (see the forward kernel: no arrival on a block before the layer above is complete there)
+            ws_wait_block(cnt_lds, cnt_tgt);
+            ws_wait_block(cnt_lds + 4u, cnt_tgt);
+          }
           ws_arrive(cnt_lds, lane);
           ws_arrive(cnt_lds + 4u, lane);
         }

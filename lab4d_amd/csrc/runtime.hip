@@ -160,6 +160,9 @@ extern "C" const char* lab4d_build_flags(void) {
 #ifdef LAB4D_WS_SYNC
   " WS_SYNC"
 #endif
+#ifdef LAB4D_WS_TOKEN
+  " WS_TOKEN"
+#endif
 #ifdef LAB4D_WS_TRACE
   " WS_TRACE"
 #endif

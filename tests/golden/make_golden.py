@@ -216,7 +216,7 @@ def gen_train(ns, tag, M, N, D, res, seed, alpha=None, num_inst=1, inst_id=None,
             gd[k] = compress_grad(gv.detach())
     out = {
         "meta": {"M": M, "N": N, "D": D, "res": res, "seed": seed, "alpha": alpha, "num_inst": num_inst, "fg_motion": fg_motion,
-                 "weight_checksum": weight_checksum(P), "flow_thresh": float(res), "w1": bool(w1)},
+                 "weight_checksum": weight_checksum(P), "flow_thresh": float(res), **({"w1": True} if w1 else {})},
         "frames": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in fr.items()},
         "hxy": hxy, "batch": batch, "rng": {"eik_inds": eik_inds.clone(), "match_perm": match_perm.clone()},
         "feat_dict": {k: v.detach() for k, v in feat_dict.items()}, "deltas": deltas.detach(),

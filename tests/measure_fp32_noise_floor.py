@@ -189,6 +189,9 @@ def eval_bench_case(name):
     out = {"index_mismatch_count": float(idx_mis), "valid_mask_mismatch_count": float(mask_mis)}
     for k in acc[32]:
         out["rendered." + k] = relmax(torch.cat(acc[32][k], 1), torch.cat(acc[64][k], 1))
+    # the normal is compared opacity-weighted (see tests/test_gpu_field.py: _run_eval_bench); the fixture's mask is the float32 reference's
+    m_ref = torch.cat([r["mask"] for r in g["rendered_bands"]], 1).double()
+    out["rendered.normal"] = relmax(torch.cat(acc[32]["normal"], 1).double() * m_ref, torch.cat(acc[64]["normal"], 1) * m_ref)
     return out
 
 

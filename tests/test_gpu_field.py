@@ -408,17 +408,26 @@ def _run_eval_bench(golden_dir, name, prec):
             ref.setdefault(ch, []).append(v)
     stats["valid_fraction"] /= stats["valid_total"]
     measured = {"rendered." + ch: rel(torch.cat(got[ch], 1), torch.cat(ref[ch], 1)) for ch in got}
+    # the rendered normal is normalize(sum_d w_d n_d / (sum_d w_d + 1e-6)) (render_utils.py:59-96): on a ray that hits nothing it is the direction of a sum of
+    # rounding errors -- any two evaluations point anywhere (the reference's own fp32 vs fp64: 4e-2 of a UNIT vector as a max over 512 rays, a heavy-tailed
+    # statistic).  It is compared where it means something: weighted by the ray's opacity (the reference's rendered mask), in this test and in the floor
+    # (tests/measure_fp32_noise_floor.py: eval_bench_case) alike
+    m_ref = torch.cat(ref["mask"], 1)
+    measured["rendered.normal"] = rel(torch.cat(got["normal"], 1) * m_ref, torch.cat(ref["normal"], 1) * m_ref)
     mse = float(((torch.cat(got["rgb"], 1) - torch.cat(ref["rgb"], 1)) ** 2).mean())
     measured["psnr_rgb_db"] = -10.0 * torch.log10(torch.tensor(max(mse, 1e-20))).item()
     return measured, stats
 
 
 # |cdf_device - cdf_reference| allowed at a cdf entry where the two implementations' importance indices differ: the cdf is a running sum of <= 62
-# normalised weights, each carrying the fp32 rounding of ten 256-wide layers upstream (density ~1e-6 relative); measured worst on MI355X: see
-# profiles/r05_parity_eval_bench_indices*.json
-INDEX_CDF_TOL = 2e-5
-# fraction of the 524,288 importance indices of a fixture that may differ (each one verified to be a one-bin shift at a near tie, see above)
-INDEX_MISMATCH_FRAC_MAX = 2e-3
+# normalised weights, each carrying the fp32 rounding of ten 256-wide layers upstream.  Measured worst on MI355X (profiles/r05_parity_eval_bench*_indices_fp32.json):
+# 2.4e-7 (W0) / 7.7e-7 (W1) -- one to six ulps of a number near 1
+INDEX_CDF_TOL = 2e-6
+# fraction of the 524,288 importance indices of a fixture that may differ -- EACH ONE asserted to be a one-bin shift at a near tie whose two cdfs agree to
+# INDEX_CDF_TOL (fixture_utils.check_index_mismatches).  Measured: 1,387 (W0) / 1,546 (W1) = 0.26 % / 0.29 %; the reference's own arithmetic evaluated in
+# float32 and in float64 disagrees on 2,915 / 2,806 of the same indices (tests/golden/fp32_noise_floor.json: index_mismatch_count), i.e. an exact tie in
+# one fp32 evaluation order is broken the other way by any other order about once in 350 indices; bound = 1.5 x measured, below that floor
+INDEX_MISMATCH_FRAC_MAX = 4.5e-3
 
 
 @pytest.mark.parametrize("name", ["eval_bench", "eval_bench_w1"])

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 CMD=${1:-"python $R/tools/bench_chain.py 2097152 base"}
-timeout -k 5 60 rocprofv3 -L > $R/gpurun_out/r04_counter_list.txt 2>&1  # every counter this box offers (names for the next round)
+[ -n "$SQ_SKIP_LIST" ] || timeout -k 5 60 rocprofv3 -L > $R/gpurun_out/r05_counter_list.txt 2>&1  # every counter this box offers
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" \
@@ -13,13 +13,14 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout -k 5 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/sq2_$i -- $CMD > /tmp/sq2_$i.log 2>&1 || tail -3 /tmp/sq2_$i.log
 done
 python - > $R/gpurun_out/${SQ_OUT:-r04_sq_counters.txt} <<'PY'
-import csv, glob, re
+import csv, glob, os, re
+FILTER = os.environ.get('SQ_FILTER', 'k_mlp_fwd|k_mlp_bwd')  # kernels of interest (regex on the symbol)
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob('/tmp/sq2_*/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name']
-        if 'k_mlp_fwd' not in k and 'k_mlp_bwd' not in k: continue
+        if not re.search(FILTER, k): continue
         k = re.sub(r'lab4d::', '', k.split('(')[0])[:60]
         acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
 for k in sorted(acc):

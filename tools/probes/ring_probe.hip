@@ -24,7 +24,28 @@ constexpr int THREADS = 512;                   // the chain kernels' workgroup
 constexpr int VEC_PER_THREAD = TILE_BYTES / 16 / THREADS;  // 8 x 16 B per thread and tile
 constexpr long SPIN_LIMIT = 1L << 24;
 
+// MODE 0: the memory model's own hand-off (agent-scope release / acquire fences: L2 write-back + invalidate on this part).
+// MODE 1..3: NO fences -- the tile's stores / loads carry cache-scope bits instead and the flag follows an s_waitcnt vmcnt(0):
+//   1: plain stores (the L1 is write-through: they land in the producer's L2), loads sc1 (agent scope: past the consumer's L1);
+//   2: stores sc1, loads sc1;   3: stores sc0 sc1, loads sc0 sc1 (system scope: through the L2s).
+// Whether a mode is COHERENT for a pairing is what "ok" reports (every vector of every tile carries its round number).
+template <int MODE>
+__device__ __forceinline__ void st16(u32x4_t* p, u32x4_t v) {
+  if constexpr (MODE == 0 || MODE == 1) *p = v;
+  else if constexpr (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+template <int MODE>
+__device__ __forceinline__ u32x4_t ld16(const u32x4_t* p) {
+  u32x4_t v;
+  if constexpr (MODE == 0) v = *p;
+  else if constexpr (MODE == 1 || MODE == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 // role: even pair member = producer, odd = consumer.  partner_stride: 8 (same XCD) or 1 (neighbouring XCD).
+template <int MODE>
 __global__ void __launch_bounds__(THREADS) k_ring(u32x4_t* ring, unsigned* ready, unsigned* freed, int slots, int tiles, int partner_stride, unsigned* err,
                                                   float* sink) {
   // workgroup -> (pair, role).  same-XCD pairing: blocks [16 k, 16 k + 8) are producers of pairs 8 k .. 8 k + 7, blocks [16 k + 8, 16 k + 16) their consumers
@@ -46,7 +67,7 @@ __global__ void __launch_bounds__(THREADS) k_ring(u32x4_t* ring, unsigned* ready
       // wait until the consumer has released this slot's previous content
       if (round > 0 && tid == 0) {
         long spins = 0;
-        while (__hip_atomic_load(&my_freed[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round) {
+        while (__hip_atomic_load(&my_freed[s], MODE == 0 ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round) {
           __builtin_amdgcn_s_sleep(2);
           if (++spins > SPIN_LIMIT) { atomicExch(err, 1u); break; }
         }
@@ -54,26 +75,31 @@ __global__ void __launch_bounds__(THREADS) k_ring(u32x4_t* ring, unsigned* ready
       __syncthreads();
       u32x4_t v = {(unsigned)t, (unsigned)tid, (unsigned)pair, 0x3f800000u};
 #pragma unroll
-      for (int i = 0; i < VEC_PER_THREAD; ++i) tile[i * THREADS + tid] = v;
-      __syncthreads();  // (every wave's stores issued; the release below orders them in front of the flag)
-      if (tid == 0) __hip_atomic_store(&my_ready[s], round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < VEC_PER_THREAD; ++i) st16<MODE>(&tile[i * THREADS + tid], v);
+      if constexpr (MODE != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have been acknowledged
+      __syncthreads();  // (every wave's stores issued / acknowledged; MODE 0: the release below orders them in front of the flag)
+      if (tid == 0) __hip_atomic_store(&my_ready[s], round + 1, MODE == 0 ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (tid == 0) {
         long spins = 0;
-        while (__hip_atomic_load(&my_ready[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round + 1) {
+        while (__hip_atomic_load(&my_ready[s], MODE == 0 ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round + 1) {
           __builtin_amdgcn_s_sleep(2);
           if (++spins > SPIN_LIMIT) { atomicExch(err, 2u); break; }
         }
       }
       __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave's L1 must drop what it may hold of the slot's previous round
+      if constexpr (MODE == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave's L1 must drop what it may hold of the slot's previous round
+      u32x4_t vv[VEC_PER_THREAD];
 #pragma unroll
-      for (int i = 0; i < VEC_PER_THREAD; ++i) {
-        const u32x4_t v = tile[i * THREADS + tid];
-        acc += __uint_as_float(v.w) + (v.x == (unsigned)t ? 0.f : 1e9f);  // (wrong round -> visible in the sink)
+      for (int i = 0; i < VEC_PER_THREAD; ++i) vv[i] = ld16<MODE>(&tile[i * THREADS + tid]);
+      if constexpr (MODE != 0) {  // the loaded registers are in/out operands of the wait: no use of them can be scheduled in front of it
+        static_assert(VEC_PER_THREAD == 8, "operand list below");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7])::"memory");
       }
+#pragma unroll
+      for (int i = 0; i < VEC_PER_THREAD; ++i) acc += __uint_as_float(vv[i].w) + (vv[i].x == (unsigned)t ? 0.f : 1e9f);  // (wrong round -> visible in the sink)
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(&my_freed[s], round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(&my_freed[s], round + 1, MODE == 0 ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (role == 1) sink[(size_t)pair * THREADS + tid] = acc;
@@ -109,8 +135,10 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  for (int mode = 0; mode < 4; ++mode)
   for (int stride : {8, 1}) {
     for (int slots : slot_sweep) {
+      if (mode > 0 && !(slots == 1 || slots == 4 || slots == 32 || slots == 128)) continue;
       float best = 1e30f;
       unsigned herr = 0;
       for (int rep = 0; rep < 3; ++rep) {
@@ -118,7 +146,8 @@ int main(int argc, char** argv) {
         CK(hipMemset(freed, 0, (size_t)pairs * max_slots * 4));
         CK(hipMemset(err, 0, 4));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_ring, dim3(2 * pairs), dim3(THREADS), 0, 0, ring, ready, freed, slots, tiles, stride, err, sink);
+        auto kern = mode == 0 ? k_ring<0> : mode == 1 ? k_ring<1> : mode == 2 ? k_ring<2> : k_ring<3>;
+        hipLaunchKernelGGL(kern, dim3(2 * pairs), dim3(THREADS), 0, 0, ring, ready, freed, slots, tiles, stride, err, sink);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -127,11 +156,13 @@ int main(int argc, char** argv) {
         if (herr) break;
         if (ms < best) best = ms;
       }
-      float s0 = 0.f;
-      CK(hipMemcpy(&s0, sink, 4, hipMemcpyDeviceToHost));
+      static float hs[512 * 512];
+      CK(hipMemcpy(hs, sink, (size_t)pairs * THREADS * 4, hipMemcpyDeviceToHost));
+      float s0 = (float)tiles * VEC_PER_THREAD;
+      for (int i = 0; i < pairs * THREADS; ++i) if (hs[i] != s0) { s0 = hs[i]; break; }  // any consumer thread that saw a stale / foreign vector
       const double bytes = (double)pairs * tiles * TILE_BYTES;
-      printf("{\"pairing\": \"%s\", \"pairs\": %d, \"slots\": %d, \"ring_mib\": %.1f, \"tiles_per_pair\": %d, \"ms\": %.3f, \"gbps\": %.1f, \"ok\": %s}\n",
-             stride == 8 ? "same_xcd" : "cross_xcd", pairs, slots, (double)pairs * slots * TILE_BYTES / 1048576.0, tiles, best, bytes / best / 1e6,
+      printf("{\"mode\": %d, \"pairing\": \"%s\", \"pairs\": %d, \"slots\": %d, \"ring_mib\": %.1f, \"tiles_per_pair\": %d, \"ms\": %.3f, \"gbps\": %.1f, \"ok\": %s}\n",
+             mode, stride == 8 ? "same_xcd" : "cross_xcd", pairs, slots, (double)pairs * slots * TILE_BYTES / 1048576.0, tiles, best, bytes / best / 1e6,
              (herr == 0 && s0 == (float)tiles * VEC_PER_THREAD) ? "true" : "false");
       fflush(stdout);
     }

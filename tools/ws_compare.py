@@ -241,7 +241,7 @@ def time_case(net, S, report, dx_only=False):
         if ws and os.environ.get("LAB4D_WS_TRACE_PRINT"):
             t = f["out"].view(-1)[:64].tolist()
             ntile = (c["S_pad"] // 128 + 255) // 256
-            names = ["top", "loop0", "epi0", "loop1", "epi1", "barrier", "posenc", "vmcnt@entry"]
+            names = ["block_wait", "loop0", "epi0", "loop1", "epi1", "barrier", "posenc", "vmcnt@entry"]
             out["trace_cycles_per_tile"] = {"wave%d" % wv: {names[i]: round(t[8 * wv + i] / ntile) for i in range(8)} for wv in range(8)}
         del f, b
         torch.cuda.empty_cache()
