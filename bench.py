@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="only the timed training step: no forward-only rate, no PSNR, no fp32 leg (used by the fp32 leg's own child run)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short fp32 run of the same step that the default bf16 run appends (fp32_leg)")
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--chunk-graph", action="store_true", help="one captured hipGraph per CHUNK (rounds 1-4) instead of the whole-step pair of graphs "
+                                                               "(TrainLoop.capture_step: every chunk + prologue + optimizer in two graph launches per step)")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays per frame of one CPU-baseline pass (1 warm-up + 3 timed passes)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the gradient all-reduce even at world size 1 "
                                                               "(exercises init order, graph capture next to RCCL's buffers and the collective call on a 1-GPU box)")
@@ -164,6 +166,29 @@ def draw_rng(M, N, S, device, gen, out=None):
         out["match_perm"].copy_(perm)
         return out
     return {"eik_inds": eik, "match_perm": perm}
+
+
+def draw_rng_all(C, M, N, S, device, gen, outs):
+    """draw_rng for the C chunks of a step in one batch of launches (the whole-step graph leaves these draws as the step's only eager work): the same
+    distributions -- a uniformly random (M N / 16)-subset in random order per chunk (the prefix of a random permutation = the arg-sort of i.i.d.
+    uniforms), 1,024 distinct uniform indices per chunk (distinct_indices, along dim 1) -- into the chunks' static buffers."""
+    k_e = max(M * N // 16, 1)
+    eik = torch.rand(C, M * N, device=device, generator=gen).argsort(dim=1)[:, :k_e]
+    k = min(1024, S)
+    if S <= 4 * k:
+        perm = torch.rand(C, S, device=device, generator=gen).argsort(dim=1)[:, :k]
+    else:
+        draws = torch.randint(0, S, (C, 2 * k), device=device, generator=gen)
+        vals, order = torch.sort(draws, dim=1, stable=True)
+        first = torch.ones_like(vals, dtype=torch.bool)
+        first[:, 1:] = vals[:, 1:] != vals[:, :-1]
+        keep = torch.zeros_like(first).scatter_(1, order, first)  # draw i survives iff it is the first occurrence of its value
+        pos = torch.cumsum(keep.to(torch.int64), 1) - 1
+        out = torch.empty_like(draws).scatter_(1, torch.where(keep, pos, pos.new_full((), 2 * k - 1)), draws)  # survivors compacted in draw order
+        perm = out[:, :k]
+    for c, o in enumerate(outs):
+        o["eik_inds"].copy_(eik[c])
+        o["match_perm"].copy_(perm[c])
 
 
 def train_chunk(DF, P, fr, hxy, batch, rng, spp, res, prec):
@@ -693,7 +718,8 @@ class TrainLoop:
     FlatAdamW.  `step()` = zero_grad -> prologue -> every chunk (hipGraph replay or eager) -> prologue backward -> [all-reduce] ->
     check_grad + AdamW -> repack.  bench.py times it; tests/test_gpu_ztrajectory.py runs it for 30+ steps."""
 
-    def __init__(self, dev, res, spp, chunks, prec, comp=False, use_graph=True, use_dist=False, world=1, rank=0, trace=False, lr=5e-4, multi=False):
+    def __init__(self, dev, res, spp, chunks, prec, comp=False, use_graph=True, use_dist=False, world=1, rank=0, trace=False, lr=5e-4, multi=False,
+                 step_graph=False):
         from lab4d_amd import mlp
         from lab4d_amd import deformable as DF
         from lab4d_amd.optim import FlatAdamW
@@ -731,8 +757,11 @@ class TrainLoop:
         self.S0 = self.M * self.N0 * (spp // 2 if comp else spp)
         self.uniform = all(h.shape == self.inputs[0][0].shape for h, _ in self.inputs)
         self.graph = None
+        self.graph_a = self.graph_b = None
         self.ar_events = []
-        if use_graph and self.uniform:
+        if use_graph and self.uniform and step_graph and not trace:
+            self.capture_step()
+        elif use_graph and self.uniform:
             self.capture()
         self.opt.zero_grad()
         self.prologue.zero_grad()  # the eager warm-up / capture passes accumulated into the leaves
@@ -765,9 +794,52 @@ class TrainLoop:
         with torch.cuda.graph(self.graph):
             self.st_loss = self.chunk(self.st_hxy, self.st_batch, self.st_rng)
 
+    def capture_step(self):
+        """Round 5 (VERDICT r04 "next" 6): the optimizer step as TWO hipGraphs instead of one graph per chunk + ~400 eager launches --
+        graph A = zero the flat gradient, prologue refresh, EVERY chunk (each reads its own resident inputs and its own static random draws: no
+        copies), prologue backward; [the data-parallel all-reduce, eager, between the two]; graph B = check_grad + AdamW (device-side discard rule and
+        step count: optim.py) + the in-place repack of the kernels' weight copies.  What stays eager per step: the chunks' random draws, batched
+        (draw_rng_all: ~15 launches).  Memory: the chunks are captured one behind the other on one stream, so a chunk's activations are freed into the
+        graph's pool before the next chunk allocates -- the pool peaks at one chunk, like the per-chunk graph."""
+        for hxy, batch in self.inputs:
+            batch["hxy"] = hxy
+        self.st_rngs = [draw_rng(self.M, self.N0, self.S0, self.dev, self.gen) for _ in self.inputs]
+
+        def body_a():
+            self.opt.flat_grad.zero_()  # (a fill kernel; the HIP runtime's memset NODES are what DESIGN.md section 2, finding 4 is about)
+            self.prologue.refresh()
+            if self.comp:
+                self.prologue_bg.refresh()
+            losses = [self.chunk(hxy, batch, rng) for (hxy, batch), rng in zip(self.inputs, self.st_rngs)]
+            self.prologue.backward()
+            if self.comp:
+                self.prologue_bg.backward()
+            return losses
+
+        def body_b():
+            self.opt.step(max_norm=5.0, skip_above=GRAD_SKIP)
+            self.mlp.repack_all()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # eager warm-up on the capture stream (allocator pools, column maps, packed weights): one whole step
+            body_a()
+            body_b()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.st_losses = body_a()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            body_b()
+        self.opt.steps -= 1  # (capturing body_b counted a step on the host that the device did not take)
+        self.st_loss = self.st_losses[-1]
+
     def release_graph(self):
-        self.st_loss = None
-        self.graph = None
+        self.st_loss = self.st_losses = None
+        self.graph = self.graph_a = self.graph_b = None
         torch.cuda.empty_cache()
 
     def trace(self, what, t=None):
@@ -786,6 +858,18 @@ class TrainLoop:
 
     def step(self):
         opt, comp = self.opt, self.comp
+        if self.graph_a is not None:
+            draw_rng_all(len(self.inputs), self.M, self.N0, self.S0, self.dev, self.gen, self.st_rngs)
+            self.graph_a.replay()
+            if self.use_dist:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                allreduce_flat(opt.flat_grad, self.world)
+                e1.record()
+                self.ar_events.append((e0, e1))
+            self.graph_b.replay()
+            opt.steps += 1
+            return self.st_loss
         opt.zero_grad()
         last = None
         self.prologue.refresh()
@@ -875,10 +959,10 @@ def rank_main(a):
         torch.cuda.empty_cache()
 
     loop = TrainLoop(dev, res, spp, plan["chunks"], prec, comp=comp, use_graph=not a.no_graph, use_dist=use_dist, world=world, rank=rank, trace=a.trace,
-                     multi=multi)
+                     multi=multi, step_graph=not a.chunk_graph)
     opt, params, inputs, step = loop.opt, loop.params, loop.inputs, loop.step
     M, N0, S0, gen = loop.M, loop.N0, loop.S0, loop.gen
-    graph = loop.graph
+    graph = loop.graph if loop.graph is not None else loop.graph_a
     ar_events = loop.ar_events
 
     for _ in range(a.warmup):
@@ -902,7 +986,8 @@ def rank_main(a):
     n_prof_chunks = len(inputs) * a.steps
     loss_last = float(last[12])
     peak_hbm = torch.cuda.max_memory_allocated()
-    launch_mode = "hipGraph replay per chunk" if graph is not None else "eager"
+    launch_mode = ("two hipGraph replays per optimizer step (all chunks + prologue | check_grad + AdamW + repack)" if loop.graph_a is not None else
+                   "hipGraph replay per chunk" if graph is not None else "eager")
     n_skipped = int(opt.steps - int(opt.dev_step))  # steps check_grad discarded (0 on a healthy run)
     if graph is not None:
         # the eager re-run below needs the memory the graph's private pool holds

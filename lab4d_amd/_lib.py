@@ -45,6 +45,11 @@ def _newer(src, dst):
 
 def build(force=False, verbose=True):
     """hipcc --offload-arch=gfx950 every csrc/*.hip, link liblab4d_hip.so in-tree."""
+    extra = os.environ.get("LAB4D_HIPCC_EXTRA", "")
+    if "amdgpu-mfma-vgpr-form" in extra and "LAB4D_MFMA_VGPR_FORM" not in extra:
+        # csrc/mlp_kernels.hpp acc_fence_if: the one-wave-per-SIMD chain kernels drop the MFMA -> inline-asm hazard fence because their accumulators live in
+        # AGPRs (a compiler-visible v_accvgpr_read sits in between); with the MFMA results forced into VGPRs that is no longer true (ADVICE r04)
+        raise RuntimeError("LAB4D_HIPCC_EXTRA passes -amdgpu-mfma-vgpr-form without -DLAB4D_MFMA_VGPR_FORM: the accumulator hazard fence would be dropped")
     os.makedirs(BUILD_DIR, exist_ok=True)
     jobs = []
     objs = []

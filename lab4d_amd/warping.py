@@ -278,7 +278,9 @@ class SkinBlendMulti(Function):
         S, (M, B) = xyz.shape[0], art_r.shape[:2]
         gx, gr = torch.empty_like(xyz), torch.empty_like(raw)
         need_p = any(ctx.needs_input_grad[2:5])
-        fused = _blend_bwd_work(0, ctx.spf, M, B, xyz.device)[1]
+        # (the fused / unfused decision is a function of S -- with S = 0 both paths size their scratch M*B*34 -- so it is asked for the
+        # real S, and that (work, fused) pair serves the first target instead of being thrown away)
+        work0, fused = _blend_bwd_work(S, ctx.spf, M, B, xyz.device)
         gar = gad = gg = None
         gse3s = []
         first = True
@@ -294,7 +296,7 @@ class SkinBlendMulti(Function):
             par = torch.empty_like(art_r) if need_p else None
             pad = torch.empty_like(art_d) if need_p else None
             pg = torch.zeros_like(gauss) if need_p else None
-            work = _blend_bwd_work(S, ctx.spf, M, B, xyz.device)[0]
+            work = work0 if first else _blend_bwd_work(S, ctx.spf, M, B, xyz.device)[0]
             with _lib.timed("k_blend_bwd+gram", (0.0, 4.0 * S * ((3 + B + 3 + 2) + (3 + B) * (1 if first else 2) + (0 if fused else 2 * (2 * B + 18))))):
                 _lib.check(_lib.lib().lab4d_skin_blend_backward_acc(_lib.ptr(xyz), _lib.ptr(art_r), _lib.ptr(art_d), _lib.ptr(gauss), _lib.ptr(raw),
                                                                     _lib.ptr(se3s[i]), _lib.ptr(se3s[i + 1]), _lib.ptr(g_out), _lib.ptr(g_ent),

@@ -191,7 +191,7 @@ def eval_bench_case(name):
         out["rendered." + k] = relmax(torch.cat(acc[32][k], 1), torch.cat(acc[64][k], 1))
     # the normal is compared opacity-weighted (see tests/test_gpu_field.py: _run_eval_bench); the fixture's mask is the float32 reference's
     m_ref = torch.cat([r["mask"] for r in g["rendered_bands"]], 1).double()
-    out["rendered.normal"] = relmax(torch.cat(acc[32]["normal"], 1).double() * m_ref, torch.cat(acc[64]["normal"], 1) * m_ref)
+    out["rendered.normal"] = rel_l2(torch.cat(acc[32]["normal"], 1).double() * m_ref, torch.cat(acc[64]["normal"], 1) * m_ref)  # relative L2 over the stored rays
     return out
 
 
