@@ -383,6 +383,68 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
     ntw = nt < ntw ? nt : ntw;
   }
 
+  // Round 5: what a tile needs from HBM before its first barrier is asked for a TILE AHEAD -- the point coordinates of the positional encoding (one
+  // float per thread: sample pe_sl, axis pe_q) -- and the per-frame bias rows are refilled only when the tile's frame differs from the previous tile's (a
+  // frame is 65,536 tiles long in the bench).  Before, every tile opened with a dependent HBM round trip that nothing could hide (all eight waves wait
+  // for it at the tile's first barrier): -2 .. -4 % on the chains (profiles/r05_ws_prefetch.json).
+  // HIDE: the nets' heads have ONE row tile (sdf: 1 output, rgb / dense: 3), so in a tile's last layer only waves 0 and 1 have an item; waves 2 .. 7 --
+  // 384 threads = 128 samples x 3 axes -- evaluate the NEXT tile's positional encoding meanwhile (sincos, octave doubling, fp32 scratch rows), into the
+  // activation buffer the last layer does not read.  The tile then opens with the scratch -> B-unit conversion straight away: one barrier and the whole
+  // sincos phase (7-15 % of a tile, profiles/r05_ws_trace_call1.txt "posenc") leave the critical path.
+  // MEASURED (round 5, two boxes, profiles/r05_ws_prefetch.json): not a win -- fg base forward 5.89 -> 5.98 ms per 4.2 M samples, fg colour forward 3.01 -> 3.16
+  // (the six waves' sincos work competes for issue slots with the head item of waves 0 / 1, which is the layer's critical path, and the colour kernel
+  // spills 17 registers around it).  Experiment switch LAB4D_WS_HIDE_POSENC, default OFF; the tile-ahead fetch above stays.
+#ifndef LAB4D_WS_HIDE_POSENC
+#define LAB4D_WS_HIDE_POSENC 0
+#endif
+  constexpr bool HIDE = LAB4D_WS_HIDE_POSENC != 0 && !TAN && ws_mt<Net>(NL - 1) == 1 && NL >= 2;
+  constexpr int SCR_BUF = HIDE ? (((NL - 1) & 1) ^ 1) : 1;  // HIDE: the buffer the last layer's input is NOT in (its own output goes to HBM)
+  float* scr = reinterpret_cast<float*>(xbuf + SCR_BUF * WS_BUF);
+  // (the thread -> (sample, axis) map is recomputed where it is used: three registers less across the MFMA loops)
+#define WS_PE_MAP                                                                             \
+  const int pe_t = HIDE ? tid - 128 : tid;                                                    \
+  const bool pe_on = pe_t >= 0 && pe_t < 384;                                                 \
+  const int pe_sl = pe_t & 127, pe_q = __builtin_amdgcn_readfirstlane((pe_t >> 7) & 3)
+  auto x_fetch = [&](int tile_, float& xp) {
+    if constexpr (!TAN) {
+      WS_PE_MAP;
+      const int s = tile_ * WS_TILE + pe_sl, sc = s < S_eff ? s : S_eff - 1;
+      if (tile_ < ntw && pe_on) xp = a.x[(size_t)sc * 3 + pe_q];
+    }
+  };
+  // phase 1 of a tile's positional encoding: thread (sample pe_sl, axis pe_q) -> its columns of the fp32 scratch row.  Same arithmetic as k_mlp_fwd's
+  // bf16 path: one accurate sincos per axis, angle doubling per octave, times the annealing weight; the raw coordinate; axis 0 also clears the padding.
+  auto posenc_rows = [&](float xa) {
+    if constexpr (!TAN) {
+      WS_PE_MAP;
+      if (pe_on) {
+        const int row = 64 * (pe_sl >> 6) + 32 * (pe_sl & 1) + ((pe_sl & 63) >> 1);  // rows ordered (block, n-tile, lane n)
+        float* dst = scr + row * ESTR;
+        float sn, cs;
+        sincosf(xa, &sn, &cs);
+#pragma unroll
+        for (int f = 0; f < L; ++f) {
+          const float wf = a.freq_w ? a.freq_w[f] : 1.0f;
+          *reinterpret_cast<float2*>(dst + 6 * f + 2 * pe_q) = make_float2(sn * wf, cs * wf);
+          sincos_double(sn, cs);
+        }
+        dst[6 * L + pe_q] = xa;
+        if (pe_q == 0) {
+#pragma unroll
+          for (int c = 6 * L + 3; c < KE; ++c) dst[c] = 0.f;
+        }
+      }
+    }
+  };
+#undef WS_PE_MAP
+  float xcur = 0.f;
+  x_fetch((int)blockIdx.x, xcur);
+  if constexpr (HIDE) {
+#ifndef LAB4D_WSABL_NOPOSENC
+    if ((int)blockIdx.x < ntw) posenc_rows(xcur);  // the first tile's; every later tile's is evaluated inside the previous tile's last layer
+#endif
+    wg_step_barrier();
+  }
   uint4 A[GMAX];  // this wave's row tile of the current layer's weights
   auto a_load = [&](auto g0c, auto g1c, const GLOBAL_AS void* Wp, int G, int mt) {
     constexpr int G0 = decltype(g0c)::value, G1 = decltype(g1c)::value;
@@ -405,8 +467,11 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   unsigned long long tlast = ws_clock();
 #endif
 
+  int f_bias = -1;  // frame whose per-frame bias rows bias_lds holds
   for (int tile = blockIdx.x; tile < ntw; tile += gridDim.x) {
     const int s0 = tile * WS_TILE;
+    float xnext = 0.f;
+    x_fetch(tile + (int)gridDim.x, xnext);
     // frame of this lane's sample in (block b, n-tile t): sample s0 + 64 b + 2 n + t
     int frame[2][2];
 #pragma unroll
@@ -425,7 +490,8 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       const int sl_ = s0 + WS_TILE - 1 < S_eff ? s0 + WS_TILE - 1 : S_eff - 1, sf_ = s0 < S_eff ? s0 : S_eff - 1;
       const int f0 = sf_ / a.spf, f1 = sl_ / a.spf;
       tile_uni = f0 == f1;
-      if (tile_uni) {
+      if (tile_uni && f0 != f_bias) {
+        f_bias = f0;
         sfor<0, NL>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
           if constexpr (Net::L[l].pf != 0) {
@@ -435,9 +501,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
         });
       }
     }
-    // ---- positional encoding, once per sample and axis: thread (sample sl, axis q) -> fp32 scratch rows (aliasing activation buffer 1) ----
-    // Same arithmetic as k_mlp_fwd's bf16 path: one accurate sincos per axis, angle doubling per octave, times the annealing weight.
-    float* scr = reinterpret_cast<float*>(xbuf + WS_BUF);
+    // ---- positional encoding, phase 1 (see posenc_rows); HIDE: already done inside the previous tile's last layer ----
 #ifndef LAB4D_WSABL_NOPOSENC
     if constexpr (TAN) {
       // raw (S, KE) tangent rows -> the scratch rows the assembly below reads (16-byte pieces, coalesced; elements behind the last valid one repeat it,
@@ -457,31 +521,11 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
         }
         *reinterpret_cast<float4*>(scr + row * ESTR + 4 * c4) = v;
       }
-    } else {
-      const int sl = tid & 127, q = __builtin_amdgcn_readfirstlane(tid >> 7);
-      const int row = 64 * (sl >> 6) + 32 * (sl & 1) + ((sl & 63) >> 1);  // rows ordered (block, n-tile, lane n)
-      const int s = s0 + sl, sc = s < S_eff ? s : S_eff - 1;
-      float* dst = scr + row * ESTR;
-      if (q < 3) {
-        const float xa = a.x[(size_t)sc * 3 + q];
-        float sn, cs;
-        sincosf(xa, &sn, &cs);
-#pragma unroll
-        for (int f = 0; f < L; ++f) {
-          const float wf = a.freq_w ? a.freq_w[f] : 1.0f;
-          *reinterpret_cast<float2*>(dst + 6 * f + 2 * q) = make_float2(sn * wf, cs * wf);
-          sincos_double(sn, cs);
-        }
-      } else {
-        dst[6 * L + 0] = a.x[(size_t)sc * 3 + 0];
-        dst[6 * L + 1] = a.x[(size_t)sc * 3 + 1];
-        dst[6 * L + 2] = a.x[(size_t)sc * 3 + 2];
-#pragma unroll
-        for (int c = 6 * L + 3; c < KE; ++c) dst[c] = 0.f;
-      }
+    } else if constexpr (!HIDE) {
+      posenc_rows(xcur);
     }
 #endif
-    wg_step_barrier();
+    if constexpr (!HIDE) wg_step_barrier();
     // ---- scratch -> B units (identity slot order: unit g of lane (n, h) = slots 16 g + 8 h + 0..7) + the stored [slot][sample] embedding ----
     for (int p = w; p < 2 * UE; p += 8) {
       const int b = p & 1, g = p >> 1;
@@ -803,6 +847,12 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       } else {
         // a wave without an item in this layer still needs the next layer's weights
         a_load(std::integral_constant<int, 0>{}, std::integral_constant<int, (Gn < G ? Gn : G)>{}, Wn, Gn, mtn);
+        if constexpr (LAST && HIDE) {
+          static_assert(!LAST || !HIDE || IT::ITEMS == 2, "HIDE: the head's two items belong to waves 0 and 1");
+#ifndef LAB4D_WSABL_NOPOSENC
+          if (tile + (int)gridDim.x < ntw) posenc_rows(xnext);  // the NEXT tile's positional encoding, under the head's matrix work (see HIDE)
+#endif
+        }
       }
       if constexpr (WS_SYNC && !LAST) {
         if (!(EARLY && active)) {  // counted out of both blocks at the end of the layer
@@ -828,6 +878,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       WS_T(5);
     });
     cnt_base += 8u * (unsigned)(NL - 1);  // NL - 1 counted layer ends per tile (the last layer ends at the tile's barrier)
+    xcur = xnext;
   }
 #ifdef LAB4D_WS_TRACE
   if (blockIdx.x == 0 && lane < 8 && a.out) {
@@ -939,8 +990,34 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
     }
   };
 
+  // Round 5 (see the forward kernel): the head gradient of the NEXT tile is requested a tile ahead (heads of up to four outputs: one to four floats per
+  // lane of waves 0 / 1) -- the tile no longer opens with an HBM round trip in front of its first barrier.
+  constexpr bool DPRE = Net::COUT <= 4;
+  constexpr int DN = DPRE ? Net::COUT : 1;
+  auto d_fetch = [&](int tile_, float (&d)[2][DN]) {
+    if constexpr (DPRE) {
+      if (w < 2 && tile_ < ntw) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int s = tile_ * WS_TILE + 64 * w + 2 * n + t;
+#pragma unroll
+          for (int r = 0; r < DN; ++r) {
+            const int f = drow(r, h);  // (= r for the lane half h = 0, >= 4 for h = 1)
+            d[t][r] = (f < Net::COUT && s < a.S) ? a.d_out[(size_t)s * Net::COUT + f] : 0.f;
+          }
+        }
+      }
+    }
+  };
+  float dcur[2][DN], dnext[2][DN];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < DN; ++r) dcur[t][r] = dnext[t][r] = 0.f;
+  d_fetch((int)blockIdx.x, dcur);
   for (int tile = blockIdx.x; tile < ntw; tile += gridDim.x) {
     const int s0 = tile * WS_TILE;
+    d_fetch(tile + (int)gridDim.x, dnext);
     float dx[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t) dx[t][0] = dx[t][1] = dx[t][2] = 0.f;
@@ -957,7 +1034,8 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int f = drow(r, h);
-          g[t][r] = (f < Net::COUT && s < a.S) ? a.d_out[(size_t)s * Net::COUT + f] : 0.f;
+          if constexpr (DPRE) g[t][r] = r < DN ? dcur[t][r < DN ? r : 0] : 0.f;  // (registers r >= 4 hold features >= 8 > COUT)
+          else g[t][r] = (f < Net::COUT && s < a.S) ? a.d_out[(size_t)s * Net::COUT + f] : 0.f;
         }
       }
       if constexpr (DZ) store_tile<P>((GLOBAL_AS void*)a.dz[NL - 1], pad32(Net::L[NL - 1].mout), s0 + 64 * b, 0, lane, g);
@@ -1191,6 +1269,10 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
     });
 
     cnt_base += 8u * (unsigned)(NL - 1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < DN; ++r) dcur[t][r] = dnext[t][r];
     // ---- input gradient: partials of the embedding items -> one sum per sample ----
     if (want_dx) {
       if (w < 2 * MTE_ANY) {

@@ -154,6 +154,9 @@ extern "C" const char* lab4d_build_flags(void) {
 #ifdef LAB4D_WS_BD
   " WS_BD"
 #endif
+#ifdef LAB4D_WS_HIDE_POSENC
+  " WS_HIDE_POSENC"
+#endif
 #ifdef LAB4D_WS_LINEAR_STORE
   " WS_LINEAR_STORE"
 #endif
