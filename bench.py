@@ -299,28 +299,50 @@ def eval_rate(DF, P, fr, inputs, spp, prec, use_graph):
 
 def psnr_vs_reference(dev):
     """Second half of BASELINE.json's metric: PSNR of the rendered colour against the REFERENCE's own render on identical rays / weights.  The
-    reference cannot run on the GPU box, so this uses the committed bench-shape fixture tests/golden/train_bench.pt: a 2-row band of a 512x512
-    frame pair x 128 samples/ray (2,048 rays, 262,144 samples) rendered by the reference's Deformable.query_field + render_pixel
-    (tests/golden/make_golden.py), every 16th ray stored.  Both precisions."""
+    reference cannot run on the GPU box, so this uses the committed bench-shape fixtures (tests/golden/make_golden.py): a 2-row band of a 512x512
+    frame pair x 128 samples/ray (2,048 rays, 262,144 samples) rendered by the reference's Deformable.query_field + render_pixel, every 16th ray
+    stored -- on W0 (train_bench.pt: raw seeded initialisation) and, round 5, on W1 (train_bench_w1.pt: the same weights after the reference's own
+    geometry_init, SURVEY 8d: a fitted, sharp surface, where compositing weights are peaked).  Both precisions; plus the eval path's render on W1
+    (eval_bench_w1.pt, first band: importance sampling, normals, compaction)."""
     import math
     from lab4d_amd import deformable as DF, mlp, synthetic
-    g = torch.load(os.path.join(ROOT, "tests", "golden", "train_bench.pt"), weights_only=False)
-    meta = g["meta"]
-    st, M, res, seed = meta["full_grid_stride"], meta["M"], meta["res"], meta["seed"]
-    P = synthetic.to_device(synthetic.make_weights(seed), dev)
-    hxy = synthetic.make_rays(res, M, rows=meta.get("rows"))
-    batch = synthetic.to_device(synthetic.make_targets(seed + 3, M, hxy.shape[1], res, hxy), dev)
-    fr = synthetic.add_codes(synthetic.to_device(dict(g["frames"]), dev), P)
-    fr["feature"] = batch["feature"]
+
+    def weights(meta):
+        P = synthetic.make_weights(meta["seed"], sdf_bias=meta.get("sdf_bias"))
+        if meta.get("w1"):  # the tensors geometry_init moved (tests/golden/w1_weights.pt; the same overlay tests/fixture_utils.fg_weights applies)
+            P.update({k: v.clone() for k, v in torch.load(os.path.join(ROOT, "tests", "golden", "w1_weights.pt"), weights_only=False)["changed"].items()})
+        return synthetic.to_device(P, dev)
+
+    psnr = lambda a, b: round(-10.0 * math.log10(max(float(((a - b) ** 2).mean()), 1e-20)), 1)  # noqa: E731
     out = {}
+    for tag, name in (("", "train_bench.pt"), ("w1_", "train_bench_w1.pt")):
+        g = torch.load(os.path.join(ROOT, "tests", "golden", name), weights_only=False)
+        meta = g["meta"]
+        st, M, res, seed = meta["full_grid_stride"], meta["M"], meta["res"], meta["seed"]
+        P = weights(meta)
+        hxy = synthetic.make_rays(res, M, rows=meta.get("rows"))
+        batch = synthetic.to_device(synthetic.make_targets(seed + 3, M, hxy.shape[1], res, hxy), dev)
+        fr = synthetic.add_codes(synthetic.to_device(dict(g["frames"]), dev), P)
+        fr["feature"] = batch["feature"]
+        with torch.no_grad():
+            for pname, prec in (("fp32", mlp.PREC_F32), ("bf16", mlp.PREC_BF16)):
+                r = DF.render_train(P, fr, hxy.to(dev), synthetic.to_device(g["rng"], dev), flow_thresh=meta["flow_thresh"], n_depth=meta["D"],
+                                    alpha=meta["alpha"], prec=prec)
+                out[tag + pname] = psnr(r["rendered"]["rgb"][:, ::st].cpu(), g["rendered"]["rgb"])
+        if not tag:
+            out["case"] = "tests/golden/train_bench.pt (the reference's own render at the bench shape: %dx%d, %d samples/ray, %d rays rendered, every %dth compared)" \
+                          % (res, res, meta["D"], hxy.shape[0] * hxy.shape[1], st)
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "eval_bench_w1.pt"), weights_only=False)
+    meta = g["meta"]
+    P = weights(meta)
+    fr = synthetic.add_codes(synthetic.to_device(dict(g["frames"]), dev), P)
+    hxy = synthetic.make_rays(meta["res"], meta["M"], rows=(meta["rows"][0], meta["rows"][0] + meta["band"]))
     with torch.no_grad():
-        for name, prec in (("fp32", mlp.PREC_F32), ("bf16", mlp.PREC_BF16)):
-            r = DF.render_train(P, fr, hxy.to(dev), synthetic.to_device(g["rng"], dev), flow_thresh=meta["flow_thresh"], n_depth=meta["D"],
-                                alpha=meta["alpha"], prec=prec)
-            mse = float(((r["rendered"]["rgb"][:, ::st].cpu() - g["rendered"]["rgb"]) ** 2).mean())
-            out[name] = round(-10.0 * math.log10(max(mse, 1e-20)), 1)
-    out["case"] = "tests/golden/train_bench.pt (the reference's own render at the bench shape: %dx%d, %d samples/ray, %d rays rendered, every %dth compared)" \
-                  % (res, res, meta["D"], hxy.shape[0] * hxy.shape[1], st)
+        for pname, prec in (("fp32", mlp.PREC_F32), ("bf16", mlp.PREC_BF16)):
+            r = DF.render_eval(P, fr, hxy.to(dev), n_depth=meta["D"], prec=prec)
+            out["eval_w1_" + pname] = psnr(r["rendered"]["rgb"][:, ::meta["full_grid_stride"]].cpu(), g["rendered_bands"][0]["rgb"])
+    out["case_w1"] = "train_bench_w1.pt / eval_bench_w1.pt: the same shapes on W1 = seed 61's weights after the reference's own geometry_init (500 Adam steps on the " \
+                     "Gaussian-bone SDF); eval: importance sampling 64 + 64, first 2-row band"
     return out
 
 

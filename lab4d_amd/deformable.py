@@ -900,7 +900,7 @@ def render_eval(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32):
 # ---------------------------------------------------------------------------------------------------
 @torch.no_grad()
 def importance_sampling_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32, prefix=""):
-    """NeRF.importance_sampling (nerf.py:686-738) with the rigid backward warp of the background field."""
+    """NeRF.importance_sampling (nerf.py:686-738) with the rigid backward warp of the background field.  Returns the samples and (inds, coarse weights)."""
     nc = n_depth // 2
     codes = {"basefield": fr["code_base"], "colorfield": fr["code_color"]}
     cam2field = Q.quaternion_translation_inverse(fr["field2cam"][0], fr["field2cam"][1])
@@ -916,7 +916,7 @@ def importance_sampling_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32
 def query_field_eval_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32, prefix=""):
     """Eval-mode NeRF.query_field of the background field: rigid warp, no valid-index compaction (get_valid_idx returns
     None for category "bg", nerf.py:524-526), zero cycle terms (nerf.py:905-925), normals through the rigid transform."""
-    (xyz_cam, dir_cam, deltas, depth, _, dir_f), inds = importance_sampling_bg(P, fr, hxy, n_depth, alpha, prec, prefix)
+    (xyz_cam, dir_cam, deltas, depth, _, dir_f), (inds, weights_coarse) = importance_sampling_bg(P, fr, hxy, n_depth, alpha, prec, prefix)
     det = lambda v: tuple(t.detach() for t in v) if isinstance(v, tuple) else (v.detach() if torch.is_tensor(v) else v)
     P = {k: det(v) for k, v in P.items()}
     fr = {k: det(v) for k, v in fr.items()}
@@ -939,7 +939,7 @@ def query_field_eval_bg(P, fr, hxy, n_depth=64, alpha=None, prec=mlp.PREC_F32, p
         fd["xyz"] = xyz
         fd["xyz_cam"] = xyz_cam
         fd["depth"] = depth / P[prefix + "logscale"].exp()
-    return fd, deltas, {"inds": inds}
+    return fd, deltas, {"inds": inds, "weights_coarse": weights_coarse}
 
 
 def query_field_train_bg(P, fr, hxy, rng, flow_thresh=None, n_depth=64, alpha=None, prec=mlp.PREC_F32, prefix=""):
@@ -1049,8 +1049,8 @@ def render_eval_comp(P_fg, fr_fg, P_bg, fr_bg, hxy, n_depth=64, alpha=None, prec
     """dvr_model.render_samples for field_type == "comp" in eval mode (engine/model.py:328-361): both fields are queried on
     the same rays, z-merged by MultiFields.compose_fields, and the composite and each field are rendered."""
     from . import multifields
-    fd_fg, d_fg, _ = query_field_eval(P_fg, fr_fg, hxy, n_depth, alpha, prec)
-    fd_bg, d_bg, _ = query_field_eval_bg(P_bg, fr_bg, hxy, n_depth, alpha, prec)
+    fd_fg, d_fg, dbg_fg = query_field_eval(P_fg, fr_fg, hxy, n_depth, alpha, prec)
+    fd_bg, d_bg, dbg_bg = query_field_eval_bg(P_bg, fr_bg, hxy, n_depth, alpha, prec)
     fd, deltas = multifields.compose_fields({"fg": fd_fg, "bg": fd_bg}, {"fg": d_fg, "bg": d_bg})
     return {"rendered": RU.render_pixel(fd, deltas), "aux_dict": {"fg": RU.render_pixel(fd_fg, d_fg), "bg": RU.render_pixel(fd_bg, d_bg)},
-            "composed": fd, "deltas": deltas}
+            "composed": fd, "deltas": deltas, "debug": {"fg": dbg_fg, "bg": dbg_bg}}

@@ -839,11 +839,11 @@ def render_train_comp(P_fg, fr_fg, P_bg, fr_bg, hxy, rng, flow_thresh=None, n_de
 def render_eval_comp(P_fg, fr_fg, P_bg, fr_bg, hxy, n_depth=64):
     """dvr_model.render_samples for field_type == "comp" in eval mode (engine/model.py:328-361): query both fields,
     compose_fields, render_pixel of the composite and of each field."""
-    fd_fg, d_fg, _ = query_field_eval(P_fg, fr_fg, hxy, n_depth)
-    fd_bg, d_bg, _ = query_field_eval_bg(P_bg, fr_bg, hxy, n_depth)
+    fd_fg, d_fg, dbg_fg = query_field_eval(P_fg, fr_fg, hxy, n_depth)
+    fd_bg, d_bg, dbg_bg = query_field_eval_bg(P_bg, fr_bg, hxy, n_depth)
     fd, deltas = compose_fields({"fg": fd_fg, "bg": fd_bg}, {"fg": d_fg, "bg": d_bg})
     return {"rendered": render_pixel(fd, deltas), "aux_dict": {"fg": render_pixel(fd_fg, d_fg), "bg": render_pixel(fd_bg, d_bg)},
-            "composed": fd, "deltas": deltas}
+            "composed": fd, "deltas": deltas, "debug": {"fg": dbg_fg, "bg": dbg_bg}}
 
 
 def render_eval(P, fr, hxy, n_depth=64, alpha=None):

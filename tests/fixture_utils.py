@@ -57,18 +57,27 @@ def cdf_of_weights(weights, eps=1e-5):
     return torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
 
 
-def check_index_mismatches(g, band, inds_dev, cdf_dev, tol):
+def unpack_bits(bits, shape):
+    import numpy as np
+    n = 1
+    for d in shape:
+        n *= d
+    return torch.from_numpy(np.unpackbits(bits.numpy())[:n].astype(bool)).view(tuple(shape))
+
+
+def check_index_mismatches(g, band, inds_dev, cdf_dev, tol, ref=None, ties=None):
     """Every importance index that differs from the reference's must be a ONE-BIN shift at a cdf entry where the two implementations' cdfs straddle the
     query point and agree to `tol`: stored in the fixture as a near tie (the reference's cdf entries within meta.tie_window of a query point).
     inds_dev (M, n, D/2) int64 / cdf_dev (M, n, D/2 - 1 + ... ) of one band.  Returns (mismatches, worst |cdf_dev - cdf_ref| over them)."""
     meta = g["meta"]
-    ref, _ = eval_bench_unpack(g)
+    if ref is None:  # (comp fixtures pass their per-field index tensor and tie list)
+        ref, _ = eval_bench_unpack(g)
     n = inds_dev.shape[1]
     ref = ref[:, band * n:(band + 1) * n]
     diff = (inds_dev != ref)
     if not bool(diff.any()):
         return 0, 0.0
-    t = g["ties"]
+    t = g["ties"] if ties is None else ties
     sel = t["band"] == band
     tie = {(int(m), int(nn), int(k)): float(c) for m, nn, k, c in zip(t["m"][sel], t["n"][sel], t["k"][sel], t["cdf"][sel])}
     u = g["u"]

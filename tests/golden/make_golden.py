@@ -363,6 +363,96 @@ def gen_eval_bench(ns, tag, res=512, D=128, seed=61, rows=(252, 260), band=2, st
           "near ties", out["ties"]["k"].numel(), "mask mean", float(torch.cat([r["mask"] for r in rendered], 1).mean()))
 
 
+def gen_comp_eval_bench(ns, tag="comp_eval_bench", res=512, D=64, seed=131, rows=(254, 258), band=2, stride=16, fg_motion="comp_skel-human_dense", frame_id=(10, 11),
+                        tie_window=1e-4):
+    """field_type "comp" in eval mode at BASELINE configs[2]'s per-GPU shape (round 5): fg Deformable(comp_skel-human_dense: 18 bones + dense post-warp) +
+    bg NeRF on the same rays, each with importance sampling n_depth = 64 (32 + 32), normals, the fg's valid-index compaction, then compose_fields
+    (z-merge to 128 samples) and render_pixel of the composite and of each field -- 4 image rows of a 512x512 pair = 4,096 rays, band by band like
+    gen_eval_bench.  Stored: both fields' importance indices (uint8) and the fg valid mask (bits) for EVERY ray, the near ties of both cdfs, every
+    stride-th ray of the three renders."""
+    import numpy as np
+    M = 2
+    num_bones = 18 if "skel-human" in fg_motion else 25
+    Pf = synthetic.make_weights(seed, sdf_bias=-0.02, num_bones=num_bones)
+    if fg_motion.startswith("comp_"):
+        Pf = synthetic.add_dense_weights(Pf, seed, 1)
+    f = build_reference_field(ns, Pf, 1, fg_motion)
+    f.eval()
+    fr0 = synthetic.make_frames(seed + 1, M, res, num_bones=num_bones)
+    fr0["frame_id"] = torch.tensor(frame_id, dtype=torch.long)
+    frf = frames_from_reference(f, fr0)
+    Pb = synthetic.make_bg_weights(seed)
+    Pb["sdf.bias"] = torch.tensor([-0.1])
+    torch.manual_seed(0)
+    di = ref_shim.synthetic_data_info(64)
+    b = ns.nerf.NeRF(di, num_freq_xyz=6, num_freq_dir=0, appr_channels=0, init_scale=0.1)
+    b.category = "bg"
+    b.load_state_dict({k: v for k, v in Pb.items()}, strict=False)
+    b.eval()
+    frb = synthetic.make_bg_frames(seed + 3, M, res)
+    for fld in (f, b):
+        orig = fld.importance_sampling
+        fld.importance_sampling = (lambda o: (lambda *a, **k: o(*a, n_depth=D, **k)))(orig)
+    captured = {}
+    _ss = torch.searchsorted
+
+    def searchsorted(cdf, u, right=False):
+        r = _ss(cdf, u, right=right)
+        captured.setdefault("ss", []).append((r.clone(), cdf.clone(), u.clone()))
+        return r
+
+    _gv = f.get_valid_idx
+
+    def get_valid_idx(*a, **k):
+        v = _gv(*a, **k)
+        captured["valid"] = v.clone()
+        return v
+
+    f.get_valid_idx = get_valid_idx
+    acc = {"inds_fg": [], "inds_bg": [], "valid": [], "rendered": [], "rendered_fg": [], "rendered_bg": [], "ties_fg": [], "ties_bg": []}
+    ns.render_utils.torch.searchsorted = searchsorted
+    det = lambda d: {k: v.detach()[:, ::stride].clone() for k, v in d.items()}  # noqa: E731
+    try:
+        for bi, r0 in enumerate(range(rows[0], rows[1], band)):
+            hxy = synthetic.make_rays(res, M, rows=(r0, r0 + band))
+            sdf_ = samples_dict_of(frf, hxy, None)
+            del sdf_["feature"]
+            sdb = {"Kinv": frb["Kinv"], "field2cam": frb["field2cam"], "frame_id": frb["frame_id"], "inst_id": frb["inst_id"], "near_far": frb["near_far"], "hxy": hxy}
+            captured["ss"] = []
+            fd_f, d_f, _ = f.query_field(sdf_)
+            fd_b, d_b, _ = b.query_field(sdb)
+            assert len(captured["ss"]) == 2  # one sample_pdf per field, fg first
+            comp, dcomp = ns.multifields.MultiFields.compose_fields({"fg": dict(fd_f), "bg": dict(fd_b)}, {"fg": d_f, "bg": d_b})
+            acc["rendered"].append(det(ns.render_utils.render_pixel(comp, dcomp)))
+            acc["rendered_fg"].append(det(ns.render_utils.render_pixel(fd_f, d_f)))
+            acc["rendered_bg"].append(det(ns.render_utils.render_pixel(fd_b, d_b)))
+            acc["valid"].append(captured["valid"].view(M, -1, D))
+            for name, (inds, cdf, u) in zip(("fg", "bg"), captured["ss"]):
+                acc["inds_" + name].append(inds.view(M, -1, D // 2))
+                cdf, u0 = cdf.view(M, -1, D // 2 - 1), u[0]
+                near = (cdf[..., None] - u0).abs().min(-1)[0] < tie_window
+                m, n, k = near.nonzero(as_tuple=True)
+                acc["ties_" + name].append({"band": torch.full_like(m, bi), "m": m, "n": n, "k": k, "cdf": cdf[m, n, k].clone()})
+            print("  band", r0, "fg valid frac %.3f" % float(captured["valid"].float().mean()), flush=True)
+    finally:
+        ns.render_utils.torch.searchsorted = _ss
+    cat = lambda xs: torch.cat(xs, 1)  # noqa: E731
+    valid = cat(acc["valid"])
+    ties = lambda ts: {k: torch.cat([t[k] for t in ts]).to(torch.int32 if k != "cdf" else torch.float32) for k in ts[0]}  # noqa: E731
+    out = {"meta": {"M": M, "N": valid.shape[1], "D": D, "res": res, "seed": seed, "rows": rows, "band": band, "full_grid_stride": stride, "fg_motion": fg_motion,
+                    "bg_sdf_bias": -0.1, "sdf_bias": -0.02, "tie_window": tie_window, "weight_checksum_fg": weight_checksum(Pf), "weight_checksum_bg": weight_checksum(Pb)},
+           "frames_fg": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in frf.items()},
+           "frames_bg": {k: (tuple(t.detach() for t in v) if isinstance(v, tuple) else v.detach()) for k, v in frb.items()},
+           "inds_fg_u8": cat(acc["inds_fg"]).to(torch.uint8), "inds_bg_u8": cat(acc["inds_bg"]).to(torch.uint8),
+           "valid_bits": torch.from_numpy(np.packbits(valid.numpy().reshape(-1))), "valid_shape": tuple(valid.shape), "u": u0.clone(),
+           "rendered_bands": acc["rendered"], "rendered_fg_bands": acc["rendered_fg"], "rendered_bg_bands": acc["rendered_bg"],
+           "ties_fg": ties(acc["ties_fg"]), "ties_bg": ties(acc["ties_bg"])}
+    path = os.path.join(OUT_DIR, tag + ".pt")
+    torch.save(out, path)
+    print(tag, "->", path, os.path.getsize(path) // 1024, "KiB", "fg valid frac", float(valid.float().mean()), "indices per field", out["inds_fg_u8"].numel(),
+          "composite mask mean", float(torch.cat([r["mask"] for r in acc["rendered"]], 1).mean()))
+
+
 def gen_ops(ns):
     """Op-level goldens straight from the reference functions."""
     g = torch.Generator().manual_seed(7)
@@ -702,6 +792,8 @@ def main(only=None):
         ("train_bench_w1", lambda: gen_train(ns, "bench_w1", M=2, N=None, D=128, res=512, seed=61, full_grid_stride=16, rows=(255, 257), w1=True)),
         ("eval_bench", lambda: gen_eval_bench(ns, "bench")),
         ("eval_bench_w1", lambda: gen_eval_bench(ns, "bench_w1", w1=True)),
+        # ... and the comp configuration's eval path at configs[2]'s shape: fg comp_skel-human_dense + bg, 32 + 32 samples per field, 4,096 rays
+        ("comp_eval_bench", lambda: gen_comp_eval_bench(ns)),
     ]
     for name, job in jobs:
         if only is None or name in only:

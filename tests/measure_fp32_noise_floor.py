@@ -22,7 +22,8 @@ OUT = os.path.join(HERE, "golden", "fp32_noise_floor.json")
 TRAIN = ["train_small", "train_alpha", "train_multi", "train_multi10", "train_compmotion", "train_human", "train_rigid", "train_dense", "train_c1", "train_bench",
          "train_multi10_bench", "train_bench_w1"]
 EVAL = ["eval_small", "eval_rigid", "eval_dense"]
-EVAL_BENCH = ["eval_bench", "eval_bench_w1"]  # round 5: the eval path at the bench size (band by band, like the fixture)
+EVAL_BENCH = ["eval_bench", "eval_bench_w1"]
+COMP_EVAL_BENCH = ["comp_eval_bench"]  # the comp configuration's eval path at configs[2]'s shape  # round 5: the eval path at the bench size (band by band, like the fixture)
 COMP = ["comp_train", "comp_bench"]  # field_type "comp": fg + bg composite (round 4)
 
 
@@ -195,15 +196,49 @@ def eval_bench_case(name):
     return out
 
 
+def comp_eval_bench_case(name):
+    """comp_eval_bench: the oracle's comp eval render in float32 against float64, band by band, in the metric of tests/test_gpu_field.py::_run_comp_eval_bench."""
+    sys.path.insert(0, HERE)
+    from fixture_utils import bg_weights, eval_bench_bands, fg_weights
+    g = torch.load(os.path.join(HERE, "golden", name + ".pt"), weights_only=False)
+    meta = g["meta"]
+    st = meta["full_grid_stride"]
+    acc = {32: {}, 64: {}}
+    mis = {"fg": 0, "bg": 0, "valid": 0}
+    for band, hxy, _ in eval_bench_bands(g):
+        outs = {}
+        for bits, dt in ((32, torch.float32), (64, torch.float64)):
+            Pf, Pb = to(fg_weights(meta), dt), to(bg_weights(meta), dt)
+            frf = synthetic.add_codes(to(dict(g["frames_fg"]), dt), Pf)
+            frb = synthetic.add_bg_codes(to(dict(g["frames_bg"]), dt), Pb)
+            o = outs[bits] = O.render_eval_comp(Pf, frf, Pb, frb, to(hxy, dt), n_depth=meta["D"])
+            for nm, r in (("rendered", o["rendered"]), ("fg", o["aux_dict"]["fg"]), ("bg", o["aux_dict"]["bg"])):
+                for k, v in r.items():
+                    acc[bits].setdefault((nm, k), []).append(v[:, ::st])
+        for fld in ("fg", "bg"):
+            mis[fld] += int((outs[32]["debug"][fld]["inds"] != outs[64]["debug"][fld]["inds"]).sum())
+        mis["valid"] += int((outs[32]["debug"]["fg"]["valid"] != outs[64]["debug"]["fg"]["valid"]).sum())
+    out = {"index_mismatch_count_fg": float(mis["fg"]), "index_mismatch_count_bg": float(mis["bg"]), "valid_mask_mismatch_count": float(mis["valid"])}
+    masks = {"rendered": "rendered_bands", "fg": "rendered_fg_bands", "bg": "rendered_bg_bands"}
+    for (nm, k) in acc[32]:
+        a, b = torch.cat(acc[32][(nm, k)], 1), torch.cat(acc[64][(nm, k)], 1)
+        if k == "normal":
+            m_ref = torch.cat([r["mask"] for r in g[masks[nm]]], 1).double()
+            out["%s.%s" % (nm, k)] = rel_l2(a.double() * m_ref, b * m_ref)
+        else:
+            out["%s.%s" % (nm, k)] = relmax(a, b)
+    return out
+
+
 def main(cases):
     torch.set_num_threads(os.cpu_count() or 8)
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for c in cases:
         t = time.time()
-        res[c] = {k: float("%.3e" % v) for k, v in (train_case(c) if c in TRAIN else comp_case(c) if c in COMP else eval_bench_case(c) if c in EVAL_BENCH else eval_case(c)).items()}
+        res[c] = {k: float("%.3e" % v) for k, v in (train_case(c) if c in TRAIN else comp_case(c) if c in COMP else eval_bench_case(c) if c in EVAL_BENCH else comp_eval_bench_case(c) if c in COMP_EVAL_BENCH else eval_case(c)).items()}
         print(c, "%.1f s" % (time.time() - t), "worst:", sorted(((v, k) for k, v in res[c].items() if not k.startswith("gradmax")), reverse=True)[:3])
         json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or TRAIN + EVAL + COMP + EVAL_BENCH)
+    main(sys.argv[1:] or TRAIN + EVAL + COMP + EVAL_BENCH + COMP_EVAL_BENCH)

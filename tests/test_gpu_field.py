@@ -468,6 +468,75 @@ def test_eval_graph_at_the_bench_size_bf16(golden_dir, name):
     assert measured["psnr_rgb_db"] > 40.0, measured["psnr_rgb_db"]
 
 
+def _run_comp_eval_bench(golden_dir, prec):
+    """comp_eval_bench.pt on the device, band by band: (measured render errors of the composite / fg / bg renders over the stored rays, index and
+    mask statistics of both fields)."""
+    from lab4d_amd import deformable as DF
+    from fixture_utils import bg_weights, cdf_of_weights, check_index_mismatches, eval_bench_bands, fg_weights, unpack_bits
+    g = torch.load(os.path.join(golden_dir, "comp_eval_bench.pt"), weights_only=False)
+    meta = g["meta"]
+    M, D, st = meta["M"], meta["D"], meta["full_grid_stride"]
+    Pf, Pb = synthetic.to_device(fg_weights(meta), DEV), synthetic.to_device(bg_weights(meta), DEV)
+    frf = synthetic.add_codes(synthetic.to_device(dict(g["frames_fg"]), DEV), Pf)
+    frb = synthetic.add_bg_codes(synthetic.to_device(dict(g["frames_bg"]), DEV), Pb)
+    valid_ref = unpack_bits(g["valid_bits"], g["valid_shape"])
+    refs = {"fg": g["inds_fg_u8"].long(), "bg": g["inds_bg_u8"].long()}
+    got, ref = {}, {}
+    stats = {"index_total": 0, "index_mismatch_fg": 0, "index_mismatch_bg": 0, "index_cdf_gap_max": 0.0, "valid_total": 0, "valid_mismatch": 0}
+    for band, hxy, sl in eval_bench_bands(g):
+        out = DF.render_eval_comp(Pf, frf, Pb, frb, hxy.to(DEV), n_depth=D, prec=prec)
+        n = hxy.shape[1]
+        valid = out["debug"]["fg"]["valid"].cpu().view(M, n, D)
+        stats["valid_total"] += valid.numel()
+        stats["valid_mismatch"] += int((valid != valid_ref[:, sl]).sum())
+        for fld in ("fg", "bg"):
+            inds = out["debug"][fld]["inds"].cpu().view(M, n, D // 2)
+            stats["index_total"] += inds.numel()
+            if prec == 0:
+                cdf = cdf_of_weights(out["debug"][fld]["weights_coarse"].reshape(M * n, D // 2)).view(M, n, -1)
+                k, gap = check_index_mismatches(g, band, inds, cdf, tol=INDEX_CDF_TOL, ref=refs[fld], ties=g["ties_" + fld])
+            else:
+                k, gap = int((inds != refs[fld][:, sl]).sum()), 0.0
+            stats["index_mismatch_" + fld] += k
+            stats["index_cdf_gap_max"] = max(stats["index_cdf_gap_max"], gap)
+        for name, bands in (("rendered", g["rendered_bands"]), ("fg", g["rendered_fg_bands"]), ("bg", g["rendered_bg_bands"])):
+            r = out["rendered"] if name == "rendered" else out["aux_dict"][name]
+            for ch, v in bands[band].items():
+                got.setdefault((name, ch), []).append(r[ch][:, ::st].detach().float().cpu())
+                ref.setdefault((name, ch), []).append(v)
+    measured = {}
+    for (name, ch) in got:
+        a, b = torch.cat(got[(name, ch)], 1), torch.cat(ref[(name, ch)], 1)
+        if ch == "normal":  # opacity-weighted relative L2 (see _run_eval_bench)
+            m_ref = torch.cat(ref[(name, "mask")], 1).double()
+            a, b = a.double() * m_ref, b.double() * m_ref
+            measured["%s.%s" % (name, ch)] = float((a - b).norm() / (b.norm() + 1e-30))
+        else:
+            measured["%s.%s" % (name, ch)] = rel(a, b)
+    return measured, stats
+
+
+def test_comp_eval_graph_at_the_bench_size_fp32(golden_dir):
+    """Round 5: the comp configuration's eval path at BASELINE configs[2]'s per-GPU shape (fg comp_skel-human_dense + bg, 32 + 32 samples per field,
+    compose_fields, three renders; 4,096 rays) against the reference: fg valid mask bit-exact (262,144 bits); both fields' importance indices
+    (2 x 131,072) with every difference asserted to be a one-bin shift at a near tie (see test_eval_graph_at_the_bench_size_fp32); every
+    channel of the three renders held to max(1e-4, 2 x measured) and to the same quantity's fp32-vs-fp64 floor."""
+    from lab4d_amd import mlp
+    measured, stats = _run_comp_eval_bench(golden_dir, mlp.PREC_F32)
+    report("comp_eval_bench_indices_fp32", {k: float(v) for k, v in stats.items()})
+    assert stats["valid_mismatch"] == 0, stats
+    assert stats["index_mismatch_fg"] + stats["index_mismatch_bg"] <= INDEX_MISMATCH_FRAC_MAX * stats["index_total"], stats
+    check("comp_eval_bench_fp32", measured, floor_case="comp_eval_bench", floor_factor=FLOOR_FACTOR_FULL)
+
+
+def test_comp_eval_graph_at_the_bench_size_bf16(golden_dir):
+    from lab4d_amd import mlp
+    measured, stats = _run_comp_eval_bench(golden_dir, mlp.PREC_BF16)
+    report("comp_eval_bench_indices_bf16", {k: float(v) for k, v in stats.items()})
+    check("comp_eval_bench_bf16", measured)
+    assert stats["valid_mismatch"] <= 1e-4 * stats["valid_total"], stats
+
+
 def test_render_samples_chunk_equals_unchunked_eval(golden_dir):
     """Chunking along N is invisible in eval mode (model.py:259-326), apart from the global mean(T) normaliser of `vis`."""
     from lab4d_amd import model

@@ -506,6 +506,30 @@ def test_eval_graph_at_the_bench_size(golden_dir, name):
         close(out["rendered"][k][:, ::st], v, "rendered." + k, rtol=2e-4)
 
 
+def test_comp_eval_graph_at_the_bench_size(golden_dir):
+    """Round 5: field_type "comp" in eval mode at BASELINE configs[2]'s shape (fg comp_skel-human_dense + bg, 32 + 32 samples per field, z-merged): the
+    oracle on one 2-row band (2,048 rays) reproduces the reference's importance indices of BOTH fields and the fg valid mask bit for bit, and the
+    stored rays of the three renders to 2e-4."""
+    from fixture_utils import bg_weights, eval_bench_bands, fg_weights, unpack_bits, weight_checksum
+    g = torch.load(os.path.join(golden_dir, "comp_eval_bench.pt"), weights_only=False)
+    meta = g["meta"]
+    Pf, Pb = fg_weights(meta), bg_weights(meta)
+    assert abs(weight_checksum(Pf) - meta["weight_checksum_fg"]) < 1e-6 * meta["weight_checksum_fg"]
+    frf = synthetic.add_codes(dict(g["frames_fg"]), Pf)
+    frb = synthetic.add_bg_codes(dict(g["frames_bg"]), Pb)
+    band, hxy, sl = eval_bench_bands(g)[1]
+    out = O.render_eval_comp(Pf, frf, Pb, frb, hxy, n_depth=meta["D"])
+    M, D = meta["M"], meta["D"]
+    assert torch.equal(out["debug"]["fg"]["inds"].view(M, -1, D // 2), g["inds_fg_u8"].long()[:, sl]), "fg importance indices must be bit-exact"
+    assert torch.equal(out["debug"]["bg"]["inds"].view(M, -1, D // 2), g["inds_bg_u8"].long()[:, sl]), "bg importance indices must be bit-exact"
+    assert torch.equal(out["debug"]["fg"]["valid"], unpack_bits(g["valid_bits"], g["valid_shape"])[:, sl]), "fg valid mask must be bit-exact"
+    st = meta["full_grid_stride"]
+    for name, ref in (("rendered", g["rendered_bands"][band]), ("fg", g["rendered_fg_bands"][band]), ("bg", g["rendered_bg_bands"][band])):
+        got = out["rendered"] if name == "rendered" else out["aux_dict"][name]
+        for k, v in ref.items():
+            close(got[k][:, ::st], v, name + "." + k, rtol=2e-4)
+
+
 @pytest.mark.parametrize("name", ["train_c1.pt", "train_bench.pt", "train_multi10_bench.pt", "train_bench_w1.pt"])
 def test_training_graph_at_baseline_sizes(golden_dir, name):
     """BASELINE.json configs[0]: the full 64x64 crop of a frame pair x 64 samples/ray (8,192 rays, 524,288 samples) through the whole
