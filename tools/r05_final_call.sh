@@ -37,4 +37,5 @@ head -8 $R/gpurun_out/r05_bench_kernel_stats.csv | cut -c1-160
 # HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and SQ issue / wait counters of the chain kernels at the bench's launch size
 cd $R && PMC_OUT=r05_pmc_traffic.json bash tools/run_pmc_mlp.sh 2>&1 | tail -4
 SQ_SKIP_LIST=1 SQ_OUT=r05_sq_counters.txt bash tools/pmc_sq2.sh "python $R/tools/bench_chain.py 16777216 base" 2>&1 | tail -2; head -34 gpurun_out/r05_sq_counters.txt
-timeout 120 python tools/clock_under_load.py 4194304 4 > gpurun_out/r05_clock_under_load.json 2>/dev/null; cat gpurun_out/r05_clock_under_load.json | cut -c1-400
+timeout 120 python tools/clock_under_load.py 4194304 4 > gpurun_out/r05_clock_under_load.json 2>/dev/null; cat gpurun_out/r05_clock_under_load.json | cut -c1-200
+timeout 300 python tools/count_step_launches.py 2>/dev/null | tail -1 | tee gpurun_out/r05_step_launches.json
