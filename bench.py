@@ -186,6 +186,10 @@ def draw_rng_all(C, M, N, S, device, gen, outs):
         pos = torch.cumsum(keep.to(torch.int64), 1) - 1
         out = torch.empty_like(draws).scatter_(1, torch.where(keep, pos, pos.new_full((), 2 * k - 1)), draws)  # survivors compacted in draw order
         perm = out[:, :k]
+    if isinstance(outs, tuple):  # (stacked (C, k) buffers whose rows the chunks' static dicts are views of: two copies for the whole step)
+        outs[0].copy_(eik)
+        outs[1].copy_(perm)
+        return
     for c, o in enumerate(outs):
         o["eik_inds"].copy_(eik[c])
         o["match_perm"].copy_(perm[c])
@@ -825,7 +829,9 @@ class TrainLoop:
         graph's pool before the next chunk allocates -- the pool peaks at one chunk, like the per-chunk graph."""
         for hxy, batch in self.inputs:
             batch["hxy"] = hxy
-        self.st_rngs = [draw_rng(self.M, self.N0, self.S0, self.dev, self.gen) for _ in self.inputs]
+        first = [draw_rng(self.M, self.N0, self.S0, self.dev, self.gen) for _ in self.inputs]
+        self.rng_stack = (torch.stack([r["eik_inds"] for r in first]).contiguous(), torch.stack([r["match_perm"] for r in first]).contiguous())
+        self.st_rngs = [{"eik_inds": self.rng_stack[0][c], "match_perm": self.rng_stack[1][c]} for c in range(len(first))]  # row views: static addresses
 
         def body_a():
             self.opt.flat_grad.zero_()  # (a fill kernel; the HIP runtime's memset NODES are what DESIGN.md section 2, finding 4 is about)
@@ -881,7 +887,7 @@ class TrainLoop:
     def step(self):
         opt, comp = self.opt, self.comp
         if self.graph_a is not None:
-            draw_rng_all(len(self.inputs), self.M, self.N0, self.S0, self.dev, self.gen, self.st_rngs)
+            draw_rng_all(len(self.inputs), self.M, self.N0, self.S0, self.dev, self.gen, self.rng_stack)
             self.graph_a.replay()
             if self.use_dist:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

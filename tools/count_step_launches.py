@@ -21,11 +21,13 @@ for mode, kw in (("step_graph", {"step_graph": True}), ("chunk_graph", {"step_gr
     for _ in range(2):
         loop.step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU]) as pr:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as pr:
         loop.step()
         torch.cuda.synchronize()
     c = collections.Counter()
     for e in pr.key_averages():
+        if e.device_type == torch.autograd.DeviceType.CUDA:
+            continue
         k = e.key
         if "GraphLaunch" in k:
             c["graph_launches"] += e.count
@@ -34,6 +36,7 @@ for mode, kw in (("step_graph", {"step_graph": True}), ("chunk_graph", {"step_gr
         elif "emcpy" in k:
             c["memcpy_calls"] += e.count
     out[mode] = dict(c)
+    out[mode]["runtime_calls_seen"] = sorted({e.key for e in pr.key_averages() if e.key.startswith(("hip", "cuda"))})[:12]
     loop.release_graph()
     del loop
     torch.cuda.empty_cache()
