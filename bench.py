@@ -825,7 +825,8 @@ class TrainLoop:
         graph A = zero the flat gradient, prologue refresh, EVERY chunk (each reads its own resident inputs and its own static random draws: no
         copies), prologue backward; [the data-parallel all-reduce, eager, between the two]; graph B = check_grad + AdamW (device-side discard rule and
         step count: optim.py) + the in-place repack of the kernels' weight copies.  What stays eager per step: the chunks' random draws, batched
-        (draw_rng_all: ~15 launches).  Memory: the chunks are captured one behind the other on one stream, so a chunk's activations are freed into the
+        (draw_rng_all: 61 kernel launches + 3 copies, tools/count_step_launches.py; the per-chunk graphs needed 344 + 88 + 4 replays).  Measured
+        time-neutral (profiles/r05_ab_*graph*.json): the eager launches were already hidden behind the running chunk.  Memory: the chunks are captured one behind the other on one stream, so a chunk's activations are freed into the
         graph's pool before the next chunk allocates -- the pool peaks at one chunk, like the per-chunk graph."""
         for hxy, batch in self.inputs:
             batch["hxy"] = hxy
