@@ -786,7 +786,14 @@ class TrainLoop:
         self.graph_a = self.graph_b = None
         self.ar_events = []
         if use_graph and self.uniform and step_graph and not trace:
-            self.capture_step()
+            try:
+                self.capture_step()
+            except Exception as e:  # a failed whole-step capture must not cost the run: fall back to the per-chunk graphs (the line's `launch` says which ran)
+                print("bench.py: whole-step graph capture failed (%r); falling back to per-chunk graphs" % (e,), file=sys.stderr)
+                self.graph_a = self.graph_b = None
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                self.capture()
         elif use_graph and self.uniform:
             self.capture()
         self.opt.zero_grad()
