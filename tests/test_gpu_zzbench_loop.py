@@ -149,3 +149,17 @@ def test_check_grad_discards_a_blown_up_step():
         for a, b in zip(ps, ref):
             assert torch.allclose(a, b, rtol=5e-6, atol=2e-7), (i, sc)
     assert int(opt.dev_step) == 4
+
+
+def test_psnr_against_the_reference_render_on_w0_and_w1():
+    """The second half of BASELINE.json's metric as bench.py reports it (`psnr_vs_ref_db`): rendered colour against the REFERENCE's own render at the bench
+    shape, training render on W0 and on W1 (the reference's geometry_init fit) and the eval render on W1, fp32 and bf16.  Measured on MI355X:
+    146.6 / 99.3 dB (W0), 146.5 / 97.2 dB (W1 training), 147.9 / 97.8 dB (W1 eval)."""
+    import bench
+    from lab4d_amd import _lib
+    _lib.lib()
+    out = bench.psnr_vs_reference(torch.device("cuda", 0))
+    for k in ("fp32", "w1_fp32", "eval_w1_fp32"):
+        assert out[k] > 135.0, (k, out[k])
+    for k in ("bf16", "w1_bf16", "eval_w1_bf16"):
+        assert out[k] > 90.0, (k, out[k])
