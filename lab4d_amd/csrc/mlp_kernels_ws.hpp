@@ -1177,24 +1177,45 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
           f32x16_t e[2];
           tile_from_raw<P>(raw, lane, e);
           constexpr int L = Net::NFREQ;
+          // Round 5: the embedding row tile `me` is resolved at COMPILE time (one copy of this block per tile, selected by a wave-uniform branch).  With a
+          // runtime `me` every accumulator register's slot -> (octave, axis, class) map was loop-invariant scalar state: the compiler hoisted ~135 values into
+          // SGPRs, spilled them to VGPR lanes (177-203 spilled SGPRs in these kernels) and read them back with v_readlane in front of every
+          // use -- on the waves that carry the layer's critical path (they run the embedding item in front of their activation items).  Now the maps are
+          // immediates; per register and lane half only the octave (an exponent for ldexpf) and the axis select remain.  Same products, same order of
+          // the additions into dx per axis; additions of +0 are no longer performed.
+          sfor<0, (MTE > 0 ? MTE : 1)>([&](auto mc) {
+            constexpr int MEc = decltype(mc)::value;
+            if (me != MEc) return;
+            sfor<0, 16>([&](auto rc) {
+              constexpr int r = decltype(rc)::value;
+              constexpr int S0 = 32 * MEc + (r & 3) + 8 * (r >> 2), S1 = S0 + 4;  // slot of this register in lane half 0 / 1 (drow)
+              constexpr int K0 = S0 < 6 * L ? 1 : (S0 < 6 * L + 3 ? 2 : 0), K1 = S1 < 6 * L ? 1 : (S1 < 6 * L + 3 ? 2 : 0);  // 1: sin / cos slot, 2: raw coordinate, 0: padding
+              if constexpr (K0 != 0 || K1 != 0) {
+                constexpr int F0 = (S0 >> 1) / 3, F1 = (S1 >> 1) / 3;
+                constexpr int A0 = K0 == 1 ? (S0 >> 1) % 3 : (K0 == 2 ? S0 - 6 * L : -1), A1 = K1 == 1 ? (S1 >> 1) % 3 : (K1 == 2 ? S1 - 6 * L : -1);
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t) {
+                  const float gv = acc[t][r];
+                  const float partner = e[t][r ^ 1];
+                  const float sp = (r & 1) ? -partner : partner;  // d/dx [w sin(2^f x)] = 2^f (w cos) ; d/dx [w cos(2^f x)] = -2^f (w sin)
+                  float c;
+                  if constexpr (K0 == 1 && K1 == 1) {
+                    c = ldexpf(sp, h ? F1 : F0) * gv;
+                  } else {
+                    const float c0 = K0 == 1 ? ldexpf(sp, F0) * gv : (K0 == 2 ? gv : 0.f);
+                    const float c1 = K1 == 1 ? ldexpf(sp, F1) * gv : (K1 == 2 ? gv : 0.f);
+                    c = h ? c1 : c0;
+                  }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int slot = 32 * me + drow(r, h);
-              const float gv = acc[t][r];
-              // me is a runtime value: the slot class is resolved per register by comparison (slot < 6 L etc. are cheap scalar-ish selects)
-              const int pair = slot >> 1, f = pair / 3, ax = pair - 3 * f;
-              const float partner = e[t][r ^ 1];
-              const float cs = ldexpf((r & 1) ? -partner : partner, f) * gv;   // d/dx [w sin(2^f x)] = 2^f (w cos) ; d/dx [w cos(2^f x)] = -2^f (w sin)
-              const bool is_sc = slot < 6 * L, is_raw = slot >= 6 * L && slot < 6 * L + 3;
-              const int axr = slot - 6 * L;
-              const float c = is_sc ? cs : (is_raw ? gv : 0.f);
-              const int axx = is_sc ? ax : axr;
-              dx[t][0] += axx == 0 ? c : 0.f;
-              dx[t][1] += axx == 1 ? c : 0.f;
-              dx[t][2] += axx == 2 ? c : 0.f;
-            }
+                  for (int k = 0; k < 3; ++k) {
+                    if (A0 == k && A1 == k) dx[t][k] += c;
+                    else if (A0 == k) dx[t][k] += h ? 0.f : c;
+                    else if (A1 == k) dx[t][k] += h ? c : 0.f;
+                  }
+                }
+              }
+            });
+          });
         }
       }
       // ---- (b) activation rows: masked dZ_{l-1} ----
