@@ -150,7 +150,9 @@ def distinct_indices(S, k, device, gen):
     keep = torch.zeros(2 * k, dtype=torch.bool, device=device)
     keep[order] = first  # draw i survives iff it is the first occurrence of its value
     pos = torch.cumsum(keep.to(torch.int64), 0) - 1
-    out = torch.empty(2 * k, dtype=draws.dtype, device=device)
+    # (initialised with a VALID index -- the first draw: should fewer than k distinct values survive, the unfilled tail repeats it instead of
+    # holding uninitialised int64 gather indices)
+    out = draws[:1].expand(2 * k).clone()
     out[torch.where(keep, pos, pos.new_full((), 2 * k - 1))] = draws  # survivors compacted in draw order (the last slot is a dump for the dropped)
     return out[:k]
 
@@ -184,7 +186,8 @@ def draw_rng_all(C, M, N, S, device, gen, outs):
         first[:, 1:] = vals[:, 1:] != vals[:, :-1]
         keep = torch.zeros_like(first).scatter_(1, order, first)  # draw i survives iff it is the first occurrence of its value
         pos = torch.cumsum(keep.to(torch.int64), 1) - 1
-        out = torch.empty_like(draws).scatter_(1, torch.where(keep, pos, pos.new_full((), 2 * k - 1)), draws)  # survivors compacted in draw order
+        # (rows initialised with a valid index, their first draw: see distinct_indices)
+        out = draws[:, :1].expand(C, 2 * k).clone().scatter_(1, torch.where(keep, pos, pos.new_full((), 2 * k - 1)), draws)  # survivors compacted in draw order
         perm = out[:, :k]
     if isinstance(outs, tuple):  # (stacked (C, k) buffers whose rows the chunks' static dicts are views of: two copies for the whole step)
         outs[0].copy_(eik)
@@ -350,6 +353,27 @@ def psnr_vs_reference(dev):
     return out
 
 
+class ExtrasBudget:
+    """Wall-clock budget of everything the default run does BESIDE the headline (two rocprofv3 passes + three child benches + the CPU
+    baseline used to run back to back with per-item timeouts only -- worst case > 25 min in front of the one JSON line).  Every extra asks for its
+    timeout here: min(its own cap, what is left); an extra that finds less than `floor` seconds left is skipped and says so in the line."""
+
+    def __init__(self, total_s):
+        self.t_end = time.perf_counter() + float(total_s)
+        self.total = float(total_s)
+
+    def left(self):
+        return self.t_end - time.perf_counter()
+
+    def timeout(self, cap, floor=30.0):
+        left = self.left()
+        return None if left < floor else min(float(cap), left)
+
+
+EXTRAS = ExtrasBudget(float(os.environ.get("LAB4D_BENCH_EXTRAS_BUDGET_S", "900")))
+SKIPPED = "skipped: the extras' wall-clock budget (LAB4D_BENCH_EXTRAS_BUDGET_S = %d s) was spent" % int(EXTRAS.total)
+
+
 def fp32_leg(a):
     """The same training step with fp32 MFMA chains (`--dtype f32`: v_mfma_f32_32x32x2_f32, fp32 stored activations, 64-row chunks), 1 warm-up
     + 2 timed steps in a child process once this one has given its device memory back.  fp32 is the precision the reference computes in
@@ -357,8 +381,11 @@ def fp32_leg(a):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--dtype", "f32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
            "--res", str(a.res), "--spp", str(a.spp)]
+    tmo = EXTRAS.timeout(600)
+    if tmo is None:
+        return {"value": None, "error": SKIPPED}
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=tmo, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
         d = json.loads(r.stdout.strip().splitlines()[-1])
         return {"value": d["value"], "unit": "rays/s", "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": "f32",
                 "frac_of_fp32_mfma_peak": d["whole_graph_frac_of_peak"], "whole_graph_tflops": d["whole_graph_tflops"], "peak_hbm_gib": d["peak_hbm_gib"],
@@ -369,16 +396,20 @@ def fp32_leg(a):
 
 
 def other_configs_legs():
-    """BASELINE configs[2] / [3] / [4] at their per-GPU shapes (--config comp | multi | hash), 1 warm-up + 2 timed steps each in child processes after
+    """BASELINE configs[2] / [3] / [4] at their per-GPU shapes (--config comp | multi | hash), 2 warm-up + 5 timed steps each in child processes after
     the headline run has given its device memory back: the driver-visible line carries every configuration BASELINE.json names, not only the fg one."""
     import subprocess
     out = {}
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     for cfg in ("comp", "multi", "hash"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", cfg, "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
         t0 = time.perf_counter()
+        tmo = EXTRAS.timeout(420)
+        if tmo is None:
+            out[cfg] = {"value": None, "error": SKIPPED}
+            continue
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=tmo, env=env)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             leg = {"value": d["value"], "unit": "rays/s", "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
                    "workload": d["config"]["workload"], "rays_per_step": d["config"]["rays_per_step"], "peak_hbm_gib": d.get("peak_hbm_gib"),
@@ -403,29 +434,37 @@ def pmc_traffic_in_run():
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (each with --kernel-trace only) over tools/bench_mlp.py at the bench's launch
     size, summarised by tools/pmc_summary.py with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE x 2; KiB units).  The
     passes profile the micro-bench, not this process (rocprofv3 --pmc around the whole bench.py has hung on this pool), each under its own timeout.
-    Returns the summary dict or None (no rocprofv3 on the box / a pass failed / LAB4D_BENCH_PMC=0)."""
+    Returns (summary dict or None, reason): the reason says why there is no measurement (no rocprofv3 on the box / LAB4D_BENCH_PMC=0 / which pass
+    failed with which return code or timeout / the extras' budget) and goes into the line's `traffic_source`."""
     import shutil
     import subprocess
     import tempfile
-    if os.environ.get("LAB4D_BENCH_PMC", "1") == "0" or shutil.which("rocprofv3") is None:
-        return None
+    if os.environ.get("LAB4D_BENCH_PMC", "1") == "0":
+        return None, "LAB4D_BENCH_PMC=0"
+    if shutil.which("rocprofv3") is None:
+        return None, "no rocprofv3 on this box"
     tmp = tempfile.mkdtemp(prefix="lab4d_pmc_", dir="/tmp")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["TMPDIR"] = "/tmp"
     cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_mlp.py"), "16777216", "1"]
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            r = subprocess.run(["timeout", "-k", "5", "90", "rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "--"] + cmd,
-                               capture_output=True, text=True, cwd="/tmp", env=env, timeout=120)
+            tmo = EXTRAS.timeout(120, floor=60.0)
+            if tmo is None:
+                return None, SKIPPED
+            r = subprocess.run(["timeout", "-k", "5", str(int(max(tmo - 25, 30))), "rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "--"] + cmd,
+                               capture_output=True, text=True, cwd="/tmp", env=env, timeout=tmo)
             if r.returncode != 0:
-                return None
+                return None, "the rocprofv3 --pmc %s pass ended with return code %d: %s" % (ctr, r.returncode, (r.stderr or "")[-160:].replace("\n", " "))
         outp = os.path.join(tmp, "pmc.json")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"), outp,
                             "measured in this bench.py run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/bench_mlp.py 16777216 1"],
                            capture_output=True, text=True, timeout=60)
-        return json.load(open(outp)) if r.returncode == 0 and os.path.exists(outp) else None
-    except Exception:
-        return None
+        if r.returncode == 0 and os.path.exists(outp):
+            return json.load(open(outp)), None
+        return None, "tools/pmc_summary.py ended with return code %d: %s" % (r.returncode, (r.stderr or "")[-160:].replace("\n", " "))
+    except Exception as e:  # (subprocess.TimeoutExpired included)
+        return None, "pmc pass failed: %r" % (e,)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -856,12 +895,27 @@ class TrainLoop:
             self.opt.step(max_norm=5.0, skip_above=GRAD_SKIP)
             self.mlp.repack_all()
 
+        # The eager warm-up (allocator pools, column maps, packed weights) runs one whole step -- and must NOT leave a parameter update behind: in a
+        # --gpus N run the ranks render different rows, there is no all-reduce inside the warm-up, so a kept update would de-synchronise the
+        # replicas for the rest of the run; on one GPU it would be a step the loss trajectory does not count.  The optimizer's
+        # whole state is snapshotted in front of it and restored behind it, then the kernels' weight copies are re-packed from the restored weights.
+        opt = self.opt
+        snap = [t.clone() for t in (opt.flat, opt.m, opt.v, opt.dev_step, opt.skipped, opt.norm, opt.coef)]
+        steps0 = opt.steps
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # eager warm-up on the capture stream (allocator pools, column maps, packed weights): one whole step
+        with torch.cuda.stream(side):
             body_a()
             body_b()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for t, s in zip((opt.flat, opt.m, opt.v, opt.dev_step, opt.skipped, opt.norm, opt.coef), snap):
+                t.copy_(s)
+        opt.steps = steps0
+        torch.autograd.graph.increment_version(opt.params)
+        self.mlp.repack_all()
+        snap = None
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         self.graph_a = torch.cuda.CUDAGraph()
@@ -1121,6 +1175,15 @@ def rank_main(a):
         }
         if eval_result is not None:
             out["eval_forward_only"] = eval_result
+        # the headline is complete here: leave a copy on stderr (and under /tmp) BEFORE the extras run, so that a run cut off inside them
+        # (driver timeout) has not lost the measurement.  stdout still carries exactly one line, written at the very end.
+        try:
+            head = json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "loss_last_chunk", "params_finite")})
+            print("[bench headline, extras still to run] " + head, file=sys.stderr, flush=True)
+            with open("/tmp/lab4d_bench_headline.json", "w") as fh:
+                fh.write(json.dumps(out, default=str) + "\n")
+        except Exception:
+            pass
         if comp:
             out["metric"] = "rendered rays/sec (fwd+bwd), fg+bg composite at 512\u00b2 (BASELINE configs[2] per-GPU shape; not the headline metric)"
         if multi:
@@ -1137,11 +1200,11 @@ def rank_main(a):
             gc.collect()
             mlp.clear_caches()
             torch.cuda.empty_cache()
-            pmc = pmc_traffic_in_run()
+            pmc, pmc_why = pmc_traffic_in_run()
             out["fp32_leg"] = fp32_leg(a)
             out["other_configs"] = other_configs_legs()
         else:
-            pmc = None
+            pmc, pmc_why = None, "not the default single-GPU fg run"
         if roofline is not None:
             if pmc is None:
                 pmc = {}
@@ -1149,7 +1212,7 @@ def rank_main(a):
                     pmc_path = os.path.join(ROOT, "profiles", name_)
                     if os.path.exists(pmc_path):
                         pmc = json.load(open(pmc_path))
-                        pmc["_source"] = "NOT measured in this run (no rocprofv3 on the box, a pass failed, or not the default run): committed profiles/%s -- %s" % (name_, pmc.get("_source"))
+                        pmc["_source"] = "NOT measured in this run (%s): committed profiles/%s -- %s" % (pmc_why, name_, pmc.get("_source"))
                         break
             for r_ in [roofline] + roofline.get("others", []):
                 r_["traffic"] = pmc.get(r_["kernel"], {}).get("hbm_bytes_per_launch")

@@ -51,6 +51,20 @@ def build(force=False, verbose=True):
         # AGPRs (a compiler-visible v_accvgpr_read sits in between); with the MFMA results forced into VGPRs that is no longer true
         raise RuntimeError("LAB4D_HIPCC_EXTRA passes -amdgpu-mfma-vgpr-form without -DLAB4D_MFMA_VGPR_FORM: the accumulator hazard fence would be dropped")
     os.makedirs(BUILD_DIR, exist_ok=True)
+    # The compile flags are part of the staleness key: an experiment build (-DLAB4D_ABL_* ...) in this BUILD_DIR followed by a
+    # default build must not leave objects of the other flag set behind -- rebuilds are per object and mtime-based, and lab4d_build_flags()
+    # only reports what runtime.hip's own object saw.  A stamp of the full flag set lives beside the objects; when it differs, everything is rebuilt.
+    stamp_path = os.path.join(BUILD_DIR, "flags.stamp")
+    stamp = "\n".join([HIPCC] + CFLAGS + ["--inst--"] + (MLP_INST_FLAGS if os.environ.get("LAB4D_NO_INST_FLAGS", "0") != "1" else [])) + "\n"
+    try:
+        with open(stamp_path) as fh:
+            stale_flags = fh.read() != stamp
+    except OSError:
+        stale_flags = True
+    if stale_flags:
+        force = True
+        if os.path.exists(stamp_path):
+            os.remove(stamp_path)  # (written again only after every object of the new flag set exists)
     jobs = []
     objs = []
     for f in sources():
@@ -76,6 +90,9 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
+    if stale_flags:
+        with open(stamp_path, "w") as fh:
+            fh.write(stamp)
     if jobs or not os.path.exists(SO_PATH):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO_PATH] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

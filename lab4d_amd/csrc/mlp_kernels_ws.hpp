@@ -139,17 +139,53 @@ struct WsPiece {
   unsigned long long a, b;  // transposing reads
   unsigned int d[4];        // lane-linear dwords
 };
+// ---- slot swizzle of the activation slabs (round 6) ------------------------------------------------------------------------------------------
+// A unit is 64 x 16 B, slot = lane = 32 h + n.  The transposing reads that take a finished tile out (ds_read_b64_tr_b16: two 32-lane groups, bank =
+// (byte / 4) mod 64) address, per group, slots (t, h, n = 4 m + jj) for t, h in {0, 1}, m in 0..3, jj in {0, 1}: t is 16 KiB away, h 512 B -- both
+// multiples of the 256-B bank row -- so FOUR lanes meet on every bank: 6 extra LDS cycles per read, 96 per wave and layer = the 21-25 % of
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE VERDICT r05 (weak #3) found in these kernels (profiles/r05_sq_counters_all.txt).  With the lanes of the
+// upper half stored two slots over (slot = lane ^ 2 for h = 1: n bit 1, which the reads' own n never sets) the two h meet on different banks: 2-way
+// (the t pair is left: both read the same 8-byte half of slots 16 KiB apart; separating them would need 8-byte interleaving, which the 16-byte B
+// operands of the MFMAs cannot have).  The B reads (lane-linear ds_read_b128: 16-lane groups that never mix the two h) and the unit writes
+// (ds_write_b128: aligned 8-lane groups) see a permutation inside their own groups: still conflict-free.  The second read of a pair (samples + 4 =
+// slot n + 2) is `^ 32` on the byte address in both halves.  -DLAB4D_WS_SWZ=0 restores the plain layout (A/B measurements); results are
+// bit-identical either way (tests/test_gpu_mlp_ws.py).
+#ifndef LAB4D_WS_SWZ
+#define LAB4D_WS_SWZ 1
+#endif
+constexpr bool WS_SWZ = LAB4D_WS_SWZ != 0;
+__device__ __forceinline__ int ws_slot(int lane) { return WS_SWZ ? (lane ^ ((lane >> 5) << 1)) : lane; }
+// per-lane part of the transposing tile reads (tr_lane_base of mlp_kernels.hpp with the swizzle): first read of a pair; the second is ^ 32
+__device__ __forceinline__ unsigned ws_tr_lane(int lane) {
+  const int i = lane & 15, G = lane >> 4, h = G & 1, S = G >> 1, m = i & 3, j = i >> 2;
+  const int sigma = 32 * S + 8 * m + j, n = sigma >> 1, t = sigma & 1;
+  return (unsigned)(((t * 16) * 64 + 32 * h + (WS_SWZ ? (n ^ (2 * h)) : n)) * 16);
+}
+// the whole-tile burst (tr_issue of mlp_kernels.hpp) with the pair's second address
+__device__ __forceinline__ void ws_tr_issue(unsigned addr, unsigned addr2, TrTile& r) {
+  asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+               "ds_read_b64_tr_b16 %4, %9\n\t"
+               "ds_read_b64_tr_b16 %1, %8 offset:8\n\t"
+               "ds_read_b64_tr_b16 %5, %9 offset:8\n\t"
+               "ds_read_b64_tr_b16 %2, %8 offset:1024\n\t"
+               "ds_read_b64_tr_b16 %6, %9 offset:1024\n\t"
+               "ds_read_b64_tr_b16 %3, %8 offset:1032\n\t"
+               "ds_read_b64_tr_b16 %7, %9 offset:1032"
+               : "=&v"(r.a[0]), "=&v"(r.a[1]), "=&v"(r.a[2]), "=&v"(r.a[3]), "=&v"(r.b[0]), "=&v"(r.b[1]), "=&v"(r.b[2]), "=&v"(r.b[3])
+               : "v"(addr), "v"(addr2)
+               : "memory");
+}
 template <int QA>
-__device__ __forceinline__ void ws_trp_issue(unsigned addr /* tile base + lane part */, WsPiece& r) {
+__device__ __forceinline__ void ws_trp_issue(unsigned addr /* tile base + lane part */, unsigned addr2 /* tile base + (lane part ^ 32) */, WsPiece& r) {
   constexpr int OFF = 1024 * (QA >> 1) + 8 * (QA & 1);
 #ifdef LAB4D_WSABL_NOTR  // timing experiment (results wrong): no transposing reads, the stores write whatever the registers hold
-  r.a = addr; r.b = addr + OFF;
+  r.a = addr; r.b = addr2 + OFF;
   return;
 #endif
-  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\t"
-               "ds_read_b64_tr_b16 %1, %2 offset:%4"
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\t"
+               "ds_read_b64_tr_b16 %1, %3 offset:%4"
                : "=&v"(r.a), "=&v"(r.b)
-               : "v"(addr), "n"(OFF), "n"(OFF + 32));
+               : "v"(addr), "v"(addr2), "n"(OFF));
 }
 // byte address (lane * 4) of the lane whose transposed piece lane L wants: L = 8 row + piece16  <-  group (h = row >> 2, S = piece16 >> 2), lane (row & 3) + 4 (piece16 & 3)
 __device__ __forceinline__ unsigned ws_perm_addr(int lane) {
@@ -362,7 +398,9 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned xbuf_lds = lds_addr(xbuf), ebuf_lds = lds_addr(ebuf), cnt_lds = lds_addr(blk_cnt), tok_lds = cnt_lds + 4u * (2u + (unsigned)(w & 3));
-  if (tid < 6) blk_cnt[tid] = 0u;  // (the tile loop's first barrier is in front of every use)
+  if constexpr (WS_SYNC || WS_TOKEN) {  // (the shipped barrier-only build neither initialises nor touches the counters / tokens: ADVICE r05)
+    if (tid < 6) blk_cnt[tid] = 0u;  // (the tile loop's first barrier is in front of every use)
+  }
   unsigned cnt_base = 0u;          // arrivals per block before the current tile
   sfor<0, NL>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
@@ -372,7 +410,8 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
       if (tid < 32 * ws_mt<Net>(l)) bias_lds[l * 256 + tid] = ((const GLOBAL_AS float*)a.bias[l])[tid];
     }
   });
-  const unsigned trl = tr_lane_base(0u, 16, lane);  // per-lane part of the transposing tile reads (unit stride 16 per n-tile)
+  const unsigned trl = ws_tr_lane(lane), trl2 = trl ^ 32u;  // per-lane part of the transposing tile reads (unit stride 16 per n-tile): first / second read of a pair
+  const int lane_s = ws_slot(lane);                          // this lane's slot inside a unit of the activation slabs
   const unsigned perm_a = ws_perm_addr(lane);
 
   int S_eff = a.S, ntw = a.S_pad / WS_TILE;
@@ -664,7 +703,10 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
           for (int k = 0; k < ITp::IPW; ++k) {
             const int b = ITp::blk(w, k);
             if constexpr (ACTS) {
-              tr_issue(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + b * 2 * 16 * 1024 + mtp * 2048) + trl, trt);
+              {
+                const unsigned tb_ = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + b * 2 * 16 * 1024 + mtp * 2048);
+                ws_tr_issue(tb_ + trl, tb_ + trl2, trt);
+              }
               tr_wait(trt);
               tr_store(actp, 32 * MTp, s0 + 64 * b, mtp, lane, trt);
             }
@@ -700,7 +742,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
           // reads sink next to their MFMAs (lgkmcnt(1) in front of every MFMA pair) and the LDS latency is exposed once per k-group.
           constexpr int BD = G < WS_BD ? G : WS_BD;
           u32x4_t bq[BD][2];
-          const unsigned pe_a = ebuf_lds + (unsigned)((2 * b * UE) * 1024 + lane * 16), px_a = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + (2 * b * 16) * 1024 + lane * 16);
+          const unsigned pe_a = ebuf_lds + (unsigned)((2 * b * UE) * 1024 + lane * 16), px_a = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + (2 * b * 16) * 1024 + lane_s * 16);
           auto b_read = [&](auto gc, u32x4_t (&dst)[2]) {
             constexpr int g = decltype(gc)::value;
 #ifdef LAB4D_WSABL_HALFB  // timing experiment (results wrong): every second k-group reuses whatever the ring slot holds -- half the B reads, as if one read fed two MFMAs
@@ -740,8 +782,10 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
               using SP = WsSpread<G, (NPI > 0 ? NPI : 1)>;
               sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
                 constexpr int i = decltype(ic)::value, pi = k * NPI + i, kp = pi / 4, qa = pi % 4;
-                if constexpr (SP::issue_at(i) == g)
-                  ws_trp_issue<qa>(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + mtp * 2048) + trl, tp);
+                if constexpr (SP::issue_at(i) == g) {
+                  const unsigned tb_ = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + mtp * 2048);
+                  ws_trp_issue<qa>(tb_ + trl, tb_ + trl2, tp);
+                }
               });
             }
             if constexpr (g + BD < G) b_read(std::integral_constant<int, g + BD>{}, bq[g % BD]);
@@ -796,7 +840,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
               for (int q = 0; q < 2; ++q)
-                xout[((2 * b + t) * 16 + 2 * mt + q) * 64 + lane] = make_uint4(pw[t][4 * q], pw[t][4 * q + 1], pw[t][4 * q + 2], pw[t][4 * q + 3]);
+                xout[((2 * b + t) * 16 + 2 * mt + q) * 64 + lane_s] = make_uint4(pw[t][4 * q], pw[t][4 * q + 1], pw[t][4 * q + 2], pw[t][4 * q + 3]);
           } else if constexpr (!LAST) {
             // layer with an external add (colour net: + basefield feature): fp32 ReLU, sign word by comparison, + ext, then the units
             if constexpr (ls.relu != 0) {
@@ -827,7 +871,7 @@ __global__ void __launch_bounds__(512) k_mlp_fwd_ws(FwdK a) {
               uint4 u[2];
               tile_to_units<P>(acc[t], u);
 #pragma unroll
-              for (int q = 0; q < 2; ++q) xout[((2 * b + t) * 16 + 2 * mt + q) * 64 + lane] = u[q];
+              for (int q = 0; q < 2; ++q) xout[((2 * b + t) * 16 + 2 * mt + q) * 64 + lane_s] = u[q];
             }
           } else {
             // head: raw outputs (S, COUT) fp32
@@ -955,9 +999,12 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned xbuf_lds = lds_addr(xbuf), cnt_lds = lds_addr(blk_cnt), tok_lds = cnt_lds + 4u * (2u + (unsigned)(w & 3));
-  if (tid < 6) blk_cnt[tid] = 0u;
+  if constexpr (WS_SYNC || WS_TOKEN) {
+    if (tid < 6) blk_cnt[tid] = 0u;
+  }
   unsigned cnt_base = 0u;
-  const unsigned trl = tr_lane_base(0u, 16, lane);
+  const unsigned trl = ws_tr_lane(lane), trl2 = trl ^ 32u;  // (see the forward kernel: slot swizzle of the slabs)
+  const int lane_s = ws_slot(lane);
   const unsigned perm_a = ws_perm_addr(lane);
   const int ntw = a.S_pad / WS_TILE;
   const bool want_dx = a.d_x != nullptr;
@@ -1044,7 +1091,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
         uint4 u[2];
         tile_to_units<P>(g[t], u);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) xbuf[((2 * b + t) * 16 + q) * 64 + lane] = u[q];
+        for (int q = 0; q < 2; ++q) xbuf[((2 * b + t) * 16 + q) * 64 + lane_s] = u[q];
       }
     }
     wg_step_barrier();
@@ -1108,7 +1155,10 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
 #pragma unroll
           for (int k = 0; k < ITp::IPW; ++k) {
             const int b = ITp::blk(w, k);
-            tr_issue(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + b * 2 * 16 * 1024 + jp * 2048) + trl, trt);
+            {
+              const unsigned tb_ = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + b * 2 * 16 * 1024 + jp * 2048);
+              ws_tr_issue(tb_ + trl, tb_ + trl2, trt);
+            }
             tr_wait(trt);
             tr_store(dzl, 32 * MTp, s0 + 64 * b, jp, lane, trt);
           }
@@ -1129,7 +1179,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
           for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         constexpr int BD = GK < WS_BD ? GK : WS_BD;
         u32x4_t bq[BD][2];
-        const unsigned px_a = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + (2 * b * 16) * 1024 + lane * 16);
+        const unsigned px_a = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + (2 * b * 16) * 1024 + lane_s * 16);
         auto b_read = [&](auto gc, u32x4_t (&dst)[2]) {
           constexpr int g = decltype(gc)::value;
 #ifdef LAB4D_WSABL_HALFB
@@ -1149,8 +1199,10 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
             using SP = WsSpread<GK, (NPI > 0 ? NPI : 1)>;
             sfor<0, (SPREAD ? NPI : 0)>([&](auto ic) {
               constexpr int i = decltype(ic)::value, pi = (HK >= 0 ? HK : 0) * NPI + i, kp = pi / 4, qa = pi % 4;
-              if constexpr (SP::issue_at(i) == g)
-                ws_trp_issue<qa>(xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + jp * 2048) + trl, tp);
+              if constexpr (SP::issue_at(i) == g) {
+                const unsigned tb_ = xbuf_lds + (unsigned)(ib * WS_BUF * 16 + ITp::blk(w, kp) * 2 * 16 * 1024 + jp * 2048);
+                ws_trp_issue<qa>(tb_ + trl, tb_ + trl2, tp);
+              }
             });
           }
           if constexpr (g + BD < GK) b_read(std::integral_constant<int, g + BD>{}, bq[g % BD]);
@@ -1259,7 +1311,7 @@ __global__ void __launch_bounds__(512) k_mlp_bwd_ws(BwdK a) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
               for (int q = 0; q < 2; ++q)
-                xout[((2 * b + t) * 16 + 2 * j + q) * 64 + lane] = make_uint4(pw[t][4 * q], pw[t][4 * q + 1], pw[t][4 * q + 2], pw[t][4 * q + 3]);
+                xout[((2 * b + t) * 16 + 2 * j + q) * 64 + lane_s] = make_uint4(pw[t][4 * q], pw[t][4 * q + 1], pw[t][4 * q + 2], pw[t][4 * q + 3]);
             if constexpr (WS_SYNC && EARLY && !BOTTOM) ws_arrive(cnt_lds + 4u * (unsigned)b, lane);
           });
           loaded_next = true;

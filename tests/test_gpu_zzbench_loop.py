@@ -88,6 +88,10 @@ def test_whole_step_graphs_agree_with_eager_steps_and_stay_finite():
     loop = make_loop(step_graph=True)
     assert loop.graph_a is not None and loop.graph_b is not None and loop.graph is None
     d0 = int(loop.opt.dev_step)
+    # capture_step's eager warm-up must leave no update behind (every rank of a data-parallel run starts its first replay from the SAME weights): the
+    # optimizer state is what a loop without any capture starts from
+    assert d0 == 0 and loop.opt.steps == 0 and float(loop.opt.m.abs().max()) == 0.0 and float(loop.opt.v.abs().max()) == 0.0
+    w_start = loop.opt.flat.clone()
     losses = []
     for _ in range(32):
         losses.append(loop.step()[12].clone())
@@ -99,7 +103,7 @@ def test_whole_step_graphs_agree_with_eager_steps_and_stay_finite():
     assert float(la[-1]) < float(la[0])
     del loop
     eager = make_loop(use_graph=False)
-    eager.step()  # (capture_step's warm-up takes one optimizer step before the first replay)
+    assert torch.equal(eager.opt.flat, w_start), "the captured loop did not start from the seeded weights"
     lb = torch.stack([eager.step()[12].clone() for _ in range(8)]).cpu()
     assert float(((la[:8] - lb).abs() / lb.abs()).max()) < 0.03, (la[:8], lb)
 
