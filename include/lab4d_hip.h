@@ -253,6 +253,12 @@ int lab4d_global_match_backward(const float* feat_px, const float* feat_c, const
  * ------------------------------------------------------------------------------------------ */
 #include "lab4d_ingest.h"
 
+/* ------------------------------------------------------------------------------------------
+ * 10. The per-frame MLPs of the pose / appearance path as one launch each way -- nnutils/embedding.py:177-217,
+ *     nnutils/base.py:65-78, nnutils/time.py:65-73, nnutils/pose.py:103-147,442-447, nnutils/intrinsics.py:73-107.  See lab4d_rowmlp.h.
+ * ------------------------------------------------------------------------------------------ */
+#include "lab4d_rowmlp.h"
+
 #ifdef __cplusplus
 }
 #endif

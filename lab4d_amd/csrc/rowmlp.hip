@@ -1,0 +1,251 @@
+// The per-frame (M-row) MLPs in front of the hot path -- TimeEmbedding, TimeMLP and the heads of CameraMLP / IntrinsicsMLP /
+// ArticulationSkelMLP / AppearanceEmbedding -- as a PROGRAM of dense layers over a per-row strip: one launch forward, two backward.
+// Contract and the reference lines it replaces: include/lab4d_rowmlp.h.
+//
+// This is a launch-count problem (M <= a few hundred rows, ~40 torch launches forward and ~100 backward per module and step in the
+// reference), not a FLOP or bandwidth one: 256 rows x 10 layers of 256 x 256 are 0.17 GFLOP.  So: plain fp32 FMA (the precision the
+// reference computes these modules in; no packing: the weights are read in nn.Linear's own (out, in) layout), a workgroup owns R
+// rows for the whole program -- rows are independent, so the layers follow each other behind workgroup barriers inside ONE launch --
+// and every global access is coalesced: the forward transposes 32-column tiles of W through LDS, the input-gradient chain reads W
+// along its rows, the parameter kernel contracts over the rows with X along its columns.  No atomics: every gradient element has one
+// owner, results are deterministic.
+#include "common.hpp"
+
+namespace lab4d {
+
+constexpr int RM_R = 8;       // rows per workgroup
+constexpr int RM_T = 256;     // threads per workgroup
+constexpr int RM_KT = 32;     // k tile of the forward's W transposition
+constexpr int RM_MAXD = 1024; // widest layer input / output
+constexpr int RM_TO = 8;      // outputs per job of the parameter kernel
+constexpr int RM_MC = 64;     // rows per staged chunk of the parameter kernel
+
+__device__ __forceinline__ float rm_tid(const lab4d_rowmlp_prog& p, long f) {
+  // embedding.py:177-184 in fp32, operation by operation: (tid_sub - vid_len / 2) / max_ts * 2, then * time_scale
+  const float sub = (float)(f - p.vstart[f]);
+  const float half = (float)p.vidlen[f] / 2.0f;
+  return (sub - half) / p.max_ts * 2.0f * p.time_scale;
+}
+
+__global__ void __launch_bounds__(RM_T) k_rowmlp_fwd(lab4d_rowmlp_prog p, float* __restrict__ work, int M) {
+  __shared__ float xs[RM_R][RM_MAXD];
+  __shared__ float wt[RM_KT][RM_T + 1];
+  const int tid = threadIdx.x, r0 = blockIdx.x * RM_R;
+  const int nr = min(RM_R, M - r0);
+  const size_t rs = (size_t)p.row_stride;
+  // ---- time prologue ----
+  if (p.frame_id != nullptr) {
+    const int nf = 2 * p.n_freq + 1;
+    for (int e = tid; e < nr * nf; e += RM_T) {
+      const int r = e / nf, c = e - r * nf;
+      const float t = rm_tid(p, (long)p.frame_id[r0 + r]);
+      float v = t;
+      if (c > 0) {
+        const float ang = exp2f((float)((c - 1) >> 1)) * t;  // freq_bands[k] * x (embedding.py:97-100)
+        v = ((c - 1) & 1) ? cosf(ang) : sinf(ang);
+      }
+      work[(r0 + r) * rs + p.four_col + c] = v;
+    }
+    for (int e = tid; e < nr * p.inst_dim; e += RM_T) {
+      const int r = e / p.inst_dim, c = e - r * p.inst_dim;
+      const long f = (long)p.frame_id[r0 + r];
+      const long row = p.inst_rows == 1 ? 0 : (long)p.vid[f];
+      work[(r0 + r) * rs + p.inst_col + c] = p.inst_W[row * p.inst_dim + c];
+    }
+    __syncthreads();
+  }
+  for (int l = 0; l < p.n_layers; ++l) {
+    const lab4d_rowmlp_layer L = p.layer[l];
+    // stage the rows' inputs
+    for (int e = tid; e < RM_R * L.in_dim; e += RM_T) {
+      const int r = e / L.in_dim, k = e - r * L.in_dim;
+      xs[r][k] = r < nr ? work[(r0 + r) * rs + L.src_col + k] : 0.f;
+    }
+    for (int o0 = 0; o0 < L.out_dim; o0 += RM_T) {
+      const int o = o0 + tid;
+      float acc[RM_R];
+      const float bias = (L.b != nullptr && o < L.out_dim) ? L.b[o] : 0.f;
+#pragma unroll
+      for (int r = 0; r < RM_R; ++r) acc[r] = bias;
+      for (int k0 = 0; k0 < L.in_dim; k0 += RM_KT) {
+        __syncthreads();  // (xs staged / the previous tile consumed)
+        // W[o0 .. o0 + 255][k0 .. k0 + 31] -> wt[k][o] : 32 consecutive lanes read 128 contiguous bytes of one row of W
+#pragma unroll 4
+        for (int it = 0; it < RM_KT; ++it) {
+          const int idx = it * RM_T + tid, ol = idx / RM_KT, kk = idx - ol * RM_KT;
+          const int oo = o0 + ol, k = k0 + kk;
+          wt[kk][ol] = (oo < L.out_dim && k < L.in_dim) ? L.W[(size_t)oo * L.in_dim + k] : 0.f;
+        }
+        __syncthreads();
+        const int kn = min(RM_KT, L.in_dim - k0);
+        for (int kk = 0; kk < kn; ++kk) {
+          const float w = wt[kk][tid];
+#pragma unroll
+          for (int r = 0; r < RM_R; ++r) acc[r] = fmaf(w, xs[r][k0 + kk], acc[r]);
+        }
+      }
+      if (o < L.out_dim) {
+#pragma unroll
+        for (int r = 0; r < RM_R; ++r)
+          if (r < nr) work[(r0 + r) * rs + L.dst_col + o] = L.relu ? fmaxf(acc[r], 0.f) : acc[r];
+      }
+    }
+    __syncthreads();  // this layer's outputs are visible to the workgroup before the next layer stages them
+  }
+}
+
+// dZ in place + input gradients accumulated into the sources, layers in reverse
+__global__ void __launch_bounds__(RM_T) k_rowmlp_bwd_chain(lab4d_rowmlp_prog p, const float* __restrict__ work, float* __restrict__ gwork, int M) {
+  __shared__ float dzs[RM_R][RM_MAXD];
+  const int tid = threadIdx.x, r0 = blockIdx.x * RM_R;
+  const int nr = min(RM_R, M - r0);
+  const size_t rs = (size_t)p.row_stride;
+  for (int l = p.n_layers - 1; l >= 0; --l) {
+    const lab4d_rowmlp_layer L = p.layer[l];
+    for (int e = tid; e < RM_R * L.out_dim; e += RM_T) {
+      const int r = e / L.out_dim, o = e - r * L.out_dim;
+      float g = 0.f;
+      if (r < nr) {
+        const size_t a = (r0 + r) * rs + L.dst_col + o;
+        g = gwork[a];
+        if (L.relu && !(work[a] > 0.f)) g = 0.f;
+        gwork[a] = g;
+      }
+      dzs[r][o] = g;
+    }
+    __syncthreads();
+    for (int i = tid; i < L.in_dim; i += RM_T) {
+      float acc[RM_R];
+#pragma unroll
+      for (int r = 0; r < RM_R; ++r) acc[r] = 0.f;
+      for (int o = 0; o < L.out_dim; ++o) {
+        const float w = L.W[(size_t)o * L.in_dim + i];  // consecutive threads: consecutive columns of one row of W
+#pragma unroll
+        for (int r = 0; r < RM_R; ++r) acc[r] = fmaf(dzs[r][o], w, acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < RM_R; ++r)
+        if (r < nr) gwork[(r0 + r) * rs + L.src_col + i] += acc[r];
+    }
+    __syncthreads();
+  }
+}
+
+// jobs: layer l has ceil(out_dim / RM_TO) jobs (dW rows o0 .. o0 + 7 and their db), then inst_rows jobs for d_inst_W
+__global__ void __launch_bounds__(RM_T) k_rowmlp_bwd_param(lab4d_rowmlp_prog p, const float* __restrict__ work, const float* __restrict__ gwork, int M) {
+  __shared__ float dzt[RM_MC][RM_TO];
+  const int tid = threadIdx.x;
+  const size_t rs = (size_t)p.row_stride;
+  int job = blockIdx.x, l = 0;
+  for (; l < p.n_layers; ++l) {
+    const int nj = (p.layer[l].out_dim + RM_TO - 1) / RM_TO;
+    if (job < nj) break;
+    job -= nj;
+  }
+  if (l == p.n_layers) {
+    // d_inst_W[v][c] = sum over the rows of video v (a single-row table takes every row)
+    if (p.d_inst_W == nullptr || p.frame_id == nullptr || job >= p.inst_rows) return;
+    for (int c = tid; c < p.inst_dim; c += RM_T) {
+      float acc = 0.f;
+      for (int m = 0; m < M; ++m) {
+        const long row = p.inst_rows == 1 ? 0 : (long)p.vid[(long)p.frame_id[m]];
+        if (row == job) acc += gwork[m * rs + p.inst_col + c];
+      }
+      p.d_inst_W[(size_t)job * p.inst_dim + c] = acc;
+    }
+    return;
+  }
+  const lab4d_rowmlp_layer L = p.layer[l];
+  if (L.dW == nullptr && L.db == nullptr) return;
+  const int o0 = job * RM_TO, no = min(RM_TO, L.out_dim - o0);
+  const int ni = (L.in_dim + RM_T - 1) / RM_T;  // column passes of this thread (<= 4)
+  float acc[4][RM_TO];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < RM_TO; ++j) acc[q][j] = 0.f;
+  float bsum = 0.f;
+  for (int m0 = 0; m0 < M; m0 += RM_MC) {
+    const int mc = min(RM_MC, M - m0);
+    __syncthreads();
+    for (int e = tid; e < RM_MC * RM_TO; e += RM_T) {
+      const int mm = e / RM_TO, j = e - mm * RM_TO;
+      dzt[mm][j] = (mm < mc && j < no) ? gwork[(m0 + mm) * rs + L.dst_col + o0 + j] : 0.f;
+    }
+    __syncthreads();
+    if (L.dW != nullptr) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = q * RM_T + tid;
+        if (q < ni && i < L.in_dim) {
+          for (int mm = 0; mm < mc; ++mm) {
+            const float x = work[(m0 + mm) * rs + L.src_col + i];
+#pragma unroll
+            for (int j = 0; j < RM_TO; ++j) acc[q][j] = fmaf(dzt[mm][j], x, acc[q][j]);
+          }
+        }
+      }
+    }
+    if (tid < RM_TO)
+      for (int mm = 0; mm < mc; ++mm) bsum += dzt[mm][tid];
+  }
+  if (L.dW != nullptr) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = q * RM_T + tid;
+      if (q < ni && i < L.in_dim)
+#pragma unroll
+        for (int j = 0; j < RM_TO; ++j)
+          if (j < no) L.dW[(size_t)(o0 + j) * L.in_dim + i] = acc[q][j];
+    }
+  }
+  if (L.db != nullptr && tid < no) L.db[o0 + tid] = bsum;
+}
+
+static int rowmlp_check(const lab4d_rowmlp_prog* p, const void* work, int M) {
+  LAB4D_REQUIRE(p != nullptr && work != nullptr && M >= 0, "rowmlp: null program / workspace or negative row count");
+  LAB4D_REQUIRE(p->n_layers >= 1 && p->n_layers <= LAB4D_ROWMLP_MAX_LAYERS && p->row_stride >= 1, "rowmlp: %d layers (1..%d), row stride %d", p->n_layers,
+                LAB4D_ROWMLP_MAX_LAYERS, p->row_stride);
+  for (int l = 0; l < p->n_layers; ++l) {
+    const lab4d_rowmlp_layer& L = p->layer[l];
+    LAB4D_REQUIRE(L.W != nullptr && L.in_dim >= 1 && L.out_dim >= 1 && L.in_dim <= RM_MAXD && L.out_dim <= RM_MAXD, "rowmlp: layer %d: weights missing or %d -> %d outside 1..%d", l,
+                  L.in_dim, L.out_dim, RM_MAXD);
+    LAB4D_REQUIRE(L.src_col >= 0 && L.dst_col >= 0 && L.src_col + L.in_dim <= p->row_stride && L.dst_col + L.out_dim <= p->row_stride,
+                  "rowmlp: layer %d: columns [%d, +%d) -> [%d, +%d) leave the row strip of %d", l, L.src_col, L.in_dim, L.dst_col, L.out_dim, p->row_stride);
+    LAB4D_REQUIRE(!(L.dst_col < L.src_col + L.in_dim && L.src_col < L.dst_col + L.out_dim), "rowmlp: layer %d writes into its own input columns", l);
+  }
+  if (p->frame_id != nullptr) {
+    LAB4D_REQUIRE(p->vstart != nullptr && p->vidlen != nullptr && p->n_freq >= 0 && p->n_freq <= 16 && p->max_ts > 0.f, "rowmlp: time prologue: frame tables missing, n_freq %d or max_ts %g",
+                  p->n_freq, (double)p->max_ts);
+    LAB4D_REQUIRE(p->four_col >= 0 && p->four_col + 2 * p->n_freq + 1 <= p->row_stride, "rowmlp: time prologue: Fourier columns leave the row strip");
+    LAB4D_REQUIRE(p->inst_dim >= 0 && (p->inst_dim == 0 || (p->inst_W != nullptr && p->inst_rows >= 1 && p->inst_col >= 0 && p->inst_col + p->inst_dim <= p->row_stride)),
+                  "rowmlp: time prologue: instance-code table / columns");
+    LAB4D_REQUIRE(!(p->inst_dim > 0 && p->inst_rows > 1 && p->vid == nullptr), "rowmlp: time prologue: a multi-row instance table needs raw_fid_to_vid");
+  }
+  return LAB4D_OK;
+}
+
+}  // namespace lab4d
+
+using namespace lab4d;
+
+extern "C" int lab4d_rowmlp_forward(const lab4d_rowmlp_prog* prog, float* work, int M, void* stream) {
+  const int rc = rowmlp_check(prog, work, M);
+  if (rc != LAB4D_OK) return rc;
+  if (M == 0) return LAB4D_OK;
+  hipLaunchKernelGGL(k_rowmlp_fwd, dim3((M + RM_R - 1) / RM_R), dim3(RM_T), 0, (hipStream_t)stream, *prog, work, M);
+  return check_launch("rowmlp_forward");
+}
+
+extern "C" int lab4d_rowmlp_backward(const lab4d_rowmlp_prog* prog, const float* work, float* gwork, int M, void* stream) {
+  const int rc = rowmlp_check(prog, work, M);
+  if (rc != LAB4D_OK) return rc;
+  LAB4D_REQUIRE(gwork != nullptr, "rowmlp_backward: null gradient workspace");
+  if (M == 0) return LAB4D_OK;
+  hipLaunchKernelGGL(k_rowmlp_bwd_chain, dim3((M + RM_R - 1) / RM_R), dim3(RM_T), 0, (hipStream_t)stream, *prog, work, gwork, M);
+  int jobs = 0;
+  for (int l = 0; l < prog->n_layers; ++l) jobs += (prog->layer[l].out_dim + RM_TO - 1) / RM_TO;
+  if (prog->frame_id != nullptr && prog->d_inst_W != nullptr) jobs += prog->inst_rows;
+  hipLaunchKernelGGL(k_rowmlp_bwd_param, dim3(jobs), dim3(RM_T), 0, (hipStream_t)stream, *prog, work, (const float*)gwork, M);
+  return check_launch("rowmlp_backward");
+}

@@ -160,6 +160,9 @@ extern "C" const char* lab4d_build_flags(void) {
 #ifdef LAB4D_WS_LINEAR_STORE
   " WS_LINEAR_STORE"
 #endif
+#ifdef LAB4D_WS_SWZ
+  " WS_SWZ"
+#endif
 #ifdef LAB4D_WS_SYNC
   " WS_SYNC"
 #endif

@@ -17,6 +17,9 @@
     ComposedWarp.forward                      nnutils/warping.py:445                       -> composed_forward
     MultiFields.compose_fields                nnutils/multifields.py:339                   -> compose_fields
     AppearanceEmbedding.get_vals              nnutils/appearance.py:8-56, time.py:107      -> appearance_get_vals
+    TimeEmbedding.forward                     nnutils/embedding.py:194-217                 -> time_embedding_forward   (rowmlp program: one launch)
+    CameraMLP.get_vals                        nnutils/pose.py:130-150                      -> camera_get_vals          (rowmlp program)
+    IntrinsicsMLP.get_vals                    nnutils/intrinsics.py:86-107                 -> intrinsics_get_vals      (rowmlp program)
     dvr_model.render / evaluate / render_samples / render_samples_chunk
                                               engine/model.py:162,217,259,328              -> dvr_*
     dvr_model.compute_loss                    engine/model.py:375-399 (+ 401-611)          -> dvr_compute_loss (fused per-ray loss kernels)
@@ -259,18 +262,13 @@ def composed_forward(self, xyz, frame_id, inst_id, backward=False, samples_dict=
 
 def appearance_get_vals(self, frame_id=None):
     """AppearanceEmbedding.get_vals (TimeMLP.get_vals, nnutils/time.py:107-117, with the AppearanceEmbedding.forward of
-    appearance.py:46-56): Fourier(t) -> TimeEmbedding -> TimeMLP(D=2, W=64) -> Linear(64, 32).  M rows: torch device GEMMs
-    ("negligible when per-frame"); what matters for the per-sample path is that the result is consumed
+    appearance.py:46-56): Fourier(t) -> TimeEmbedding -> TimeMLP(D=2, W=64) -> Linear(64, 32).  M rows: rowmlp programs on the GPU since
+    round 6 ("negligible when per-frame"); what matters for the per-sample path is that the result is consumed
     as a per-FRAME bias of the rgb head (lab4d_amd.mlp.pf_bias_of) instead of being broadcast to every sample
     (nerf.py:201-205) -- including in the compacted eval path, where the reference evaluates this MLP per SAMPLE
     (nerf.py:795-798)."""
     from . import pose
-    P = params_of(self, "appr.")
-    info = pose.time_info_of(self.time_embedding)
-    t_embed = pose.time_embedding(P, "appr.time_embedding", frame_id, info)
-    n_hidden = sum(1 for k in P if k.startswith("appr.linear_") and k.endswith(".0.weight") and k.split(".")[1][7:].isdigit())
-    feat = pose.time_mlp(P, "appr", t_embed, D=n_hidden)
-    return torch.nn.functional.linear(feat, P["appr.output.weight"], P["appr.output.bias"])
+    return pose.appearance_vals(params_of(self, "appr."), "appr", frame_id, _time_info(self.time_embedding))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -604,7 +602,7 @@ INGEST_BINDINGS = [("lab4d.dataloader.vidloader", "VidDataset", "load_data", vid
 # ---------------------------------------------------------------------------------------------------
 def articulation_skel_forward(self, t_embed, inst_id, return_so3=False, override_so3=None, override_log_bone_len=None,
                               override_local_rest_joints=None):
-    """ArticulationSkelMLP.forward (nnutils/pose.py:417-470).  The time MLP and the two heads stay device GEMMs on M rows; the
+    """ArticulationSkelMLP.forward (nnutils/pose.py:417-470).  The time MLP and the so3 head are one rowmlp program (round 6); the
     bone lengths, the forward kinematics over the tree (`fk_se3`: a Python loop of clone + matmul + index_put per joint in the
     reference), `matrix_to_quaternion` and `shift_joints_to_bones_dq` are ONE launch each way (csrc/fk.hip)."""
     from . import pose
@@ -630,6 +628,50 @@ def articulation_skel_forward(self, t_embed, inst_id, return_so3=False, override
         skel = {"edges": self.edges, "symm_idx": self.symm_idx, "rest_joints": self.rest_joints}
         qr, qd = pose.skel_bones(so3_rows, ll, P["a.logscale"], skel, P["a.shift"])
     return qr.reshape(*lead, self.num_se3, 4), qd.reshape(*lead, self.num_se3, 4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-frame MLPs: TimeEmbedding / CameraMLP / IntrinsicsMLP as rowmlp programs
+# ---------------------------------------------------------------------------------------------------
+def _time_info(te):
+    """pose.time_info_of(te), cached on the module (the frame tables are fixed at construction; the cache follows the module across devices)."""
+    from . import pose
+    hit = te.__dict__.get("_lab4d_time_info")
+    if hit is None or hit["frame_mapping"].device != te.frame_mapping.device:
+        hit = pose.time_info_of(te)
+        te.__dict__["_lab4d_time_info"] = hit
+    return hit
+
+
+def time_embedding_forward(self, frame_id=None):
+    """TimeEmbedding.forward (nnutils/embedding.py:194-217): frame ids -> time coordinate -> Fourier features -> mapping1, the video's
+    InstEmbedding row, mapping2 -- ONE launch (csrc/rowmlp.hip time prologue + two layers) instead of ~12."""
+    from . import pose
+    P = params_of(self, "te.")
+    info = _time_info(self)
+    if frame_id is None:
+        return pose.time_embedding(P, "te", None, info)
+    if not torch.is_tensor(frame_id):
+        frame_id = torch.tensor(frame_id).to(self.frame_to_vid.device)
+    if frame_id.ndim == 1:
+        return pose.time_embedding(P, "te", frame_id, info)
+    if frame_id.shape[-1] != 1:  # (the reference's PosEmbedding(1, F) takes the LAST axis as its single channel: anything else fails there too)
+        raise RuntimeError("TimeEmbedding.forward: frame_id must be (M,) or (..., 1), got %s" % (tuple(frame_id.shape),))
+    out = pose.time_embedding(P, "te", frame_id.reshape(-1), info)
+    return out.reshape(*frame_id.shape[:-1], out.shape[-1])
+
+
+def camera_get_vals(self, frame_id=None):
+    """CameraMLP.get_vals (nnutils/pose.py:130-150): time prologue + TimeEmbedding + TimeMLP + both heads as ONE rowmlp program (12 layers, one
+    launch forward, two backward), then normalize + the per-video base rotation through the library's quaternion_mul."""
+    from . import pose
+    return pose.camera_vals(params_of(self, "c."), "c", frame_id, _time_info(self.time_embedding))
+
+
+def intrinsics_get_vals(self, frame_id=None):
+    """IntrinsicsMLP.get_vals (nnutils/intrinsics.py:86-107): one rowmlp program (10 layers) + the per-video focal / principal-point algebra."""
+    from . import pose
+    return pose.intrinsics_vals(params_of(self, "k."), "k", frame_id, _time_info(self.time_embedding))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -660,6 +702,9 @@ def bindings():
         ("lab4d.nnutils.multifields", "MultiFields", "compose_fields", compose_fields, True),
         ("lab4d.nnutils.appearance", "AppearanceEmbedding", "get_vals", appearance_get_vals, False),
         ("lab4d.nnutils.pose", "ArticulationSkelMLP", "forward", articulation_skel_forward, False),
+        ("lab4d.nnutils.embedding", "TimeEmbedding", "forward", time_embedding_forward, False),
+        ("lab4d.nnutils.pose", "CameraMLP", "get_vals", camera_get_vals, False),
+        ("lab4d.nnutils.intrinsics", "IntrinsicsMLP", "get_vals", intrinsics_get_vals, False),
         ("lab4d.engine.model", "dvr_model", "render", dvr_render, False),
         ("lab4d.engine.model", "dvr_model", "evaluate", dvr_evaluate, False),
         ("lab4d.engine.model", "dvr_model", "render_samples", dvr_render_samples, False),

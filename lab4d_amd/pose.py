@@ -4,8 +4,14 @@ lab4d/nnutils/time.py (`TimeMLP`) and the forward kinematics of lab4d/utils/skel
 
 What is native: the kinematic tree -- bone lengths, `so3_to_exp_map`, `fk_se3`, `matrix_to_quaternion`,
 `shift_joints_to_bones_dq` and their adjoint -- is ONE gfx950 kernel each way (csrc/fk.hip, include/lab4d_pose.h) where
-the reference runs a 25-step Python loop.  The (M-row x 256) time MLPs in front of it are dense layers on M <= a few
-hundred rows and stay torch device GEMMs; the camera's quaternion product uses the library's quaternion_mul kernel.
+the reference runs a 25-step Python loop.  Round 6: the (M-row x W) MLPs in front of it -- TimeEmbedding (frame -> time
+coordinate -> Fourier features -> mapping1 | InstEmbedding row -> mapping2), TimeMLP and the heads of CameraMLP /
+IntrinsicsMLP / Articulation*MLP / AppearanceEmbedding -- are a PROGRAM of dense layers executed by csrc/rowmlp.hip
+(include/lab4d_rowmlp.h, lab4d_amd/rowmlp.py): one launch forward, two backward per module, where the reference (and
+rounds 1-5) issued one launch per nn.Linear / ReLU / cat / index.  Tensors on the GPU always take the kernels (no
+fallback: a missing library raises); the torch algebra below is kept for CPU tensors only -- it is what the CPU suite
+holds against the real reference modules (tests/test_patch_*.py) and what the kernels are held to on the GPU.  The
+camera's quaternion product uses the library's quaternion_mul kernel.
 
 Weights: flat dict keyed by the reference's state_dict names under a prefix (e.g. "warp.articulation" / "camera_mlp").
 `info` holds TimeEmbedding's frame tables (embedding.py:153-175): frame_to_vid, frame_mapping, raw_fid_to_vid,
@@ -18,6 +24,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib
+from . import rowmlp  # noqa: F401  (registers the lab4d_rowmlp_* signatures)
 from .quat_utils import quaternion_mul
 
 vp, ci = _lib.vp, _lib.ci
@@ -186,8 +193,70 @@ def _vid_code(P, prefix, inst_id):
     return w[torch.zeros_like(inst_id) if w.shape[0] == 1 else inst_id]
 
 
+# ---- the same modules as rowmlp programs (GPU tensors) -------------------------------------------------------------------------
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def _lin_layer(P, name, src, dst, relu):
+    return {"W": P[name + ".weight"], "b": P.get(name + ".bias"), "src": src, "dst": dst, "relu": relu}
+
+
+def _time_prologue(P, te_prefix, frame_id, info):
+    """The time prologue + TimeEmbedding's two Linear layers as program pieces: (time dict, layers, column of t_embed, width, next free column)."""
+    fid = info["frame_mapping"] if frame_id is None else frame_id
+    fid = fid.reshape(-1).long()
+    info = dict(info, **{k: info[k].long() for k in ("raw_fid_to_vstart", "raw_fid_to_vidlen", "raw_fid_to_vid")})  # (no-ops on the reference's int64 buffers)
+    nf = 2 * max(int(info["num_freq_t"]), 0) + 1
+    w1, w2 = P[te_prefix + ".mapping1.weight"], P[te_prefix + ".mapping2.weight"]
+    W = w1.shape[0]
+    inst_W = P[te_prefix + ".inst_embedding.mapping.weight"]
+    c_cat = _pad4(nf)
+    c_te = c_cat + w2.shape[1]
+    time = {"frame_id": fid, "vstart": info["raw_fid_to_vstart"], "vidlen": info["raw_fid_to_vidlen"], "vid": info["raw_fid_to_vid"],
+            "max_ts": info["max_ts"], "time_scale": info.get("time_scale", 1.0), "n_freq": info["num_freq_t"], "four_col": 0, "inst_W": inst_W,
+            "inst_col": c_cat + W}
+    layers = [_lin_layer(P, te_prefix + ".mapping1", 0, c_cat, False), _lin_layer(P, te_prefix + ".mapping2", c_cat, c_te, False)]
+    return time, layers, c_te, w2.shape[0], c_te + w2.shape[0], fid.shape[0]
+
+
+def _time_mlp_layers(P, prefix, src, col, D):
+    """TimeMLP.forward (time.py:65-73) as layers reading column `src`, writing from column `col`: (layers, column of the feature, width, next column)."""
+    layers = []
+    for i in range(D):
+        name = f"{prefix}.linear_{i+1}.0"
+        layers.append(_lin_layer(P, name, src, col, True))
+        src, col = col, col + P[name + ".weight"].shape[0]
+    name = f"{prefix}.linear_final.0"
+    layers.append(_lin_layer(P, name, src, col, True))
+    width = P[name + ".weight"].shape[0]
+    return layers, col, width, col + width
+
+
+def _head_layers(P, prefix, src, col):
+    """nn.Sequential(Linear, ReLU, Linear) (pose.py:70-79): (layers, column of the output, width, next column)."""
+    w0, w2 = P[prefix + ".0.weight"].shape[0], P[prefix + ".2.weight"].shape[0]
+    return [_lin_layer(P, prefix + ".0", src, col, True), _lin_layer(P, prefix + ".2", col, col + w0, False)], col + w0, w2, _pad4(col + w0 + w2)
+
+
+def _mlp_depth(P, prefix):
+    D = 0
+    while f"{prefix}.linear_{D+1}.0.weight" in P:
+        D += 1
+    return D
+
+
+def _on_gpu(P, key):
+    return P[key].is_cuda
+
+
 def time_embedding(P, prefix, frame_id, info):
     """TimeEmbedding.forward (embedding.py:194-217)."""
+    if _on_gpu(P, prefix + ".mapping1.weight"):
+        time, layers, c_te, W, _, M = _time_prologue(P, prefix, frame_id, info)
+        return rowmlp.run(layers, M, [(c_te, W)], time=time)[0]
     if frame_id is None:
         inst_id, t = info["frame_to_vid"], frame_tid(info["frame_mapping"], info)
     else:
@@ -203,6 +272,10 @@ def time_embedding_mean(P, prefix, info):
 
 def time_mlp(P, prefix, t_embed, D=5):
     """TimeMLP.forward (time.py:65-73): D x (Linear + ReLU) + final Linear + ReLU."""
+    if t_embed.is_cuda:
+        W0 = t_embed.shape[-1]
+        layers, c_f, Wf, _ = _time_mlp_layers(P, prefix, 0, _pad4(W0), D)
+        return rowmlp.run(layers, t_embed.shape[0], [(c_f, Wf)], inputs=[((0, W0), t_embed)])[0]
     x = t_embed
     for i in range(D):
         x = F.relu(_linear(P, f"{prefix}.linear_{i+1}.0", x))
@@ -215,11 +288,33 @@ def _head(P, prefix, x):
 
 def camera_vals(P, prefix, frame_id, info):
     """CameraMLP.get_vals (pose.py:116-147) -> (quat (M,4), trans (M,3))."""
+    if _on_gpu(P, prefix + ".base_quat"):
+        # ONE program: time prologue, TimeEmbedding, TimeMLP, both heads (12 layers)
+        time, layers, c_te, _, col, M = _time_prologue(P, prefix + ".time_embedding", frame_id, info)
+        l2, c_f, _, col = _time_mlp_layers(P, prefix, c_te, col, _mlp_depth(P, prefix))
+        lt, c_t, w_t, col = _head_layers(P, prefix + ".trans", c_f, col)
+        lq, c_q, w_q, col = _head_layers(P, prefix + ".quat", c_f, col)
+        trans, quat = rowmlp.run(layers + l2 + lt + lq, M, [(c_t, w_t), (c_q, w_q)], time=time)
+        quat = F.normalize(quat, dim=-1)
+        inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]
+        return quaternion_mul(quat, F.normalize(P[prefix + ".base_quat"][inst_id], dim=-1)), trans
     feat = time_mlp(P, prefix, time_embedding(P, prefix + ".time_embedding", frame_id, info))
     quat = F.normalize(_head(P, prefix + ".quat", feat), dim=-1)
     inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]
     base = F.normalize(P[prefix + ".base_quat"][inst_id], dim=-1)
     return quaternion_mul(quat, base), _head(P, prefix + ".trans", feat)
+
+
+def appearance_vals(P, prefix, frame_id, info):
+    """AppearanceEmbedding.get_vals (time.py:107-117 + appearance.py:46-56): TimeEmbedding -> TimeMLP(D, W) -> Linear(W, C), one program on the GPU."""
+    D = _mlp_depth(P, prefix)
+    if _on_gpu(P, prefix + ".output.weight"):
+        time, layers, c_te, _, col, M = _time_prologue(P, prefix + ".time_embedding", frame_id, info)
+        l2, c_f, _, col = _time_mlp_layers(P, prefix, c_te, col, D)
+        C = P[prefix + ".output.weight"].shape[0]
+        return rowmlp.run(layers + l2 + [_lin_layer(P, prefix + ".output", c_f, col, False)], M, [(col, C)], time=time)[0]
+    feat = time_mlp(P, prefix, time_embedding(P, prefix + ".time_embedding", frame_id, info), D=D)
+    return _linear(P, prefix + ".output", feat)
 
 
 def log_bone_len(P, prefix, inst_id, rows):
@@ -233,6 +328,11 @@ def log_bone_len(P, prefix, inst_id, rows):
 
 def articulation_so3(P, prefix, t_embed):
     """pose.py:442-447: joint angles (M,B,3)."""
+    if t_embed.is_cuda:
+        W0 = t_embed.shape[-1]
+        layers, c_f, _, col = _time_mlp_layers(P, prefix, 0, _pad4(W0), _mlp_depth(P, prefix))
+        lh, c_o, w_o, _ = _head_layers(P, prefix + ".so3", c_f, col)
+        return rowmlp.run(layers + lh, t_embed.shape[0], [(c_o, w_o)], inputs=[((0, W0), t_embed)])[0].reshape(t_embed.shape[0], -1, 3)
     return _head(P, prefix + ".so3", time_mlp(P, prefix, t_embed)).reshape(t_embed.shape[0], -1, 3)
 
 
@@ -265,16 +365,30 @@ def axis_angle_to_quaternion(aa):
 def articulation_flat_forward(P, prefix, t_embed):
     """ArticulationFlatMLP.forward (pose.py:287-303), bag-of-bones motion ("bob"): ((M,B,4), (M,B,4)).  The dual part is
     0.5 * (0,t) x q on the library's quaternion_mul kernel (3-vector operand = pure quaternion, quaternion.cu:46-57)."""
-    feat = time_mlp(P, prefix, t_embed)
-    trans = (_head(P, prefix + ".trans", feat) * 0.1).reshape(t_embed.shape[0], -1, 3)
-    qr = axis_angle_to_quaternion(_head(P, prefix + ".so3", feat).reshape(t_embed.shape[0], -1, 3))
+    if t_embed.is_cuda:
+        W0 = t_embed.shape[-1]
+        layers, c_f, _, col = _time_mlp_layers(P, prefix, 0, _pad4(W0), _mlp_depth(P, prefix))
+        lt, c_t, w_t, col = _head_layers(P, prefix + ".trans", c_f, col)
+        ls, c_s, w_s, col = _head_layers(P, prefix + ".so3", c_f, col)
+        tr, so3 = rowmlp.run(layers + lt + ls, t_embed.shape[0], [(c_t, w_t), (c_s, w_s)], inputs=[((0, W0), t_embed)])
+    else:
+        feat = time_mlp(P, prefix, t_embed)
+        tr, so3 = _head(P, prefix + ".trans", feat), _head(P, prefix + ".so3", feat)
+    trans = (tr * 0.1).reshape(t_embed.shape[0], -1, 3)
+    qr = axis_angle_to_quaternion(so3.reshape(t_embed.shape[0], -1, 3))
     return qr, 0.5 * quaternion_mul(trans, qr)
 
 
 def intrinsics_vals(P, prefix, frame_id, info):
     """IntrinsicsMLP.get_vals (intrinsics.py:86-107) -> (M,4) [fx, fy, px, py].  `info`: the module's own TimeEmbedding tables
     (num_freq_t = 0 and time_scale = 0.1 by default)."""
-    focal = _head(P, prefix + ".focal", time_mlp(P, prefix, time_embedding(P, prefix + ".time_embedding", frame_id, info))).exp()
+    if _on_gpu(P, prefix + ".base_logfocal"):
+        time, layers, c_te, _, col, M = _time_prologue(P, prefix + ".time_embedding", frame_id, info)
+        l2, c_f, _, col = _time_mlp_layers(P, prefix, c_te, col, _mlp_depth(P, prefix))
+        lf, c_o, w_o, col = _head_layers(P, prefix + ".focal", c_f, col)
+        focal = rowmlp.run(layers + l2 + lf, M, [(c_o, w_o)], time=time)[0].exp()
+    else:
+        focal = _head(P, prefix + ".focal", time_mlp(P, prefix, time_embedding(P, prefix + ".time_embedding", frame_id, info))).exp()
     inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]
     focal = focal * P[prefix + ".base_logfocal"][inst_id].exp()
     focal = (focal + focal.flip(-1)) / 2

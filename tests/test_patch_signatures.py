@@ -182,6 +182,43 @@ def test_appearance_get_vals_equals_the_reference(ns):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
 
 
+def test_per_frame_mlp_adapters_equal_the_reference_modules(ns):
+    """Round 6: what patch() binds to TimeEmbedding.forward / CameraMLP.get_vals / IntrinsicsMLP.get_vals, on the REAL reference modules (two videos
+    of different length: the per-video normalisation and the InstEmbedding rows matter).  CPU tensors take lab4d_amd.pose's torch algebra -- the same
+    algebra the rowmlp programs are held to (tests/test_rowmlp_programs_cpu.py here, tests/test_gpu_rowmlp.py on the MI355X)."""
+    import importlib
+
+    import numpy as np
+    from lab4d_amd import patch
+    pose_ref = importlib.import_module("lab4d.nnutils.pose")
+    intr_ref = importlib.import_module("lab4d.nnutils.intrinsics")
+    T = 64
+    frame_info = {"frame_offset": np.asarray([0, 40, T]), "frame_offset_raw": np.asarray([0, 40, T]), "frame_mapping": list(range(T))}
+    torch.manual_seed(2)
+    cam = pose_ref.CameraMLP(ref_shim.synthetic_data_info(T)["rtmat"], frame_info=frame_info, W=64)
+    intr = intr_ref.IntrinsicsMLP(np.tile(np.asarray([[64.0, 64.0, 32.0, 32.0]], dtype=np.float32), (T, 1)), frame_info=frame_info, W=64)
+    with torch.no_grad():
+        cam.base_quat.copy_(torch.randn(2, 4))
+        intr.base_logfocal.copy_(torch.tensor([[4.1, 4.2], [4.0, 3.9]]))
+        for m in (cam, intr):
+            for q in m.parameters():
+                q.add_(0.03 * torch.randn_like(q))
+    for fid in (torch.tensor([3, 39, 40, 63]), None):
+        q0, t0 = cam.get_vals(fid)
+        q1, t1 = patch.camera_get_vals(cam, fid)
+        assert torch.allclose(q1, q0, rtol=1e-5, atol=1e-6) and torch.allclose(t1, t0, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(patch.intrinsics_get_vals(intr, fid), intr.get_vals(fid), rtol=1e-5, atol=1e-5)
+        te0 = cam.time_embedding(fid)
+        assert torch.allclose(patch.time_embedding_forward(cam.time_embedding, fid), te0, rtol=1e-5, atol=1e-6)
+    fid = torch.tensor([5, 41])
+    assert torch.allclose(patch.time_embedding_forward(cam.time_embedding, fid[:, None]), cam.time_embedding(fid[:, None]), rtol=1e-5, atol=1e-6)
+    leaves = [cam.base_quat, cam.quat[2].weight, cam.linear_1[0].weight, cam.time_embedding.mapping1.weight, cam.time_embedding.inst_embedding.mapping.weight]
+    ga = torch.autograd.grad(sum(x.sin().sum() for x in patch.camera_get_vals(cam, fid)), leaves)
+    gb = torch.autograd.grad(sum(x.sin().sum() for x in cam.get_vals(fid)), leaves)
+    for a, b in zip(ga, gb):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
 def test_draw_rng_follows_the_reference_draw_order():
     """multinomial (nerf.py:437-440) first, then randperm (feature.py:177): same generator state -> same draws."""
     from lab4d_amd import patch
