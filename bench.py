@@ -1049,7 +1049,7 @@ def rank_main(a):
         torch.cuda.empty_cache()
 
     loop = TrainLoop(dev, res, spp, plan["chunks"], prec, comp=comp, use_graph=not a.no_graph, use_dist=use_dist, world=world, rank=rank, trace=a.trace,
-                     multi=multi, step_graph=not a.chunk_graph and not comp)  # (the comp configuration keeps its per-chunk graphs: capturing the bg prologue crashed the HIP runtime, r05 final call)
+                     multi=multi, step_graph=not a.chunk_graph)  # (round 6: comp too -- the bg prologue's backward is an explicit index_add_, deformable.BgPrologue.backward)
     opt, params, inputs, step = loop.opt, loop.params, loop.inputs, loop.step
     M, N0, S0, gen = loop.M, loop.N0, loop.S0, loop.gen
     graph = loop.graph if loop.graph is not None else loop.graph_a

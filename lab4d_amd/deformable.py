@@ -477,14 +477,18 @@ class BgPrologue(FramePrologue):
     KEYS = {"code_base": "basefield.inst_embedding.mapping.weight", "code_color": "colorfield.inst_embedding.mapping.weight",
             "code_vis": "vis_mlp.basefield.inst_embedding.mapping.weight"}
 
+    def _idx(self, w):
+        return self.fr["inst_id"] if w.shape[0] > 1 else torch.zeros_like(self.fr["inst_id"])
+
     def refresh(self):
-        idx = lambda w: self.fr["inst_id"] if w.shape[0] > 1 else torch.zeros_like(self.fr["inst_id"])  # noqa: E731
-        self.outs = {k: self.P[n][idx(self.P[n])] for k, n in self.KEYS.items()}
+        # (no autograd graph: the adjoint of a row lookup is written out in backward() below)
+        with torch.no_grad():
+            self.outs = {k: self.P[n][self._idx(self.P[n])] for k, n in self.KEYS.items()}
         if self.leaves is None:
             self.leaves = {}
             for k, v in self.outs.items():
                 leaf = v.detach().clone().contiguous()
-                if v.requires_grad:
+                if self.P[self.KEYS[k]].requires_grad:
                     leaf.requires_grad_(True)
                     leaf.grad = torch.zeros_like(leaf)
                 self.leaves[k] = leaf
@@ -493,6 +497,22 @@ class BgPrologue(FramePrologue):
                 for k, v in self.outs.items():
                     self.leaves[k].copy_(v)
         return dict(self.fr, **self.leaves)
+
+    def backward(self):
+        """d table[row] += sum of the leaf gradients of the frames that looked the row up -- as an explicit index_add_ (atomic adds, no host
+        round trip), not autograd's IndexBackward: that one goes through index_put_(accumulate=True) = a sort + segmented reduction whose capture
+        into the whole-step hipGraph took the HIP runtime down (round 5: "capturing the background prologue crashed the runtime"; the comp
+        configuration was left on per-chunk graphs for it).  Same values; the instance tables' .grad are views of FlatAdamW's flat gradient."""
+        with torch.no_grad():
+            for k, n in self.KEYS.items():
+                w, g = self.P[n], self.leaves[k].grad
+                if g is None or not w.requires_grad:
+                    continue
+                if w.grad is None:
+                    w.grad = torch.zeros_like(w)
+                w.grad.index_add_(0, self._idx(w), g)
+                g.zero_()
+        self.outs = None
 
 
 def _warp_fn(P, fr, prec):

@@ -68,7 +68,7 @@ def test_fan_out_and_two_outputs():
     assert rel(a, ra) < 1e-5 and rel(b, rb) < 1e-5
     ca, cb = torch.randn(M, 3, generator=g).to(DEV), torch.randn(M, 4, generator=g).to(DEV)
     leaves = [x, W0, b0, Wa, ba, Wb, bb]
-    for u, v in zip(torch.autograd.grad((a * ca).sum() + (b * cb).sum(), leaves), torch.autograd.grad((ra * ca).sum() + (rb * cb).sum(), leaves)):
+    for u, v in zip(torch.autograd.grad((a * ca).sum() + (b * cb).sum(), leaves), torch.autograd.grad((ra * ca).sum() + (rb * cb).sum(), leaves, retain_graph=True)):
         assert rel(u, v) < 2e-5
     # only one of the two outputs used downstream: the other's gradient is None
     a2, _ = rowmlp.run(layers, M, [(128, 3), (132, 4)], inputs=[((0, W), x)])
@@ -97,7 +97,7 @@ def test_time_prologue_matches_the_torch_algebra(n_vid, n_freq, time_scale):
     cot = torch.randn(len(fid), W, generator=g)
     res = []
     for dev in ("cpu", DEV):
-        P = {k: v.to(dev).requires_grad_(True) for k, v in P0.items()}
+        P = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in P0.items()}
         inf = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in info.items()}
         te = pose.time_embedding(P, "te", fid.to(dev), inf)
         (te * cot.to(dev)).sum().backward()
