@@ -492,6 +492,39 @@ def trainer_optimizer_init(self, is_resumed=False):
     _original("lab4d.engine.trainer.Trainer.optimizer_init")(self, is_resumed)
     TorchFlatAdamW.adopt(self.optimizer)
     _mlp.FUSED_GRAD_ACCUM = True
+    ddp_local_accumulation(self.model)
+
+
+def ddp_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def ddp_local_accumulation(model):
+    """Data-parallel training through the reference's own Trainer (engine/trainer.py:108-113 wraps the model in DistributedDataParallel with
+    find_unused_parameters=False; lab4d/train.py:28-33 starts one process per GPU).  With FUSED_GRAD_ACCUM the weight-gradient kernels ADD into
+    `weight.grad` -- views of the optimizer's flat fp32 buffer -- and hand autograd None for those inputs, so their AccumulateGrad hooks never fire and
+    DDP's reducer would wait for them ("Expected to have finished reduction in the prior iteration").  The reduction therefore is what SURVEY 8e asks
+    for anyway: ONE all-reduce (mean) of the flat gradient buffer per step, issued by trainer_check_grad in front of the clip (allreduce_flat_grad
+    below) -- and DDP, which has already broadcast rank 0's weights at construction and keeps broadcasting the buffers, is told to stop reducing:
+    require_backward_grad_sync = False is exactly what its no_sync() context sets.  Returns True when a DDP wrapper was switched."""
+    from torch.nn.parallel import DistributedDataParallel
+    if isinstance(model, DistributedDataParallel):
+        model.require_backward_grad_sync = False
+        return True
+    return False
+
+
+def allreduce_flat_grad(opt):
+    """The data-parallel collective of the patched Trainer: one all-reduce of TorchFlatAdamW's flat gradient buffer, averaged over the ranks (DDP's
+    semantics: every rank normalises its loss over its own rays, gradients are averaged; RCCL over xGMI on the GPUs, gloo in the CPU tests).  No-op
+    on one rank."""
+    world = ddp_world()
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(opt.flat.flat_grad)
+        opt.flat.flat_grad.div_(world)
+    return world
 
 
 def trainer_check_grad(self, thresh=5.0):
@@ -501,6 +534,7 @@ def trainer_check_grad(self, thresh=5.0):
     optimizer.step(); the host only looks at the decision when there is a cache to roll back to -- the one place the reference
     synchronises as well (`if grad_norm > thresh`)."""
     opt = self.optimizer
+    allreduce_flat_grad(opt)  # (data-parallel runs: the rank-mean of the flat gradient, see ddp_local_accumulation)
     grad_norm = opt.check_grad(thresh)
     if self.model_cache[0] is not None and int(opt.skipped):
         opt.zero_grad()

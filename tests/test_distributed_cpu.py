@@ -133,3 +133,93 @@ def test_flat_gradient_allreduce_is_the_mean_of_the_rank_gradients(world, res, p
         used[off:off + p.numel()] = True
         off += (p.numel() + 3) // 4 * 4
     assert float(flat[~used].abs().sum()) == 0.0
+
+
+# ---- the reference's own Trainer under DistributedDataParallel with the patched optimizer ----------------------------------
+class _FusedLinear(torch.autograd.Function):
+    """The FUSED_GRAD_ACCUM contract of lab4d_amd.mlp (mlp.py `_grad_sink`): the weight gradient is ADDED into weight.grad by the kernel, autograd is
+    handed None for the weight -- here with a CPU matmul standing in for the weight-gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return x @ W.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        W.grad.add_(g.t() @ x)
+        return g @ W, None
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.chain = torch.nn.Linear(6, 5, bias=False)   # a chain-kernel weight: fused accumulation
+        self.head = torch.nn.Linear(5, 3)                # a per-frame module: plain autograd
+        self.register_buffer("aabb", torch.ones(2, 3))   # (DDP broadcasts buffers every forward)
+
+    def forward(self, x):
+        return self.head(torch.relu(_FusedLinear.apply(x, self.chain.weight)))
+
+
+def _toy_data(rank, it):
+    g = torch.Generator().manual_seed(100 * it + rank)
+    return torch.randn(7 + rank, 6, generator=g), torch.randn(7 + rank, 3, generator=g)
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from torch.nn.parallel import DistributedDataParallel
+    from lab4d_amd import patch
+    from lab4d_amd.optim import TorchFlatAdamW
+    model = DistributedDataParallel(_Toy(), find_unused_parameters=False)   # engine/trainer.py:108-113
+    opt = torch.optim.AdamW([{"params": [p], "lr": 1e-3} for p in model.parameters()], betas=(0.9, 0.999), weight_decay=1e-4)  # one group per parameter (trainer.py:164-190)
+    TorchFlatAdamW.adopt(opt)                                               # what patch.trainer_optimizer_init does ...
+    assert patch.ddp_local_accumulation(model)                              # ... incl. switching DDP's own reduction off
+    opt.zero_grad()
+    out = []
+    for it in range(3):   # several iterations: an unreduced DDP bucket would raise at the second forward
+        x, y = _toy_data(rank, it)
+        loss = (model(x) - y).pow(2).mean()
+        loss.backward()
+        assert patch.allreduce_flat_grad(opt) == world                      # what patch.trainer_check_grad does in front of the clip
+        out.append(opt.flat.flat_grad.numpy().copy())
+        opt.zero_grad()
+        assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_patched_trainer_semantics_under_ddp_with_fused_grad_accum():
+    """A model wrapped in DistributedDataParallel the way the reference's Trainer wraps it, the optimizer adopted the way patch() adopts it, one
+    parameter on the fused-accumulation contract (autograd sees None for it): three iterations run (no "finished reduction" error from DDP's
+    reducer), every rank ends every iteration with the SAME flat gradient = the mean over the ranks of each rank's own gradient."""
+    world, port = 2, 29591
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = dict(q.get(timeout=600) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    for it in range(3):
+        assert (got[0][it] == got[1][it]).all()
+        expect = None
+        for r in range(world):
+            m = _Toy()
+            for p in m.parameters():
+                p.grad = torch.zeros_like(p)
+            x, y = _toy_data(r, it)
+            (m(x) - y).pow(2).mean().backward()
+            gs = [p.grad / world for p in m.parameters()]
+            expect = gs if expect is None else [e + g for e, g in zip(expect, gs)]
+        flat, off = torch.from_numpy(got[0][it]), 0
+        for e in expect:
+            assert torch.allclose(flat[off:off + e.numel()].view_as(e), e, rtol=1e-5, atol=1e-7)
+            off += (e.numel() + 3) // 4 * 4
