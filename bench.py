@@ -1043,6 +1043,15 @@ def rank_main(a):
             fail("the process group holds %d rank(s), --gpus says %d" % (dist.get_world_size(), a.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if use_dist:
+        # the communicator is built lazily at the first collective: build it NOW, before any hipGraph is captured and before the training loop's
+        # private pools exist (a first-use setup of RCCL's buffers / IPC handles behind 150 GiB of captured pools is one more thing an 8-GPU box
+        # would meet for the first time); also a loud early failure when the ranks cannot reach each other
+        probe = torch.full((1,), float(rank + 1), device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        if abs(float(probe) - world * (world + 1) / 2.0) > 1e-3:
+            fail("rank %d: the process group's first all-reduce returned %g, expected %g" % (rank, float(probe), world * (world + 1) / 2.0))
 
     from lab4d_amd import _lib, mlp
     from lab4d_amd import deformable as DF

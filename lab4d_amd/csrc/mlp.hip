@@ -392,7 +392,11 @@ __global__ void __launch_bounds__(64 * NW) k_mlp_wgrad_dma(const unsigned short*
   // B pieces past the end of a short B operand (nb < KB) re-fetch its last piece: every wave issues exactly PW transfers
   const int nbp = nb / 16;
   auto issue = [&](int st_idx, int buf) {
-    const int blk = (s_begin >> 6) + (st_idx >> 1), half = st_idx & 1;
+    int blk = (s_begin >> 6) + (st_idx >> 1);
+    const int half = st_idx & 1;
+#ifdef LAB4D_ABL_WGRAD_L2  // timing experiment (results wrong): every workgroup keeps re-reading the same 2,048-sample window, so the operands come from the
+    blk &= 31;             // L2 instead of HBM -- the matrix-side ceiling of this kernel as a "weight-gradient server" fed through the cache
+#endif
     unsigned char* st = lds + buf * STAGE;
     const unsigned char* ga = reinterpret_cast<const unsigned char*>(dz + (size_t)blk * block_stride(MO)) + half * 64 + lane_src;
 #pragma unroll

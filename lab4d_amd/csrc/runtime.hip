@@ -79,6 +79,9 @@ extern "C" const char* lab4d_build_flags(void) {
 #ifdef LAB4D_ABL_WGRAD4
   " ABL_WGRAD4"
 #endif
+#ifdef LAB4D_ABL_WGRAD_L2
+  " ABL_WGRAD_L2"
+#endif
 #ifdef LAB4D_ACACHE_G
   " ACACHE_G"
 #endif
