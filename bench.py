@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--chunk-graph", action="store_true", help="one captured hipGraph per CHUNK (rounds 1-4) instead of the whole-step pair of graphs "
                                                                "(TrainLoop.capture_step: every chunk + prologue + optimizer in two graph launches per step)")
+    ap.add_argument("--hash-no-compact", action="store_true", help="--config hash: evaluate the field on every sample (the round-5 form) instead of the inside-box samples only")
     ap.add_argument("--sustain-steps", type=int, default=75, help="default single-GPU fg run: steps the loop is continued for behind the timed region (the sustained rate, reported beside the headline)")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays per frame of one CPU-baseline pass: 2 x 4,096 = one 8,192-ray chunk of the reference's chunking of configs[1]")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the gradient all-reduce even at world size 1 "
@@ -624,10 +625,27 @@ def hash_main(a):
         tgt = {"rgb": torch.rand(2, hxy.shape[1], 3, generator=g).to(dev), "mask": ((hxy[..., :2] - res / 2).norm(dim=-1, keepdim=True) < res / 4).float()}
         inputs.append((hxy, tgt))
     M, N0 = inputs[0][0].shape[:2]
+    # Round 6: the field is evaluated on the samples inside the box only (hashfield.forward_compacted: device-side stream compaction into a buffer of
+    # STATIC capacity, the chunk is a captured graph).  The capacity is set from the chunks' own inside counts (the rays are the bench's fixed pixel grid;
+    # a training loader's random rays would size it from the box / frustum geometry the same way) with a 25 % margin; the device-side overflow flags
+    # are checked behind the run -- a dropped sample fails the leg, it does not flatter it.
+    S_chunk = M * N0 * spp
+    counts = []
+    with torch.no_grad():
+        for hxy, _ in inputs:
+            xyz = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=spp)[4].reshape(-1, 3)
+            x01 = (xyz - P["aabb"][0]) / (P["aabb"][1] - P["aabb"][0])
+            counts.append(int(((x01 >= 0) & (x01 <= 1)).all(-1).sum()))
+    cap = min(S_chunk, (int(1.25 * max(counts)) + 1023) // 1024 * 1024) if not a.hash_no_compact else None
+    overflow_any = torch.zeros(1, dtype=torch.bool, device=dev)
 
     def chunk(hxy, tgt):
         _, _, deltas, _, xyz, dirs = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=spp)
-        rgb, dens = hashfield.forward(P, cfg, xyz.reshape(-1, 3), dirs.reshape(-1, 3), spf=N0 * spp, prec=prec, res=hres)
+        if cap is None:
+            rgb, dens = hashfield.forward(P, cfg, xyz.reshape(-1, 3), dirs.reshape(-1, 3), spf=N0 * spp, prec=prec, res=hres)
+        else:
+            rgb, dens, _, ovf = hashfield.forward_compacted(P, cfg, xyz.reshape(-1, 3), dirs.reshape(-1, 3), cap, prec=prec, res=hres)
+            overflow_any.logical_or_(ovf)
         r = RU.render_pixel({"rgb": rgb.view(M, N0, spp, 3), "density": dens.view(M, N0, spp, 1)}, deltas)
         loss = (r["rgb"] - tgt["rgb"]).pow(2).mean() + 0.1 * (r["mask"] - tgt["mask"]).pow(2).mean()
         loss.backward()
@@ -679,14 +697,23 @@ def hash_main(a):
     _lib.PROF = None
     rays = 2 * res * res
     value = rays * a.steps / dt
-    with torch.no_grad():  # how much of the step carries a field at all: the grid is defined on the box only (hashfield.forward)
-        n_in = n_all = 0
-        for hxy, _ in inputs[:: max(len(inputs) // 8, 1)]:
-            xyz = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=spp)[4].reshape(-1, 3)
-            x01 = (xyz - P["aabb"][0]) / (P["aabb"][1] - P["aabb"][0])
-            n_in += int(((x01 >= 0) & (x01 <= 1)).all(-1).sum())
-            n_all += x01.shape[0]
+    n_in, n_all = sum(counts), S_chunk * len(inputs)  # how much of the step carries a field at all: the grid is defined on the box only
+    if bool(overflow_any):
+        fail("--config hash: a chunk held more inside-box samples than the compaction buffer (%d rows): samples were dropped" % cap)
     kern = {k: {"ms_per_step": round(v[1] / 4 * len(inputs), 2), "GBps": round(v[3] / v[1] / 1e6, 1) if v[3] else None} for k, v in sorted(prof.items())}
+    # roofline of the leg's dominant kernel (by event-measured time over the 4 profiled chunks): the table gradient is bound by the L2's atomic rate,
+    # not by bytes -- both are stated: algorithmic bytes (2 x 8 vertices x F floats per level read / added, the point, the encoding gradient row) against
+    # 8 TB/s, and scalar fp32 atomic adds per second (inside samples x L x 8 x F; runs of equal vertices across a wave are combined first, so fewer reach the L2)
+    roof = None
+    ranked = sorted(((k, v) for k, v in prof.items() if v[3] > 0), key=lambda kv: -kv[1][1])
+    if ranked:
+        name, (launches, ms, _, nbytes) = ranked[0]
+        roof = {"bound": "hbm", "kernel": name, "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4),
+                "traffic": None, "launches": launches, "avg_ms": round(ms / launches, 4), "algorithmic_per_launch": {"bytes": nbytes / launches},
+                "measured": "HIP events around every launch in an eager re-run of 4 chunks right after the timed region"}
+        if name == "k_hashgrid_bwd":
+            roof["atomic_adds_per_s_upper"] = round(sum(counts[:4]) * cfg["L"] * 8 * cfg["F"] / (ms * 1e-3), 0)
+            roof["note"] = "bound by the L2's fp32 atomic-add rate, not by bytes: the fraction of the HBM roof is reported for the contract, the atomic rate is what the kernel sits at"
     out = {"metric": "rendered rays/sec (fwd+bwd), hash-grid field at %dx%d x %d samples (BASELINE configs[4] per-GPU shape; no reference counterpart, not the headline metric)" % (res, res, spp),
            "value": round(value, 1), "unit": "rays/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
@@ -694,10 +721,13 @@ def hash_main(a):
                                   "rays -> samples -> field -> compositing -> rgb + mask loss -> backward -> AdamW" % (res, res, spp),
                       "rays_per_step": rays, "chunk_rays": 2 * rows * res, "launch": "hipGraph replay per chunk" if graph is not None else "eager",
                       "inside_box_fraction": round(n_in / max(n_all, 1), 4),
+                      "field_rows_per_chunk": (cap if cap is not None else S_chunk), "samples_per_chunk": S_chunk,
+                      "compaction": ("the field (encoding, both nets, their weight gradients, the table gradient) runs on the inside-box samples only: device-side "
+                                     "stream compaction into %d rows per chunk (max inside count %d + 25 %%), overflow checked" % (cap, max(counts))) if cap is not None else "off (--hash-no-compact)",
                       "field_support": "the box only (Instant-NGP 5.4): samples outside carry no density / colour and no table gradient -- not comparable with the "
                                        "rounds 1-3 numbers of this leg, which clamped them onto the boundary cells",
                       "parity": "unpinned: the reference has no hash grid"},
-           "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1), "kernels": kern,
+           "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1), "kernels": kern, "roofline": roof,
            "loss_last_chunk": float(last), "params_finite": bool(all(bool(torch.isfinite(p).all()) for p in params))}
     sys.stdout.flush()
     real_stdout.write(json.dumps(out) + "\n")

@@ -367,6 +367,60 @@ def gather_rows(src, idx, count):
     return out
 
 
+class _GatherRowsAD(torch.autograd.Function):
+    """(S,C) -> (cap,C): row j = src[idx[j]] for j < count, zeros after; the adjoint scatters the row gradients back (rows nobody gathered: zero)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, count, cap):
+        src = src.contiguous().float()
+        _lib.require_device(src, idx, count)
+        out = torch.empty(int(cap), src.shape[1], device=src.device)
+        _lib.check(_lib.lib().lab4d_gather_rows(_lib.ptr(src), _lib.ptr(idx), _lib.ptr(count), int(cap), src.shape[1], _lib.ptr(out), _lib.stream()), "gather_rows")
+        ctx.save_for_backward(idx, count)
+        ctx.n_rows = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, count = ctx.saved_tensors
+        g = g.contiguous().float()
+        dst = torch.zeros(ctx.n_rows, g.shape[1], device=g.device)
+        _lib.check(_lib.lib().lab4d_scatter_rows(_lib.ptr(g), _lib.ptr(idx), _lib.ptr(count), g.shape[0], g.shape[1], _lib.ptr(dst), _lib.stream()), "scatter_rows")
+        return dst, None, None, None
+
+
+class _ScatterRowsAD(torch.autograd.Function):
+    """(cap,C) -> zeros (n_rows,C) with row idx[j] = src[j] for j < min(count, cap); the adjoint gathers."""
+
+    @staticmethod
+    def forward(ctx, src, idx, count, n_rows):
+        src = src.contiguous().float()
+        _lib.require_device(src, idx, count)
+        dst = torch.zeros(int(n_rows), src.shape[1], device=src.device)
+        _lib.check(_lib.lib().lab4d_scatter_rows(_lib.ptr(src), _lib.ptr(idx), _lib.ptr(count), src.shape[0], src.shape[1], _lib.ptr(dst), _lib.stream()), "scatter_rows")
+        ctx.save_for_backward(idx, count)
+        ctx.cap = src.shape[0]
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, count = ctx.saved_tensors
+        g = g.contiguous().float()
+        out = torch.empty(ctx.cap, g.shape[1], device=g.device)
+        _lib.check(_lib.lib().lab4d_gather_rows(_lib.ptr(g), _lib.ptr(idx), _lib.ptr(count), ctx.cap, g.shape[1], _lib.ptr(out), _lib.stream()), "gather_rows")
+        return out, None, None, None
+
+
+def gather_rows_ad(src, idx, count, cap):
+    """Differentiable gather_rows into a buffer of `cap` rows (a static capacity: the count stays on the device)."""
+    return _GatherRowsAD.apply(src, idx, count, cap)
+
+
+def scatter_rows_ad(src, idx, count, n_rows):
+    """Differentiable scatter_rows of the first min(count, rows of src) rows of src into zeros (n_rows, C)."""
+    return _ScatterRowsAD.apply(src, idx, count, n_rows)
+
+
 @torch.no_grad()
 def scatter_rows(src, idx, count, n_rows):
     """zeros (n_rows,C) with row idx[j] = src[j] for j < count (query_nerf's scatter into zeros, nerf.py:812-816)."""
