@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every chunk eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--chunk-graph", action="store_true", help="one captured hipGraph per CHUNK (rounds 1-4) instead of the whole-step pair of graphs "
                                                                "(TrainLoop.capture_step: every chunk + prologue + optimizer in two graph launches per step)")
+    ap.add_argument("--hash-f32-table-grad", action="store_true", help="--config hash: every level's table gradient through fp32 atomics (the round-5 form) instead of packed fp16 atomics on the hashed levels")
     ap.add_argument("--hash-no-compact", action="store_true", help="--config hash: evaluate the field on every sample (the round-5 form) instead of the inside-box samples only")
     ap.add_argument("--sustain-steps", type=int, default=75, help="default single-GPU fg run: steps the loop is continued for behind the timed region (the sustained rate, reported beside the headline)")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays per frame of one CPU-baseline pass: 2 x 4,096 = one 8,192-ray chunk of the reference's chunking of configs[1]")
@@ -638,13 +639,14 @@ def hash_main(a):
             counts.append(int(((x01 >= 0) & (x01 <= 1)).all(-1).sum()))
     cap = min(S_chunk, (int(1.25 * max(counts)) + 1023) // 1024 * 1024) if not a.hash_no_compact else None
     overflow_any = torch.zeros(1, dtype=torch.bool, device=dev)
+    f16g = not a.hash_f32_table_grad
 
     def chunk(hxy, tgt):
         _, _, deltas, _, xyz, dirs = RU.ray_samples(hxy, fr["Kinv"], fr["near_far"], cam2field, n_depth=spp)
         if cap is None:
-            rgb, dens = hashfield.forward(P, cfg, xyz.reshape(-1, 3), dirs.reshape(-1, 3), spf=N0 * spp, prec=prec, res=hres)
+            rgb, dens = hashfield.forward(P, cfg, xyz.reshape(-1, 3), dirs.reshape(-1, 3), spf=N0 * spp, prec=prec, res=hres, table_grad_f16=f16g)
         else:
-            rgb, dens, _, ovf = hashfield.forward_compacted(P, cfg, xyz.reshape(-1, 3), dirs.reshape(-1, 3), cap, prec=prec, res=hres)
+            rgb, dens, _, ovf = hashfield.forward_compacted(P, cfg, xyz.reshape(-1, 3), dirs.reshape(-1, 3), cap, prec=prec, res=hres, table_grad_f16=f16g)
             overflow_any.logical_or_(ovf)
         r = RU.render_pixel({"rgb": rgb.view(M, N0, spp, 3), "density": dens.view(M, N0, spp, 1)}, deltas)
         loss = (r["rgb"] - tgt["rgb"]).pow(2).mean() + 0.1 * (r["mask"] - tgt["mask"]).pow(2).mean()
@@ -722,6 +724,9 @@ def hash_main(a):
                       "rays_per_step": rays, "chunk_rays": 2 * rows * res, "launch": "hipGraph replay per chunk" if graph is not None else "eager",
                       "inside_box_fraction": round(n_in / max(n_all, 1), 4),
                       "field_rows_per_chunk": (cap if cap is not None else S_chunk), "samples_per_chunk": S_chunk,
+                      "table_gradient": ("dense levels: fp32 atomics with wave-level run combining; hashed levels: ONE packed 2 x fp16 atomic per vertex at a per-launch "
+                                         "power-of-two scale (Instant-NGP's fp16 gradient accumulation), flushed into the fp32 gradient after every chunk") if f16g
+                                        else "fp32 atomics on every level (--hash-f32-table-grad)",
                       "compaction": ("the field (encoding, both nets, their weight gradients, the table gradient) runs on the inside-box samples only: device-side "
                                      "stream compaction into %d rows per chunk (max inside count %d + 25 %%), overflow checked" % (cap, max(counts))) if cap is not None else "off (--hash-no-compact)",
                       "field_support": "the box only (Instant-NGP 5.4): samples outside carry no density / colour and no table gradient -- not comparable with the "

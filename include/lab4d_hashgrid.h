@@ -25,4 +25,18 @@ int lab4d_hashgrid_forward_inside(const float* x, const float* table, const int3
 int lab4d_hashgrid_backward(const float* x, const float* table, const int32_t* res, const float* g_out, int S, int L, int log2_T, int F,
                             float* g_table, float* g_x, void* stream);
 
+/* Round 6: the table gradient of the HASHED levels through packed 2 x fp16 atomics (F = 2 only).  The fp32 atomics above run at the L2 channels'
+ * atomic rate (21 G per second on MI355X whatever the footprint, scope or type: tools/probes/atomic_scope.hip), so the lever is their number: one
+ * packed atomic carries both features of a vertex.  Levels l < first_f16_level (the dense, direct-indexed ones: thousands of hits per vertex, runs
+ * of equal vertices along a ray combined in the wave) keep their fp32 atomics into g_table; levels l >= first_f16_level (hashed: a handful of hits
+ * per vertex and launch) are accumulated in g16 -- (L, 2^log2_T) 32-bit words, two halves per vertex, zero on entry -- at a power-of-two scale
+ * taken from the launch's largest |g_out| entry (Instant-NGP accumulates its table gradient in fp16 under a loss scale the same way).
+ *   lab4d_hashgrid_absmax: *absmax_bits (zero on entry) = bits of max |g_out[i]|, i < n.
+ *   lab4d_hashgrid_backward_f16: as lab4d_hashgrid_backward with the split above.
+ *   lab4d_hashgrid_flush_f16: g_table[l][v][f] += fp16(g16[l][v][f]) / scale for l >= first_f16_level; g16 cleared for the next launch. */
+int lab4d_hashgrid_absmax(const float* g_out, long n, uint32_t* absmax_bits, void* stream);
+int lab4d_hashgrid_backward_f16(const float* x, const float* table, const int32_t* res, const float* g_out, int S, int L, int log2_T,
+                                int first_f16_level, float* g_table, uint32_t* g16, const uint32_t* absmax_bits, float* g_x, void* stream);
+int lab4d_hashgrid_flush_f16(uint32_t* g16, const uint32_t* absmax_bits, int L, int log2_T, int first_f16_level, float* g_table, void* stream);
+
 #endif /* LAB4D_HASHGRID_H */

@@ -95,10 +95,48 @@ __device__ __forceinline__ void wave_run_add(float* g_tab, uint32_t v, const flo
 }
 #endif
 
+#if defined(__HIPCC__)
+typedef _Float16 lab4d_h2 __attribute__((ext_vector_type(2)));
+// scale of the packed-fp16 accumulation from the largest |gradient entry| of the launch (bits of a non-negative float): a power of two that puts the
+// largest single contribution at 2^8 -- 8 binades of headroom for a vertex's sum below fp16's 65504, 22 below for the small contributions
+__device__ __forceinline__ float h2_scale_of(uint32_t absmax_bits) {
+    const float m = __uint_as_float(absmax_bits);
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+    return exp2f(8.f - ceilf(log2f(m)));
+}
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same for F = 2 with ONE packed 2 x fp16 atomic per run (global_atomic_pk_add_f16) into a table of 32-bit words (one word = the two features of
+// a vertex): the runs are combined in fp32 as above, the run's sum is scaled and rounded to fp16 once.  Why: the fp32 atomics of the table gradient
+// run at the L2 channels' atomic rate -- 21 G per second on this part whatever the footprint (1 MiB or 64 MiB), the scope or the data type
+// (tools/probes/atomic_scope.hip, profiles/r06_atomic_scope.jsonl) -- so the lever is the NUMBER of atomics, and a packed one carries both features.
+__device__ __forceinline__ void wave_run_add_h2(uint32_t* g16, uint32_t vertex, float v0, float v1, float scale, int lane) {
+    const uint32_t prev = (uint32_t)__shfl_up((int)vertex, 1, 64);
+    int flag = (lane == 0) || (prev != vertex);
+    float a0 = v0, a1 = v1;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int of = __shfl_up(flag, off, 64);
+        const float o0 = __shfl_up(a0, off, 64), o1 = __shfl_up(a1, off, 64);
+        if (lane >= off && !flag) {
+            a0 += o0;
+            a1 += o1;
+            flag |= of;
+        }
+    }
+    const uint32_t next = (uint32_t)__shfl_down((int)vertex, 1, 64);
+    if ((lane == 63 || next != vertex) && (a0 != 0.f || a1 != 0.f)) {
+        const lab4d_h2 h = {(_Float16)(a0 * scale), (_Float16)(a1 * scale)};
+        __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) lab4d_h2*)(g16 + vertex), h);
+    }
+}
+#endif
+
 // adjoint: g_tab[vertex][f] += weight * g[f] (atomic on the device); gx[a] += d out / d x_a . g  (gx may be null)
-// WAVE = true (device only): the whole wave calls this together and the table updates go through wave_run_add
+// WAVE = true (device only): the whole wave calls this together and the table updates go through wave_run_add; with g16 != NULL (F = 2) through
+// wave_run_add_h2 into the level's slab of packed words instead
 template <bool WAVE = false>
-LAB4D_HD void encode_level_bwd(const float* x, const float* tab, int res, int log2_T, int F, const float* g, float* g_tab, float* gx, int lane = 0) {
+LAB4D_HD void encode_level_bwd(const float* x, const float* tab, int res, int log2_T, int F, const float* g, float* g_tab, float* gx, int lane = 0,
+                               uint32_t* g16 = nullptr, float scale = 1.f) {
     uint32_t i0[3];
     float w[3];
     cell_of(x, res, i0, w);
@@ -110,17 +148,21 @@ LAB4D_HD void encode_level_bwd(const float* x, const float* tab, int res, int lo
         float dot = 0.f;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (WAVE) {
-            if (g_tab) {
+            if (g16) {
+                const float wt = wx * wy * wz;
+                wave_run_add_h2(g16, (uint32_t)(v / 2), wt * g[0], wt * g[1], scale, lane);
+            } else if (g_tab) {
                 float val[MAXF];
                 for (int f = 0; f < F; ++f) val[f] = wx * wy * wz * g[f];
                 wave_run_add(g_tab, (uint32_t)v, val, F, lane);
             }
-            for (int f = 0; f < F; ++f) dot += tab[v + f] * g[f];
+            if (gx)  // (the table is only READ for d/dx: a launch that wants the table gradient alone -- fixed rays -- skips these 8 gathers per level)
+                for (int f = 0; f < F; ++f) dot += tab[v + f] * g[f];
         } else
 #endif
         for (int f = 0; f < F; ++f) {
             if (g_tab) LAB4D_ATOMIC_ADD(g_tab + v + f, wx * wy * wz * g[f]);
-            dot += tab[v + f] * g[f];
+            if (gx) dot += tab[v + f] * g[f];
         }
         acc[0] += (dx ? 1.f : -1.f) * wy * wz * dot;
         acc[1] += wx * (dy ? 1.f : -1.f) * wz * dot;

@@ -42,7 +42,7 @@ def resolutions(cfg, device):
     return torch.tensor(hashgrid.level_resolutions(cfg["L"], cfg["n_min"], cfg["n_max"]), dtype=torch.int32, device=device)
 
 
-def forward(P, cfg, xyz, dirs, spf, prec=mlp.PREC_F32, res=None, get_density=True):
+def forward(P, cfg, xyz, dirs, spf, prec=mlp.PREC_F32, res=None, get_density=True, table_grad_f16=False):
     """xyz, dirs (S,3) -> rgb (S,3), density or sdf (S,1).  spf = samples per frame (the chain kernels' frame stride; the hash nets have
     no per-frame conditioning, any positive value does)."""
     if cfg["L"] * cfg["F"] != 32:
@@ -51,7 +51,8 @@ def forward(P, cfg, xyz, dirs, spf, prec=mlp.PREC_F32, res=None, get_density=Tru
     x01 = (xyz - lo) / (hi - lo)
     if res is None:
         res = resolutions(cfg, xyz.device)
-    enc = hashgrid.hash_encode(x01, P["hash.table"], res, cfg["log2_T"], inside_only=True)  # (S, 32); zero rows outside the box (masked below)
+    f16_from = hashgrid.first_hashed_level(hashgrid.level_resolutions(cfg["L"], cfg["n_min"], cfg["n_max"]), cfg["log2_T"]) if table_grad_f16 else None
+    enc = hashgrid.hash_encode(x01, P["hash.table"], res, cfg["log2_T"], inside_only=True, f16_from=f16_from)  # (S, 32); zero rows outside the box (masked below)
     geo = mlp.run_chain(mlp.NET_HASH_GEO, prec, P, enc, spf)                       # (S, 16)
     sdf = geo[:, :1]
     rgb = torch.sigmoid(mlp.run_chain(mlp.NET_HASH_COLOR, prec, P, torch.cat([geo, dirs], -1), spf))
@@ -63,7 +64,7 @@ def forward(P, cfg, xyz, dirs, spf, prec=mlp.PREC_F32, res=None, get_density=Tru
     return rgb * inside, ((volsdf_density(sdf, P["logibeta"]) * inside) if get_density else sdf)
 
 
-def forward_compacted(P, cfg, xyz, dirs, cap, prec=mlp.PREC_F32, res=None, get_density=True):
+def forward_compacted(P, cfg, xyz, dirs, cap, prec=mlp.PREC_F32, res=None, get_density=True, table_grad_f16=False):
     """forward() with the field evaluated on the samples INSIDE the box only (round 6; VERDICT r05 "next" 6): the box mask, the library's stream
     compaction (device-side count, no host round trip: csrc/compact.hip, what the eval path's get_valid_idx uses), a gather of the points / view
     directions into a buffer of `cap` rows, encoding + both nets + the table gradient on that buffer, a scatter of colour / density into zeros.
@@ -83,7 +84,7 @@ def forward_compacted(P, cfg, xyz, dirs, cap, prec=mlp.PREC_F32, res=None, get_d
     xyz_c = RU.gather_rows_ad(xyz, idx, count, cap)
     xyz_c = torch.where(live, xyz_c, (hi + (hi - lo)).expand_as(xyz_c))  # rows behind the count: a point outside the box
     dirs_c = RU.gather_rows_ad(dirs, idx, count, cap)
-    rgb_c, d_c = forward(P, cfg, xyz_c, dirs_c, spf=cap, prec=prec, res=res, get_density=get_density)
+    rgb_c, d_c = forward(P, cfg, xyz_c, dirs_c, spf=cap, prec=prec, res=res, get_density=get_density, table_grad_f16=table_grad_f16)
     if not get_density:
         d_c = d_c * live.to(d_c.dtype)  # (forward() masks density and colour, not the raw sdf)
     return RU.scatter_rows_ad(rgb_c, idx, count, S), RU.scatter_rows_ad(d_c, idx, count, S), count, overflow

@@ -15,6 +15,9 @@ vp, ci = _lib.vp, _lib.ci
 _lib.register("lab4d_hashgrid_forward", [vp, vp, vp, ci, ci, ci, ci, vp, vp])
 _lib.register("lab4d_hashgrid_forward_inside", [vp, vp, vp, ci, ci, ci, ci, vp, vp])
 _lib.register("lab4d_hashgrid_backward", [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp])
+_lib.register("lab4d_hashgrid_absmax", [vp, __import__("ctypes").c_long, vp, vp])
+_lib.register("lab4d_hashgrid_backward_f16", [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp])
+_lib.register("lab4d_hashgrid_flush_f16", [vp, vp, ci, ci, ci, vp, vp])
 
 
 def level_resolutions(L, n_min, n_max):
@@ -23,9 +26,21 @@ def level_resolutions(L, n_min, n_max):
     return [int(math.floor(n_min * b ** l + 1e-9)) for l in range(L)]
 
 
+_G16 = {}
+
+
+def first_hashed_level(res_list, log2_T):
+    """Index of the first level whose (res + 1)^3 vertices do not fit the table (hashgrid_math.hpp vertex_index): the levels in front of it are
+    direct-indexed (dense), it and the finer ones go through the spatial hash."""
+    for l, r in enumerate(res_list):
+        if (int(r) + 1) ** 3 > (1 << log2_T):
+            return l
+    return len(res_list)
+
+
 class _HashEncode(Function):
     @staticmethod
-    def forward(ctx, x, table, res, log2_T, inside_only=False):
+    def forward(ctx, x, table, res, log2_T, inside_only=False, f16_from=None):
         x, table = x.contiguous().float(), table.contiguous().float()
         _lib.require_device(x, table, res)
         S, (L, T, F) = x.shape[0], table.shape
@@ -37,7 +52,7 @@ class _HashEncode(Function):
             fn = _lib.lib().lab4d_hashgrid_forward_inside if inside_only else _lib.lib().lab4d_hashgrid_forward
             _lib.check(fn(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), S, L, log2_T, F, _lib.ptr(out), _lib.stream()), "hashgrid_forward")
         ctx.save_for_backward(x, table, res)
-        ctx.log2_T = log2_T
+        ctx.log2_T, ctx.f16_from = log2_T, f16_from
         return out
 
     @staticmethod
@@ -49,15 +64,34 @@ class _HashEncode(Function):
         g_table = torch.zeros_like(table) if ctx.needs_input_grad[1] else None
         g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         if g_table is None and g_x is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
+        if g_table is not None and ctx.f16_from is not None and ctx.f16_from < L:
+            # the hashed levels' table gradient through packed 2 x fp16 atomics at a per-launch power-of-two scale (include/lab4d_hashgrid.h)
+            if F != 2:
+                raise NotImplementedError("hash_encode: the packed fp16 table gradient needs F = 2 (two features per vertex = one 32-bit word)")
+            key = (x.device, L, ctx.log2_T)
+            if key not in _G16:  # persistent scratch: the flush kernel hands the words back cleared, so a launch costs no 33 MB zero-fill
+                _G16[key] = (torch.zeros(L << ctx.log2_T, dtype=torch.int32, device=x.device), torch.zeros(1, dtype=torch.int32, device=x.device))
+            g16, amax = _G16[key]
+            amax.zero_()
+            lib = _lib.lib()
+            with _lib.timed("k_hashgrid_bwd", (0.0, 4.0 * S * (2 * 8 * L * F + 6 + L * F))):
+                _lib.check(lib.lab4d_hashgrid_absmax(_lib.ptr(g), g.numel(), _lib.ptr(amax), _lib.stream()), "hashgrid_absmax")
+                _lib.check(lib.lab4d_hashgrid_backward_f16(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), _lib.ptr(g), S, L, ctx.log2_T, int(ctx.f16_from),
+                                                           _lib.ptr(g_table), _lib.ptr(g16), _lib.ptr(amax), _lib.ptr(g_x), _lib.stream()), "hashgrid_backward_f16")
+                _lib.check(lib.lab4d_hashgrid_flush_f16(_lib.ptr(g16), _lib.ptr(amax), L, ctx.log2_T, int(ctx.f16_from), _lib.ptr(g_table), _lib.stream()),
+                           "hashgrid_flush_f16")
+            return g_x, g_table, None, None, None, None
         with _lib.timed("k_hashgrid_bwd", (0.0, 4.0 * S * (2 * 8 * L * F + 6 + L * F))):  # vertices read (d/dx) and atomically added to
             _lib.check(_lib.lib().lab4d_hashgrid_backward(_lib.ptr(x), _lib.ptr(table), _lib.ptr(res), _lib.ptr(g), S, L, ctx.log2_T, F, _lib.ptr(g_table),
                                                           _lib.ptr(g_x), _lib.stream()), "hashgrid_backward")
-        return g_x, g_table, None, None, None
+        return g_x, g_table, None, None, None, None
 
 
-def hash_encode(x, table, res, log2_T, inside_only=False):
+def hash_encode(x, table, res, log2_T, inside_only=False, f16_from=None):
     """x (..., 3) in [0,1]^3, table (L, 2^log2_T, F), res: int32 device tensor (L) from level_resolutions -> (..., L*F).
-    inside_only: points outside [0,1]^3 get the zero encoding and never touch the table (a field defined on the box masks them anyway)."""
-    out = _HashEncode.apply(x.reshape(-1, 3), table, res, log2_T, inside_only)
+    inside_only: points outside [0,1]^3 get the zero encoding and never touch the table (a field defined on the box masks them anyway).
+    f16_from: None = the table gradient through fp32 atomics (exact accumulation); an int = the levels from that index on (use first_hashed_level)
+    accumulate theirs through packed 2 x fp16 atomics at a per-launch scale (F = 2): half the atomics, fp16 rounding of every run's contribution."""
+    out = _HashEncode.apply(x.reshape(-1, 3), table, res, log2_T, inside_only, f16_from)
     return out.view(x.shape[:-1] + (out.shape[-1],))
