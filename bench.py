@@ -362,8 +362,12 @@ class ExtrasBudget:
     timeout here: min(its own cap, what is left); an extra that finds less than `floor` seconds left is skipped and says so in the line."""
 
     def __init__(self, total_s):
-        self.t_end = time.perf_counter() + float(total_s)
         self.total = float(total_s)
+        self.start()
+
+    def start(self):
+        """(Re)start the clock: called when the headline has been measured and the extras begin."""
+        self.t_end = time.perf_counter() + self.total
 
     def left(self):
         return self.t_end - time.perf_counter()
@@ -1260,6 +1264,7 @@ def rank_main(a):
             out["eval_forward_only"] = eval_result
         # the headline is complete here: leave a copy on stderr (and under /tmp) BEFORE the extras run, so that a run cut off inside them
         # (driver timeout) has not lost the measurement.  stdout still carries exactly one line, written at the very end.
+        EXTRAS.start()  # the budget covers what follows, not the headline run above
         try:
             head = json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "loss_last_chunk", "params_finite")})
             print("[bench headline, extras still to run] " + head, file=sys.stderr, flush=True)

@@ -213,6 +213,15 @@ static int rowmlp_check(const lab4d_rowmlp_prog* p, const void* work, int M) {
     LAB4D_REQUIRE(L.src_col >= 0 && L.dst_col >= 0 && L.src_col + L.in_dim <= p->row_stride && L.dst_col + L.out_dim <= p->row_stride,
                   "rowmlp: layer %d: columns [%d, +%d) -> [%d, +%d) leave the row strip of %d", l, L.src_col, L.in_dim, L.dst_col, L.out_dim, p->row_stride);
     LAB4D_REQUIRE(!(L.dst_col < L.src_col + L.in_dim && L.src_col < L.dst_col + L.out_dim), "rowmlp: layer %d writes into its own input columns", l);
+    // every column range is written by ONE producer (the backward turns a layer's output gradient into dZ in place)
+    for (int k = 0; k < l; ++k) {
+      const lab4d_rowmlp_layer& K = p->layer[k];
+      LAB4D_REQUIRE(!(L.dst_col < K.dst_col + K.out_dim && K.dst_col < L.dst_col + L.out_dim), "rowmlp: layers %d and %d write overlapping columns", k, l);
+    }
+    if (p->frame_id != nullptr) {
+      LAB4D_REQUIRE(!(L.dst_col < p->four_col + 2 * p->n_freq + 1 && p->four_col < L.dst_col + L.out_dim), "rowmlp: layer %d writes into the Fourier columns", l);
+      LAB4D_REQUIRE(p->inst_dim == 0 || !(L.dst_col < p->inst_col + p->inst_dim && p->inst_col < L.dst_col + L.out_dim), "rowmlp: layer %d writes into the instance-code columns", l);
+    }
   }
   if (p->frame_id != nullptr) {
     LAB4D_REQUIRE(p->vstart != nullptr && p->vidlen != nullptr && p->n_freq >= 0 && p->n_freq <= 16 && p->max_ts > 0.f, "rowmlp: time prologue: frame tables missing, n_freq %d or max_ts %g",

@@ -70,7 +70,7 @@ class _HashEncode(Function):
             if F != 2:
                 raise NotImplementedError("hash_encode: the packed fp16 table gradient needs F = 2 (two features per vertex = one 32-bit word)")
             key = (x.device, L, ctx.log2_T)
-            if key not in _G16:  # persistent scratch: the flush kernel hands the words back cleared, so a launch costs no 33 MB zero-fill
+            if key not in _G16:  # persistent scratch (one per device and table shape; launches on ONE stream at a time): the flush kernel hands the words back cleared, so a launch costs no 33 MB zero-fill.  Create it OUTSIDE a hipGraph capture (bench.py's eager warm-up does): a buffer born in a graph's private pool must not be touched by eager calls.
                 _G16[key] = (torch.zeros(L << ctx.log2_T, dtype=torch.int32, device=x.device), torch.zeros(1, dtype=torch.int32, device=x.device))
             g16, amax = _G16[key]
             amax.zero_()

@@ -134,3 +134,29 @@ def test_product_package_never_imports_the_oracle():
         uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
         assert uses == (fn.name == "cpu_baseline"), fn.name
     assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in tree.body)
+
+
+def test_rowmlp_programs_are_validated_before_any_launch(so):
+    """include/lab4d_rowmlp.h's contract on the CPU (argument checks run before the launch): a layer writing into its own input, two layers writing
+    overlapping columns, columns leaving the strip, too many layers -- all refused with LAB4D_EINVAL and a message."""
+    from lab4d_amd import rowmlp
+    so.lab4d_last_error.restype = ctypes.c_char_p
+    so.lab4d_rowmlp_forward.argtypes = [ctypes.POINTER(rowmlp._Prog), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+
+    def prog(layers, stride=64):
+        p = rowmlp._Prog()
+        p.n_layers, p.row_stride = len(layers), stride
+        for i, (i_dim, o_dim, src, dst) in enumerate(layers):
+            q = p.layer[i]
+            q.W, q.in_dim, q.out_dim, q.src_col, q.dst_col = 0x1000, i_dim, o_dim, src, dst  # (never dereferenced: the checks fail first)
+        return p
+
+    fake = ctypes.c_void_p(0x2000)
+    for layers, word in [([(8, 8, 0, 4)], b"own input"), ([(8, 8, 0, 16), (8, 8, 16, 20)], b"own input"), ([(8, 8, 0, 16), (8, 8, 0, 20)], b"overlapping"),
+                         ([(8, 8, 0, 60)], b"leave the row strip"), ([(2000, 8, 0, 16)], b"outside")]:
+        p = prog(layers, stride=64 if layers[0][0] < 100 else 4096)
+        assert so.lab4d_rowmlp_forward(ctypes.byref(p), fake, 4, None) == -1
+        assert word in so.lab4d_last_error(), (layers, so.lab4d_last_error())
+    p = prog([(8, 8, 0, 16)])
+    p.n_layers = 17
+    assert so.lab4d_rowmlp_forward(ctypes.byref(p), fake, 4, None) == -1
