@@ -51,7 +51,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=None, help="ranks of the data-parallel job, one per GPU.  Without a launcher in front (no WORLD_SIZE in the environment) "
                                                            "and N > 1 this process starts the N ranks itself (torch.distributed.run, like the reference's scripts/train.sh:12-16) "
                                                            "after checking that the box has N GPUs; under a launcher N must equal WORLD_SIZE.  Default: WORLD_SIZE, else 1")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend: nccl (= RCCL on ROCm) for the GPU job; gloo only with --dry-step")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend: nccl (= RCCL on ROCm) for the GPU job; gloo with --dry-step (no GPU) or --share-gpu")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="FUNCTIONAL multi-rank run on a box with fewer GPUs than ranks (needs --backend gloo): every rank renders its own rows with the real kernels on "
+                         "cuda:(local rank mod device count), the flat gradient is all-reduced over gloo.  Not a performance number (the ranks share a GPU): it exercises the "
+                         "N > 1 code path end to end -- partition, per-rank graphs, collective, timing gather -- and checks that the replicas' weights stay identical.")
     ap.add_argument("--dry-step", action="store_true", help="no GPU work: every rank builds its row plan and the product's flat gradient bucket on the CPU, runs the step's ONE "
                                                             "collective (allreduce_flat) through the process group and rank 0 prints the JSON line -- the launch / rendezvous / "
                                                             "collective path of --gpus N exercised where there are no GPUs (CPU tests)")
@@ -758,6 +762,8 @@ def launch_ranks(a):
         found = torch.cuda.device_count()
         if found < a.gpus:
             fail("--gpus %d needs %d GPUs, found %d" % (a.gpus, a.gpus, found))
+    if a.share_gpu and torch.cuda.device_count() < 1:
+        fail("--share-gpu needs at least one GPU")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -819,8 +825,10 @@ def main():
         a.gpus = int(env_world) if env_world else 1
     if a.gpus < 1:
         fail("--gpus must be >= 1")
-    if a.backend == "gloo" and not a.dry_step:
-        fail("--backend gloo runs no GPU work: use it with --dry-step")
+    if a.backend == "gloo" and not (a.dry_step or a.share_gpu):
+        fail("--backend gloo runs no GPU work: use it with --dry-step, or with --share-gpu for a functional multi-rank run on fewer GPUs than ranks")
+    if a.share_gpu and a.backend != "gloo":
+        fail("--share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
     if env_world is None and a.gpus > 1:
         return launch_ranks(a)  # does not return
     if env_world is not None and int(env_world) != a.gpus:
@@ -1065,6 +1073,8 @@ def rank_main(a):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.share_gpu:
+        local = local % max(torch.cuda.device_count(), 1)
     if a.poison:
         torch.use_deterministic_algorithms(True, warn_only=True)
         torch.utils.deterministic.fill_uninitialized_memory = True
@@ -1077,7 +1087,10 @@ def rank_main(a):
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL on ROCm, bound to this rank's GPU
+        if a.share_gpu:
+            dist.init_process_group("gloo")  # (CUDA tensors are staged through the host: functional, not fast)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL on ROCm, bound to this rank's GPU
         if dist.get_world_size() != a.gpus and not a.force_dist:
             fail("the process group holds %d rank(s), --gpus says %d" % (dist.get_world_size(), a.gpus))
     torch.cuda.set_device(local)
@@ -1194,6 +1207,16 @@ def rank_main(a):
         dt = max(float(x) for x in ts)  # the job is as slow as its slowest rank
         timed_ar = ar_events[-a.steps:]
         allreduce_ms = sum(e0.elapsed_time(e1) for e0, e1 in timed_ar) / max(len(timed_ar), 1)
+    # data-parallel invariant: every replica holds the SAME weights after the same steps (identical initialisation, identical all-reduced gradients,
+    # identical optimizer arithmetic) -- bit for bit.  Three checksums of the flat parameter buffer, gathered and compared (a replica that took a local
+    # step the others did not -- the round-5 capture warm-up did -- shows up here).
+    replicas_identical = None
+    if use_dist:
+        wv = opt.flat
+        chk = torch.stack([wv.double().sum(), wv.double().abs().sum(), wv.view(torch.int32).long().sum().double()])
+        chks = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(chks, chk)
+        replicas_identical = bool(all(torch.equal(c, chks[0]) for c in chks))
     value = rays_per_step * a.steps / dt
 
     if rank == 0:
@@ -1248,6 +1271,8 @@ def rank_main(a):
                                     "weight gradients accumulated into it by the wgrad kernels; a step whose pre-clip norm exceeds 5 (or is not finite) is "
                                     "discarded on the device like Trainer.check_grad does (steps_discarded below)"},
             "rank_ms_per_step": [round(x, 2) for x in rank_ms], "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
+            "replicas_identical": replicas_identical,
+            "shared_gpu": ("FUNCTIONAL run: %d ranks on %d GPU(s) over gloo -- value / ms_per_step are NOT a performance measurement" % (world, torch.cuda.device_count())) if a.share_gpu else None,
             "rank_plan": {k: plan[k] for k in ("rows", "chunk_sizes", "rays_per_step", "est_peak_hbm_gib")},
             "peak_hbm_gib": round(peak_hbm / 2**30, 1),
             "whole_graph_tflops": round(value * flop_per_ray / 1e12, 2),

@@ -167,3 +167,25 @@ def test_psnr_against_the_reference_render_on_w0_and_w1():
         assert out[k] > 135.0, (k, out[k])
     for k in ("bf16", "w1_bf16", "eval_w1_bf16"):
         assert out[k] > 90.0, (k, out[k])
+
+
+def test_two_ranks_on_one_gpu_keep_their_replicas_identical():
+    """The N > 1 code path END TO END with the real kernels on the one GPU of this box (`bench.py --gpus 2 --backend gloo --share-gpu`: the launcher,
+    the row partition, each rank's whole-step graphs, the flat-gradient all-reduce over gloo, the timing gather, one JSON line): finite, no step
+    discarded, and the two replicas' weights BIT-identical after the steps -- which the round-5 capture warm-up (a local optimizer step per rank with no
+    all-reduce) broke.  Not a performance number: the ranks share the GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--res", "128", "--spp", "32", "--chunk-rows", "32",
+                          "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and len(d["rank_ms_per_step"]) == 2
+    assert d["replicas_identical"] is True
+    assert d["params_finite"] and d["steps_discarded_by_check_grad"] == 0 and d["loss_last_chunk"] == d["loss_last_chunk"]
+    assert "two hipGraph replays" in d["config"]["launch"]
