@@ -515,6 +515,15 @@ def ddp_local_accumulation(model):
     return False
 
 
+def ddp_keep_buffer_sync(model):
+    """DDP re-broadcasts rank 0's buffers (aabb, near / far, proxy tables ...) at every forward only while its gradient reduction is on (its
+    _post_forward clears `require_forward_param_sync` otherwise); with the reduction moved to allreduce_flat_grad the flag is set again once per
+    iteration, so the reference's behaviour -- buffers follow rank 0 -- is kept."""
+    from torch.nn.parallel import DistributedDataParallel
+    if isinstance(model, DistributedDataParallel):
+        model.require_forward_param_sync = True
+
+
 def allreduce_flat_grad(opt):
     """The data-parallel collective of the patched Trainer: one all-reduce of TorchFlatAdamW's flat gradient buffer, averaged over the ranks (DDP's
     semantics: every rank normalises its loss over its own rays, gradients are averaged; RCCL over xGMI on the GPUs, gloo in the CPU tests).  No-op
@@ -535,6 +544,7 @@ def trainer_check_grad(self, thresh=5.0):
     synchronises as well (`if grad_norm > thresh`)."""
     opt = self.optimizer
     allreduce_flat_grad(opt)  # (data-parallel runs: the rank-mean of the flat gradient, see ddp_local_accumulation)
+    ddp_keep_buffer_sync(self.model)
     grad_norm = opt.check_grad(thresh)
     if self.model_cache[0] is not None and int(opt.skipped):
         opt.zero_grad()

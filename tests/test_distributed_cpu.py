@@ -185,9 +185,13 @@ def _ddp_worker(rank, world, port, q):
     out = []
     for it in range(3):   # several iterations: an unreduced DDP bucket would raise at the second forward
         x, y = _toy_data(rank, it)
+        if it > 0 and rank == 1:
+            model.module.aabb.fill_(7.0)  # a buffer that drifted on one rank ...
         loss = (model(x) - y).pow(2).mean()
+        assert float(model.module.aabb.sum()) == 6.0, "... is overwritten by rank 0's at the next forward, as under the reference's DDP"
         loss.backward()
         assert patch.allreduce_flat_grad(opt) == world                      # what patch.trainer_check_grad does in front of the clip
+        patch.ddp_keep_buffer_sync(model)                                   # ... and: buffers keep following rank 0 (checked below)
         out.append(opt.flat.flat_grad.numpy().copy())
         opt.zero_grad()
         assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
