@@ -52,8 +52,16 @@ __global__ void __launch_bounds__(RM_T) k_rowmlp_fwd(lab4d_rowmlp_prog p, float*
       const long row = p.inst_rows == 1 ? 0 : (long)p.vid[f];
       work[(r0 + r) * rs + p.inst_col + c] = p.inst_W[row * p.inst_dim + c];
     }
-    __syncthreads();
   }
+  // ---- external inputs -> the strip ----
+  for (int q = 0; q < p.n_in; ++q) {
+    const lab4d_rowmlp_io io = p.in[q];
+    for (int e = tid; e < nr * io.width; e += RM_T) {
+      const int r = e / io.width, c = e - r * io.width;
+      work[(r0 + r) * rs + io.col + c] = io.ptr[(size_t)(r0 + r) * io.width + c];
+    }
+  }
+  __syncthreads();
   for (int l = 0; l < p.n_layers; ++l) {
     const lab4d_rowmlp_layer L = p.layer[l];
     // stage the rows' inputs
@@ -92,6 +100,15 @@ __global__ void __launch_bounds__(RM_T) k_rowmlp_fwd(lab4d_rowmlp_prog p, float*
     }
     __syncthreads();  // this layer's outputs are visible to the workgroup before the next layer stages them
   }
+  // ---- the strip -> the caller's output tensors ----
+  for (int q = 0; q < p.n_out; ++q) {
+    const lab4d_rowmlp_io io = p.out[q];
+    if (io.ptr == nullptr) continue;
+    for (int e = tid; e < nr * io.width; e += RM_T) {
+      const int r = e / io.width, c = e - r * io.width;
+      io.ptr[(size_t)(r0 + r) * io.width + c] = work[(r0 + r) * rs + io.col + c];
+    }
+  }
 }
 
 // dZ in place + input gradients accumulated into the sources, layers in reverse
@@ -100,6 +117,21 @@ __global__ void __launch_bounds__(RM_T) k_rowmlp_bwd_chain(lab4d_rowmlp_prog p, 
   const int tid = threadIdx.x, r0 = blockIdx.x * RM_R;
   const int nr = min(RM_R, M - r0);
   const size_t rs = (size_t)p.row_stride;
+  // ---- dL/d(strip) of this workgroup's rows: zero, then the gradients of the outputs the caller consumed ----
+  for (int e = tid; e < nr * p.row_stride; e += RM_T) {
+    const int r = e / p.row_stride, c = e - r * p.row_stride;
+    gwork[(r0 + r) * rs + c] = 0.f;
+  }
+  __syncthreads();
+  for (int q = 0; q < p.n_out; ++q) {
+    const lab4d_rowmlp_io io = p.out[q];
+    if (io.ptr == nullptr) continue;
+    for (int e = tid; e < nr * io.width; e += RM_T) {
+      const int r = e / io.width, c = e - r * io.width;
+      gwork[(r0 + r) * rs + io.col + c] += io.ptr[(size_t)(r0 + r) * io.width + c];  // (+=: two outputs may name overlapping columns)
+    }
+    __syncthreads();
+  }
   for (int l = p.n_layers - 1; l >= 0; --l) {
     const lab4d_rowmlp_layer L = p.layer[l];
     for (int e = tid; e < RM_R * L.out_dim; e += RM_T) {
@@ -129,6 +161,15 @@ __global__ void __launch_bounds__(RM_T) k_rowmlp_bwd_chain(lab4d_rowmlp_prog p, 
     }
     __syncthreads();
   }
+  // ---- gradients of the external inputs ----
+  for (int q = 0; q < p.n_in; ++q) {
+    const lab4d_rowmlp_io io = p.in[q];
+    if (io.ptr == nullptr) continue;
+    for (int e = tid; e < nr * io.width; e += RM_T) {
+      const int r = e / io.width, c = e - r * io.width;
+      io.ptr[(size_t)(r0 + r) * io.width + c] = gwork[(r0 + r) * rs + io.col + c];
+    }
+  }
 }
 
 // jobs: layer l has ceil(out_dim / RM_TO) jobs (dW rows o0 .. o0 + 7 and their db), then inst_rows jobs for d_inst_W
@@ -151,7 +192,8 @@ __global__ void __launch_bounds__(RM_T) k_rowmlp_bwd_param(lab4d_rowmlp_prog p, 
         const long row = p.inst_rows == 1 ? 0 : (long)p.vid[(long)p.frame_id[m]];
         if (row == job) acc += gwork[m * rs + p.inst_col + c];
       }
-      p.d_inst_W[(size_t)job * p.inst_dim + c] = acc;
+      float* dst = p.d_inst_W + (size_t)job * p.inst_dim + c;
+      *dst = p.acc_inst ? *dst + acc : acc;
     }
     return;
   }
@@ -196,10 +238,98 @@ __global__ void __launch_bounds__(RM_T) k_rowmlp_bwd_param(lab4d_rowmlp_prog p, 
       if (q < ni && i < L.in_dim)
 #pragma unroll
         for (int j = 0; j < RM_TO; ++j)
-          if (j < no) L.dW[(size_t)(o0 + j) * L.in_dim + i] = acc[q][j];
+          if (j < no) {
+            float* dst = L.dW + (size_t)(o0 + j) * L.in_dim + i;
+            *dst = (L.acc & 1) ? *dst + acc[q][j] : acc[q][j];
+          }
     }
   }
-  if (L.db != nullptr && tid < no) L.db[o0 + tid] = bsum;
+  if (L.db != nullptr && tid < no) L.db[o0 + tid] = (L.acc & 2) ? L.db[o0 + tid] + bsum : bsum;
+}
+
+// ---- epilogues of the per-frame modules: the handful of M x 4 element-wise ops behind the heads, one launch each way instead of ~12 / ~25 ----------
+__device__ __forceinline__ long row_video(const int64_t* frame_id, const int64_t* vid, int V, int m) {
+  return V == 1 ? 0 : (long)vid[(long)frame_id[m]];
+}
+// CameraMLP.get_vals behind the heads (pose.py:126-147): quat = F.normalize(raw); base = F.normalize(base_quat[video]); out = quaternion_mul(quat, base)
+__global__ void __launch_bounds__(256) k_cam_epi_fwd(const float* __restrict__ raw, const float* __restrict__ base, const int64_t* __restrict__ frame_id,
+                                                     const int64_t* __restrict__ vid, int M, int V, float* __restrict__ out) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float4 r = *reinterpret_cast<const float4*>(raw + 4 * (size_t)m);
+  const float4 b = *reinterpret_cast<const float4*>(base + 4 * row_video(frame_id, vid, V, m));
+  const float ir = 1.f / fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);  // F.normalize: x / max(|x|, eps)
+  const float ib = 1.f / fmaxf(sqrtf(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w), 1e-12f);
+  const float aw = r.x * ir, ax = r.y * ir, ay = r.z * ir, az = r.w * ir, bw = b.x * ib, bx = b.y * ib, by = b.z * ib, bz = b.w * ib;
+  *reinterpret_cast<float4*>(out + 4 * (size_t)m) = make_float4(aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                                                                 aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw);
+}
+// adjoint per row: g_raw (M,4) written; the row's gradient wrt its video's UN-normalised base quaternion -> rowg (M,4) (reduced per video below)
+__global__ void __launch_bounds__(256) k_cam_epi_bwd(const float* __restrict__ raw, const float* __restrict__ base, const int64_t* __restrict__ frame_id,
+                                                     const int64_t* __restrict__ vid, const float* __restrict__ g_out, int M, int V,
+                                                     float* __restrict__ g_raw, float* __restrict__ rowg) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float4 r = *reinterpret_cast<const float4*>(raw + 4 * (size_t)m);
+  const float4 b = *reinterpret_cast<const float4*>(base + 4 * row_video(frame_id, vid, V, m));
+  const float4 g = *reinterpret_cast<const float4*>(g_out + 4 * (size_t)m);
+  const float nr = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), nb = sqrtf(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
+  const float ir = 1.f / fmaxf(nr, 1e-12f), ib = 1.f / fmaxf(nb, 1e-12f);
+  const float aw = r.x * ir, ax = r.y * ir, ay = r.z * ir, az = r.w * ir, bw = b.x * ib, bx = b.y * ib, by = b.z * ib, bz = b.w * ib;
+  // ga = g (x) conj(b), gb = conj(a) (x) g   (csrc/quaternion.hip k_qmul_bwd)
+  float ga[4] = {g.x * bw + g.y * bx + g.z * by + g.w * bz, -g.x * bx + g.y * bw - g.z * bz + g.w * by, -g.x * by + g.y * bz + g.z * bw - g.w * bx,
+                 -g.x * bz - g.y * by + g.z * bx + g.w * bw};
+  float gb[4] = {g.x * aw + g.y * ax + g.z * ay + g.w * az, -g.x * ax + g.y * aw + g.z * az - g.w * ay, -g.x * ay - g.y * az + g.z * aw + g.w * ax,
+                 -g.x * az + g.y * ay - g.z * ax + g.w * aw};
+  // y = x / max(|x|, eps): dx = (dy - y (y . dy)) / |x| above the clamp, dy / eps below it
+  const float da = aw * ga[0] + ax * ga[1] + ay * ga[2] + az * ga[3], db = bw * gb[0] + bx * gb[1] + by * gb[2] + bz * gb[3];
+  const float ka = nr > 1e-12f ? da : 0.f, kb = nb > 1e-12f ? db : 0.f;
+  *reinterpret_cast<float4*>(g_raw + 4 * (size_t)m) = make_float4((ga[0] - aw * ka) * ir, (ga[1] - ax * ka) * ir, (ga[2] - ay * ka) * ir, (ga[3] - az * ka) * ir);
+  *reinterpret_cast<float4*>(rowg + 4 * (size_t)m) = make_float4((gb[0] - bw * kb) * ib, (gb[1] - bx * kb) * ib, (gb[2] - by * kb) * ib, (gb[3] - bz * kb) * ib);
+}
+// dst[v][c] (+)= sum over the rows m of video v of rowg[m][c]: one workgroup per video, fixed summation order (deterministic)
+__global__ void __launch_bounds__(256) k_rows_to_video(const float* __restrict__ rowg, int C, const int64_t* __restrict__ frame_id, const int64_t* __restrict__ vid,
+                                                       int M, int V, float* __restrict__ dst, int acc) {
+  __shared__ float part[256];
+  const int v = blockIdx.x;
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (int m = threadIdx.x; m < M; m += 256)
+      if (row_video(frame_id, vid, V, m) == v) s += rowg[(size_t)m * C + c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dst[(size_t)v * C + c] = acc ? dst[(size_t)v * C + c] + part[0] : part[0];
+    __syncthreads();
+  }
+}
+// IntrinsicsMLP.get_vals behind the head (intrinsics.py:94-107): f = exp(raw) * exp(base_logfocal[video]); both focal lengths = their mean ("square pixels");
+// out = [f_mean, f_mean, ppoint[video]]
+__global__ void __launch_bounds__(256) k_intr_epi_fwd(const float* __restrict__ raw, const float* __restrict__ logfocal, const float* __restrict__ ppoint,
+                                                      const int64_t* __restrict__ frame_id, const int64_t* __restrict__ vid, int M, int V, float* __restrict__ out) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const long v = row_video(frame_id, vid, V, m);
+  const float f0 = expf(raw[2 * (size_t)m]) * expf(logfocal[2 * v]), f1 = expf(raw[2 * (size_t)m + 1]) * expf(logfocal[2 * v + 1]);
+  const float fm = (f0 + f1) / 2.f;
+  *reinterpret_cast<float4*>(out + 4 * (size_t)m) = make_float4(fm, fm, ppoint[2 * v], ppoint[2 * v + 1]);
+}
+// adjoint per row: g_raw (M,2) written; rowg (M,4) = [d logfocal (2) | d ppoint (2)] of the row's video
+__global__ void __launch_bounds__(256) k_intr_epi_bwd(const float* __restrict__ raw, const float* __restrict__ logfocal, const int64_t* __restrict__ frame_id,
+                                                      const int64_t* __restrict__ vid, const float* __restrict__ g_out, int M, int V, float* __restrict__ g_raw,
+                                                      float* __restrict__ rowg) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const long v = row_video(frame_id, vid, V, m);
+  const float4 g = *reinterpret_cast<const float4*>(g_out + 4 * (size_t)m);
+  const float f0 = expf(raw[2 * (size_t)m]) * expf(logfocal[2 * v]), f1 = expf(raw[2 * (size_t)m + 1]) * expf(logfocal[2 * v + 1]);
+  const float gf = (g.x + g.y) / 2.f;  // both outputs are the mean of the two
+  g_raw[2 * (size_t)m] = gf * f0;
+  g_raw[2 * (size_t)m + 1] = gf * f1;
+  *reinterpret_cast<float4*>(rowg + 4 * (size_t)m) = make_float4(gf * f0, gf * f1, g.z, g.w);
 }
 
 static int rowmlp_check(const lab4d_rowmlp_prog* p, const void* work, int M) {
@@ -222,6 +352,13 @@ static int rowmlp_check(const lab4d_rowmlp_prog* p, const void* work, int M) {
       LAB4D_REQUIRE(!(L.dst_col < p->four_col + 2 * p->n_freq + 1 && p->four_col < L.dst_col + L.out_dim), "rowmlp: layer %d writes into the Fourier columns", l);
       LAB4D_REQUIRE(p->inst_dim == 0 || !(L.dst_col < p->inst_col + p->inst_dim && p->inst_col < L.dst_col + L.out_dim), "rowmlp: layer %d writes into the instance-code columns", l);
     }
+  }
+  LAB4D_REQUIRE(p->n_in >= 0 && p->n_in <= LAB4D_ROWMLP_MAX_IO && p->n_out >= 0 && p->n_out <= LAB4D_ROWMLP_MAX_IO, "rowmlp: %d inputs / %d outputs (0..%d)", p->n_in, p->n_out,
+                LAB4D_ROWMLP_MAX_IO);
+  for (int q = 0; q < p->n_in + p->n_out; ++q) {
+    const lab4d_rowmlp_io& io = q < p->n_in ? p->in[q] : p->out[q - p->n_in];
+    LAB4D_REQUIRE(io.col >= 0 && io.width >= 1 && io.col + io.width <= p->row_stride, "rowmlp: %s %d: columns [%d, +%d) leave the row strip of %d", q < p->n_in ? "input" : "output",
+                  q < p->n_in ? q : q - p->n_in, io.col, io.width, p->row_stride);
   }
   if (p->frame_id != nullptr) {
     LAB4D_REQUIRE(p->vstart != nullptr && p->vidlen != nullptr && p->n_freq >= 0 && p->n_freq <= 16 && p->max_ts > 0.f, "rowmlp: time prologue: frame tables missing, n_freq %d or max_ts %g",
@@ -257,4 +394,43 @@ extern "C" int lab4d_rowmlp_backward(const lab4d_rowmlp_prog* prog, const float*
   if (prog->frame_id != nullptr && prog->d_inst_W != nullptr) jobs += prog->inst_rows;
   hipLaunchKernelGGL(k_rowmlp_bwd_param, dim3(jobs), dim3(RM_T), 0, (hipStream_t)stream, *prog, work, (const float*)gwork, M);
   return check_launch("rowmlp_backward");
+}
+
+#define EPI_CHECKS(name)                                                                                                   \
+  LAB4D_REQUIRE(M >= 0 && V >= 1, name ": bad sizes M=%d V=%d", M, V);                                                   \
+  LAB4D_REQUIRE(V == 1 || (frame_id != nullptr && vid != nullptr), name ": several videos need the frame ids and raw_fid_to_vid"); \
+  if (M == 0) return LAB4D_OK;
+
+extern "C" int lab4d_camera_epilogue_forward(const float* raw, const float* base_quat, const int64_t* frame_id, const int64_t* vid, int M, int V, float* out,
+                                             void* stream) {
+  EPI_CHECKS("camera_epilogue_forward");
+  LAB4D_REQUIRE(raw && base_quat && out, "camera_epilogue_forward: null pointer");
+  hipLaunchKernelGGL(k_cam_epi_fwd, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw, base_quat, frame_id, vid, M, V, out);
+  return check_launch("camera_epilogue_forward");
+}
+
+extern "C" int lab4d_camera_epilogue_backward(const float* raw, const float* base_quat, const int64_t* frame_id, const int64_t* vid, const float* g_out, int M,
+                                              int V, float* g_raw, float* row_scratch, float* g_base, int acc_base, void* stream) {
+  EPI_CHECKS("camera_epilogue_backward");
+  LAB4D_REQUIRE(raw && base_quat && g_out && g_raw && row_scratch, "camera_epilogue_backward: null pointer");
+  hipLaunchKernelGGL(k_cam_epi_bwd, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw, base_quat, frame_id, vid, g_out, M, V, g_raw, row_scratch);
+  if (g_base) hipLaunchKernelGGL(k_rows_to_video, dim3(V), dim3(256), 0, (hipStream_t)stream, (const float*)row_scratch, 4, frame_id, vid, M, V, g_base, acc_base);
+  return check_launch("camera_epilogue_backward");
+}
+
+extern "C" int lab4d_intrinsics_epilogue_forward(const float* raw, const float* base_logfocal, const float* base_ppoint, const int64_t* frame_id, const int64_t* vid,
+                                                 int M, int V, float* out, void* stream) {
+  EPI_CHECKS("intrinsics_epilogue_forward");
+  LAB4D_REQUIRE(raw && base_logfocal && base_ppoint && out, "intrinsics_epilogue_forward: null pointer");
+  hipLaunchKernelGGL(k_intr_epi_fwd, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw, base_logfocal, base_ppoint, frame_id, vid, M, V, out);
+  return check_launch("intrinsics_epilogue_forward");
+}
+
+extern "C" int lab4d_intrinsics_epilogue_backward(const float* raw, const float* base_logfocal, const int64_t* frame_id, const int64_t* vid, const float* g_out, int M,
+                                                  int V, float* g_raw, float* row_scratch, float* g_video /* (V,4): [d logfocal | d ppoint] */, void* stream) {
+  EPI_CHECKS("intrinsics_epilogue_backward");
+  LAB4D_REQUIRE(raw && base_logfocal && g_out && g_raw && row_scratch, "intrinsics_epilogue_backward: null pointer");
+  hipLaunchKernelGGL(k_intr_epi_bwd, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw, base_logfocal, frame_id, vid, g_out, M, V, g_raw, row_scratch);
+  if (g_video) hipLaunchKernelGGL(k_rows_to_video, dim3(V), dim3(256), 0, (hipStream_t)stream, (const float*)row_scratch, 4, frame_id, vid, M, V, g_video, 0);
+  return check_launch("intrinsics_epilogue_backward");
 }

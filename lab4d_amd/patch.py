@@ -492,7 +492,7 @@ def trainer_optimizer_init(self, is_resumed=False):
     _original("lab4d.engine.trainer.Trainer.optimizer_init")(self, is_resumed)
     TorchFlatAdamW.adopt(self.optimizer)
     _mlp.FUSED_GRAD_ACCUM = True
-    ddp_local_accumulation(self.model)
+    ddp_local_accumulation(getattr(self, "model", None))
 
 
 def ddp_world():
@@ -544,7 +544,7 @@ def trainer_check_grad(self, thresh=5.0):
     synchronises as well (`if grad_norm > thresh`)."""
     opt = self.optimizer
     allreduce_flat_grad(opt)  # (data-parallel runs: the rank-mean of the flat gradient, see ddp_local_accumulation)
-    ddp_keep_buffer_sync(self.model)
+    ddp_keep_buffer_sync(getattr(self, "model", None))
     grad_norm = opt.check_grad(thresh)
     if self.model_cache[0] is not None and int(opt.skipped):
         opt.zero_grad()

@@ -33,6 +33,12 @@ _lib.register("lab4d_fk_backward", [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, 
 _lib.register("lab4d_skel_bones_forward", [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp])
 _lib.register("lab4d_skel_bones_backward", [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp])
 
+i64_ = __import__("ctypes").c_int64
+_lib.register("lab4d_camera_epilogue_forward", [vp, vp, vp, vp, ci, ci, vp, vp])
+_lib.register("lab4d_camera_epilogue_backward", [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, ci, vp])
+_lib.register("lab4d_intrinsics_epilogue_forward", [vp, vp, vp, vp, vp, ci, ci, vp, vp])
+_lib.register("lab4d_intrinsics_epilogue_backward", [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp])
+
 _SKEL_CACHE = {}
 
 
@@ -81,6 +87,63 @@ class _Fk(Function):
                                                 _lib.ptr(parent), _lib.ptr(g_qr), _lib.ptr(g_qd), R, B, bones, _lib.ptr(g_so3), _lib.ptr(g_local),
                                                 _lib.ptr(g_shift), _lib.stream()), "fk_backward")
         return g_so3, g_local, (g_shift.sum(0) if has_shift else None), None, None, None
+
+
+class _CameraEpilogue(Function):
+    """CameraMLP.get_vals behind the heads (pose.py:126-147): quaternion_mul(F.normalize(raw), F.normalize(base_quat[video])) as ONE launch (two backward:
+    the per-row adjoint, the per-video reduction of the base rotations' gradient -- added straight into a fused-accumulation sink when there is one)."""
+
+    @staticmethod
+    def forward(ctx, raw, base, frame_id, vid):
+        raw, basec = raw.detach().contiguous().float(), base.detach().contiguous().float()
+        _lib.require_device(raw, basec)
+        M, V = raw.shape[0], basec.shape[0]
+        out = torch.empty(M, 4, device=raw.device)
+        _lib.check(_lib.lib().lab4d_camera_epilogue_forward(_lib.ptr(raw), _lib.ptr(basec), _lib.ptr(frame_id), _lib.ptr(vid), M, V, _lib.ptr(out), _lib.stream()),
+                   "camera_epilogue_forward")
+        ctx.save_for_backward(raw, basec, frame_id, vid)
+        ctx.base_ref = base
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from . import mlp
+        raw, base, frame_id, vid = ctx.saved_tensors
+        M, V = raw.shape[0], base.shape[0]
+        g = g.contiguous().float()
+        g_raw, scratch = torch.empty_like(raw), torch.empty_like(raw)
+        sink = mlp._grad_sink(ctx.base_ref) if ctx.needs_input_grad[1] else None
+        g_base = sink if sink is not None else (torch.empty_like(base) if ctx.needs_input_grad[1] else None)
+        _lib.check(_lib.lib().lab4d_camera_epilogue_backward(_lib.ptr(raw), _lib.ptr(base), _lib.ptr(frame_id), _lib.ptr(vid), _lib.ptr(g), M, V, _lib.ptr(g_raw),
+                                                             _lib.ptr(scratch), _lib.ptr(g_base), int(sink is not None), _lib.stream()), "camera_epilogue_backward")
+        return g_raw, (None if sink is not None else g_base), None, None
+
+
+class _IntrinsicsEpilogue(Function):
+    """IntrinsicsMLP.get_vals behind the head (intrinsics.py:94-107) as one launch each way (+ the per-video reduction)."""
+
+    @staticmethod
+    def forward(ctx, raw, logfocal, ppoint, frame_id, vid):
+        raw, lf, pp = raw.detach().contiguous().float(), logfocal.detach().contiguous().float(), ppoint.detach().contiguous().float()
+        _lib.require_device(raw, lf, pp)
+        M, V = raw.shape[0], lf.shape[0]
+        out = torch.empty(M, 4, device=raw.device)
+        _lib.check(_lib.lib().lab4d_intrinsics_epilogue_forward(_lib.ptr(raw), _lib.ptr(lf), _lib.ptr(pp), _lib.ptr(frame_id), _lib.ptr(vid), M, V, _lib.ptr(out),
+                                                                _lib.stream()), "intrinsics_epilogue_forward")
+        ctx.save_for_backward(raw, lf, frame_id, vid)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        raw, lf, frame_id, vid = ctx.saved_tensors
+        M, V = raw.shape[0], lf.shape[0]
+        g = g.contiguous().float()
+        g_raw, scratch, g_video = torch.empty_like(raw), torch.empty(M, 4, device=raw.device), torch.empty(V, 4, device=raw.device)
+        _lib.check(_lib.lib().lab4d_intrinsics_epilogue_backward(_lib.ptr(raw), _lib.ptr(lf), _lib.ptr(frame_id), _lib.ptr(vid), _lib.ptr(g), M, V, _lib.ptr(g_raw),
+                                                                 _lib.ptr(scratch), _lib.ptr(g_video), _lib.stream()), "intrinsics_epilogue_backward")
+        return g_raw, g_video[:, :2], g_video[:, 2:], None, None
 
 
 def _rows(x, B, C):
@@ -295,9 +358,7 @@ def camera_vals(P, prefix, frame_id, info):
         lt, c_t, w_t, col = _head_layers(P, prefix + ".trans", c_f, col)
         lq, c_q, w_q, col = _head_layers(P, prefix + ".quat", c_f, col)
         trans, quat = rowmlp.run(layers + l2 + lt + lq, M, [(c_t, w_t), (c_q, w_q)], time=time)
-        quat = F.normalize(quat, dim=-1)
-        inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]
-        return quaternion_mul(quat, F.normalize(P[prefix + ".base_quat"][inst_id], dim=-1)), trans
+        return _CameraEpilogue.apply(quat, P[prefix + ".base_quat"], time["frame_id"], time["vid"]), trans
     feat = time_mlp(P, prefix, time_embedding(P, prefix + ".time_embedding", frame_id, info))
     quat = F.normalize(_head(P, prefix + ".quat", feat), dim=-1)
     inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]
@@ -386,7 +447,8 @@ def intrinsics_vals(P, prefix, frame_id, info):
         time, layers, c_te, _, col, M = _time_prologue(P, prefix + ".time_embedding", frame_id, info)
         l2, c_f, _, col = _time_mlp_layers(P, prefix, c_te, col, _mlp_depth(P, prefix))
         lf, c_o, w_o, col = _head_layers(P, prefix + ".focal", c_f, col)
-        focal = rowmlp.run(layers + l2 + lf, M, [(c_o, w_o)], time=time)[0].exp()
+        raw = rowmlp.run(layers + l2 + lf, M, [(c_o, w_o)], time=time)[0]
+        return _IntrinsicsEpilogue.apply(raw, P[prefix + ".base_logfocal"], P[prefix + ".base_ppoint"], time["frame_id"], time["vid"])
     else:
         focal = _head(P, prefix + ".focal", time_mlp(P, prefix, time_embedding(P, prefix + ".time_embedding", frame_id, info))).exp()
     inst_id = info["frame_to_vid"] if frame_id is None else info["raw_fid_to_vid"][frame_id]

@@ -21,34 +21,43 @@ vp, ci, cf, i32 = _lib.vp, _lib.ci, _lib.cf, ctypes.c_int32
 
 class _Layer(ctypes.Structure):
     _fields_ = [("W", vp), ("b", vp), ("dW", vp), ("db", vp), ("in_dim", i32), ("out_dim", i32), ("src_col", i32), ("dst_col", i32), ("relu", i32),
-                ("pad_", i32)]
+                ("acc", i32)]
+
+
+class _IO(ctypes.Structure):
+    _fields_ = [("ptr", vp), ("col", i32), ("width", i32)]
+
+
+MAX_IO = 4
 
 
 class _Prog(ctypes.Structure):
     _fields_ = [("n_layers", i32), ("row_stride", i32), ("frame_id", vp), ("vstart", vp), ("vidlen", vp), ("vid", vp), ("inst_W", vp), ("d_inst_W", vp),
                 ("max_ts", cf), ("time_scale", cf), ("n_freq", i32), ("four_col", i32), ("inst_col", i32), ("inst_dim", i32), ("inst_rows", i32),
-                ("pad_", i32), ("layer", _Layer * MAX_LAYERS)]
+                ("acc_inst", i32), ("n_in", i32), ("n_out", i32), ("inp", _IO * MAX_IO), ("out", _IO * MAX_IO), ("layer", _Layer * MAX_LAYERS)]
 
 
 _lib.register("lab4d_rowmlp_forward", [ctypes.POINTER(_Prog), vp, ci, vp])
 _lib.register("lab4d_rowmlp_backward", [ctypes.POINTER(_Prog), vp, vp, ci, vp])
 
 
-def _prog(spec, M, tensors, grads=None):
-    """ctypes program of `spec` over the tensors `tensors` (weights / biases / inst table in spec order); grads: matching output tensors or None."""
+def _prog(spec, tensors, ins, outs, grads=None, acc=None):
+    """ctypes program of `spec` over the tensors `tensors` (weights / biases / inst table in spec order); ins / outs: the tensors (or None) bound to the
+    program's input / output column ranges; grads: the gradient targets matching `tensors` (or None), acc[i]: grads[i] is accumulated into."""
     p = _Prog()
     p.n_layers, p.row_stride = len(spec["layers"]), spec["row_stride"]
     it = iter(range(len(tensors)))
+    g = (lambda i: _lib.ptr(grads[i]) if grads is not None and grads[i] is not None else None)
+    ac = (lambda i: bool(acc is not None and acc[i]))
     for l, L in enumerate(spec["layers"]):
         q = p.layer[l]
         iw = next(it)
-        q.W = _lib.ptr(tensors[iw])
-        q.dW = _lib.ptr(grads[iw]) if grads is not None else None
+        q.W, q.dW, a = _lib.ptr(tensors[iw]), g(iw), int(ac(iw))
         if L["bias"]:
             ib = next(it)
-            q.b = _lib.ptr(tensors[ib])
-            q.db = _lib.ptr(grads[ib]) if grads is not None else None
-        q.in_dim, q.out_dim, q.src_col, q.dst_col, q.relu = L["in_dim"], L["out_dim"], L["src"], L["dst"], int(L["relu"])
+            q.b, q.db = _lib.ptr(tensors[ib]), g(ib)
+            a |= 2 * int(ac(ib))
+        q.in_dim, q.out_dim, q.src_col, q.dst_col, q.relu, q.acc = L["in_dim"], L["out_dim"], L["src"], L["dst"], int(L["relu"]), a
     t = spec.get("time")
     if t is not None:
         p.frame_id, p.vstart, p.vidlen = _lib.ptr(t["frame_id"]), _lib.ptr(t["vstart"]), _lib.ptr(t["vidlen"])
@@ -56,45 +65,61 @@ def _prog(spec, M, tensors, grads=None):
         p.max_ts, p.time_scale, p.n_freq, p.four_col = float(t["max_ts"]), float(t["time_scale"]), int(t["n_freq"]), int(t["four_col"])
         if t["inst_dim"] > 0:
             ii = next(it)
-            p.inst_W = _lib.ptr(tensors[ii])
-            p.d_inst_W = _lib.ptr(grads[ii]) if grads is not None else None
+            p.inst_W, p.d_inst_W, p.acc_inst = _lib.ptr(tensors[ii]), g(ii), int(ac(ii))
         p.inst_col, p.inst_dim, p.inst_rows = int(t["inst_col"]), int(t["inst_dim"]), int(t["inst_rows"])
+    p.n_in, p.n_out = len(spec["inputs"]), len(spec["outs"])
+    for q, ((c, w), x) in enumerate(zip(spec["inputs"], ins)):
+        p.inp[q].ptr, p.inp[q].col, p.inp[q].width = (_lib.ptr(x) if x is not None else None), c, w
+    for q, ((c, w), x) in enumerate(zip(spec["outs"], outs)):
+        p.out[q].ptr, p.out[q].col, p.out[q].width = (_lib.ptr(x) if x is not None else None), c, w
     return p
 
 
 class _Run(Function):
-    """(spec, n_inputs, *inputs, *params) -> the output column ranges.  spec is a plain dict (shapes, columns, frame tables)."""
+    """(spec, n_inputs, *inputs, *params) -> the output column ranges as fresh (M, width) tensors.  spec is a plain dict (shapes, columns, frame tables).
+    Gradients of parameters whose `.grad` is a fused-accumulation sink (lab4d_amd.mlp.FUSED_GRAD_ACCUM: views of FlatAdamW's flat buffer) are ADDED
+    there by the parameter kernel and autograd is handed None for them -- no AccumulateGrad launch per parameter; the others are returned."""
 
     @staticmethod
     def forward(ctx, spec, n_in, *args):
-        ins, params = args[:n_in], [a.detach().contiguous() for a in args[n_in:]]
         M, rs = spec["M"], spec["row_stride"]
+        ins = [a.detach().reshape(M, w).contiguous().float() for a, (_, w) in zip(args[:n_in], spec["inputs"])]
+        params = [a.detach().contiguous() for a in args[n_in:]]
         dev = params[0].device
-        _lib.require_device(*params)
+        _lib.require_device(*params, *ins)
         work = torch.empty(M, rs, device=dev)
-        for (col, width), x in zip(spec["inputs"], ins):
-            work[:, col:col + width] = x.detach().reshape(M, width)
-        p = _prog(spec, M, params)
+        outs = [torch.empty(M, w, device=dev) for _, w in spec["outs"]]
+        p = _prog(spec, params, ins, outs)
         _lib.check(_lib.lib().lab4d_rowmlp_forward(ctypes.byref(p), _lib.ptr(work), M, _lib.stream()), "rowmlp_forward")
-        ctx.spec, ctx.n_in = spec, n_in
+        ctx.spec, ctx.n_in, ctx.param_refs = spec, n_in, args[n_in:]
         ctx.save_for_backward(work, *params)
-        return tuple(work[:, c:c + w].clone() for c, w in spec["outs"])
+        return tuple(outs)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, *gouts):
+        from . import mlp  # (the fused-accumulation switch lives there)
         spec, n_in = ctx.spec, ctx.n_in
         work, params = ctx.saved_tensors[0], list(ctx.saved_tensors[1:])
         M, rs = spec["M"], spec["row_stride"]
-        gwork = torch.zeros(M, rs, device=work.device)
-        for (c, w), g in zip(spec["outs"], gouts):
-            if g is not None:
-                gwork[:, c:c + w] = g.reshape(M, w)
-        grads = [torch.empty_like(t) for t in params]
-        p = _prog(spec, M, params, grads)
+        dev = work.device
+        gwork = torch.empty(M, rs, device=dev)  # (cleared by the chain kernel)
+        gos = [None if g is None else g.reshape(M, w).contiguous().float() for g, (_, w) in zip(gouts, spec["outs"])]
+        gins = [torch.empty(M, w, device=dev) if ctx.needs_input_grad[2 + i] else None for i, (_, w) in enumerate(spec["inputs"])]
+        grads, acc, ret = [], [], []
+        for i, (t, ref) in enumerate(zip(params, ctx.param_refs)):
+            if not ctx.needs_input_grad[2 + n_in + i]:
+                grads.append(None); acc.append(False); ret.append(None)
+                continue
+            sink = mlp._grad_sink(ref)
+            if sink is not None:
+                grads.append(sink); acc.append(True); ret.append(None)
+            else:
+                gt = torch.empty_like(t)
+                grads.append(gt); acc.append(False); ret.append(gt)
+        p = _prog(spec, params, gins, gos, grads, acc)
         _lib.check(_lib.lib().lab4d_rowmlp_backward(ctypes.byref(p), _lib.ptr(work), _lib.ptr(gwork), M, _lib.stream()), "rowmlp_backward")
-        gin = [gwork[:, c:c + w].clone() for c, w in spec["inputs"]]
-        return (None, None) + tuple(gin) + tuple(grads)
+        return (None, None) + tuple(gins) + tuple(ret)
 
 
 def run(layers, M, outs, time=None, inputs=(), row_stride=None):
@@ -104,6 +129,8 @@ def run(layers, M, outs, time=None, inputs=(), row_stride=None):
     "inst_col"} = the TimeEmbedding prologue.  Returns one (M, width) tensor per entry of outs."""
     if len(layers) < 1 or len(layers) > MAX_LAYERS:
         raise RuntimeError("rowmlp.run: %d layers (1..%d)" % (len(layers), MAX_LAYERS))
+    if len(outs) > MAX_IO or len(inputs) > MAX_IO:
+        raise RuntimeError("rowmlp.run: at most %d inputs and %d outputs" % (MAX_IO, MAX_IO))
     spec_layers, params = [], []
     end = 0
     for L in layers:

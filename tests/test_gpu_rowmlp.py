@@ -164,6 +164,32 @@ def test_adapters_with_stand_in_modules(pose_fx):
     assert rel(patch.intrinsics_get_vals(intr), pose_fx["intr"]["all_frames"]) < 1e-4
 
 
+def test_parameter_gradients_accumulate_into_fused_sinks():
+    """With lab4d_amd.mlp.FUSED_GRAD_ACCUM (what patch.trainer_optimizer_init switches on) the parameter kernel ADDS dW / db / the InstEmbedding rows' gradient
+    into `.grad` -- views of the optimizer's flat buffer -- and autograd is handed None: two backward passes sum, the values equal the returned-gradient
+    path, parameters without a sink still get theirs from autograd."""
+    from lab4d_amd import mlp, rowmlp
+    g = torch.Generator().manual_seed(9)
+    M = 19
+    x = leaf(M, 12, g=g)
+    W0, b0, W1 = leaf(20, 12, g=g), leaf(20, g=g), leaf(5, 20, g=g)
+    layers = [{"W": W0, "b": b0, "src": 0, "dst": 12, "relu": True}, {"W": W1, "b": None, "src": 12, "dst": 32, "relu": False}]
+    cot = torch.randn(M, 5, generator=g).to(DEV)
+    ref = torch.autograd.grad((rowmlp.run(layers, M, [(32, 5)], inputs=[((0, 12), x)])[0] * cot).sum(), [x, W0, b0, W1])
+    flat = torch.zeros(W0.numel() + b0.numel(), device=DEV)
+    W0.grad, b0.grad = flat[:W0.numel()].view_as(W0), flat[W0.numel():].view_as(b0)  # sinks: contiguous fp32 views of one flat buffer; W1 has none
+    old = mlp.FUSED_GRAD_ACCUM
+    mlp.FUSED_GRAD_ACCUM = True
+    try:
+        for _ in range(2):
+            (rowmlp.run(layers, M, [(32, 5)], inputs=[((0, 12), x)])[0] * cot).sum().backward()
+    finally:
+        mlp.FUSED_GRAD_ACCUM = old
+    assert W0.grad.data_ptr() == flat.data_ptr(), "the sink was replaced instead of accumulated into"
+    assert rel(W0.grad, 2 * ref[1]) < 1e-6 and rel(b0.grad, 2 * ref[2]) < 1e-6
+    assert rel(W1.grad, 2 * ref[3]) < 1e-6 and rel(x.grad, 2 * ref[0]) < 1e-6
+
+
 def test_one_launch_forward_two_backward(pose_fx):
     """The point of the row: launch count.  CameraMLP.get_vals' MLP part is ONE library launch forward and TWO backward (the torch modules:
     ~40 / ~100); counted with the library's own per-entry-point profile."""
@@ -182,3 +208,5 @@ def test_one_launch_forward_two_backward(pose_fx):
         _lib.PROF = None
     calls = {k: v[0] for k, v in prof.items()}
     assert calls.get("rowmlp_forward") == 1 and calls.get("rowmlp_backward") == 1, calls
+    assert calls.get("camera_epilogue_forward") == 1 and calls.get("camera_epilogue_backward") == 1, calls
+    assert "quaternion_mul_forward" not in calls  # (normalize x 2 + the product + their adjoints are the epilogue's two entry points now)

@@ -71,6 +71,32 @@ def emulate_run(layers, M, outs, time=None, inputs=(), row_stride=None):
     return tuple(read(c, w) for c, w in outs)
 
 
+class EmulatedCameraEpilogue:
+    """The contract of lab4d_camera_epilogue_forward in torch."""
+
+    @staticmethod
+    def apply(raw, base, frame_id, vid):
+        v = torch.zeros_like(frame_id) if base.shape[0] == 1 else vid[frame_id]
+        from lab4d_amd.quat_utils import quaternion_mul
+        return quaternion_mul(F.normalize(raw, dim=-1), F.normalize(base[v], dim=-1))
+
+
+class EmulatedIntrinsicsEpilogue:
+    @staticmethod
+    def apply(raw, logfocal, ppoint, frame_id, vid):
+        v = torch.zeros_like(frame_id) if logfocal.shape[0] == 1 else vid[frame_id]
+        f = raw.exp() * logfocal[v].exp()
+        f = (f + f.flip(-1)) / 2
+        return torch.cat([f, ppoint[v].expand_as(f)], -1)
+
+
+def emulate(monkeypatch):
+    monkeypatch.setattr(rowmlp, "run", emulate_run)
+    monkeypatch.setattr(pose, "_on_gpu", lambda P_, key: True)
+    monkeypatch.setattr(pose, "_CameraEpilogue", EmulatedCameraEpilogue)
+    monkeypatch.setattr(pose, "_IntrinsicsEpilogue", EmulatedIntrinsicsEpilogue)
+
+
 @pytest.fixture(scope="module")
 def fx():
     return torch.load(os.path.join(ROOT, "tests", "golden", "pose.pt"), weights_only=False)
@@ -89,8 +115,7 @@ def test_camera_intrinsics_time_programs_equal_the_algebra(fx, monkeypatch):
     Pk = {"intr." + k: v for k, v in fx["intr_state"].items()}
     info_k = dict(info, **fx["intr_time"])
     k_ref = pose.intrinsics_vals(Pk, "intr", fid, info_k)
-    monkeypatch.setattr(rowmlp, "run", emulate_run)
-    monkeypatch.setattr(pose, "_on_gpu", lambda P_, key: True)
+    emulate(monkeypatch)
     got = pose.camera_vals(P, "cam", fid, info)       # the rowmlp program, emulated
     got_all = pose.camera_vals(P, "cam", None, info)
     for a, b in zip(got + got_all, ref + ref_all):
@@ -119,8 +144,7 @@ def test_articulation_and_appearance_programs_equal_the_algebra(fx, monkeypatch)
     Pa["appr.output.weight"], Pa["appr.output.bias"] = torch.randn(32, 64, generator=g) * 0.2, torch.randn(32, generator=g) * 0.1
     appr_ref = pose.appearance_vals(Pa, "appr", fid, info)
 
-    monkeypatch.setattr(rowmlp, "run", emulate_run)
-    monkeypatch.setattr(pose, "_on_gpu", lambda P_, key: True)
+    emulate(monkeypatch)
 
     class Cuda(torch.Tensor):  # a CPU tensor that answers is_cuda = True: the tensor-input functions take their program branch
         @property
