@@ -160,3 +160,19 @@ def test_rowmlp_programs_are_validated_before_any_launch(so):
     p = prog([(8, 8, 0, 16)])
     p.n_layers = 17
     assert so.lab4d_rowmlp_forward(ctypes.byref(p), fake, 4, None) == -1
+
+
+def test_rowmlp_ctypes_structs_have_the_c_layout(tmp_path):
+    """lab4d_amd/rowmlp.py mirrors lab4d_rowmlp_prog / _layer / _io with ctypes.Structure: sizes and the offsets of the arrays must equal what a C compiler
+    gives include/lab4d_rowmlp.h (a field added on one side only would shift every pointer behind it)."""
+    import subprocess
+    from lab4d_amd import rowmlp
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdint.h>\n#include <stddef.h>\n#include <stdio.h>\n#include "lab4d_rowmlp.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lab4d_rowmlp_prog), sizeof(lab4d_rowmlp_layer), sizeof(lab4d_rowmlp_io),'
+                   ' offsetof(lab4d_rowmlp_prog, in), offsetof(lab4d_rowmlp_prog, out), offsetof(lab4d_rowmlp_prog, layer), offsetof(lab4d_rowmlp_prog, max_ts));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    c = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    P = rowmlp._Prog
+    assert c == [ctypes.sizeof(P), ctypes.sizeof(rowmlp._Layer), ctypes.sizeof(rowmlp._IO), P.inp.offset, P.out.offset, P.layer.offset, P.max_ts.offset]
