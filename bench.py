@@ -407,13 +407,15 @@ def fp32_leg(a):
 
 
 def other_configs_legs():
-    """BASELINE configs[2] / [3] / [4] at their per-GPU shapes (--config comp | multi | hash), 2 warm-up + 5 timed steps each in child processes after
+    """BASELINE configs[0]'s shape (64 x 64 x 64 through the fg loop) and configs[2] / [3] / [4] at their per-GPU shapes (--config comp | multi | hash), 2 warm-up + 5 timed steps each (50 for the small shape) in child processes after
     the headline run has given its device memory back: the driver-visible line carries every configuration BASELINE.json names, not only the fg one."""
     import subprocess
     out = {}
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    for cfg in ("comp", "multi", "hash"):
+    for cfg in ("config0_shape", "comp", "multi", "hash"):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", cfg, "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+        if cfg == "config0_shape":  # BASELINE configs[0]'s shape through the fg loop: a 64 x 64 crop of the frame pair, 64 samples/ray = 8,192 rays per step (launch-bound: 50 steps)
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--res", "64", "--spp", "64", "--chunk-rows", "64", "--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--no-extras"]
         t0 = time.perf_counter()
         tmo = EXTRAS.timeout(420)
         if tmo is None:
