@@ -382,6 +382,15 @@ def log_bone_len(P, prefix, inst_id, rows):
     """CondMLP(num_inst, in_channels=0, D=2, W=64) (pose.py:381-388): the instance code alone; inst_id None -> mean code."""
     w = P[prefix + ".inst_embedding.mapping.weight"]
     x = w.mean(0).expand(rows, -1) if inst_id is None else w[torch.zeros_like(inst_id) if w.shape[0] == 1 else inst_id]
+    if x.is_cuda:  # one program: the code rows as an external input, 2 x (Linear + ReLU), Linear
+        C = x.shape[-1]
+        layers, src, col = [], 0, _pad4(C)
+        for i in range(2):
+            name = f"{prefix}.linear_{i+1}.0"
+            layers.append(_lin_layer(P, name, src, col, True))
+            src, col = col, col + P[name + ".weight"].shape[0]
+        layers.append(_lin_layer(P, prefix + ".linear_final", src, col, False))
+        return rowmlp.run(layers, x.shape[0], [(col, P[prefix + ".linear_final.weight"].shape[0])], inputs=[((0, C), x)])[0]
     for i in range(2):
         x = F.relu(_linear(P, f"{prefix}.linear_{i+1}.0", x))
     return _linear(P, prefix + ".linear_final", x)
