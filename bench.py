@@ -1092,7 +1092,9 @@ def rank_main(a):
         if a.share_gpu:
             dist.init_process_group("gloo")  # (CUDA tensors are staged through the host: functional, not fast)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL on ROCm, bound to this rank's GPU
+            import datetime
+            # (a collective that cannot complete -- a rank that died, a fabric that is not up -- aborts after 5 minutes instead of holding the node until the driver's limit)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))  # RCCL on ROCm, bound to this rank's GPU
         if dist.get_world_size() != a.gpus and not a.force_dist:
             fail("the process group holds %d rank(s), --gpus says %d" % (dist.get_world_size(), a.gpus))
     torch.cuda.set_device(local)
