@@ -270,6 +270,8 @@ def _lin_layer(P, name, src, dst, relu):
 def _time_prologue(P, te_prefix, frame_id, info):
     """The time prologue + TimeEmbedding's two Linear layers as program pieces: (time dict, layers, column of t_embed, width, next free column)."""
     fid = info["frame_mapping"] if frame_id is None else frame_id
+    if not torch.is_tensor(fid):  # (the reference's frame_to_tid accepts lists / ints, embedding.py:178-179)
+        fid = torch.as_tensor(fid)
     fid = fid.reshape(-1).long().to(info["raw_fid_to_vid"].device)  # (the reference indexes its device tables with whatever index tensor it is handed)
     info = dict(info, **{k: info[k].long() for k in ("raw_fid_to_vstart", "raw_fid_to_vidlen", "raw_fid_to_vid")})  # (no-ops on the reference's int64 buffers)
     nf = 2 * max(int(info["num_freq_t"]), 0) + 1
